@@ -1,0 +1,74 @@
+"""Host-side mirror of the reference's evaluation engines for the forward hot path.
+
+Reference: BaseTester / FullyCNNTester (model_utils/tester.py:18-90) and InferenceEngine
+(infer.py:19-52): read cfg -> creat_graph() -> _init_session() -> _load_checkpoint() ->
+test_step(ndarray[N,T,129,1]) -> ndarray[N,T,129,1].  Only that slice is mirrored; the dataset
+loop, ISTFT rebuild and PESQ/STOI/SDR scoring (tester.py:92-167) are outside the hot path.
+"""
+
+import numpy as np
+
+from . import model as _model, spec, weights as _weights
+
+
+class FullyCNNTester(object):
+    """test_config: a configparser-like object (config.py:9-12) or None with keyword overrides.
+
+    Keys read, as the reference does: [model] net_work (tester.py:21-22), [testing]
+    checkpoint_filepath (tester.py:20) -- here a .npz of TF variables --, [data] feature_dim
+    (tester.py:54).  The shipped infer cfgs name the section [inference]: both are accepted.
+    """
+
+    def __init__(self, test_config=None, net_work=None, checkpoint_file=None, weights=None, device=0):
+        self.device = device
+        self.net_work = net_work
+        self.checkpoint_file = checkpoint_file
+        self.feature_dim = spec.FEATURE_DIM
+        if test_config is not None:
+            self.net_work = test_config.get("model", "net_work")
+            for section in ("testing", "inference"):
+                if test_config.has_section(section) and test_config.has_option(section, "checkpoint_filepath"):
+                    self.checkpoint_file = test_config.get(section, "checkpoint_filepath")
+                    break
+            if test_config.has_option("data", "feature_dim"):
+                self.feature_dim = int(test_config.get("data", "feature_dim"))
+        if self.feature_dim != spec.FEATURE_DIM:
+            raise ValueError("feature_dim must be %d (nfft 256), got %d" % (spec.FEATURE_DIM, self.feature_dim))
+        self._weights = weights
+        self.creat_graph()
+        self._load_checkpoint()
+
+    def creat_graph(self):
+        """tester.py:69-83: pick the model by net_work and build pred = model(input_x)."""
+        if self.net_work not in ("FullyCNNV2", "FullyCNNV3"):
+            print("net_work set default or not wright. Use FullyCNN")
+        self.model = _model.build_model(self.net_work, is_training=False, device=self.device)
+
+    def _load_checkpoint(self):
+        """tester.py:36-39."""
+        if self._weights is not None:
+            self.model.restore(self._weights)
+        elif self.checkpoint_file:
+            self.model.restore(_weights.load_npz(self.checkpoint_file))
+            print("recover from checkpoint_file: {}".format(self.checkpoint_file))
+
+    def param_count(self):
+        """tester.py:41-47."""
+        n = self.model.param_count()
+        print("\nTotal number of Parameters: {}\n".format(n))
+        return n
+
+    def test_step(self, input_x):
+        """tester.py:85-90: output = sess.run(self.pred, {self.input_x: input_x})."""
+        return self.model(input_x)
+
+
+class InferenceEngine(FullyCNNTester):
+    """infer.py:19-52, the forward slice: `denoise_magnitude` is infer.py:62-65 without the
+    STFT/ISTFT around it."""
+
+    def denoise_magnitude(self, mag):
+        mag = np.asarray(mag, dtype=np.float32)
+        if mag.ndim == 2:  # [T, 129] -> [1, T, 129, 1]  (a transpose-correct version of infer.py:59)
+            mag = mag[None, :, :, None]
+        return self.test_step(mag)

@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference's model classes, over the C ABI (include/rced.h).
+
+Reference surface kept (model_utils/model.py):
+    FullyCNNSEModel(is_training)(x)     model.py:6-29   R-CED 10 layers
+    FullyCNNSEModelV2(is_training)(x)   model.py:32-61  R-CED 16 layers
+    FullyCNNSEModelV3(is_training)(x)   model.py:64-96  CR-CED 16 layers
+x is [N, T, 129, 1] float32 NHWC and the result has the same shape.  In the reference `model(x)`
+adds nodes to a TF graph and `sess.run` executes them (tester.py:85-90); here `model(x)` executes:
+  * numpy in  -> numpy out   (host buffers, H2D/D2H inside; the reference's own calling convention)
+  * torch.cuda tensor in -> torch.cuda tensor out (device-resident, zero copy, current stream)
+Weights are the TF variables by name (weights.py); `restore()` plays Saver.restore.
+There is no CPU path: a missing HIP extension or GPU raises.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib, spec, weights as _weights
+
+
+def _is_torch(x):
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class _RcedNet(object):
+    variant = None
+    _handle = None
+
+    def __init__(self, is_training, weights=None, device=0, seed=None):
+        if is_training:
+            # trainer.py:156-179 builds the same graph with is_training=True (batch-stat BN + Adam);
+            # that is SURVEY 8(f) N3, not part of the forward hot path.
+            raise NotImplementedError("is_training=True (train-mode BatchNorm / backward) is not built; "
+                                      "use is_training=False for the forward pass")
+        self.is_training = False
+        self.device = int(device)
+        self._handle = None
+        self._weights = None
+        self._path = _lib.PATH_AUTO
+        self.restore(weights if weights is not None else _weights.initial_weights(self.variant, seed))
+
+    # -- weights ---------------------------------------------------------------------------
+    def restore(self, weights):
+        """Saver.restore analogue (tester.py:36-39): dict keyed by TF variable names, or a .npz path."""
+        if isinstance(weights, str):
+            weights = _weights.load_npz(weights)
+        blob = _weights.pack_blob(self.variant, weights)
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(lib.rced_create(self.variant, blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), blob.size,
+                                   self.device, ctypes.byref(h)))
+        self._release()
+        self._handle = h
+        self._weights = {k: np.array(v, dtype=np.float32) for k, v in weights.items()}
+        if self._path != _lib.PATH_AUTO:
+            self.set_path(self._path)
+        return self
+
+    @property
+    def weights(self):
+        return self._weights
+
+    def param_count(self):
+        """BaseTester.param_count (tester.py:41-47): trainable scalars."""
+        return spec.num_trainable(self.variant)
+
+    # -- options ---------------------------------------------------------------------------
+    def set_path(self, path):
+        """'auto' | 'layerwise' | 'fused' (rced.h RCED_PATH_*)."""
+        code = {"auto": _lib.PATH_AUTO, "layerwise": _lib.PATH_LAYERWISE, "fused": _lib.PATH_FUSED}.get(path, path)
+        _lib.check(_lib.load().rced_set_option(self._handle, b"path", int(code)))
+        self._path = int(code)
+        return self
+
+    def set_option(self, key, value):
+        _lib.check(_lib.load().rced_set_option(self._handle, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = ctypes.c_int()
+        _lib.check(_lib.load().rced_get_option(self._handle, key.encode(), ctypes.byref(v)))
+        return v.value
+
+    def reserve(self, n, t):
+        _lib.check(_lib.load().rced_reserve(self._handle, int(n), int(t)))
+
+    def profile(self, on=True):
+        self.set_option("profile", 1 if on else 0)
+
+    def profile_query(self, kind):
+        ms, cnt = ctypes.c_float(), ctypes.c_int()
+        _lib.check(_lib.load().rced_profile_query(self._handle, int(kind), ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
+    # -- forward ---------------------------------------------------------------------------
+    @staticmethod
+    def _check_shape(shape):
+        if len(shape) != 4 or shape[2] != spec.FEATURE_DIM or shape[3] != 1:
+            raise ValueError("input must be [N, T, %d, 1] (NHWC), got %s" % (spec.FEATURE_DIM, tuple(shape)))
+
+    def __call__(self, x):
+        lib = _lib.load()
+        if _is_torch(x):
+            import torch
+            self._check_shape(x.shape)
+            if not x.is_cuda:
+                raise ValueError("torch input must be a CUDA/HIP tensor (pass numpy for host buffers)")
+            if x.device.index != self.device:
+                raise ValueError("input on cuda:%d, model on cuda:%d" % (x.device.index, self.device))
+            if x.dtype != torch.float32:
+                x = x.float()
+            x = x.contiguous()
+            y = torch.empty_like(x)
+            n, t = int(x.shape[0]), int(x.shape[1])
+            if n and t:
+                st = torch.cuda.current_stream(x.device).cuda_stream
+                _lib.check(lib.rced_forward(self._handle, x.data_ptr(), y.data_ptr(), n, t, st))
+            return y
+        x = np.asarray(x)
+        self._check_shape(x.shape)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty_like(x)
+        n, t = x.shape[0], x.shape[1]
+        if n and t:
+            _lib.check(lib.rced_forward_host(self._handle, x.ctypes.data, y.ctypes.data, n, t))
+        return y
+
+    # -- lifetime --------------------------------------------------------------------------
+    def _release(self):
+        if self._handle is not None:
+            try:
+                _lib.load().rced_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    def close(self):
+        self._release()
+
+    def __del__(self):
+        self._release()
+
+
+class FullyCNNSEModel(_RcedNet):
+    """R-CED, 10 layers, 32,765 parameters (model.py:6-29, readme.md:65)."""
+    variant = spec.V1
+
+
+class FullyCNNSEModelV2(_RcedNet):
+    """R-CED, 16 layers, 32,192 parameters (model.py:32-61, readme.md:66)."""
+    variant = spec.V2
+
+
+class FullyCNNSEModelV3(_RcedNet):
+    """CR-CED, 16 layers, 32,653 parameters (model.py:64-96, readme.md:67)."""
+    variant = spec.V3
+
+
+def build_model(net_work, is_training=False, **kw):
+    """The selection block of tester.py:76-82 / infer.py:45-51."""
+    if net_work == "FullyCNNV2":
+        return FullyCNNSEModelV2(is_training, **kw)
+    if net_work == "FullyCNNV3":
+        return FullyCNNSEModelV3(is_training, **kw)
+    return FullyCNNSEModel(is_training, **kw)
+
+
+def conv_bn_relu(inputs, out_channels, kernel_size, stride=(1, 1), is_training=False, padding="SAME",
+                 use_norm=True, use_act=True, scope="conv", skip_input=None, params=None):
+    """The single op of model_utils/module.py:11-34 on the GPU (inference BN).
+
+    inputs: torch.cuda float32 [N,T,F,cin]; params: dict with "{scope}/kernel", "{scope}/bias" and, if
+    use_norm, "{scope}/batch_norm/{gamma,beta,moving_mean,moving_variance}" (numpy or torch).
+    Returns a torch.cuda tensor [N,T,F,out_channels].
+    """
+    import torch
+    if is_training:
+        raise NotImplementedError("is_training=True is not built (SURVEY 8f N3)")
+    if tuple(stride) != (1, 1) or padding != "SAME":
+        raise ValueError("only stride (1,1), padding 'SAME' (all the reference ever passes)")
+    if params is None:
+        raise ValueError("params (the layer's TF variables) are required")
+    x = inputs
+    if not (_is_torch(x) and x.is_cuda):
+        raise ValueError("inputs must be a torch CUDA/HIP tensor")
+    x = x.float().contiguous()
+    n, t, f, cin = (int(s) for s in x.shape)
+    kh, kw = int(kernel_size[0]), int(kernel_size[1])
+    dev = x.device
+
+    def dev_t(a, shape):
+        a = torch.as_tensor(np.asarray(a.detach().cpu()) if _is_torch(a) else np.asarray(a), dtype=torch.float32)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError("parameter shape %s, expected %s" % (tuple(a.shape), tuple(shape)))
+        return a.contiguous().to(dev)
+
+    k = dev_t(params[scope + "/kernel"], (kh, kw, cin, out_channels))
+    b = dev_t(params[scope + "/bias"], (out_channels,))
+    bn = None
+    if use_norm:
+        p = scope + "/batch_norm/"
+        bn = torch.cat([dev_t(params[p + v], (out_channels,)) for v in ("gamma", "beta", "moving_mean", "moving_variance")])
+    skip = None
+    if skip_input is not None:
+        skip = skip_input.float().contiguous()
+        if tuple(skip.shape) != (n, t, f, out_channels):
+            raise ValueError("skip_input shape %s, expected %s" % (tuple(skip.shape), (n, t, f, out_channels)))
+    y = torch.empty((n, t, f, out_channels), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(_lib.load().rced_conv_bn_relu(
+        x.data_ptr(), y.data_ptr(), k.data_ptr(), b.data_ptr(), bn.data_ptr() if bn is not None else None,
+        skip.data_ptr() if skip is not None else None, 1 if use_act else 0, n, t, f, cin, out_channels, kh, kw,
+        dev.index, st))
+    return y

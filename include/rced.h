@@ -1,0 +1,114 @@
+/*
+ * rced.h -- C ABI of the MI355X-native R-CED / CR-CED forward pass (librced_hip.so).
+ *
+ * This is the drop-in boundary for the one hot path of phecda-xu/FullyCNNSpeechEnhancement:
+ * what the reference runs as `sess.run(self.pred, {self.input_x: x})`
+ *   (model_utils/tester.py:85-90, infer.py:62-65, model_utils/trainer.py:245-250)
+ * over the graph built by `self.pred = self.model(self.input_x)`
+ *   (model_utils/tester.py:69-83; model_utils/model.py:6-96; model_utils/module.py:11-34).
+ *
+ * Plain C types only; integer status codes; caller-owned buffers; no exceptions cross the
+ * boundary.  A model handle is NOT thread-safe (one stream per call, like the reference's
+ * single tf.Session).  There is no CPU fallback: every entry point that computes needs a
+ * gfx950 device and fails with RCED_ERR_HIP otherwise.
+ *
+ * Tensor layout (module.py:15, data_loader.py:206-208): NHWC float32,
+ *   x, y : [N, T, 129, 1]   N utterances, T time frames, 129 frequency bins.
+ *
+ * Weight blob (float32), per layer in graph order -- exactly the TF variables of
+ * module.py:27,29, raw (BatchNorm is folded inside rced_create, not by the caller):
+ *   "{scope}/kernel"                      [kh, kw, cin, cout]  (HWIO)
+ *   "{scope}/bias"                        [cout]
+ *   "{scope}/batch_norm/gamma"            [cout]   } only for layers with use_norm
+ *   "{scope}/batch_norm/beta"             [cout]   }
+ *   "{scope}/batch_norm/moving_mean"      [cout]   }
+ *   "{scope}/batch_norm/moving_variance"  [cout]   }
+ */
+#ifndef RCED_H_
+#define RCED_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCED_FEATURE_DIM 129 /* cfg [data] feature_dim (Work/.../fully_cnn_*.cfg) */
+
+/* net_work selection of infer.py:45-51 / tester.py:76-82 */
+#define RCED_V1 1 /* FullyCNNSEModel    R-CED 10 layers  model.py:6-29  */
+#define RCED_V2 2 /* FullyCNNSEModelV2  R-CED 16 layers  model.py:32-61 */
+#define RCED_V3 3 /* FullyCNNSEModelV3  CR-CED 16 layers model.py:64-96 */
+
+/* status codes */
+#define RCED_OK 0
+#define RCED_ERR_ARG 1    /* bad argument (shape, null pointer, unknown variant)  */
+#define RCED_ERR_HIP 2    /* HIP runtime error or no gfx950 device                */
+#define RCED_ERR_ALLOC 3  /* device or host allocation failed                     */
+#define RCED_ERR_STATE 4  /* handle used after destroy / wrong device             */
+
+/* execution paths (rced_set_option "path") */
+#define RCED_PATH_AUTO 0      /* fused kernels where available, else layerwise      */
+#define RCED_PATH_LAYERWISE 1 /* one generic direct-conv launch per layer           */
+#define RCED_PATH_FUSED 2     /* fused multi-layer MFMA kernels; error if unavailable */
+
+typedef struct rced_model rced_model;
+
+/* Topology queries (host only; no device needed).  Replace reading model.py by hand. */
+int rced_num_layers(int variant);                 /* 10 / 16 / 16, or -1 */
+size_t rced_num_weights(int variant);             /* blob length in floats, or 0 */
+size_t rced_num_trainable(int variant);           /* 32765 / 32192 / 32653 (readme.md:65-67) */
+/* Layer i of `variant`: out[0..8] = cout,kh,kw,use_norm,use_act,src,skip_pre,skip_post,cin.
+ * src/skip ids: 0 = network input, k+1 = output of layer k, -1 = none. */
+int rced_layer_desc(int variant, int layer, int out[9]);
+const char* rced_layer_scope(int variant, int layer); /* TF variable scope, e.g. "CE1_encode_1" */
+
+/* Model(is_training=False) + Saver.restore: tester.py:69-83, 36-39.
+ * blob: host pointer, n_floats == rced_num_weights(variant).  device: HIP ordinal. */
+int rced_create(int variant, const float* blob, size_t n_floats, int device, rced_model** out);
+void rced_destroy(rced_model* m);
+
+/* y = model(x).  x_dev / y_dev: DEVICE pointers to [N,T,129,1] float32, resident on the
+ * model's device.  stream: a hipStream_t (NULL = default stream).  Asynchronous: returns
+ * after enqueueing.  Replaces sess.run(self.pred, ...) with device-resident tensors. */
+int rced_forward(rced_model* m, const float* x_dev, float* y_dev, int N, int T, void* stream);
+
+/* Same with HOST pointers (the reference boundary hands numpy arrays: tester.py:85-90).
+ * Copies H2D, runs, copies D2H, synchronises. */
+int rced_forward_host(rced_model* m, const float* x_host, float* y_host, int N, int T);
+
+/* Pre-size the internal workspace for shapes up to [N,T,...] so that rced_forward performs
+ * no allocation (needed before stream capture into a hipGraph). */
+int rced_reserve(rced_model* m, int N, int T);
+
+/* Options: "path" = RCED_PATH_*.  Returns RCED_ERR_ARG for unknown keys/values. */
+int rced_set_option(rced_model* m, const char* key, int value);
+int rced_get_option(rced_model* m, const char* key, int* value);
+
+/* The single op, module.py:11-34 conv_bn_relu with is_training=False, on DEVICE pointers:
+ *   x [N,T,F,cin] -> y [N,T,F,cout];  kernel [kh,kw,cin,cout], bias [cout] (device);
+ *   bn = gamma,beta,moving_mean,moving_variance (4*cout floats, device) or NULL (use_norm=False);
+ *   skip_input [N,T,F,cout] or NULL; use_act 0/1.  padding SAME, stride 1. */
+int rced_conv_bn_relu(const float* x, float* y, const float* kernel, const float* bias,
+                      const float* bn, const float* skip_input, int use_act, int N, int T, int F,
+                      int cin, int cout, int kh, int kw, int device, void* stream);
+
+/* Average device time (ms) of the dominant kernel of the last rced_forward, measured with HIP
+ * events on the launch stream when profiling is on ("profile" option = 1).  <0 if none. */
+float rced_last_kernel_ms(rced_model* m);
+
+/* HIP-event profiler ("profile" option = 1 arms it and clears old samples): total device time
+ * and launch count of kernel kind 0 = generic layer, 1 = fused multi-layer kernel, 2 = final
+ * 1x129 Toeplitz GEMM, over every rced_forward since it was armed.  Synchronises. */
+int rced_profile_query(rced_model* m, int kind, float* total_ms, int* launches);
+
+/* Thread-local description of the last error on this thread ("" if none). */
+const char* rced_last_error(void);
+
+/* Library / build identification, e.g. "rced-hip 0.1 gfx950". */
+const char* rced_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCED_H_ */

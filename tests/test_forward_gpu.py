@@ -1,0 +1,220 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI,
+against the fp64 oracle and the committed golden vectors.  Tolerance: BASELINE.json north_star,
+"masks within 1e-4 rel fp32" -> max|y - ref| <= 1e-4 * max|ref|  (conftest.RTOL)."""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import NETS, RTOL, load_golden, rel_err
+from oracle import layers as L, rced_c, rced_np
+
+pytestmark = pytest.mark.gpu
+
+PATHS = ["layerwise", "auto"]
+
+
+def make_model(variant, w, path="auto"):
+    from fullycnnspeechenhancement_amd import model as M
+    cls = {1: M.FullyCNNSEModel, 2: M.FullyCNNSEModelV2, 3: M.FullyCNNSEModelV3}[variant]
+    m = cls(False, weights=w, device=0)
+    m.set_path(path)
+    return m
+
+
+def test_extension_is_loaded_and_is_the_hip_one(built):
+    import torch
+    from fullycnnspeechenhancement_amd import _lib
+    assert torch.cuda.is_available()
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    assert "librced_hip.so" in maps
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_golden_vectors(net_work, tag, variant, path, built):
+    w, g = load_golden(tag)
+    m = make_model(variant, w, path)
+    for key in ("small", "long"):
+        y = m(g["x_" + key])
+        assert y.shape == g["y_" + key].shape and y.dtype == np.float32
+        assert rel_err(y, g["y_" + key]) < RTOL
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+@pytest.mark.parametrize("shape", [(1, 1), (1, 2), (1, 3), (1, 7), (3, 8), (2, 9), (5, 33), (1, 256), (7, 64)])
+def test_parity_vs_oracle_shapes(net_work, tag, variant, path, shape, built):
+    """Includes T < 8 (fewer frames than the first kernel is tall) and T not a multiple of any tile."""
+    n, t = shape
+    w = rced_np.make_weights(net_work, seed=100 + variant)
+    x = rced_np.make_input(n, t, seed=n * 1000 + t)
+    ref = rced_c.forward(net_work, w, x, np.float64)
+    y = make_model(variant, w, path)(x)
+    assert rel_err(y, ref) < RTOL
+
+
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_device_resident_path_equals_host_path(net_work, tag, variant, built):
+    import torch
+    w, g = load_golden(tag)
+    m = make_model(variant, w)
+    x = g["x_small"]
+    y_host = m(x)
+    xd = torch.from_numpy(x).cuda()
+    yd = m(xd)
+    assert yd.is_cuda and yd.shape == xd.shape
+    assert np.array_equal(yd.cpu().numpy(), y_host)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y2 = m(xd)
+    s.synchronize()
+    assert np.array_equal(y2.cpu().numpy(), y_host)
+
+
+def test_empty_and_degenerate_batches(built):
+    w, _ = load_golden("v3")
+    m = make_model(3, w)
+    assert m(np.zeros((0, 5, 129, 1), np.float32)).shape == (0, 5, 129, 1)
+    assert m(np.zeros((2, 0, 129, 1), np.float32)).shape == (2, 0, 129, 1)
+    with pytest.raises(ValueError):
+        m(np.zeros((2, 5, 128, 1), np.float32))
+    y0 = m(np.zeros((1, 4, 129, 1), np.float32))       # all-zero input: output is the bias path only
+    ref = rced_c.forward("FullyCNNV3", w, np.zeros((1, 4, 129, 1), np.float32))
+    assert rel_err(y0, ref) < RTOL
+
+
+def test_ragged_batch_zero_padding_matches_reference_loader(built):
+    """data_loader.py:198-209 zero-pads short utterances to the longest T; the net then runs on the
+    padded tensor.  The frames of a short utterance at least 4 frames before its end are unaffected."""
+    w, _ = load_golden("v2")
+    m = make_model(2, w)
+    lens = [40, 17, 29]
+    xs = [rced_np.make_input(1, t, seed=50 + t)[0] for t in lens]
+    batch = np.zeros((3, 40, 129, 1), np.float32)
+    for i, x in enumerate(xs):
+        batch[i, :lens[i]] = x
+    y = m(batch)
+    assert rel_err(y, rced_c.forward("FullyCNNV2", w, batch)) < RTOL
+    for i, x in enumerate(xs):
+        alone = m(x[None])
+        keep = lens[i] - 4 if lens[i] < 40 else lens[i]
+        assert np.abs(alone[0, :keep] - y[i, :keep]).max() <= 1e-6 * np.abs(alone).max()
+
+
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_batch_and_time_shard_invariance(net_work, tag, variant, built):
+    """Size-independent properties: utterances are independent; frame t needs frames t-3..t+4 only."""
+    w = rced_np.make_weights(net_work, seed=9)
+    m = make_model(variant, w)
+    x = rced_np.make_input(6, 48, seed=10)
+    y = m(x)
+    for i in (0, 3, 5):
+        assert np.array_equal(m(x[i:i + 1])[0], y[i])
+    a = m(x[:, :28])          # frames 0..27 -> valid 0..23
+    b = m(x[:, 21:])          # frames 21..47 -> valid 24..47
+    scale = np.abs(y).max()
+    assert np.abs(a[:, :24] - y[:, :24]).max() <= 1e-6 * scale
+    assert np.abs(b[:, 3:] - y[:, 24:]).max() <= 1e-6 * scale
+
+
+def test_full_size_config3_sampled_against_oracle(built):
+    """BASELINE config 3 (CR-CED, batch 256, 129x512) on the device path; a random sample of output
+    frames is checked against the oracle run on each frame's 8-frame receptive field."""
+    import torch
+    w = rced_np.make_weights("FullyCNNV3", seed=42)
+    m = make_model(3, w)
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.randn((256, 512, 129, 1), generator=g, device="cuda").abs_()
+    y = m(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    rng = np.random.default_rng(0)
+    picks = [(0, 0), (0, 1), (255, 511), (255, 508), (17, 3), (200, 510)] + \
+            [(int(rng.integers(256)), int(rng.integers(512))) for _ in range(26)]
+    scale = float(y.abs().max())
+    for n, t in picks:
+        lo, hi = max(t - 3, 0), min(t + 5, 512)
+        win = x[n:n + 1, lo:hi].cpu().numpy()
+        ref = rced_c.forward("FullyCNNV3", w, win, np.float64)[0, t - lo]
+        got = y[n, t].cpu().numpy()
+        assert np.abs(got - ref).max() <= RTOL * scale, (n, t)
+    # utterances are independent: rerunning a slice of the batch reproduces it bit for bit
+    assert torch.equal(m(x[100:104].contiguous()), y[100:104])
+
+
+def test_single_op_conv_bn_relu_known_answers(built):
+    """rced_conv_bn_relu against the analytic cases of test_oracle.py, and against the oracle op."""
+    import torch
+    from fullycnnspeechenhancement_amd import conv_bn_relu
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1)
+    # kh = 8 asymmetry: 3 past / 4 future
+    x = torch.ones((1, 12, 129, 1), device=dev)
+    p = {"c/kernel": np.ones((8, 1, 1, 1), np.float32), "c/bias": np.zeros(1, np.float32)}
+    y = conv_bn_relu(x, 1, (8, 1), (1, 1), False, use_norm=False, use_act=False, scope="c", params=p).cpu().numpy()
+    assert y[0, 0, 0, 0] == 5 and y[0, 11, 0, 0] == 4 and y[0, 5, 0, 0] == 8
+    # random layers of every shape class the three nets use, with BN, skip and ReLU
+    for (kh, kw, cin, cout) in ((8, 13, 1, 12), (1, 11, 12, 16), (1, 5, 15, 19), (1, 9, 30, 8), (1, 129, 8, 1), (1, 7, 25, 23)):
+        xin = rng.standard_normal((2, 9, 129, cin)).astype(np.float32)
+        k = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+        b = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+        bn = (rng.uniform(0.5, 1.5, cout), rng.uniform(-0.1, 0.1, cout), rng.normal(0, 0.1, cout), rng.uniform(0.5, 1.5, cout))
+        bn = tuple(a.astype(np.float32) for a in bn)
+        skip = rng.standard_normal((2, 9, 129, cout)).astype(np.float32)
+        p = {"s/kernel": k, "s/bias": b, "s/batch_norm/gamma": bn[0], "s/batch_norm/beta": bn[1],
+             "s/batch_norm/moving_mean": bn[2], "s/batch_norm/moving_variance": bn[3]}
+        ref = rced_np.conv_bn_relu(xin, k, b, bn, skip, True)
+        y = conv_bn_relu(torch.from_numpy(xin).to(dev), cout, (kh, kw), (1, 1), False, scope="s",
+                         skip_input=torch.from_numpy(skip).to(dev), params=p).cpu().numpy()
+        assert rel_err(y, ref) < RTOL
+        ref = rced_np.conv_bn_relu(xin, k, b, None, None, False)
+        y = conv_bn_relu(torch.from_numpy(xin).to(dev), cout, (kh, kw), (1, 1), False, use_norm=False,
+                         use_act=False, scope="s", params=p).cpu().numpy()
+        assert rel_err(y, ref) < RTOL
+
+
+def test_engine_test_step_surface(built):
+    """tester.py:85-90 surface: ndarray [N,T,129,1] -> ndarray [N,T,129,1]."""
+    import configparser
+    from fullycnnspeechenhancement_amd import FullyCNNTester
+    w, g = load_golden("v3")
+    cfg = configparser.ConfigParser()
+    cfg.read_dict({"model": {"net_arch": "FullyCNN", "net_work": "FullyCNNV3"}, "data": {"feature_dim": "129"},
+                   "inference": {"checkpoint_filepath": ""}})
+    eng = FullyCNNTester(cfg, weights=w)
+    assert eng.param_count() == 32653
+    out = eng.test_step(g["x_small"])
+    assert isinstance(out, np.ndarray) and rel_err(out, g["y_small"]) < RTOL
+
+
+def test_restore_swaps_weights(built):
+    w1 = rced_np.make_weights("FullyCNN", seed=1)
+    w2 = rced_np.make_weights("FullyCNN", seed=2)
+    x = rced_np.make_input(1, 10, seed=3)
+    m = make_model(1, w1)
+    y1 = m(x)
+    m.restore(w2)
+    y2 = m(x)
+    assert rel_err(y1, rced_c.forward("FullyCNN", w1, x)) < RTOL
+    assert rel_err(y2, rced_c.forward("FullyCNN", w2, x)) < RTOL
+    assert np.abs(y1 - y2).max() > 1e-3
+
+
+def test_c_abi_status_codes_on_device(built):
+    from fullycnnspeechenhancement_amd import _lib, weights
+    lib = _lib.load()
+    blob = weights.pack_blob(3, rced_np.make_weights("FullyCNNV3", seed=1))
+    h = ctypes.c_void_p()
+    assert lib.rced_create(3, blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), blob.size, 99, ctypes.byref(h)) == _lib.RCED_ERR_ARG
+    bad = blob.copy()
+    bad[5] = np.inf
+    assert lib.rced_create(3, bad.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), bad.size, 0, ctypes.byref(h)) == _lib.RCED_ERR_ARG
+    assert lib.rced_create(3, blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), blob.size, 0, ctypes.byref(h)) == 0
+    assert lib.rced_forward(h, None, None, 1, 1, None) == _lib.RCED_ERR_ARG
+    assert lib.rced_forward(h, None, None, 0, 7, None) == 0            # empty batch is fine
+    assert lib.rced_forward(h, None, None, -1, 7, None) == _lib.RCED_ERR_ARG
+    assert lib.rced_set_option(h, b"nonsense", 1) == _lib.RCED_ERR_ARG
+    lib.rced_destroy(h)
