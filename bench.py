@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- spectrogram frames/sec of the CR-CED-16 (V3) forward pass on N MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by torch.distributed.run, one rank per GPU; utterances shard over the batch
+  axis with NO data-path collective (each rank owns B utterances resident in its HBM) -> weak scaling.
+A "step" = one forward of the hot path (model_utils/model.py:93-96 via the C ABI) over one batch
+of B x T x 129 synthetic magnitude frames already resident in HBM.
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel vs the fp32 MFMA/VALU peak, HIP
+events inside the timed region) and `cpu_baseline` (the CPU restatement timed on this box's cores).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3   # MI355X dense fp32, vector = matrix (MI355X_MICROARCH.md chip table)
+NET_WORK = {1: "FullyCNN", 2: "FullyCNNV2", 3: "FullyCNNV3"}
+
+
+def cpu_baseline(variant, weights, frames_t, budget_s):
+    """The oracle's torch-CPU fp32 restatement (kind "port": TF 1.14 itself cannot run here) on a
+    bounded sample of the same workload: batches of 8 utterances x T frames until ~budget_s."""
+    import torch
+    from oracle import rced_np, torch_ref
+    ref = torch_ref.TorchRef(NET_WORK[variant], weights)
+    x = torch.from_numpy(rced_np.make_input(8, frames_t, seed=1234))
+    ref(x[:1])  # warm-up (oneDNN primitive creation)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        ref(x)
+        done += x.shape[0] * x.shape[1]
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {"value": done / el, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "torch-CPU fp32 restatement (oracle/torch_ref.py), %d frames = %d batches of [8,%d,129,1] in %.1f s, host has %d logical cpus"
+                      % (done, done // (8 * frames_t), frames_t, el, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU (config 3: 256)")
+    ap.add_argument("--frames", type=int, default=512, help="time frames per utterance (config 3: 512)")
+    ap.add_argument("--variant", type=int, default=3, choices=(1, 2, 3))
+    ap.add_argument("--path", default="auto", choices=("auto", "layerwise", "fused"))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not time the dominant kernel with HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == max(args.gpus, 1) or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build_hip()
+    if world > 1:
+        dist.barrier()
+    from fullycnnspeechenhancement_amd import _lib, build_model, spec
+    from oracle import rced_np  # synthetic weights/inputs generator + cpu_baseline only
+
+    variant = args.variant
+    weights = rced_np.make_weights(NET_WORK[variant], seed=42)          # random-init, SURVEY 8(d2)
+    model = build_model(NET_WORK[variant], False, weights=weights, device=local_rank)
+    model.set_path(args.path)
+    B, T = args.batch, args.frames
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    x = torch.randn((B, T, spec.FEATURE_DIM, 1), generator=g, device="cuda").abs_()   # |N(0,1)| magnitudes
+    y = torch.empty_like(x)
+    model.reserve(B, T)
+    lib = _lib.load()
+    stream = torch.cuda.current_stream()
+    h, xp, yp = model._handle, x.data_ptr(), y.data_ptr()
+
+    def step():
+        _lib.check(lib.rced_forward(h, xp, yp, B, T, stream.cuda_stream))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if not args.no_profile:
+        model.profile(True)     # HIP events around every kernel launch, on the launch stream
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    frames_total = world * B * T * args.steps
+    flops_frame = spec.flops_per_frame(variant)
+    out = {
+        "metric": "spectrogram frames/sec (CR-CED-16 fwd, 129-bin)" if variant == 3 else
+                  "spectrogram frames/sec (%s fwd, 129-bin)" % NET_WORK[variant],
+        "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CR-CED V3 (16-layer, skip connections) forward, batch %d per GPU, 129x%d, fp32 "
+                               "(BASELINE configs[2])" % (B, T) if variant == 3 else
+                               "%s forward, batch %d per GPU, 129x%d, fp32" % (NET_WORK[variant], B, T),
+                   "variant": NET_WORK[variant], "batch_per_gpu": B, "frames": T, "bins": spec.FEATURE_DIM,
+                   "global_batch": world * B, "path": {0: "auto", 1: "layerwise", 2: "fused"}[model.get_option("path")],
+                   "fused_available": bool(model.get_option("has_fused")), "parallelism": "batch-shard x%d" % world,
+                   "weights": "random-init (glorot, seed 42)"},
+    }
+    if rank == 0:
+        roof = None
+        if not args.no_profile:
+            kinds = {_lib.K_GENERIC: "conv_layer_generic", _lib.K_FUSED: "rced_fused", _lib.K_FINAL: "rced_final_gemm"}
+            times = {k: model.profile_query(k) for k in kinds}
+            dom = max(times, key=lambda k: times[k][0])
+            ms, launches = times[dom]
+            if launches:
+                # FLOPs the dominant kernel kind performs per forward (nominal dense count)
+                if dom == _lib.K_GENERIC:
+                    kflops = flops_frame
+                else:
+                    final = 2 * spec.FEATURE_DIM * sum(l.kh * l.kw * l.cin * l.cout for l in spec.layers(variant)[-1:])
+                    kflops = final if dom == _lib.K_FINAL else flops_frame - final
+                achieved = kflops * B * T * args.steps / (ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": kinds[dom], "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                        "avg_launch_ms": ms / launches, "launches": launches,
+                        "flop_per_frame": kflops, "frames_per_forward": B * T,
+                        "other_kernels_ms_per_step": {kinds[k]: times[k][0] / args.steps for k in kinds if k != dom and times[k][1]},
+                        "note": "compute-bound path (7950 FLOP/B): peak = dense fp32 157.3 TFLOP/s, not HBM; "
+                                "algorithmic HBM bytes are 1032 B/frame"}
+        out["roofline"] = roof
+        out["cpu_baseline"] = cpu_baseline(variant, weights, T, args.cpu_seconds) if args.cpu_seconds > 0 else None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
