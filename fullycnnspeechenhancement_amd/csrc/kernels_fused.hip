@@ -1,12 +1,210 @@
-// Fused-kernel runtime: placeholder until the MFMA kernels land (no variant is fused yet).
+// Fused-kernel runtime: packs BN-folded weights into MFMA A-fragment streams, owns the hand-off
+// workspace, launches the fused multi-layer kernel + the final Toeplitz GEMM.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
 #include "../../include/rced.h"
+#include "kernels_fused_v3.h"
 #include "rced_internal.h"
 
-int fused_create(rced_model* m) { m->fused = nullptr; return RCED_OK; }
-void fused_destroy(rced_model*) {}
-int fused_reserve(rced_model*, int, int) { return RCED_OK; }
-int fused_forward(rced_model*, const float*, float*, int, int, hipStream_t) {
-  return rced_fail(RCED_ERR_STATE, "no fused path");
+using namespace rced;
+
+struct rced_fused {
+  float* wpack = nullptr;     // v3::kWTotal
+  float* shifts = nullptr;    // 15 x 32
+  float* fin_apack = nullptr; // v3::kFinPack
+  float fin_bias = 0.f;
+  float* h = nullptr;         // [frames, 129, 8] hand-off to the final layer
+  size_t h_bytes = 0;
+  int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
+};
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return rced_fail(e_ == hipErrorOutOfMemory ? RCED_ERR_ALLOC : RCED_ERR_HIP, "%s: %s", #expr, \
+                       hipGetErrorString(e_));                                                 \
+  } while (0)
+
+namespace {
+
+// BN-folded weight of layer L: [kh,kw,cin,cout4] host copy
+inline float wq(const rced_layer_dev& d, int tap, int ci, int co, int cin) {
+  return d.host_w[((size_t)tap * cin + ci) * d.cout4 + co];
 }
-int fused_set_option(rced_model*, const char*, int) { return RCED_ERR_ARG; }
-int fused_get_option(rced_model*, const char*, int*) { return RCED_ERR_ARG; }
+
+void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>* shifts, std::vector<float>* fin,
+             float* fin_bias) {
+  wpack->assign(v3::kWTotal, 0.f);
+  shifts->assign(15 * v3::kShiftPerLayer, 0.f);
+  float* dst = wpack->data();
+  for (int blk = 0; blk < 5; ++blk) {
+    const rced_layer_dev& l1 = m->layers[3 * blk + 0];
+    const rced_layer_dev& l2 = m->layers[3 * blk + 1];
+    const rced_layer_dev& l3 = m->layers[3 * blk + 2];
+    // ---- layer 1
+    if (blk == 0) {  // 8x9x1 -> 18: [s = ih*9 + j][mt][lane], lane = (i, kq), time tap = 4*ih + kq
+      for (int s = 0; s < 18; ++s)
+        for (int mt = 0; mt < 2; ++mt)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4, ih = s / 9, j = s % 9;
+            const int co = 16 * mt + i, ti = 4 * ih + kq;
+            dst[(s * 2 + mt) * 64 + lane] = co < 18 ? wq(l1, ti * 9 + j, 0, co, 1) : 0.f;
+          }
+    } else {  // 1x9, 8 -> 18: [s][mt][lane][e], k = 8s + 2kq + e = tap*8 + ci
+      for (int s = 0; s < 9; ++s)
+        for (int mt = 0; mt < 2; ++mt)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 2; ++e) {
+              const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
+              const int co = 16 * mt + i;
+              dst[(s * 2 + mt) * 128 + lane * 2 + e] = co < 18 ? wq(l1, k / 8, k % 8, co, 8) : 0.f;
+            }
+    }
+    dst += v3::kW1;
+    // ---- layer 2: 1x5, 18 -> 30, K = 90
+    for (int s = 0; s < 12; ++s)
+      for (int mt = 0; mt < 2; ++mt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 2; ++e) {
+            const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
+            const int co = 16 * mt + i;
+            dst[(s * 2 + mt) * 128 + lane * 2 + e] = (k < 90 && co < 30) ? wq(l2, k / 18, k % 18, co, 18) : 0.f;
+          }
+    dst += v3::kW2;
+    // ---- layer 3: 1x9, 30 -> 8 on pixel pairs: row i = (phase r, co), k = u*30 + ci, tap = u - r
+    for (int s = 0; s < 38; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 2; ++e) {
+          const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
+          const int r = i >> 3, co = i & 7, u = k / 30, ci = k % 30, tap = u - r;
+          dst[s * 128 + lane * 2 + e] = (k < 300 && tap >= 0 && tap < 9) ? wq(l3, tap, ci, co, 30) : 0.f;
+        }
+    dst += v3::kW3;
+    for (int j = 0; j < 3; ++j) {
+      const rced_layer_dev& l = m->layers[3 * blk + j];
+      const int cout = m->net->layer[3 * blk + j].cout;
+      for (int c = 0; c < cout; ++c) (*shifts)[(3 * blk + j) * v3::kShiftPerLayer + c] = l.host_shift[c];
+    }
+  }
+  // ---- decode_final as Toeplitz A-fragments: [s][m][lane][e]; row f = 16m + i; k = f'*8 + ci
+  const rced_layer_dev& lf = m->layers[15];
+  fin->assign(v3::kFinPack, 0.f);
+  for (int s = 0; s < v3::kFinSteps; ++s)
+    for (int mt = 0; mt < v3::kFinMT; ++mt)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 2; ++e) {
+          const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
+          const int f = 16 * mt + i, fp = k / 8, ci = k % 8, tap = fp - f + 64;
+          (*fin)[((size_t)s * v3::kFinMT + mt) * 128 + lane * 2 + e] =
+              (f < 129 && tap >= 0 && tap < 129) ? wq(lf, tap, ci, 0, 8) : 0.f;
+        }
+  *fin_bias = lf.host_shift[0];
+}
+
+int upload(float** dev, const std::vector<float>& host) {
+  HIP_TRY(hipMalloc(dev, host.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  return RCED_OK;
+}
+
+}  // namespace
+
+int fused_create(rced_model* m) {
+  m->fused = nullptr;
+  if (m->variant != RCED_V3) return RCED_OK;  // V1 / V2 run layerwise for now
+  rced_fused* f = new rced_fused();
+  std::vector<float> wpack, shifts, fin;
+  pack_v3(m, &wpack, &shifts, &fin, &f->fin_bias);
+  int rc = upload(&f->wpack, wpack);
+  if (!rc) rc = upload(&f->shifts, shifts);
+  if (!rc) rc = upload(&f->fin_apack, fin);
+  if (!rc) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3::fused_v3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLdsBytes);
+    if (e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(LDS %d): %s", v3::kLdsBytes, hipGetErrorString(e));
+  }
+  m->fused = f;
+  if (rc) {
+    fused_destroy(m);
+    return rc;
+  }
+  return RCED_OK;
+}
+
+void fused_destroy(rced_model* m) {
+  rced_fused* f = m->fused;
+  if (!f) return;
+  if (f->wpack) (void)hipFree(f->wpack);
+  if (f->shifts) (void)hipFree(f->shifts);
+  if (f->fin_apack) (void)hipFree(f->fin_apack);
+  if (f->h) (void)hipFree(f->h);
+  delete f;
+  m->fused = nullptr;
+}
+
+int fused_reserve(rced_model* m, int N, int T) {
+  rced_fused* f = m->fused;
+  const size_t need = (size_t)N * T * v3::kF * v3::kHCh * sizeof(float);
+  if (need <= f->h_bytes) return RCED_OK;
+  if (f->h) {
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(f->h);
+    f->h = nullptr;
+    f->h_bytes = 0;
+  }
+  HIP_TRY(hipMalloc(&f->h, need));
+  f->h_bytes = need;
+  return RCED_OK;
+}
+
+int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStream_t st) {
+  rced_fused* f = m->fused;
+  if (int rc = fused_reserve(m, N, T)) return rc;
+  v3::Params P;
+  P.x = x;
+  P.h = f->h;
+  P.wpack = f->wpack;
+  P.shifts = f->shifts;
+  P.N = N;
+  P.T = T;
+  P.tiles_per_utt = (T + v3::kTF - 1) / v3::kTF;
+  P.total_tiles = N * P.tiles_per_utt;
+  const int cus = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
+  const int grid = std::min(P.total_tiles, cus);
+  m->prof_begin(RCED_K_FUSED, st);
+  hipLaunchKernelGGL(v3::fused_v3_kernel, dim3(grid), dim3(v3::kThreads), v3::kLdsBytes, st, P);
+  m->prof_end(RCED_K_FUSED, st);
+  HIP_TRY(hipGetLastError());
+  const int frames = N * T;
+  m->prof_begin(RCED_K_FINAL, st);
+  hipLaunchKernelGGL(v3::final_gemm_kernel, dim3((frames + v3::kFinFrames - 1) / v3::kFinFrames),
+                     dim3(v3::kFinThreads), 0, st, (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y,
+                     frames);
+  m->prof_end(RCED_K_FINAL, st);
+  HIP_TRY(hipGetLastError());
+  return RCED_OK;
+}
+
+int fused_set_option(rced_model* m, const char* key, int value) {
+  if (!m->fused) return RCED_ERR_ARG;
+  if (!strcmp(key, "fused_grid")) {
+    if (value < 0) return RCED_ERR_ARG;
+    m->fused->grid_limit = value;
+    return RCED_OK;
+  }
+  return RCED_ERR_ARG;
+}
+
+int fused_get_option(rced_model* m, const char* key, int* value) {
+  if (!m->fused) return RCED_ERR_ARG;
+  if (!strcmp(key, "fused_grid")) {
+    *value = m->fused->grid_limit;
+    return RCED_OK;
+  }
+  return RCED_ERR_ARG;
+}

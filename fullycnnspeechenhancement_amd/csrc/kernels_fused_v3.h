@@ -53,7 +53,7 @@ constexpr int kLdsBytes = kLdsFloats * 4;                 // 162,272 B of the 16
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 // input rows of the 8x9 first layer alias the (not yet live) B30 buffer, from its pixel-0 row on
 constexpr int kX0Rows = kTF + 7;
-constexpr int kX0Floats = ((kX0Rows * kS + 16 + 3) / 4) * 4;   // 1480
+constexpr int kX0Floats = ((kX0Rows * kS + 24 + 3) / 4) * 4;   // 1488: max index 543 + 7*133 + 8
 constexpr int kX0Off = kB30Off + kB30Pad * 30;
 static_assert(kX0Floats <= 60 * 30, "X0 must sit inside rows that layer 2 rewrites");
 
@@ -85,28 +85,33 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// Issue the global loads of a packed layer (<= 3 float4 per thread) ...
+// Issue the global loads of a packed layer (<= 3 float4 per thread; out-of-range threads re-read
+// the last float4 so that every register is defined) ...
 struct WStage {
-  float4 v[3];
+  f32x4 v0, v1, v2;
 };
 template <int NFLOATS>
-__device__ __forceinline__ void wstage_load(WStage& st, const float* __restrict__ src, int tid) {
+__device__ __forceinline__ WStage wstage_load(const float* __restrict__ src, int tid) {
   constexpr int n4 = NFLOATS / 4;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int idx = tid + i * kThreads;
-    if (i * kThreads < n4 && idx < n4) st.v[i] = reinterpret_cast<const float4*>(src)[idx];
-  }
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+  WStage st;
+  st.v0 = s4[tid < n4 ? tid : n4 - 1];
+  st.v1 = st.v0;
+  st.v2 = st.v0;
+  if constexpr (n4 > kThreads) st.v1 = s4[tid + kThreads < n4 ? tid + kThreads : n4 - 1];
+  if constexpr (n4 > 2 * kThreads) st.v2 = s4[tid + 2 * kThreads < n4 ? tid + 2 * kThreads : n4 - 1];
+  return st;
 }
 // ... and park them in the other weight region once the current layer's math is issued.
 template <int NFLOATS>
 __device__ __forceinline__ void wstage_store(const WStage& st, float* dst, int tid) {
   constexpr int n4 = NFLOATS / 4;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int idx = tid + i * kThreads;
-    if (i * kThreads < n4 && idx < n4) reinterpret_cast<float4*>(dst)[idx] = st.v[i];
-  }
+  f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+  if (tid < n4) d4[tid] = st.v0;
+  if constexpr (n4 > kThreads)
+    if (tid + kThreads < n4) d4[tid + kThreads] = st.v1;
+  if constexpr (n4 > 2 * kThreads)
+    if (tid + 2 * kThreads < n4) d4[tid + 2 * kThreads] = st.v2;
 }
 
 // One implicit-GEMM pass over NT N-tiles with b64 steps.
@@ -195,7 +200,8 @@ __device__ __forceinline__ void run_tile(const Params& P, float* lds, int tile, 
   float* b18 = lds + kB18Off + kB18Pad * 18;
   float* b30 = lds + kB30Off + kB30Pad * 30;
   float* x0 = lds + kX0Off;
-  float* wreg[2] = {lds + kWOff, lds + kWOff + kWRegion};
+  float* const wbase = lds + kWOff;
+#define WREG(i) (wbase + (i) * kWRegion)
 
   const int utt = tile / P.tiles_per_utt;
   const int t0 = (tile - utt * P.tiles_per_utt) * kTF;   // first frame of the tile
@@ -247,6 +253,8 @@ __device__ __forceinline__ void run_tile(const Params& P, float* lds, int tile, 
   __syncthreads();
 
   f32x4 skip_ce1[NT32], skip_ce2[NT32];
+#pragma unroll
+  for (int t = 0; t < NT32; ++t) skip_ce1[t] = skip_ce2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* wsrc = P.wpack;
   const float* shsrc = P.shifts;
 
@@ -254,8 +262,7 @@ __device__ __forceinline__ void run_tile(const Params& P, float* lds, int tile, 
   for (int blk = 0; blk < 5; ++blk) {
     // ======== layer 1 of the block: (8x9, 1->18) for block 0, (1x9, 8->18) otherwise =========
     {
-      WStage st;
-      wstage_load<kW2>(st, wsrc + kW1, tid);
+      const WStage st = wstage_load<kW2>(wsrc + kW1, tid);
       f32x4 acc[NT16][2];
       f32x4 sh[2];
 #pragma unroll
@@ -263,19 +270,18 @@ __device__ __forceinline__ void run_tile(const Params& P, float* lds, int tile, 
 #pragma unroll
       for (int t = 0; t < NT16; ++t) { acc[t][0] = sh[0]; acc[t][1] = sh[1]; }
       if (blk == 0) {
-        first_pass<NT16>(x0, off_x0, wreg[wcur], lane, acc);
+        first_pass<NT16>(x0, off_x0, WREG(wcur), lane, acc);
       } else {
-        gemm_pass<NT16, 2, 9>(b8, off_b8, 0, wreg[wcur], lane, acc);
+        gemm_pass<NT16, 2, 9>(b8, off_b8, 0, WREG(wcur), lane, acc);
       }
       store_p1<NT16, 18>(b18, acc, px16, ok16, kq);
-      wstage_store<kW2>(st, wreg[wcur ^ 1], tid);
+      wstage_store<kW2>(st, WREG(wcur ^ 1), tid);
       wcur ^= 1;
       __syncthreads();
     }
     // ======== layer 2: (1x5, 18->30) ==========================================================
     {
-      WStage st;
-      wstage_load<kW3>(st, wsrc + kW1 + kW2, tid);
+      const WStage st = wstage_load<kW3>(wsrc + kW1 + kW2, tid);
       f32x4 acc[NT16][2];
       f32x4 sh[2];
 #pragma unroll
@@ -283,31 +289,30 @@ __device__ __forceinline__ void run_tile(const Params& P, float* lds, int tile, 
         sh[mt] = *reinterpret_cast<const f32x4*>(shsrc + kShiftPerLayer + 16 * mt + 4 * kq);
 #pragma unroll
       for (int t = 0; t < NT16; ++t) { acc[t][0] = sh[0]; acc[t][1] = sh[1]; }
-      gemm_pass<NT16, 2, 12>(b18, off_b18, tail2, wreg[wcur], lane, acc);
+      gemm_pass<NT16, 2, 12>(b18, off_b18, tail2, WREG(wcur), lane, acc);
       store_p1<NT16, 30>(b30, acc, px16, ok16, kq);
-      wstage_store<kW3>(st, wreg[wcur ^ 1], tid);
+      wstage_store<kW3>(st, WREG(wcur ^ 1), tid);
       wcur ^= 1;
       __syncthreads();
     }
     // ======== layer 3: (1x9, 30->8) on pixel pairs; block skips; hand-off =====================
     {
-      WStage st;
       // next: layer 1 of the next block, or of block 0 of the next tile (stream wraps around)
       const float* nxt = (blk == 4) ? P.wpack : wsrc + kWBlock;
-      wstage_load<kW1>(st, nxt, tid);
+      const WStage st = wstage_load<kW1>(nxt, tid);
       f32x4 acc[NT32][1];
       const f32x4 sh = *reinterpret_cast<const f32x4*>(shsrc + 2 * kShiftPerLayer + 4 * (kq & 1));
 #pragma unroll
       for (int t = 0; t < NT32; ++t) acc[t][0] = sh;
-      gemm_pass<NT32, 1, 38>(b30, off_b30, tail3, wreg[wcur], lane, acc);
+      gemm_pass<NT32, 1, 38>(b30, off_b30, tail3, WREG(wcur), lane, acc);
 #pragma unroll
       for (int t = 0; t < NT32; ++t) {
         f32x4 v = relu4(acc[t][0]);
         if (blk == 3) v += skip_ce2[t];   // CD1 + CE2 (model.py:87, 75-76: after the ReLU)
         if (blk == 4) v += skip_ce1[t];   // CD2 + CE1 (model.py:88)
         if (!((ok32 >> t) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (blk == 0) skip_ce1[t] = v;
-        if (blk == 1) skip_ce2[t] = v;
+        skip_ce1[t] = (blk == 0) ? v : skip_ce1[t];
+        skip_ce2[t] = (blk == 1) ? v : skip_ce2[t];
         if (blk < 4) {
           *reinterpret_cast<f32x4*>(b8 + px32[t] * 8 + 4 * (kq & 1)) = v;
         } else if ((st32 >> t) & 1u) {
@@ -315,13 +320,14 @@ __device__ __forceinline__ void run_tile(const Params& P, float* lds, int tile, 
           *reinterpret_cast<f32x4*>(hp) = v;
         }
       }
-      wstage_store<kW1>(st, wreg[wcur ^ 1], tid);
+      wstage_store<kW1>(st, WREG(wcur ^ 1), tid);
       wcur ^= 1;
       __syncthreads();
     }
     wsrc += kWBlock;
     shsrc += 3 * kShiftPerLayer;
   }
+#undef WREG
 }
 
 __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
@@ -335,8 +341,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   __syncthreads();
   // weights of the very first layer into region 0
   {
-    WStage st;
-    wstage_load<kW1>(st, P.wpack, tid);
+    const WStage st = wstage_load<kW1>(P.wpack, tid);
     wstage_store<kW1>(st, lds + kWOff, tid);
   }
   int wcur = 0;
