@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "librced_hip.so")
+# RCED_LIB: A/B experiments only (an alternative build of the same ABI); the product is librced_hip.so
+SO_PATH = os.environ.get("RCED_LIB") or os.path.join(_HERE, "librced_hip.so")
 
 RCED_OK, RCED_ERR_ARG, RCED_ERR_HIP, RCED_ERR_ALLOC, RCED_ERR_STATE = 0, 1, 2, 3, 4
 PATH_AUTO, PATH_LAYERWISE, PATH_FUSED = 0, 1, 2

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -14,11 +15,11 @@ using namespace rced;
 
 struct rced_fused {
   float* wpack = nullptr;     // v3::kWTotal
-  float* shifts = nullptr;    // 15 x 32
   float* fin_apack = nullptr; // v3::kFinPack
   float fin_bias = 0.f;
   float* h = nullptr;         // [frames, 129, 8] hand-off to the final layer
   size_t h_bytes = 0;
+  unsigned long long* stamps = nullptr;  // diagnostic builds (RCED_STAMPS) only
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
 };
 
@@ -37,34 +38,50 @@ inline float wq(const rced_layer_dev& d, int tap, int ci, int co, int cin) {
   return d.host_w[((size_t)tap * cin + ci) * d.cout4 + co];
 }
 
-void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>* shifts, std::vector<float>* fin,
-             float* fin_bias) {
+void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>* fin, float* fin_bias) {
   wpack->assign(v3::kWTotal, 0.f);
-  shifts->assign(15 * v3::kShiftPerLayer, 0.f);
+  auto put_shift = [&](float* at, int layer) {  // the packet's last 32 floats: shift[co]
+    const int cout = m->net->layer[layer].cout;
+    for (int c = 0; c < cout; ++c) at[c] = m->layers[layer].host_shift[c];
+  };
   float* dst = wpack->data();
   for (int blk = 0; blk < 5; ++blk) {
     const rced_layer_dev& l1 = m->layers[3 * blk + 0];
     const rced_layer_dev& l2 = m->layers[3 * blk + 1];
     const rced_layer_dev& l3 = m->layers[3 * blk + 2];
-    // ---- layer 1
-    if (blk == 0) {  // 8x9x1 -> 18: [s = ih*9 + j][mt][lane], lane = (i, kq), time tap = 4*ih + kq
+    // ---- layer 1 = main pass (channels 0..15) + remainder pass (channels 16,17 x 8 pixel phases)
+    if (blk == 0) {
+      // 8x9x1: main [s = ih*9 + j][lane]; lane = (row i = co, kq), time tap = 4*ih + kq
       for (int s = 0; s < 18; ++s)
-        for (int mt = 0; mt < 2; ++mt)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int i = lane & 15, kq = lane >> 4, ih = s / 9, j = s % 9;
-            const int co = 16 * mt + i, ti = 4 * ih + kq;
-            dst[(s * 2 + mt) * 64 + lane] = co < 18 ? wq(l1, ti * 9 + j, 0, co, 1) : 0.f;
-          }
-    } else {  // 1x9, 8 -> 18: [s][mt][lane][e], k = 8s + 2kq + e = tap*8 + ci
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, ih = s / 9, j = s % 9, ti = 4 * ih + kq;
+          dst[s * 64 + lane] = wq(l1, ti * 9 + j, 0, i, 1);
+        }
+      // remainder [s = ih*16 + u][lane]; row i = (phase r = i>>1, channel 16 + (i&1)); freq tap = u - r
+      for (int s = 0; s < 32; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, ih = s / 16, u = s % 16, ti = 4 * ih + kq;
+          const int r = i >> 1, co = 16 + (i & 1), tap = u - r;
+          dst[v3::kW1Main + s * 64 + lane] = (tap >= 0 && tap < 9) ? wq(l1, ti * 9 + tap, 0, co, 1) : 0.f;
+        }
+    } else {
+      // 1x9, 8 -> 18: main [s][lane][e], k = 8s + 2kq + e = tap*8 + ci
       for (int s = 0; s < 9; ++s)
-        for (int mt = 0; mt < 2; ++mt)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < 2; ++e) {
-              const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
-              const int co = 16 * mt + i;
-              dst[(s * 2 + mt) * 128 + lane * 2 + e] = co < 18 ? wq(l1, k / 8, k % 8, co, 8) : 0.f;
-            }
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 2; ++e) {
+            const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
+            dst[s * 128 + lane * 2 + e] = wq(l1, k / 8, k % 8, i, 8);
+          }
+      // remainder: k = u*8 + ci over 16 taps; row i = (phase r, channel 16 + (i&1)); tap = u - r
+      for (int s = 0; s < 16; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 2; ++e) {
+            const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
+            const int r = i >> 1, co = 16 + (i & 1), u = k / 8, ci = k % 8, tap = u - r;
+            dst[v3::kW1Main + s * 128 + lane * 2 + e] = (tap >= 0 && tap < 9) ? wq(l1, tap, ci, co, 8) : 0.f;
+          }
     }
+    put_shift(dst + v3::kW1Data, 3 * blk + 0);
     dst += v3::kW1;
     // ---- layer 2: 1x5, 18 -> 30, K = 90
     for (int s = 0; s < 12; ++s)
@@ -75,6 +92,7 @@ void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>*
             const int co = 16 * mt + i;
             dst[(s * 2 + mt) * 128 + lane * 2 + e] = (k < 90 && co < 30) ? wq(l2, k / 18, k % 18, co, 18) : 0.f;
           }
+    put_shift(dst + v3::kW2Data, 3 * blk + 1);
     dst += v3::kW2;
     // ---- layer 3: 1x9, 30 -> 8 on pixel pairs: row i = (phase r, co), k = u*30 + ci, tap = u - r
     for (int s = 0; s < 38; ++s)
@@ -84,12 +102,8 @@ void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>*
           const int r = i >> 3, co = i & 7, u = k / 30, ci = k % 30, tap = u - r;
           dst[s * 128 + lane * 2 + e] = (k < 300 && tap >= 0 && tap < 9) ? wq(l3, tap, ci, co, 30) : 0.f;
         }
+    put_shift(dst + v3::kW3Data, 3 * blk + 2);
     dst += v3::kW3;
-    for (int j = 0; j < 3; ++j) {
-      const rced_layer_dev& l = m->layers[3 * blk + j];
-      const int cout = m->net->layer[3 * blk + j].cout;
-      for (int c = 0; c < cout; ++c) (*shifts)[(3 * blk + j) * v3::kShiftPerLayer + c] = l.host_shift[c];
-    }
   }
   // ---- decode_final as Toeplitz A-fragments: [s][m][lane][e]; row f = 16m + i; k = f'*8 + ci
   const rced_layer_dev& lf = m->layers[15];
@@ -118,16 +132,18 @@ int fused_create(rced_model* m) {
   m->fused = nullptr;
   if (m->variant != RCED_V3) return RCED_OK;  // V1 / V2 run layerwise for now
   rced_fused* f = new rced_fused();
-  std::vector<float> wpack, shifts, fin;
-  pack_v3(m, &wpack, &shifts, &fin, &f->fin_bias);
+  std::vector<float> wpack, fin;
+  pack_v3(m, &wpack, &fin, &f->fin_bias);
   int rc = upload(&f->wpack, wpack);
-  if (!rc) rc = upload(&f->shifts, shifts);
   if (!rc) rc = upload(&f->fin_apack, fin);
   if (!rc) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3::fused_v3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLdsBytes);
     if (e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(LDS %d): %s", v3::kLdsBytes, hipGetErrorString(e));
   }
+#if RCED_STAMPS
+  if (!rc && hipMalloc(&f->stamps, 8 * 8 * sizeof(unsigned long long)) != hipSuccess) f->stamps = nullptr;
+#endif
   m->fused = f;
   if (rc) {
     fused_destroy(m);
@@ -140,7 +156,6 @@ void fused_destroy(rced_model* m) {
   rced_fused* f = m->fused;
   if (!f) return;
   if (f->wpack) (void)hipFree(f->wpack);
-  if (f->shifts) (void)hipFree(f->shifts);
   if (f->fin_apack) (void)hipFree(f->fin_apack);
   if (f->h) (void)hipFree(f->h);
   delete f;
@@ -169,11 +184,11 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   P.x = x;
   P.h = f->h;
   P.wpack = f->wpack;
-  P.shifts = f->shifts;
   P.N = N;
   P.T = T;
   P.tiles_per_utt = (T + v3::kTF - 1) / v3::kTF;
   P.total_tiles = N * P.tiles_per_utt;
+  P.stamps = f->stamps;
   const int cus = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
   const int grid = std::min(P.total_tiles, cus);
   m->prof_begin(RCED_K_FUSED, st);
@@ -202,6 +217,16 @@ int fused_set_option(rced_model* m, const char* key, int value) {
 
 int fused_get_option(rced_model* m, const char* key, int* value) {
   if (!m->fused) return RCED_ERR_ARG;
+#if RCED_STAMPS
+  if (!strncmp(key, "stamp", 5) && m->fused->stamps) {  // "stampNN": kilo-cycles, NN = wave*8 + slot
+    unsigned long long h[64];
+    if (hipMemcpy(h, m->fused->stamps, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return RCED_ERR_HIP;
+    const int i = atoi(key + 5);
+    if (i < 0 || i >= 64) return RCED_ERR_ARG;
+    *value = (int)(h[i] / 1000);
+    return RCED_OK;
+  }
+#endif
   if (!strcmp(key, "fused_grid")) {
     *value = m->fused->grid_limit;
     return RCED_OK;

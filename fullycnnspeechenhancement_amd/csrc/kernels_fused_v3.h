@@ -9,20 +9,47 @@
 //     the B operand of v_mfma_f32_16x16x4_f32 is read straight out of LDS with ds_read_b64,
 //     no im2col copy, no shuffles;
 //   * weights are pre-packed on the host into MFMA A-fragment order, BN folded, and streamed
-//     L2 -> LDS one layer ahead (ping-pong);
-//   * cout sits on the MFMA M axis (16 rows).  18 and 30 pad to 2 M-tiles; the 30->8 layers use
-//     two pixel phases as rows (8 cout x 2 adjacent pixels = 16 rows, K = 10 taps instead of 9),
-//     which is 90 % efficient instead of 50 %;
+//     L2 -> LDS by LDS-DMA one layer ahead (ping-pong), each packet carrying its 32 shift values;
+//   * cout sits on the MFMA M axis (16 rows).  30 pads to 2 M-tiles; the 30->8 layers use two
+//     pixel phases as rows (8 cout x 2 adjacent pixels = 16 rows, K = 10 taps instead of 9); the
+//     ->18 layers run channels 0..15 as one M-tile plus a remainder pass that computes channels
+//     16,17 for 8 adjacent pixels at once (rows = 8 phases x 2 channels, K = 16 taps);
 //   * the two CR-CED block skips (model.py:75-76, added after ReLU) never touch LDS: they stay in
-//     the accumulator registers of the wave that produced them.
+//     the accumulator registers of the wave that produced them;
+//   * operands are software-pipelined by hand (read step s+1 or s+2, then the MFMAs of step s):
+//     left alone, hipcc issues each LDS read right before its use and the MFMA pipe starves.
 //
 // Pixel space of a tile: kTF frames, frame i at flat pixels [i*kS, i*kS+129); the kS-129 = 4 gap
 // pixels between frames are always zero and serve as the SAME-padding halo of both neighbours.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef RCED_EXP_SKIP
+#define RCED_EXP_SKIP 0   // timing experiments only: bit0 skip L1 math, bit1 L2, bit2 L3 (results wrong)
+#endif
+#ifndef RCED_STAMPS
+#define RCED_STAMPS 0     // diagnostic build: s_memtime stamps around every layer's math and barrier
+#endif
+
 namespace rced {
 namespace v3 {
+
+#if RCED_STAMPS
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP_BEGIN() const unsigned long long st_a_ = stamp()
+#define STAMP_MATH(i) const unsigned long long st_b_ = stamp(); tsum[i] += st_b_ - st_a_
+#define STAMP_WAIT(i) tsum[(i) + ((i) < 3 ? 3 : 1)] += stamp() - st_b_
+#else
+#define STAMP_BEGIN()
+#define STAMP_MATH(i)
+#define STAMP_WAIT(i)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -31,303 +58,414 @@ constexpr int kF = 129;
 constexpr int kTF = 4;                       // frames per tile
 constexpr int kS = 133;                      // pixel stride of a frame (129 + 4 zero gap)
 constexpr int kNPX = kTF * kS;               // 532 pixels per tile
-constexpr int kTiles16 = (kNPX + 15) / 16;   // 34 N-tiles of 16 pixels
-constexpr int kTiles32 = (kNPX + 31) / 32;   // 17 N-tiles of 16 pixel PAIRS
-constexpr int kPX = kTiles16 * 16;           // 544 pixels computed (the tail past 532 is masked)
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kHCh = 8;                      // channels of the tensor handed to the final layer
 
 // ---- LDS map, in floats -----------------------------------------------------------------
+// B8 keeps its 8 channels at a pixel stride of 10 floats: with 8 channels one b64-step of the
+// 9-tap window is exactly one pixel, so the stride is free, and 10 turns the remainder pass's
+// 16-way bank conflict (column stride 8 pixels x 8 floats = 64 banks) into 4-way.
+// Rows past the last pixel any VALID output needs are not allocated: reads that run past a buffer
+// land in the next one (always finite floats) and only feed masked outputs.
+constexpr int kB8S = 10;                                  // B8 pixel stride (floats)
 constexpr int kB8Pad = 4, kB18Pad = 2, kB30Pad = 4;       // leading zero rows (pixels -pad..-1)
-constexpr int kB8Rows = kB8Pad + kPX + 4;                 // 9-tap windows reach pixel 547
-constexpr int kB18Rows = kB18Pad + kPX + 2;               // 5-tap windows reach pixel 545
-constexpr int kB30Rows = kB30Pad + kPX + 4;               // 10-tap pair windows reach pixel 547
+constexpr int kB8Rows = kB8Pad + kNPX + 4;                // pixels -4 .. 535
+constexpr int kB18Rows = kB18Pad + kNPX;                  // pixels -2 .. 531
+constexpr int kB30Rows = kB30Pad + kNPX;                  // pixels -4 .. 531
 constexpr int kB8Off = 0;
-constexpr int kB18Off = kB8Off + kB8Rows * 8;
+constexpr int kB18Off = kB8Off + kB8Rows * kB8S;
 constexpr int kB30Off = kB18Off + kB18Rows * 18;
-constexpr int kWRegion = 38 * 128;                        // largest layer: 30->8, 38 b64-steps
+constexpr int kWRegion = 38 * 128 + 32;                   // largest packet: 30->8, 38 b64-steps + shifts
 constexpr int kWOff = kB30Off + kB30Rows * 30;
 constexpr int kLdsFloats = kWOff + 2 * kWRegion;
-constexpr int kLdsBytes = kLdsFloats * 4;                 // 162,272 B of the 163,840 B
+constexpr int kLdsBytes = kLdsFloats * 4;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+static_assert((kWOff * 4) % 16 == 0 && (kWRegion * 4) % 16 == 0, "LDS-DMA destinations are 16-byte aligned");
+static_assert((kB18Off % 2) == 0 && (kB30Off % 2) == 0, "8-byte aligned buffers");
 // input rows of the 8x9 first layer alias the (not yet live) B30 buffer, from its pixel-0 row on
 constexpr int kX0Rows = kTF + 7;
-constexpr int kX0Floats = ((kX0Rows * kS + 24 + 3) / 4) * 4;   // 1488: max index 543 + 7*133 + 8
+constexpr int kX0Floats = ((kX0Rows * kS + 24 + 3) / 4) * 4;   // 1488: max main-pass index 527 + 7*133 + 8
 constexpr int kX0Off = kB30Off + kB30Pad * 30;
 static_assert(kX0Floats <= 60 * 30, "X0 must sit inside rows that layer 2 rewrites");
 
 // ---- packed weight stream (floats), per layer --------------------------------------------
-//  first layer (8x9x1->18): 18 k-steps x 2 M-tiles x 64 lanes, one float per lane (b32 steps)
-//  L1 (1x9, 8->18):  9 b64-steps x 2 M-tiles x 64 lanes x 2
+//  first layer main (8x9x1 -> ch 0..15): 18 k-steps x 64 lanes (b32 steps, k = (time tap, freq tap))
+//  first layer rem  (ch 16,17 x 8 phases): 32 k-steps x 64 lanes (k = (time tap, 16 freq taps))
+//  L1 main (1x9, 8 -> ch 0..15):  9 b64-steps x 64 lanes x 2
+//  L1 rem  (ch 16,17 x 8 phases): 16 b64-steps x 64 x 2   (K = 16 taps x 8)
 //  L2 (1x5, 18->30): 12 b64-steps x 2 M-tiles x 64 x 2   (K = 90, last step 2 valid)
 //  L3 (1x9, 30->8):  38 b64-steps x 1 M-tile x 64 x 2    (K = 300 = 10 taps x 30, pixel pairs)
-constexpr int kWFirst = 18 * 2 * 64;      // 2304
-constexpr int kW1 = 9 * 2 * 128;          // 2304
-constexpr int kW2 = 12 * 2 * 128;         // 3072
-constexpr int kW3 = 38 * 1 * 128;         // 4864
-constexpr int kWBlock = kW1 + kW2 + kW3;  // block 0 uses kWFirst in place of kW1 (same size)
-static_assert(kWFirst == kW1, "block 0 and blocks 1..4 share one stream layout");
+// Every packet ends with its 32 shift values (bias + folded BatchNorm).
+constexpr int kShiftPerLayer = 32;
+constexpr int kW1Main = 9 * 128;          // 1152 (= 18 * 64 for the first layer)
+constexpr int kW1Rem = 16 * 128;          // 2048 (= 32 * 64 for the first layer)
+constexpr int kW1Data = kW1Main + kW1Rem; // 3200
+constexpr int kW2Data = 12 * 2 * 128;     // 3072
+constexpr int kW3Data = 38 * 1 * 128;     // 4864
+constexpr int kW1 = kW1Data + kShiftPerLayer;
+constexpr int kW2 = kW2Data + kShiftPerLayer;
+constexpr int kW3 = kW3Data + kShiftPerLayer;
+constexpr int kWBlock = kW1 + kW2 + kW3;
 constexpr int kWTotal = 5 * kWBlock;
-constexpr int kShiftPerLayer = 32;        // shift[co], zero padded
+
+// ---- tile -> wave assignment ---------------------------------------------------------------
+// 16-pixel tiles 0..32 (pixels 0..527; 528..531 is gap): wave w owns tiles w + 8*slot, slot < 4
+// ("regular": one address register per wave, everything else immediates); tile 32 and, in layer 1,
+// tile 31 are handed out as "extra" tiles.  Pair tiles 0..16: w + 8*slot, slot < 2; extra 16.
+// Remainder tiles (128 pixels) 0..4 go one each to waves 4,5,6 and two to wave 7, which gives up
+// main tile 31.  Waves w and w+4 share a SIMD; MFMA counts per SIMD pair in layer 1:
+// 194, 194, 176, 190 (18 per main tile, 32 per remainder tile); layer 2: 9,8,8,8 tiles; layer 3:
+// 4,4,4,5 pair tiles.
 
 struct Params {
   const float* x;       // [N, T, 129]
   float* h;             // [N*T, 129, 8]  output of CD2 (input of decode_final)
   const float* wpack;   // kWTotal floats
-  const float* shifts;  // 15 x 32 floats
   int N, T;
   int tiles_per_utt;    // ceil(T / kTF)
   int total_tiles;      // N * tiles_per_utt
+  unsigned long long* stamps;  // diagnostic builds only (RCED_STAMPS): [wave][8] cycle sums of workgroup 0
 };
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
 
-// Issue the global loads of a packed layer (<= 3 float4 per thread; out-of-range threads re-read
-// the last float4 so that every register is defined) ...
-struct WStage {
-  f32x4 v0, v1, v2;
-};
+// Stream one weight packet global -> LDS with LDS-DMA (no VGPR staging, no ds_write): wave w copies
+// the 1-KiB chunks w, w+8, w+16; lane l of a chunk moves 16 bytes.  Completion: vmcnt(0) + barrier
+// at the end of the layer during which it was issued.
 template <int NFLOATS>
-__device__ __forceinline__ WStage wstage_load(const float* __restrict__ src, int tid) {
+__device__ __forceinline__ void packet_dma(const float* __restrict__ src, float* dst, int wave, int lane) {
   constexpr int n4 = NFLOATS / 4;
-  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-  WStage st;
-  st.v0 = s4[tid < n4 ? tid : n4 - 1];
-  st.v1 = st.v0;
-  st.v2 = st.v0;
-  if constexpr (n4 > kThreads) st.v1 = s4[tid + kThreads < n4 ? tid + kThreads : n4 - 1];
-  if constexpr (n4 > 2 * kThreads) st.v2 = s4[tid + 2 * kThreads < n4 ? tid + 2 * kThreads : n4 - 1];
-  return st;
+  constexpr int chunks = (n4 + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < (chunks + kWaves - 1) / kWaves; ++i) {
+    const int c = wave + i * kWaves;
+    if (c < chunks) {
+      const int idx = c * 64 + lane;
+      if (idx < n4)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (size_t)idx * 4),
+            (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
+    }
+  }
 }
-// ... and park them in the other weight region once the current layer's math is issued.
-template <int NFLOATS>
-__device__ __forceinline__ void wstage_store(const WStage& st, float* dst, int tid) {
-  constexpr int n4 = NFLOATS / 4;
-  f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-  if (tid < n4) d4[tid] = st.v0;
-  if constexpr (n4 > kThreads)
-    if (tid + kThreads < n4) d4[tid + kThreads] = st.v1;
-  if constexpr (n4 > 2 * kThreads)
-    if (tid + 2 * kThreads < n4) d4[tid + 2 * kThreads] = st.v2;
+__device__ __forceinline__ void layer_end_sync() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
+  __syncthreads();
 }
 
-// One implicit-GEMM pass over NT N-tiles with b64 steps.
-//   act  : LDS buffer base (float index of pixel 0, channel 0)
-//   boff : per slot, float offset of this lane's window start (+ 2*kq)
-//   tail : float delta applied in the last step so that lanes past the window re-read in-window
-//          data (their weights are zero); keeps every read inside the pixel's own window
-//   w    : LDS weight region, [step][mt][lane][2]
-template <int NT, int MT, int STEPS>
-__device__ __forceinline__ void gemm_pass(const float* act, const int (&boff)[NT], int tail, const float* w,
-                                          int lane, f32x4 (&acc)[NT][MT]) {
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM pass, b64 steps, hand-pipelined DEPTH steps ahead.
+//   NR regular slots at float offsets off0 + t*STRIDE, NX (0/1) extra slot at offx.
+//   w: LDS packet, [step][mt][lane][2].  tail: float delta of the last step (lanes past the
+//   window re-read in-window data; their weights are zero).
+// ---------------------------------------------------------------------------------------------
+template <int NR, int NX, int MT, int STEPS, int STRIDE, int DEPTH>
+__device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, int tail, const float* w, int lane,
+                                          f32x4 (&acc)[NR + NX][MT]) {
+  constexpr int NT = NR + NX;
+  constexpr int RING = DEPTH + 1;
   const f32x2* wp = reinterpret_cast<const f32x2*>(w) + lane;
+  f32x2 a[RING][MT], b[RING][NT];
+  auto load = [&](int s, f32x2(&as)[MT], f32x2(&bs)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) as[mt] = wp[(s * MT + mt) * 64];
+    const int d = 8 * s + (s == STEPS - 1 ? tail : 0);
+#pragma unroll
+    for (int t = 0; t < NR; ++t) bs[t] = *reinterpret_cast<const f32x2*>(act + off0 + t * STRIDE + d);
+    if constexpr (NX > 0) bs[NR] = *reinterpret_cast<const f32x2*>(act + offx + d);
+  };
+#pragma unroll
+  for (int s = 0; s < DEPTH && s < STEPS; ++s) load(s, a[s % RING], b[s % RING]);
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
-    f32x2 a[MT], b[NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = wp[(s * MT + mt) * 64];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int off = boff[t] + 8 * s + (s == STEPS - 1 ? tail : 0);
-      b[t] = *reinterpret_cast<const f32x2*>(act + off);
-    }
+    if (s + DEPTH < STEPS) load(s + DEPTH, a[(s + DEPTH) % RING], b[(s + DEPTH) % RING]);
+    pin();
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(a[mt][e], b[t][e], acc[t][mt]);
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(a[s % RING][mt][e], b[s % RING][t][e], acc[t][mt]);
+    pin();
   }
 }
 
-// First layer, 8x9 kernel on the 1-channel input: k-step s = ih*9 + j, lane kq <-> time tap 4*ih+kq.
-template <int NT>
-__device__ __forceinline__ void first_pass(const float* x0, const int (&boff)[NT], const float* w, int lane,
-                                           f32x4 (&acc)[NT][2]) {
-  const float* wp = w + lane;
+// Layer 1 of blocks 1..4: main pass (NM = NMR regular + NMX extra tiles, 9 b64-steps) and remainder
+// pass (NR tiles of 8-pixel columns, 16 b64-steps) issued as ONE pipelined stream of 16 slots; the
+// remainder accumulates even / odd steps in two independent chains.
+template <int NMR, int NMX, int NR>
+__device__ __forceinline__ void l1_pass(const float* b8, int offm0, int offmx, const int (&offr)[NR == 0 ? 1 : NR],
+                                        const float* w, int lane, f32x4 (&accm)[NMR + NMX][1],
+                                        f32x4 (&accr)[NR == 0 ? 1 : NR][2]) {
+  constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR, DEPTH = 2, RING = DEPTH + 1;
+  constexpr int SLOTS = NR > 0 ? 16 : 9;
+  const f32x2* wm = reinterpret_cast<const f32x2*>(w) + lane;
+  const f32x2* wr = reinterpret_cast<const f32x2*>(w + kW1Main) + lane;
+  f32x2 am[RING], bm[RING][NM], ar[RING], br[RING][NRA];
+  // main step issued in slot i (or -1): 9 main steps spread over the 16 remainder steps
+  auto main_step = [](int i) { return NR > 0 ? ((i * 9) / 16 != ((i + 1) * 9) / 16 ? (i * 9) / 16 : -1) : i; };
+  auto load = [&](int i, int buf) {
+    if constexpr (NR > 0) {
+      ar[buf] = wr[i * 64];
 #pragma unroll
-  for (int ih = 0; ih < 2; ++ih)
+      for (int t = 0; t < NR; ++t) br[buf][t] = *reinterpret_cast<const f32x2*>(b8 + offr[t] + kB8S * i);
+    }
+    const int m = main_step(i);
+    if (m >= 0) {
+      am[buf] = wm[m * 64];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int s = ih * 9 + j;
-      const float a0 = wp[(s * 2 + 0) * 64], a1 = wp[(s * 2 + 1) * 64];
+      for (int t = 0; t < NMR; ++t)
+        bm[buf][t] = *reinterpret_cast<const f32x2*>(b8 + offm0 + t * 128 * kB8S + kB8S * m);
+      if constexpr (NMX > 0) bm[buf][NMR] = *reinterpret_cast<const f32x2*>(b8 + offmx + kB8S * m);
+    }
+  };
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float b = x0[boff[t] + ih * 4 * kS + j];
-        acc[t][0] = mfma(a0, b, acc[t][0]);
-        acc[t][1] = mfma(a1, b, acc[t][1]);
+  for (int i = 0; i < DEPTH; ++i) load(i, i % RING);
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    if (i + DEPTH < SLOTS) load(i + DEPTH, (i + DEPTH) % RING);
+    pin();
+    const int buf = i % RING;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if constexpr (NR > 0) {
+#pragma unroll
+        for (int t = 0; t < NR; ++t) accr[t][i & 1] = mfma(ar[buf][e], br[buf][t][e], accr[t][i & 1]);
+      }
+      if (main_step(i) >= 0) {
+#pragma unroll
+        for (int t = 0; t < NM; ++t) accm[t][0] = mfma(am[buf][e], bm[buf][t][e], accm[t][0]);
       }
     }
+    pin();
+  }
 }
 
-__device__ __forceinline__ f32x4 relu4(f32x4 v) {
-  f32x4 r;
-  r.x = fmaxf(v.x, 0.f);
-  r.y = fmaxf(v.y, 0.f);
-  r.z = fmaxf(v.z, 0.f);
-  r.w = fmaxf(v.w, 0.f);
+// The same for block 0 (8x9 kernel on the 1-channel input, b32 steps): main 18 k-steps (ih, j<9),
+// remainder 32 k-steps (ih, u<16); lane kq <-> time tap 4*ih + kq.
+template <int NMR, int NMX, int NR>
+__device__ __forceinline__ void l1_first_pass(const float* x0, int offm0, int offmx,
+                                              const int (&offr)[NR == 0 ? 1 : NR], const float* w, int lane,
+                                              f32x4 (&accm)[NMR + NMX][1], f32x4 (&accr)[NR == 0 ? 1 : NR][2]) {
+  constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR, DEPTH = 3, RING = DEPTH + 1;
+  constexpr int SLOTS = NR > 0 ? 32 : 18;
+  const float* wm = w + lane;
+  const float* wr = w + kW1Main + lane;
+  float am[RING], bm[RING][NM], ar[RING], br[RING][NRA];
+  auto main_step = [](int i) { return NR > 0 ? ((i * 18) / 32 != ((i + 1) * 18) / 32 ? (i * 18) / 32 : -1) : i; };
+  auto load = [&](int i, int buf) {
+    if constexpr (NR > 0) {
+      ar[buf] = wr[i * 64];
+#pragma unroll
+      for (int t = 0; t < NR; ++t) br[buf][t] = x0[offr[t] + (i / 16) * 4 * kS + (i % 16)];
+    }
+    const int m = main_step(i);
+    if (m >= 0) {
+      am[buf] = wm[m * 64];
+      const int d = (m / 9) * 4 * kS + (m % 9);
+#pragma unroll
+      for (int t = 0; t < NMR; ++t) bm[buf][t] = x0[offm0 + t * 128 + d];
+      if constexpr (NMX > 0) bm[buf][NMR] = x0[offmx + d];
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) load(i, i % RING);
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    if (i + DEPTH < SLOTS) load(i + DEPTH, (i + DEPTH) % RING);
+    pin();
+    const int buf = i % RING;
+    if constexpr (NR > 0) {
+#pragma unroll
+      for (int t = 0; t < NR; ++t) accr[t][i & 1] = mfma(ar[buf], br[buf][t], accr[t][i & 1]);
+    }
+    if (main_step(i) >= 0) {
+#pragma unroll
+      for (int t = 0; t < NM; ++t) accm[t][0] = mfma(am[buf], bm[buf][t], accm[t][0]);
+    }
+    pin();
+  }
+}
+
+// ReLU as ONE v_max_f32 per element: fmaxf() on an MFMA result makes hipcc add a canonicalising
+// v_max_f32 v,v,v in front (cdna_hip_programming.md, attention notes), doubling the epilogue VALU.
+__device__ __forceinline__ float relu1(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
   return r;
 }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  return f32x4{relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)};
+}
 
-// Epilogue of a P = 1 pass (rows = 16*mt + 4*kq + j output channels, column = pixel):
+__device__ __forceinline__ bool px_valid(int px) {   // a real frequency bin (not gap, not past the tile)
+  const int fr = px / kS;
+  return px < kNPX && (px - fr * kS) < kF;
+}
+
+// Epilogue of a P = 1 pass for one slot (rows = 16*mt + 4*kq + j output channels, column = pixel):
 // ReLU, zero the gap pixels, store [pixel][COUT] with 8-byte stores.
-template <int NT, int COUT>
-__device__ __forceinline__ void store_p1(float* out, const f32x4 (&acc)[NT][2], const int (&px)[NT],
-                                         unsigned valid_bits, int kq) {
+template <int MT, int COUT>
+__device__ __forceinline__ void store_p1(float* out, const f32x4 (&acc)[MT], int px, int kq) {
+  const bool ok = px_valid(px);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const bool ok = (valid_bits >> t) & 1u;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int co0 = 16 * mt + 4 * kq;
-      f32x4 v = relu4(acc[t][mt]);
-      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      float* p = out + px[t] * COUT + co0;
-      if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
-      if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
-    }
+  for (int mt = 0; mt < MT; ++mt) {
+    const int co0 = 16 * mt + 4 * kq;
+    f32x4 v = relu4(acc[mt]);
+    if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* p = out + px * COUT + co0;
+    if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
+    if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
   }
 }
 
-template <int NT16, int NT32>
-__device__ __forceinline__ void run_tile(const Params& P, float* lds, int tile, int& wcur, int tid, int lane,
-                                         int wave) {
+// Epilogue of the layer-1 remainder pass: rows 4*kq+j = (phase 2*kq + (j>>1), channel 16 + (j&1)),
+// column = pixel octet.  Two 8-byte stores per lane: channels 16,17 of two adjacent pixels.
+__device__ __forceinline__ void store_rem(float* b18, f32x4 acc, int px0, int kq) {
+  const f32x4 v = relu4(acc);
+  const int pa = px0 + 2 * kq;
+  if (px_valid(pa)) *reinterpret_cast<f32x2*>(b18 + pa * 18 + 16) = f32x2{v.x, v.y};
+  if (px_valid(pa + 1)) *reinterpret_cast<f32x2*>(b18 + (pa + 1) * 18 + 16) = f32x2{v.z, v.w};
+}
+
+// The 11 input rows of a tile (frames t0-3 .. t0+7 of one utterance): 3 floats per thread, loaded one
+// tile ahead into registers, written to the X0 area (aliasing B30) once B30 is dead.
+struct XStage {
+  float v0, v1, v2;
+};
+__device__ __forceinline__ float xstage_one(const Params& P, bool live, const float* xu, int t0, int e) {
+  const int q = e - 4;
+  const int r = q >= 0 ? q / kS : -1;
+  const int f = q - r * kS;
+  const int tt = t0 + r - 3;
+  float v = 0.f;
+  if (live && e < kX0Floats && q >= 0 && r < kX0Rows && f < kF && tt >= 0 && tt < P.T) v = xu[(size_t)tt * kF + f];
+  return v;
+}
+__device__ __forceinline__ XStage xstage_load(const Params& P, int tile, int tid) {
+  const bool live = tile < P.total_tiles;
+  const int utt = live ? tile / P.tiles_per_utt : 0;
+  const int t0 = live ? (tile - utt * P.tiles_per_utt) * kTF : 0;
+  const float* xu = P.x + (size_t)utt * P.T * kF;
+  XStage st;
+  st.v0 = xstage_one(P, live, xu, t0, tid);
+  st.v1 = xstage_one(P, live, xu, t0, tid + kThreads);
+  st.v2 = xstage_one(P, live, xu, t0, tid + 2 * kThreads);
+  return st;
+}
+__device__ __forceinline__ void xstage_store(const XStage& st, float* x0, int tid) {
+  x0[tid] = st.v0;
+  x0[tid + kThreads] = st.v1;
+  if (tid + 2 * kThreads < kX0Floats) x0[tid + 2 * kThreads] = st.v2;
+}
+static_assert(kX0Floats <= 3 * kThreads, "XStage holds 3 floats per thread");
+
+// ---- the three layer kinds, templated on the calling wave's tile signature -------------------
+template <int NMR, int NMX, int NR>
+__device__ __forceinline__ void layer1(float* lds, const float* w, bool first, int wave, int lane, int xm, int xr0,
+                                       int xr1) {
+  constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR;
   const int n = lane & 15, kq = lane >> 4;
-  float* b8 = lds + kB8Off + kB8Pad * 8;
+  float* b8 = lds + kB8Off + kB8Pad * kB8S;
   float* b18 = lds + kB18Off + kB18Pad * 18;
+  const float* x0 = lds + kX0Off;
+  const int px0 = 16 * wave + n, pxx = 16 * xm + n;
+  int pxr[NRA] = {8 * (16 * xr0 + n)};
+  if constexpr (NR > 1) pxr[1] = 8 * (16 * xr1 + n);
+  int offr[NRA];
+  f32x4 accm[NM][1], accr[NRA][2];
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(w + kW1Data + 4 * kq);
+  const f32x2 s2 = *reinterpret_cast<const f32x2*>(w + kW1Data + 16);
+#pragma unroll
+  for (int t = 0; t < NM; ++t) accm[t][0] = sh;
+#pragma unroll
+  for (int t = 0; t < NRA; ++t) {
+    accr[t][0] = f32x4{s2.x, s2.y, s2.x, s2.y};
+    accr[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (!(RCED_EXP_SKIP & 1)) {
+    if (first) {
+#pragma unroll
+      for (int t = 0; t < NRA; ++t) offr[t] = pxr[t] + kq * kS;
+      l1_first_pass<NMR, NMX, NR>(x0, px0 + kq * kS, pxx + kq * kS, offr, w, lane, accm, accr);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NRA; ++t) offr[t] = (pxr[t] - 4) * kB8S + 2 * kq;
+      l1_pass<NMR, NMX, NR>(b8, (px0 - 4) * kB8S + 2 * kq, (pxx - 4) * kB8S + 2 * kq, offr, w, lane, accm, accr);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NMR; ++t) store_p1<1, 18>(b18, accm[t], px0 + 128 * t, kq);
+  if constexpr (NMX > 0) store_p1<1, 18>(b18, accm[NMR], pxx, kq);
+  if constexpr (NR > 0) {
+#pragma unroll
+    for (int t = 0; t < NR; ++t) store_rem(b18, accr[t][0] + accr[t][1], pxr[t], kq);
+  }
+}
+
+template <int NX>
+__device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int lane, int x2) {
+  constexpr int NT = 4 + NX;
+  const int n = lane & 15, kq = lane >> 4;
+  const float* b18 = lds + kB18Off + kB18Pad * 18;
   float* b30 = lds + kB30Off + kB30Pad * 30;
-  float* x0 = lds + kX0Off;
-  float* const wbase = lds + kWOff;
-#define WREG(i) (wbase + (i) * kWRegion)
+  const int px0 = 16 * wave + n, pxx = 16 * x2 + n;
+  f32x4 acc[NT][2];
+  f32x4 sh[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) sh[mt] = *reinterpret_cast<const f32x4*>(w + kW2Data + 16 * mt + 4 * kq);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc[t][0] = sh[0]; acc[t][1] = sh[1]; }
+  const int tail2 = 2 * (0 - kq);   // K = 90: only pair 0 of the last step is real
+  if (!(RCED_EXP_SKIP & 2))
+    gemm_pass<4, NX, 2, 12, 128 * 18, 1>(b18, (px0 - 2) * 18 + 2 * kq, (pxx - 2) * 18 + 2 * kq, tail2, w, lane, acc);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) store_p1<2, 30>(b30, acc[t], px0 + 128 * t, kq);
+  if constexpr (NX > 0) store_p1<2, 30>(b30, acc[4], pxx, kq);
+}
 
-  const int utt = tile / P.tiles_per_utt;
-  const int t0 = (tile - utt * P.tiles_per_utt) * kTF;   // first frame of the tile
-
-  // ---- per-lane tile geometry (tile-invariant except the T edge) ---------------------------
-  int px16[NT16], px32[NT32];
-  unsigned ok16 = 0, ok32 = 0, st32 = 0;   // valid pixel / valid pixel AND frame < T (global store)
-  int hidx[NT32];
+template <int NX>
+__device__ __forceinline__ void layer3(const Params& P, float* lds, const float* w, int blk, int wave, int lane, int x3,
+                                       int utt, int t0, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
+  constexpr int NT = 2 + NX;
+  const int n = lane & 15, kq = lane >> 4;
+  const float* b30 = lds + kB30Off + kB30Pad * 30;
+  float* b8 = lds + kB8Off + kB8Pad * kB8S;
+  const int q0 = 16 * wave + n, qx = 16 * x3 + n;   // pixel pair indices
+  f32x4 acc[NT][1];
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(w + kW3Data + 4 * (kq & 1));
 #pragma unroll
-  for (int t = 0; t < NT16; ++t) {
-    px16[t] = 16 * (wave + kWaves * t) + n;
-    const int fr = px16[t] / kS, f = px16[t] - fr * kS;
-    if (px16[t] < kNPX && f < kF) ok16 |= 1u << t;
-  }
+  for (int t = 0; t < NT; ++t) acc[t][0] = sh;
+  const int tail3 = 2 * ((kq < 2 ? kq : kq - 2) - kq);   // K = 300: pairs 0,1 of the last step are real
+  if (!(RCED_EXP_SKIP & 4))
+    gemm_pass<2, NX, 1, 38, 128 * 60, 2>(b30, (2 * q0 - 4) * 30 + 2 * kq, (2 * qx - 4) * 30 + 2 * kq, tail3, w, lane,
+                                         acc);
 #pragma unroll
-  for (int t = 0; t < NT32; ++t) {
-    px32[t] = 2 * (16 * (wave + kWaves * t) + n) + (kq >> 1);
-    const int fr = px32[t] / kS, f = px32[t] - fr * kS;
-    const bool v = px32[t] < kNPX && f < kF;
-    if (v) ok32 |= 1u << t;
-    if (v && t0 + fr < P.T) st32 |= 1u << t;
-    hidx[t] = (fr * kF + f) * kHCh + 4 * (kq & 1);
-  }
-  int off_b8[NT16], off_b18[NT16], off_b30[NT32], off_x0[NT16];
-#pragma unroll
-  for (int t = 0; t < NT16; ++t) {
-    off_b8[t] = (px16[t] - 4) * 8 + 2 * kq;
-    off_b18[t] = (px16[t] - 2) * 18 + 2 * kq;
-    off_x0[t] = px16[t] + kq * kS;
-  }
-#pragma unroll
-  for (int t = 0; t < NT32; ++t) off_b30[t] = (2 * (16 * (wave + kWaves * t) + n) - 4) * 30 + 2 * kq;
-  const int tail2 = 2 * (0 - kq);                      // K = 90: only pair 0 of the last step is real
-  const int tail3 = 2 * ((kq < 2 ? kq : kq - 2) - kq);  // K = 300: pairs 0,1 of the last step are real
-
-  // ---- stage the 11 input rows of the tile (zero outside [0,T) and in the gaps) -------------
-  {
-    const float* xu = P.x + (size_t)utt * P.T * kF;
-    for (int e = tid; e < kX0Floats; e += kThreads) {
-      const int q = e - 4;
-      const int r = q >= 0 ? q / kS : -1;
-      const int f = q - r * kS;
-      const int tt = t0 + r - 3;
-      float v = 0.f;
-      if (q >= 0 && r < kX0Rows && f < kF && tt >= 0 && tt < P.T) v = xu[(size_t)tt * kF + f];
-      x0[e] = v;
+  for (int t = 0; t < NT; ++t) {
+    const int q = (t < 2) ? q0 + 128 * t : qx;
+    const int px = 2 * q + (kq >> 1);   // this lane's output pixel (phase = kq >> 1)
+    f32x4 v = relu4(acc[t][0]);
+    if (blk == 3) v += skip_ce2[t];   // CD1 + CE2 (model.py:87, 75-76: after the ReLU)
+    if (blk == 4) v += skip_ce1[t];   // CD2 + CE1 (model.py:88)
+    const int fr = px / kS, f = px - fr * kS;
+    const bool ok = px < kNPX && f < kF;
+    if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    skip_ce1[t] = (blk == 0) ? v : skip_ce1[t];
+    skip_ce2[t] = (blk == 1) ? v : skip_ce2[t];
+    if (blk < 4) {
+      if (px >= kNPX) continue;   // rows past the tile are not allocated
+      float* bp = b8 + px * kB8S + 4 * (kq & 1);   // 8-byte aligned (stride 10): two b64 stores
+      *reinterpret_cast<f32x2*>(bp) = f32x2{v.x, v.y};
+      *reinterpret_cast<f32x2*>(bp + 2) = f32x2{v.z, v.w};
+    } else if (ok && t0 + fr < P.T) {
+      float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * kHCh + 4 * (kq & 1);
+      *reinterpret_cast<f32x4*>(hp) = v;
     }
   }
-  __syncthreads();
-
-  f32x4 skip_ce1[NT32], skip_ce2[NT32];
-#pragma unroll
-  for (int t = 0; t < NT32; ++t) skip_ce1[t] = skip_ce2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* wsrc = P.wpack;
-  const float* shsrc = P.shifts;
-
-#pragma unroll 1
-  for (int blk = 0; blk < 5; ++blk) {
-    // ======== layer 1 of the block: (8x9, 1->18) for block 0, (1x9, 8->18) otherwise =========
-    {
-      const WStage st = wstage_load<kW2>(wsrc + kW1, tid);
-      f32x4 acc[NT16][2];
-      f32x4 sh[2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) sh[mt] = *reinterpret_cast<const f32x4*>(shsrc + 16 * mt + 4 * kq);
-#pragma unroll
-      for (int t = 0; t < NT16; ++t) { acc[t][0] = sh[0]; acc[t][1] = sh[1]; }
-      if (blk == 0) {
-        first_pass<NT16>(x0, off_x0, WREG(wcur), lane, acc);
-      } else {
-        gemm_pass<NT16, 2, 9>(b8, off_b8, 0, WREG(wcur), lane, acc);
-      }
-      store_p1<NT16, 18>(b18, acc, px16, ok16, kq);
-      wstage_store<kW2>(st, WREG(wcur ^ 1), tid);
-      wcur ^= 1;
-      __syncthreads();
-    }
-    // ======== layer 2: (1x5, 18->30) ==========================================================
-    {
-      const WStage st = wstage_load<kW3>(wsrc + kW1 + kW2, tid);
-      f32x4 acc[NT16][2];
-      f32x4 sh[2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        sh[mt] = *reinterpret_cast<const f32x4*>(shsrc + kShiftPerLayer + 16 * mt + 4 * kq);
-#pragma unroll
-      for (int t = 0; t < NT16; ++t) { acc[t][0] = sh[0]; acc[t][1] = sh[1]; }
-      gemm_pass<NT16, 2, 12>(b18, off_b18, tail2, WREG(wcur), lane, acc);
-      store_p1<NT16, 30>(b30, acc, px16, ok16, kq);
-      wstage_store<kW3>(st, WREG(wcur ^ 1), tid);
-      wcur ^= 1;
-      __syncthreads();
-    }
-    // ======== layer 3: (1x9, 30->8) on pixel pairs; block skips; hand-off =====================
-    {
-      // next: layer 1 of the next block, or of block 0 of the next tile (stream wraps around)
-      const float* nxt = (blk == 4) ? P.wpack : wsrc + kWBlock;
-      const WStage st = wstage_load<kW1>(nxt, tid);
-      f32x4 acc[NT32][1];
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(shsrc + 2 * kShiftPerLayer + 4 * (kq & 1));
-#pragma unroll
-      for (int t = 0; t < NT32; ++t) acc[t][0] = sh;
-      gemm_pass<NT32, 1, 38>(b30, off_b30, tail3, WREG(wcur), lane, acc);
-#pragma unroll
-      for (int t = 0; t < NT32; ++t) {
-        f32x4 v = relu4(acc[t][0]);
-        if (blk == 3) v += skip_ce2[t];   // CD1 + CE2 (model.py:87, 75-76: after the ReLU)
-        if (blk == 4) v += skip_ce1[t];   // CD2 + CE1 (model.py:88)
-        if (!((ok32 >> t) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        skip_ce1[t] = (blk == 0) ? v : skip_ce1[t];
-        skip_ce2[t] = (blk == 1) ? v : skip_ce2[t];
-        if (blk < 4) {
-          *reinterpret_cast<f32x4*>(b8 + px32[t] * 8 + 4 * (kq & 1)) = v;
-        } else if ((st32 >> t) & 1u) {
-          float* hp = P.h + ((size_t)utt * P.T + t0) * (kF * kHCh) + hidx[t];
-          *reinterpret_cast<f32x4*>(hp) = v;
-        }
-      }
-      wstage_store<kW1>(st, WREG(wcur ^ 1), tid);
-      wcur ^= 1;
-      __syncthreads();
-    }
-    wsrc += kWBlock;
-    shsrc += 3 * kShiftPerLayer;
-  }
-#undef WREG
 }
 
 __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
@@ -335,24 +473,90 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const wbase = lds + kWOff;
+#define WREG(i) (wbase + (i) * kWRegion)
 
   // zero all of LDS once: gap pixels and margins are never written afterwards
   for (int e = tid; e < kLdsFloats; e += kThreads) lds[e] = 0.f;
   __syncthreads();
-  // weights of the very first layer into region 0
-  {
-    const WStage st = wstage_load<kW1>(P.wpack, tid);
-    wstage_store<kW1>(st, lds + kWOff, tid);
-  }
+  // packet of the very first layer into region 0; input rows of the first tile into registers
+  packet_dma<kW1>(P.wpack, WREG(0), wave, lane);
   int wcur = 0;
-  __syncthreads();
+  XStage xst = xstage_load(P, blockIdx.x, tid);
+#if RCED_STAMPS
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  layer_end_sync();
+
+  // extra tiles of this wave (see the assignment comment above)
+  const int xm = wave == 0 ? 32 : 31;                           // layer 1 main, waves 0 and 1
+  const int xr0 = wave == 7 ? 3 : wave - 4, xr1 = 4;            // layer 1 remainder, waves 4..7
 
   for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
-    // waves 0,1 own five 16-pixel tiles (others four); wave 0 owns three pair tiles (others two)
-    if (wave == 0) run_tile<5, 3>(P, lds, tile, wcur, tid, lane, wave);
-    else if (wave == 1) run_tile<5, 2>(P, lds, tile, wcur, tid, lane, wave);
-    else run_tile<4, 2>(P, lds, tile, wcur, tid, lane, wave);
+    const int utt = tile / P.tiles_per_utt;
+    const int t0 = (tile - utt * P.tiles_per_utt) * kTF;   // first frame of the tile
+    // input rows prefetched during the previous tile -> X0 (B30 is dead: its last reader finished
+    // before the barrier that ended the previous tile)
+    xstage_store(xst, lds + kX0Off, tid);
+    __syncthreads();
+
+    f32x4 skip_ce1[3], skip_ce2[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) skip_ce1[t] = skip_ce2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wsrc = P.wpack;
+
+#pragma unroll 1
+    for (int blk = 0; blk < 5; ++blk) {
+      {  // ---- layer 1: (8x9, 1->18) for block 0, (1x9, 8->18) otherwise
+        STAMP_BEGIN();
+        packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
+        const float* w = WREG(wcur);
+        if (wave < 2) layer1<4, 1, 0>(lds, w, blk == 0, wave, lane, xm, 0, 0);
+        else if (wave < 4) layer1<4, 0, 0>(lds, w, blk == 0, wave, lane, 0, 0, 0);
+        else if (wave < 7) layer1<4, 0, 1>(lds, w, blk == 0, wave, lane, 0, xr0, 0);
+        else layer1<3, 0, 2>(lds, w, blk == 0, wave, lane, 0, xr0, xr1);
+        wcur ^= 1;
+#if RCED_STAMPS
+        const unsigned long long st_b_ = stamp();
+        tsum[blk == 0 ? 6 : 0] += st_b_ - st_a_;
+        layer_end_sync();
+        tsum[blk == 0 ? 7 : 3] += stamp() - st_b_;
+#else
+        layer_end_sync();
+#endif
+      }
+      {  // ---- layer 2: (1x5, 18->30)
+        STAMP_BEGIN();
+        packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane);
+        const float* w = WREG(wcur);
+        if (wave == 2) layer2<1>(lds, w, wave, lane, 32);
+        else layer2<0>(lds, w, wave, lane, 0);
+        wcur ^= 1;
+        STAMP_MATH(1);
+        layer_end_sync();
+        STAMP_WAIT(1);
+      }
+      {  // ---- layer 3: (1x9, 30->8) on pixel pairs; block skips; hand-off
+        STAMP_BEGIN();
+        // next packet: layer 1 of the next block, or of block 0 of the next tile (the stream wraps)
+        packet_dma<kW1>(blk == 4 ? P.wpack : wsrc + kWBlock, WREG(wcur ^ 1), wave, lane);
+        if (blk == 4) xst = xstage_load(P, tile + gridDim.x, tid);   // next tile's input rows
+        const float* w = WREG(wcur);
+        if (wave == 3) layer3<1>(P, lds, w, blk, wave, lane, 16, utt, t0, skip_ce1, skip_ce2);
+        else layer3<0>(P, lds, w, blk, wave, lane, 0, utt, t0, skip_ce1, skip_ce2);
+        wcur ^= 1;
+        STAMP_MATH(2);
+        layer_end_sync();
+        STAMP_WAIT(2);
+      }
+      wsrc += kWBlock;
+    }
   }
+#undef WREG
+#if RCED_STAMPS
+  if (P.stamps && blockIdx.x == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) P.stamps[wave * 8 + i] = tsum[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Diagnostic: run one forward with the RCED_STAMPS build (exp/librced_stamps.so) and print, for
+each wave of workgroup 0, kilo-cycles spent in each layer kind's math and barrier wait."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("RCED_LIB", os.path.join(ROOT, "exp", "librced_stamps.so"))
+sys.path.insert(0, ROOT)
+import torch
+from fullycnnspeechenhancement_amd import build_model
+from oracle import rced_np
+m = build_model("FullyCNNV3", False, weights=rced_np.make_weights("FullyCNNV3"))
+x = torch.randn((256, 512, 129, 1), device="cuda").abs_()
+for _ in range(2):
+    y = m(x)
+torch.cuda.synchronize()
+print("wave   L1math  L2math  L3math | L1wait  L2wait  L3wait | L1first math/wait   (kilo-cycles)")
+for w in range(8):
+    v = [m.get_option("stamp%d" % (w * 8 + i)) for i in range(8)]
+    print("%4d  %7d %7d %7d | %7d %7d %7d | %7d %7d   total %d" % (w, *v, sum(v)))

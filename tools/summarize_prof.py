@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into a small text summary (what gets committed
+under profiles/): per-kernel time stats from --kernel-trace --stats and per-kernel PMC averages."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+
+
+def short(name):
+    for key in ("fused_v3_kernel", "final_gemm_kernel", "conv_layer_generic", "fused_v1", "fused_v2"):
+        if key in name:
+            return key
+    return name[:60]
+
+
+def main(out):
+    print("# rocprofv3 summary:", os.path.basename(out))
+    for f in find(os.path.join(out, "trace"), "*kernel_stats.csv"):
+        print("\n## kernel-trace --stats (%s)" % os.path.basename(f))
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                n = row.get("Name", "")
+                if any(k in n for k in ("rced", "fused", "final_gemm", "conv_layer")):
+                    print("%-22s calls=%s total_ns=%s avg_ns=%s min_ns=%s max_ns=%s pct=%s" % (
+                        short(n), row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"),
+                        row.get("MinNs"), row.get("MaxNs"), row.get("Percentage")))
+    for f in find(os.path.join(out, "trace"), "*kernel_trace.csv"):
+        with open(f) as fh:
+            rows = list(csv.DictReader(fh))
+        seen = {}
+        for r in rows:
+            k = short(r.get("Kernel_Name", ""))
+            if k not in seen and any(s in k for s in ("fused", "final", "conv_layer")):
+                seen[k] = r
+        print("\n## dispatch resources (kernel_trace.csv)")
+        for k, r in seen.items():
+            print("%-22s grid=%s wg=%s VGPR=%s accum=%s SGPR=%s LDS=%s scratch=%s" % (
+                k, r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("VGPR_Count"), r.get("Accum_VGPR_Count"),
+                r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size")))
+    print("\n## PMC (average per dispatch)")
+    for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        acc = defaultdict(lambda: [0.0, 0])
+        for f in find(d, "*counter_collection.csv"):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    k = (short(r.get("Kernel_Name", "")), r.get("Counter_Name"))
+                    if any(s in k[0] for s in ("fused", "final", "conv_layer")):
+                        acc[k][0] += float(r.get("Counter_Value", 0) or 0)
+                        acc[k][1] += 1
+        for (k, c), (tot, n) in sorted(acc.items()):
+            print("%-22s %-28s avg=%.6g  (n=%d)" % (k, c, tot / max(n, 1), n))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
