@@ -43,6 +43,24 @@ def cpu_baseline(variant, weights, frames_t, budget_s):
                       % (done, done // (8 * frames_t), frames_t, el, os.cpu_count())}
 
 
+def pmc_traffic(variant, batch, frames, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json; FETCH_SIZE + WRITE_SIZE, collected by tools/profile.sh on this
+    same command).  None when the workload differs from the profiled one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            d = json.load(fh)
+        wl = d["workload"]
+        key = {"rced_fused": "fused_v3_kernel", "rced_final_gemm": "final_gemm_kernel"}.get(kernel)
+        if key and (wl["variant"], wl["batch"], wl["frames"]) == (variant, batch, frames):
+            return {"bytes": 1024 * (d[key]["fetch_kib"] + d[key]["write_kib"]), "unit": "B/launch",
+                    "algorithmic_bytes": 1032 * batch * frames,
+                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_traffic.json"}
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,8 +166,9 @@ def main():
                     final = 2 * spec.FEATURE_DIM * sum(l.kh * l.kw * l.cin * l.cout for l in spec.layers(variant)[-1:])
                     kflops = final if dom == _lib.K_FINAL else flops_frame - final
                 achieved = kflops * B * T * args.steps / (ms * 1e-3) / 1e12
+                traffic = pmc_traffic(variant, B, T, kinds[dom])
                 roof = {"bound": "mfma", "kernel": kinds[dom], "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                        "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                         "avg_launch_ms": ms / launches, "launches": launches,
                         "flop_per_frame": kflops, "frames_per_forward": B * T,
                         "other_kernels_ms_per_step": {kinds[k]: times[k][0] / args.steps for k in kinds if k != dom and times[k][1]},
