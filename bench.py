@@ -53,9 +53,7 @@ def pmc_traffic(variant, batch, frames, kernel):
         wl = d["workload"]
         key = {"rced_fused": "fused_v3_kernel", "rced_final_gemm": "final_gemm_kernel"}.get(kernel)
         if key and (wl["variant"], wl["batch"], wl["frames"]) == (variant, batch, frames):
-            return {"bytes": 1024 * (d[key]["fetch_kib"] + d[key]["write_kib"]), "unit": "B/launch",
-                    "algorithmic_bytes": 1032 * batch * frames,
-                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_traffic.json"}
+            return 1024 * (d[key]["fetch_kib"] + d[key]["write_kib"])
     except Exception:
         pass
     return None
@@ -169,6 +167,8 @@ def main():
                 traffic = pmc_traffic(variant, B, T, kinds[dom])
                 roof = {"bound": "mfma", "kernel": kinds[dom], "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
+                        "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE "
+                                        "(profiles/r01_pmc_traffic.json); algorithmic bytes per launch = %d" % (1032 * B * T),
                         "avg_launch_ms": ms / launches, "launches": launches,
                         "flop_per_frame": kflops, "frames_per_forward": B * T,
                         "other_kernels_ms_per_step": {kinds[k]: times[k][0] / args.steps for k in kinds if k != dom and times[k][1]},
