@@ -83,25 +83,36 @@ void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>*
     }
     put_shift(dst + v3::kW1Data, 3 * blk + 0);
     dst += v3::kW1;
-    // ---- layer 2: 1x5, 18 -> 30, K = 90
-    for (int s = 0; s < 12; ++s)
+    // ---- layer 2: 1x5, 18 -> 30, K = 90: 11 b64 steps (k = 8s + 2kq + e) + b32 tail (k = 88 + kq)
+    {
+      auto w2 = [&](int i, int mt, int k) {
+        const int co = 16 * mt + i;
+        return (k < 90 && co < 30) ? wq(l2, k / 18, k % 18, co, 18) : 0.f;
+      };
+      for (int s = 0; s < v3::kL2Steps; ++s)
+        for (int mt = 0; mt < 2; ++mt)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 2; ++e)
+              dst[(s * 2 + mt) * 128 + lane * 2 + e] = w2(lane & 15, mt, 8 * s + 2 * (lane >> 4) + e);
       for (int mt = 0; mt < 2; ++mt)
         for (int lane = 0; lane < 64; ++lane)
-          for (int e = 0; e < 2; ++e) {
-            const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
-            const int co = 16 * mt + i;
-            dst[(s * 2 + mt) * 128 + lane * 2 + e] = (k < 90 && co < 30) ? wq(l2, k / 18, k % 18, co, 18) : 0.f;
-          }
+          dst[v3::kL2Steps * 2 * 128 + mt * 64 + lane] = w2(lane & 15, mt, 8 * v3::kL2Steps + (lane >> 4));
+    }
     put_shift(dst + v3::kW2Data, 3 * blk + 1);
     dst += v3::kW2;
-    // ---- layer 3: 1x9, 30 -> 8 on pixel pairs: row i = (phase r, co), k = u*30 + ci, tap = u - r
-    for (int s = 0; s < 38; ++s)
+    // ---- layer 3: 1x9, 30 -> 8 on pixel pairs: row i = (phase r, co), k = u*30 + ci, tap = u - r;
+    //      37 b64 steps + b32 tail (k = 296 + kq)
+    {
+      auto w3 = [&](int i, int k) {
+        const int r = i >> 3, co = i & 7, u = k / 30, ci = k % 30, tap = u - r;
+        return (k < 300 && tap >= 0 && tap < 9) ? wq(l3, tap, ci, co, 30) : 0.f;
+      };
+      for (int s = 0; s < v3::kL3Steps; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 2; ++e) dst[s * 128 + lane * 2 + e] = w3(lane & 15, 8 * s + 2 * (lane >> 4) + e);
       for (int lane = 0; lane < 64; ++lane)
-        for (int e = 0; e < 2; ++e) {
-          const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
-          const int r = i >> 3, co = i & 7, u = k / 30, ci = k % 30, tap = u - r;
-          dst[s * 128 + lane * 2 + e] = (k < 300 && tap >= 0 && tap < 9) ? wq(l3, tap, ci, co, 30) : 0.f;
-        }
+        dst[v3::kL3Steps * 128 + lane] = w3(lane & 15, 8 * v3::kL3Steps + (lane >> 4));
+    }
     put_shift(dst + v3::kW3Data, 3 * blk + 2);
     dst += v3::kW3;
   }

@@ -27,6 +27,18 @@
 #ifndef RCED_EXP_SKIP
 #define RCED_EXP_SKIP 0   // timing experiments only: bit0 skip L1 math, bit1 L2, bit2 L3 (results wrong)
 #endif
+#ifndef RCED_D1
+#define RCED_D1 2   // operand prefetch depth (steps) of the layer-1 / layer-2 / layer-3 passes
+#endif
+#ifndef RCED_D2
+#define RCED_D2 1
+#endif
+#ifndef RCED_D3
+#define RCED_D3 2
+#endif
+#ifndef RCED_EXP_WGLOBAL
+#define RCED_EXP_WGLOBAL 0   // experiment: A fragments straight from global/L2 instead of the LDS packet
+#endif
 #ifndef RCED_STAMPS
 #define RCED_STAMPS 0     // diagnostic build: s_memtime stamps around every layer's math and barrier
 #endif
@@ -76,7 +88,7 @@ constexpr int kB30Rows = kB30Pad + kNPX;                  // pixels -4 .. 531
 constexpr int kB8Off = 0;
 constexpr int kB18Off = kB8Off + kB8Rows * kB8S;
 constexpr int kB30Off = kB18Off + kB18Rows * 18;
-constexpr int kWRegion = 38 * 128 + 32;                   // largest packet: 30->8, 38 b64-steps + shifts
+constexpr int kWRegion = 37 * 128 + 64 + 32;              // largest packet: 30->8 (b64 steps + tail + shifts)
 constexpr int kWOff = kB30Off + kB30Rows * 30;
 constexpr int kLdsFloats = kWOff + 2 * kWRegion;
 constexpr int kLdsBytes = kLdsFloats * 4;
@@ -94,15 +106,17 @@ static_assert(kX0Floats <= 60 * 30, "X0 must sit inside rows that layer 2 rewrit
 //  first layer rem  (ch 16,17 x 8 phases): 32 k-steps x 64 lanes (k = (time tap, 16 freq taps))
 //  L1 main (1x9, 8 -> ch 0..15):  9 b64-steps x 64 lanes x 2
 //  L1 rem  (ch 16,17 x 8 phases): 16 b64-steps x 64 x 2   (K = 16 taps x 8)
-//  L2 (1x5, 18->30): 12 b64-steps x 2 M-tiles x 64 x 2   (K = 90, last step 2 valid)
-//  L3 (1x9, 30->8):  38 b64-steps x 1 M-tile x 64 x 2    (K = 300 = 10 taps x 30, pixel pairs)
+//  L2 (1x5, 18->30): 11 b64-steps x 2 M-tiles x 64 x 2 + a b32 tail step (k = 88 + kq; K = 90)
+//  L3 (1x9, 30->8):  37 b64-steps x 64 x 2 + a b32 tail step (k = 296 + kq; K = 300 = 10 taps x 30,
+//                    rows = 2 pixel phases x 8 channels)
 // Every packet ends with its 32 shift values (bias + folded BatchNorm).
 constexpr int kShiftPerLayer = 32;
 constexpr int kW1Main = 9 * 128;          // 1152 (= 18 * 64 for the first layer)
 constexpr int kW1Rem = 16 * 128;          // 2048 (= 32 * 64 for the first layer)
 constexpr int kW1Data = kW1Main + kW1Rem; // 3200
-constexpr int kW2Data = 12 * 2 * 128;     // 3072
-constexpr int kW3Data = 38 * 1 * 128;     // 4864
+constexpr int kL2Steps = 11, kL3Steps = 37;                  // b64 steps; each pass ends with one b32 step
+constexpr int kW2Data = kL2Steps * 2 * 128 + 2 * 64;   // 2944
+constexpr int kW3Data = kL3Steps * 128 + 64;           // 4800
 constexpr int kW1 = kW1Data + kShiftPerLayer;
 constexpr int kW2 = kW2Data + kShiftPerLayer;
 constexpr int kW3 = kW3Data + kShiftPerLayer;
@@ -115,8 +129,9 @@ constexpr int kWTotal = 5 * kWBlock;
 // tile 31 are handed out as "extra" tiles.  Pair tiles 0..16: w + 8*slot, slot < 2; extra 16.
 // Remainder tiles (128 pixels) 0..4 go one each to waves 4,5,6 and two to wave 7, which gives up
 // main tile 31.  Waves w and w+4 share a SIMD; MFMA counts per SIMD pair in layer 1:
-// 194, 194, 176, 190 (18 per main tile, 32 per remainder tile); layer 2: 9,8,8,8 tiles; layer 3:
-// 4,4,4,5 pair tiles.
+// 194, 194, 176, 190 (18 per main tile, 32 per remainder tile).  Layer 2: tile 32's two M-tiles go
+// to waves 2 and 3 (17,17,16,16 M-tile units per SIMD).  Layer 3: pair tile 16 is split along K
+// between waves 0 and 1 (323, 323, 304, 304 MFMAs per SIMD).
 
 struct Params {
   const float* x;       // [N, T, 129]
@@ -158,39 +173,69 @@ __device__ __forceinline__ void layer_end_sync() {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Implicit-GEMM pass, b64 steps, hand-pipelined DEPTH steps ahead.
-//   NR regular slots at float offsets off0 + t*STRIDE, NX (0/1) extra slot at offx.
-//   w: LDS packet, [step][mt][lane][2].  tail: float delta of the last step (lanes past the
-//   window re-read in-window data; their weights are zero).
+// Implicit-GEMM pass: NB64 b64 steps (k = 8s + 2kq + e) plus one b32 tail step (k = 8*NB64 + kq),
+// hand-pipelined DEPTH steps ahead.
+//   NR regular slots at float offsets off0 + t*STRIDE run every step and every M-tile.
+//   NX (0/1) extra slot at offx runs b64 steps [XS0, XS1), the tail iff XTAIL, and only M-tile XMT
+//   (XMT < 0: all) -- this is how an odd tile is shared between two waves (by M-tile or along K).
+//   w: LDS packet [NB64][MT][lane][2] then tail [MT][lane].  tailoff: per-lane float delta of the
+//   tail read relative to off + 8*NB64 (kq_eff - 2*kq: lanes past K re-read in-window data, their
+//   weights are zero).
 // ---------------------------------------------------------------------------------------------
-template <int NR, int NX, int MT, int STEPS, int STRIDE, int DEPTH>
-__device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, int tail, const float* w, int lane,
+template <int NR, int NX, int MT, int XMT, int NB64, int XS0, int XS1, bool XTAIL, int STRIDE, int DEPTH>
+__device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, int tailoff, const float* w, int lane,
                                           f32x4 (&acc)[NR + NX][MT]) {
   constexpr int NT = NR + NX;
   constexpr int RING = DEPTH + 1;
   const f32x2* wp = reinterpret_cast<const f32x2*>(w) + lane;
+  const float* wt = w + NB64 * MT * 128 + lane;
   f32x2 a[RING][MT], b[RING][NT];
+  float at[MT], bt[NT];
+  auto xlive = [](int s) { return NX > 0 && s >= XS0 && s < XS1; };
+  auto xmt = [](int mt) { return XMT < 0 || mt == XMT; };
   auto load = [&](int s, f32x2(&as)[MT], f32x2(&bs)[NT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) as[mt] = wp[(s * MT + mt) * 64];
-    const int d = 8 * s + (s == STEPS - 1 ? tail : 0);
 #pragma unroll
-    for (int t = 0; t < NR; ++t) bs[t] = *reinterpret_cast<const f32x2*>(act + off0 + t * STRIDE + d);
-    if constexpr (NX > 0) bs[NR] = *reinterpret_cast<const f32x2*>(act + offx + d);
+    for (int t = 0; t < NR; ++t) bs[t] = *reinterpret_cast<const f32x2*>(act + off0 + t * STRIDE + 8 * s);
+    if constexpr (NX > 0)
+      if (xlive(s)) bs[NR] = *reinterpret_cast<const f32x2*>(act + offx + 8 * s);
   };
+  // tail operands first: they are needed last and cost MT + NT registers
 #pragma unroll
-  for (int s = 0; s < DEPTH && s < STEPS; ++s) load(s, a[s % RING], b[s % RING]);
+  for (int mt = 0; mt < MT; ++mt) at[mt] = wt[mt * 64];
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    if (s + DEPTH < STEPS) load(s + DEPTH, a[(s + DEPTH) % RING], b[(s + DEPTH) % RING]);
+  for (int t = 0; t < NR; ++t) bt[t] = act[off0 + t * STRIDE + 8 * NB64 + tailoff];
+  if constexpr (NX > 0 && XTAIL) bt[NR] = act[offx + 8 * NB64 + tailoff];
+#pragma unroll
+  for (int s = 0; s < DEPTH && s < NB64; ++s) load(s, a[s % RING], b[s % RING]);
+#pragma unroll
+  for (int s = 0; s < NB64; ++s) {
+    if (s + DEPTH < NB64) load(s + DEPTH, a[(s + DEPTH) % RING], b[(s + DEPTH) % RING]);
     pin();
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < 2; ++e) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NR; ++t)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(a[s % RING][mt][e], b[s % RING][t][e], acc[t][mt]);
+      if constexpr (NX > 0)
+        if (xlive(s)) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            if (xmt(mt)) acc[NR][mt] = mfma(a[s % RING][mt][e], b[s % RING][NR][e], acc[NR][mt]);
+        }
+    }
     pin();
+  }
+#pragma unroll
+  for (int t = 0; t < NR; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(at[mt], bt[t], acc[t][mt]);
+  if constexpr (NX > 0 && XTAIL) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      if (xmt(mt)) acc[NR][mt] = mfma(at[mt], bt[NR], acc[NR][mt]);
   }
 }
 
@@ -201,7 +246,7 @@ template <int NMR, int NMX, int NR>
 __device__ __forceinline__ void l1_pass(const float* b8, int offm0, int offmx, const int (&offr)[NR == 0 ? 1 : NR],
                                         const float* w, int lane, f32x4 (&accm)[NMR + NMX][1],
                                         f32x4 (&accr)[NR == 0 ? 1 : NR][2]) {
-  constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR, DEPTH = 2, RING = DEPTH + 1;
+  constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR, DEPTH = RCED_D1, RING = DEPTH + 1;
   constexpr int SLOTS = NR > 0 ? 16 : 9;
   const f32x2* wm = reinterpret_cast<const f32x2*>(w) + lane;
   const f32x2* wr = reinterpret_cast<const f32x2*>(w + kW1Main) + lane;
@@ -291,12 +336,14 @@ __device__ __forceinline__ void l1_first_pass(const float* x0, int offm0, int of
   }
 }
 
-// ReLU as ONE v_max_f32 per element: fmaxf() on an MFMA result makes hipcc add a canonicalising
-// v_max_f32 v,v,v in front (cdna_hip_programming.md, attention notes), doubling the epilogue VALU.
+// ReLU as ONE integer max per element: for IEEE floats max(bits, 0) == bits of relu(x) (negative
+// floats are negative ints).  fmaxf() on an MFMA result makes hipcc add a canonicalising
+// v_max_f32 v,v,v in front (2 VALU per element); an inline-asm v_max_f32 is NOT an option: hipcc pads
+// no MFMA -> VALU wait states inside asm, and a ReLU issued right behind the last MFMA then reads the
+// accumulator before it lands (seen as rare wrong values in each wave's first tile).
 __device__ __forceinline__ float relu1(float v) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-  return r;
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   return f32x4{relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)};
@@ -321,6 +368,18 @@ __device__ __forceinline__ void store_p1(float* out, const f32x4 (&acc)[MT], int
     if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
     if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
   }
+}
+
+// One M-tile of the same (used where a tile's two M-tiles belong to different waves).
+template <int COUT>
+__device__ __forceinline__ void store_p1_mt(float* out, f32x4 acc, int px, int kq, int mt) {
+  const bool ok = px_valid(px);
+  const int co0 = 16 * mt + 4 * kq;
+  f32x4 v = relu4(acc);
+  if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+  float* p = out + px * COUT + co0;
+  if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
+  if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
 }
 
 // Epilogue of the layer-1 remainder pass: rows 4*kq+j = (phase 2*kq + (j>>1), channel 16 + (j&1)),
@@ -407,45 +466,83 @@ __device__ __forceinline__ void layer1(float* lds, const float* w, bool first, i
   }
 }
 
-template <int NX>
-__device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int lane, int x2) {
-  constexpr int NT = 4 + NX;
+// Layer 2.  XMT < 0: four regular tiles.  XMT = 0/1: plus M-tile XMT of tile 32 (its two M-tiles go
+// to two waves on different SIMDs).
+template <int XMT>
+__device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int lane) {
+  constexpr int NX = XMT >= 0 ? 1 : 0, NT = 4 + NX;
   const int n = lane & 15, kq = lane >> 4;
   const float* b18 = lds + kB18Off + kB18Pad * 18;
   float* b30 = lds + kB30Off + kB30Pad * 30;
-  const int px0 = 16 * wave + n, pxx = 16 * x2 + n;
+  const int px0 = 16 * wave + n, pxx = 16 * 32 + n;
   f32x4 acc[NT][2];
   f32x4 sh[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) sh[mt] = *reinterpret_cast<const f32x4*>(w + kW2Data + 16 * mt + 4 * kq);
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = sh[0]; acc[t][1] = sh[1]; }
-  const int tail2 = 2 * (0 - kq);   // K = 90: only pair 0 of the last step is real
+  const int tailoff = (kq < 1 ? kq : 1) - 2 * kq;   // K = 90: tail k = 88 + kq is real for kq < 2
   if (!(RCED_EXP_SKIP & 2))
-    gemm_pass<4, NX, 2, 12, 128 * 18, 1>(b18, (px0 - 2) * 18 + 2 * kq, (pxx - 2) * 18 + 2 * kq, tail2, w, lane, acc);
+    gemm_pass<4, NX, 2, XMT, kL2Steps, 0, kL2Steps, true, 128 * 18, RCED_D2>(
+        b18, (px0 - 2) * 18 + 2 * kq, (pxx - 2) * 18 + 2 * kq, tailoff, w, lane, acc);
 #pragma unroll
   for (int t = 0; t < 4; ++t) store_p1<2, 30>(b30, acc[t], px0 + 128 * t, kq);
-  if constexpr (NX > 0) store_p1<2, 30>(b30, acc[4], pxx, kq);
+  if constexpr (NX > 0) store_p1_mt<30>(b30, acc[4][XMT], pxx, kq, XMT);
 }
 
-template <int NX>
-__device__ __forceinline__ void layer3(const Params& P, float* lds, const float* w, int blk, int wave, int lane, int x3,
-                                       int utt, int t0, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
-  constexpr int NT = 2 + NX;
+// Layer 3 roles: every wave has two regular pair tiles; pair tile 16 is split ALONG K between a
+// reducer wave (steps [0,19), owns the epilogue and the skip registers) and a helper wave on another
+// SIMD (steps [19,37) + tail), which hands its partial sums over through a 1-KiB scratch in the
+// (dead during layer 3) B18 buffer and a tagged flag word -- a pairwise hand-off, no extra barrier.
+constexpr int kRolePlain = 0, kRoleReducer = 1, kRoleHelper = 2;
+constexpr int kL3Split = 19;
+constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;   // pixels 8..22 of frame 0: always rewritten by layer 1
+constexpr int kFlagOff = kScratchOff + 256;
+static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
+
+template <int ROLE>
+__device__ __forceinline__ void layer3(const Params& P, float* lds, const float* w, int blk, int wave, int lane,
+                                       unsigned tag, int utt, int t0, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
+  constexpr int NX = ROLE == kRolePlain ? 0 : 1, NT = 2 + NX;
+  constexpr int NEPI = ROLE == kRoleHelper ? 2 : NT;   // tiles this wave finishes
   const int n = lane & 15, kq = lane >> 4;
   const float* b30 = lds + kB30Off + kB30Pad * 30;
   float* b8 = lds + kB8Off + kB8Pad * kB8S;
-  const int q0 = 16 * wave + n, qx = 16 * x3 + n;   // pixel pair indices
+  const int q0 = 16 * wave + n, qx = 16 * 16 + n;   // pixel pair indices
   f32x4 acc[NT][1];
   const f32x4 sh = *reinterpret_cast<const f32x4*>(w + kW3Data + 4 * (kq & 1));
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t][0] = sh;
-  const int tail3 = 2 * ((kq < 2 ? kq : kq - 2) - kq);   // K = 300: pairs 0,1 of the last step are real
-  if (!(RCED_EXP_SKIP & 4))
-    gemm_pass<2, NX, 1, 38, 128 * 60, 2>(b30, (2 * q0 - 4) * 30 + 2 * kq, (2 * qx - 4) * 30 + 2 * kq, tail3, w, lane,
-                                         acc);
+  for (int t = 0; t < NT; ++t) acc[t][0] = (t == 2 && ROLE == kRoleHelper) ? f32x4{0.f, 0.f, 0.f, 0.f} : sh;
+  const int tailoff = -kq;   // K = 300: tail k = 296 + kq, all four real
+  if (!(RCED_EXP_SKIP & 4)) {
+#ifdef RCED_EXP_NOSPLIT   // experiment: reducer does the whole tile, helper publishes zeros
+    constexpr int XS0 = ROLE == kRoleHelper ? kL3Steps : 0;
+    constexpr int XS1 = kL3Steps;
+    constexpr bool XT = ROLE == kRoleReducer;
+#else
+    constexpr int XS0 = ROLE == kRoleHelper ? kL3Split : 0;
+    constexpr int XS1 = ROLE == kRoleReducer ? kL3Split : kL3Steps;
+    constexpr bool XT = ROLE == kRoleHelper;
+#endif
+    gemm_pass<2, NX, 1, -1, kL3Steps, XS0, XS1, XT, 128 * 60, RCED_D3>(
+        b30, (2 * q0 - 4) * 30 + 2 * kq, (2 * qx - 4) * 30 + 2 * kq, tailoff, w, lane, acc);
+  }
+  if constexpr (ROLE == kRoleHelper) {   // publish the partial sums of pair tile 16
+    *reinterpret_cast<f32x4*>(lds + kScratchOff + 4 * lane) = acc[2][0];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) *reinterpret_cast<volatile unsigned*>(lds + kFlagOff) = tag;
+  }
+  if constexpr (ROLE == kRoleReducer) {  // collect them (bounded spin: both waves are resident)
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(lds + kFlagOff);
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      if (__builtin_amdgcn_readfirstlane(*flag) == tag) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    acc[2][0] += *reinterpret_cast<const f32x4*>(lds + kScratchOff + 4 * lane);
+  }
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  for (int t = 0; t < NEPI; ++t) {
     const int q = (t < 2) ? q0 + 128 * t : qx;
     const int px = 2 * q + (kq >> 1);   // this lane's output pixel (phase = kq >> 1)
     f32x4 v = relu4(acc[t][0]);
@@ -482,6 +579,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   // packet of the very first layer into region 0; input rows of the first tile into registers
   packet_dma<kW1>(P.wpack, WREG(0), wave, lane);
   int wcur = 0;
+  unsigned epoch = 0;   // layer-3 instances so far (tags the K-split hand-off)
   XStage xst = xstage_load(P, blockIdx.x, tid);
 #if RCED_STAMPS
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -509,8 +607,8 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
     for (int blk = 0; blk < 5; ++blk) {
       {  // ---- layer 1: (8x9, 1->18) for block 0, (1x9, 8->18) otherwise
         STAMP_BEGIN();
-        packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
-        const float* w = WREG(wcur);
+        if (!RCED_EXP_WGLOBAL) packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
+        const float* w = RCED_EXP_WGLOBAL ? wsrc : WREG(wcur);
         if (wave < 2) layer1<4, 1, 0>(lds, w, blk == 0, wave, lane, xm, 0, 0);
         else if (wave < 4) layer1<4, 0, 0>(lds, w, blk == 0, wave, lane, 0, 0, 0);
         else if (wave < 7) layer1<4, 0, 1>(lds, w, blk == 0, wave, lane, 0, xr0, 0);
@@ -527,10 +625,11 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
       }
       {  // ---- layer 2: (1x5, 18->30)
         STAMP_BEGIN();
-        packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane);
-        const float* w = WREG(wcur);
-        if (wave == 2) layer2<1>(lds, w, wave, lane, 32);
-        else layer2<0>(lds, w, wave, lane, 0);
+        if (!RCED_EXP_WGLOBAL) packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane);
+        const float* w = RCED_EXP_WGLOBAL ? wsrc + kW1 : WREG(wcur);
+        if (wave == 2) layer2<0>(lds, w, wave, lane);
+        else if (wave == 3) layer2<1>(lds, w, wave, lane);
+        else layer2<-1>(lds, w, wave, lane);
         wcur ^= 1;
         STAMP_MATH(1);
         layer_end_sync();
@@ -539,11 +638,14 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
       {  // ---- layer 3: (1x9, 30->8) on pixel pairs; block skips; hand-off
         STAMP_BEGIN();
         // next packet: layer 1 of the next block, or of block 0 of the next tile (the stream wraps)
-        packet_dma<kW1>(blk == 4 ? P.wpack : wsrc + kWBlock, WREG(wcur ^ 1), wave, lane);
+        if (!RCED_EXP_WGLOBAL) packet_dma<kW1>(blk == 4 ? P.wpack : wsrc + kWBlock, WREG(wcur ^ 1), wave, lane);
         if (blk == 4) xst = xstage_load(P, tile + gridDim.x, tid);   // next tile's input rows
-        const float* w = WREG(wcur);
-        if (wave == 3) layer3<1>(P, lds, w, blk, wave, lane, 16, utt, t0, skip_ce1, skip_ce2);
-        else layer3<0>(P, lds, w, blk, wave, lane, 0, utt, t0, skip_ce1, skip_ce2);
+        const float* w = RCED_EXP_WGLOBAL ? wsrc + kW1 + kW2 : WREG(wcur);
+        ++epoch;
+        const unsigned tag = 0x80000000u | epoch;   // sign bit set: never the bits of a ReLU output
+        if (wave == 0) layer3<kRoleReducer>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        else if (wave == 1) layer3<kRoleHelper>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        else layer3<kRolePlain>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
         wcur ^= 1;
         STAMP_MATH(2);
         layer_end_sync();

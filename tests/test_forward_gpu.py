@@ -147,6 +147,23 @@ def test_full_size_config3_sampled_against_oracle(built):
     assert torch.equal(m(x[100:104].contiguous()), y[100:104])
 
 
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_repeated_launches_are_bit_identical(net_work, tag, variant, built):
+    """Race screen: the fused kernels hand tiles between waves (K-split hand-off, LDS-DMA packets,
+    hand-placed pipelines); a hazard shows up as run-to-run differences long before it shows up as a
+    tolerance failure.  Many small launches (1 tile per workgroup) and a few large ones."""
+    w = rced_np.make_weights(net_work, seed=21)
+    m = make_model(variant, w)
+    for shape, reps in (((1, 40), 12), ((3, 7), 6), ((64, 128), 3)):
+        x = rced_np.make_input(*shape, seed=sum(shape))
+        ref = rced_c.forward(net_work, w, x, np.float64) if shape[0] * shape[1] <= 64 else None
+        y0 = m(x)
+        if ref is not None:
+            assert rel_err(y0, ref) < RTOL
+        for _ in range(reps):
+            assert np.array_equal(m(x), y0)
+
+
 def test_single_op_conv_bn_relu_known_answers(built):
     """rced_conv_bn_relu against the analytic cases of test_oracle.py, and against the oracle op."""
     import torch
