@@ -153,7 +153,7 @@ int fused_create(rced_model* m) {
     if (e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(LDS %d): %s", v3::kLdsBytes, hipGetErrorString(e));
   }
 #if RCED_STAMPS
-  if (!rc && hipMalloc(&f->stamps, 8 * 8 * sizeof(unsigned long long)) != hipSuccess) f->stamps = nullptr;
+  if (!rc && hipMalloc(&f->stamps, (64 + 24) * sizeof(unsigned long long)) != hipSuccess) f->stamps = nullptr;
 #endif
   m->fused = f;
   if (rc) {
@@ -230,10 +230,10 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
   if (!m->fused) return RCED_ERR_ARG;
 #if RCED_STAMPS
   if (!strncmp(key, "stamp", 5) && m->fused->stamps) {  // "stampNN": kilo-cycles, NN = wave*8 + slot
-    unsigned long long h[64];
+    unsigned long long h[88];
     if (hipMemcpy(h, m->fused->stamps, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return RCED_ERR_HIP;
     const int i = atoi(key + 5);
-    if (i < 0 || i >= 64) return RCED_ERR_ARG;
+    if (i < 0 || i >= 88) return RCED_ERR_ARG;
     *value = (int)(h[i] / 1000);
     return RCED_OK;
   }

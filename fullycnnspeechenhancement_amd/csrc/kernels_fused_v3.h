@@ -354,16 +354,23 @@ __device__ __forceinline__ bool px_valid(int px) {   // a real frequency bin (no
   return px < kNPX && (px - fr * kS) < kF;
 }
 
+// Wave-uniform: does the pixel span [p0, p0+len) contain a gap pixel or run past the tile?  Only 3 of
+// the 33 sixteen-pixel tiles and 4 of the 17 pair tiles do, so the masking VALU is behind a scalar branch.
+__device__ __forceinline__ bool span_has_gap(int p0, int len) {
+  const int fr = p0 / kS;
+  return p0 + len > kNPX || (p0 - fr * kS) + len > kF;
+}
+
 // Epilogue of a P = 1 pass for one slot (rows = 16*mt + 4*kq + j output channels, column = pixel):
 // ReLU, zero the gap pixels, store [pixel][COUT] with 8-byte stores.
 template <int MT, int COUT>
-__device__ __forceinline__ void store_p1(float* out, const f32x4 (&acc)[MT], int px, int kq) {
-  const bool ok = px_valid(px);
+__device__ __forceinline__ void store_p1(float* out, const f32x4 (&acc)[MT], int px, int kq, bool gap) {
+  const bool ok = gap ? px_valid(px) : true;   // `gap` is wave-uniform
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int co0 = 16 * mt + 4 * kq;
     f32x4 v = relu4(acc[mt]);
-    if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (gap && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
     float* p = out + px * COUT + co0;
     if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
     if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
@@ -373,10 +380,8 @@ __device__ __forceinline__ void store_p1(float* out, const f32x4 (&acc)[MT], int
 // One M-tile of the same (used where a tile's two M-tiles belong to different waves).
 template <int COUT>
 __device__ __forceinline__ void store_p1_mt(float* out, f32x4 acc, int px, int kq, int mt) {
-  const bool ok = px_valid(px);
-  const int co0 = 16 * mt + 4 * kq;
+  const int co0 = 16 * mt + 4 * kq;   // only used for tile 32 (pixels 512..527): no gap inside
   f32x4 v = relu4(acc);
-  if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
   float* p = out + px * COUT + co0;
   if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
   if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
@@ -384,11 +389,11 @@ __device__ __forceinline__ void store_p1_mt(float* out, f32x4 acc, int px, int k
 
 // Epilogue of the layer-1 remainder pass: rows 4*kq+j = (phase 2*kq + (j>>1), channel 16 + (j&1)),
 // column = pixel octet.  Two 8-byte stores per lane: channels 16,17 of two adjacent pixels.
-__device__ __forceinline__ void store_rem(float* b18, f32x4 acc, int px0, int kq) {
+__device__ __forceinline__ void store_rem(float* b18, f32x4 acc, int px0, int kq, bool gap) {
   const f32x4 v = relu4(acc);
   const int pa = px0 + 2 * kq;
-  if (px_valid(pa)) *reinterpret_cast<f32x2*>(b18 + pa * 18 + 16) = f32x2{v.x, v.y};
-  if (px_valid(pa + 1)) *reinterpret_cast<f32x2*>(b18 + (pa + 1) * 18 + 16) = f32x2{v.z, v.w};
+  if (!gap || px_valid(pa)) *reinterpret_cast<f32x2*>(b18 + pa * 18 + 16) = f32x2{v.x, v.y};
+  if (!gap || px_valid(pa + 1)) *reinterpret_cast<f32x2*>(b18 + (pa + 1) * 18 + 16) = f32x2{v.z, v.w};
 }
 
 // The 11 input rows of a tile (frames t0-3 .. t0+7 of one utterance): 3 floats per thread, loaded one
@@ -458,13 +463,18 @@ __device__ __forceinline__ void layer1(float* lds, const float* w, bool first, i
     }
   }
 #pragma unroll
-  for (int t = 0; t < NMR; ++t) store_p1<1, 18>(b18, accm[t], px0 + 128 * t, kq);
-  if constexpr (NMX > 0) store_p1<1, 18>(b18, accm[NMR], pxx, kq);
+  for (int t = 0; t < NMR; ++t) store_p1<1, 18>(b18, accm[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
+  if constexpr (NMX > 0) store_p1<1, 18>(b18, accm[NMR], pxx, kq, span_has_gap(16 * xm, 16));
   if constexpr (NR > 0) {
 #pragma unroll
-    for (int t = 0; t < NR; ++t) store_rem(b18, accr[t][0] + accr[t][1], pxr[t], kq);
+    for (int t = 0; t < NR; ++t)
+      store_rem(b18, accr[t][0] + accr[t][1], pxr[t], kq, span_has_gap(128 * (t == 0 ? xr0 : xr1), 128));
   }
 }
+
+#if RCED_STAMPS
+__device__ unsigned long long g_fine[8][4];   // [wave][prologue, gemm, epilogue, -] of layer 2, workgroup 0
+#endif
 
 // Layer 2.  XMT < 0: four regular tiles.  XMT = 0/1: plus M-tile XMT of tile 32 (its two M-tiles go
 // to two waves on different SIMDs).
@@ -474,6 +484,9 @@ __device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int
   const int n = lane & 15, kq = lane >> 4;
   const float* b18 = lds + kB18Off + kB18Pad * 18;
   float* b30 = lds + kB30Off + kB30Pad * 30;
+#if RCED_STAMPS
+  const unsigned long long f0 = stamp();
+#endif
   const int px0 = 16 * wave + n, pxx = 16 * 32 + n;
   f32x4 acc[NT][2];
   f32x4 sh[2];
@@ -482,12 +495,26 @@ __device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = sh[0]; acc[t][1] = sh[1]; }
   const int tailoff = (kq < 1 ? kq : 1) - 2 * kq;   // K = 90: tail k = 88 + kq is real for kq < 2
+#if RCED_STAMPS
+  const unsigned long long f1 = stamp();
+#endif
   if (!(RCED_EXP_SKIP & 2))
     gemm_pass<4, NX, 2, XMT, kL2Steps, 0, kL2Steps, true, 128 * 18, RCED_D2>(
         b18, (px0 - 2) * 18 + 2 * kq, (pxx - 2) * 18 + 2 * kq, tailoff, w, lane, acc);
+#if RCED_STAMPS
+  const unsigned long long f2 = stamp();
+#endif
 #pragma unroll
-  for (int t = 0; t < 4; ++t) store_p1<2, 30>(b30, acc[t], px0 + 128 * t, kq);
+  for (int t = 0; t < 4; ++t) store_p1<2, 30>(b30, acc[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
   if constexpr (NX > 0) store_p1_mt<30>(b30, acc[4][XMT], pxx, kq, XMT);
+#if RCED_STAMPS
+  const unsigned long long f3 = stamp();
+  if (blockIdx.x == 0 && lane == 0) {
+    g_fine[wave][0] += f1 - f0;
+    g_fine[wave][1] += f2 - f1;
+    g_fine[wave][2] += f3 - f2;
+  }
+#endif
 }
 
 // Layer 3 roles: every wave has two regular pair tiles; pair tile 16 is split ALONG K between a
@@ -548,13 +575,14 @@ __device__ __forceinline__ void layer3(const Params& P, float* lds, const float*
     f32x4 v = relu4(acc[t][0]);
     if (blk == 3) v += skip_ce2[t];   // CD1 + CE2 (model.py:87, 75-76: after the ReLU)
     if (blk == 4) v += skip_ce1[t];   // CD2 + CE1 (model.py:88)
+    const bool gap = span_has_gap(32 * (t < 2 ? wave + 8 * t : 16), 32);   // wave-uniform
     const int fr = px / kS, f = px - fr * kS;
-    const bool ok = px < kNPX && f < kF;
-    if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool ok = gap ? (px < kNPX && f < kF) : true;
+    if (gap && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
     skip_ce1[t] = (blk == 0) ? v : skip_ce1[t];
     skip_ce2[t] = (blk == 1) ? v : skip_ce2[t];
     if (blk < 4) {
-      if (px >= kNPX) continue;   // rows past the tile are not allocated
+      if (gap && px >= kNPX) continue;   // rows past the tile are not allocated
       float* bp = b8 + px * kB8S + 4 * (kq & 1);   // 8-byte aligned (stride 10): two b64 stores
       *reinterpret_cast<f32x2*>(bp) = f32x2{v.x, v.y};
       *reinterpret_cast<f32x2*>(bp + 2) = f32x2{v.z, v.w};
@@ -658,6 +686,8 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
 #if RCED_STAMPS
   if (P.stamps && blockIdx.x == 0 && lane == 0)
     for (int i = 0; i < 8; ++i) P.stamps[wave * 8 + i] = tsum[i];
+  if (P.stamps && blockIdx.x == 0 && lane == 0)
+    for (int i = 0; i < 3; ++i) P.stamps[64 + wave * 3 + i] = g_fine[wave][i];
 #endif
 }
 

@@ -10,10 +10,13 @@ from fullycnnspeechenhancement_amd import build_model
 from oracle import rced_np
 m = build_model("FullyCNNV3", False, weights=rced_np.make_weights("FullyCNNV3"))
 x = torch.randn((256, 512, 129, 1), device="cuda").abs_()
-for _ in range(2):
-    y = m(x)
+y = m(x)
 torch.cuda.synchronize()
 print("wave   L1math  L2math  L3math | L1wait  L2wait  L3wait | L1first math/wait   (kilo-cycles)")
 for w in range(8):
     v = [m.get_option("stamp%d" % (w * 8 + i)) for i in range(8)]
     print("%4d  %7d %7d %7d | %7d %7d %7d | %7d %7d   total %d" % (w, *v, sum(v)))
+print("layer 2 fine (kilo-cycles): wave  prologue  gemm  epilogue")
+for w in range(8):
+    v = [m.get_option("stamp%d" % (64 + w * 3 + i)) for i in range(3)]
+    print("%4d %8d %8d %8d" % (w, *v))
