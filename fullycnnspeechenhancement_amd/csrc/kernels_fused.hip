@@ -8,13 +8,16 @@
 #include <vector>
 
 #include "../../include/rced.h"
+#include "kernels_fused_chain.h"
 #include "kernels_fused_v3.h"
 #include "rced_internal.h"
 
 using namespace rced;
 
 struct rced_fused {
-  float* wpack = nullptr;     // v3::kWTotal
+  float* scratch = nullptr;   // V1/V2: skip fragments, per workgroup
+  size_t scratch_bytes = 0;
+  float* wpack = nullptr;     // packed A-fragment stream
   float* fin_apack = nullptr; // v3::kFinPack
   float fin_bias = 0.f;
   float* h = nullptr;         // [frames, 129, 8] hand-off to the final layer
@@ -131,6 +134,106 @@ void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>*
   *fin_bias = lf.host_shift[0];
 }
 
+int upload(float** dev, const std::vector<float>& host);
+
+// ---- R-CED V1 / V2 (kernels_fused_chain.h) ---------------------------------------------------
+template <class N>
+void pack_chain(const rced_model* m, std::vector<float>* wpack, std::vector<float>* fin, float* fin_bias) {
+  using G = chain::Geo<N>;
+  wpack->assign(G::kWTotal, 0.f);
+  float* dst = wpack->data();
+  for (int l = 0; l < N::kLayers; ++l) {
+    const rced_layer_dev& L = m->layers[l];
+    const chain::LayerDesc d = N::layer[l];
+    const int MT = G::MT(l);
+    if (l == 0) {  // 8 x taps x 1: [s = ih*taps + j][lane]; lane = (row i = co, kq), time tap = 4*ih + kq
+      for (int s = 0; s < 2 * d.taps; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, ih = s / d.taps, j = s % d.taps, ti = 4 * ih + kq;
+          dst[s * 64 + lane] = i < d.cout ? wq(L, ti * d.taps + j, 0, i, 1) : 0.f;
+        }
+    } else {
+      const int K = G::K(l), NB = G::NB64(l), NTL = G::NTAIL(l);
+      auto wv = [&](int i, int mt, int k) {
+        const int co = 16 * mt + i, tap = k / d.cinp, ci = k % d.cinp;
+        return (k < K && co < d.cout && ci < d.cin) ? wq(L, tap, ci, co, d.cin) : 0.f;
+      };
+      for (int s = 0; s < NB; ++s)
+        for (int mt = 0; mt < MT; ++mt)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 2; ++e)
+              dst[(s * MT + mt) * 128 + lane * 2 + e] = wv(lane & 15, mt, 8 * s + 2 * (lane >> 4) + e);
+      for (int j = 0; j < NTL; ++j)
+        for (int mt = 0; mt < MT; ++mt)
+          for (int lane = 0; lane < 64; ++lane)
+            dst[NB * MT * 128 + (j * MT + mt) * 64 + lane] = wv(lane & 15, mt, 8 * NB + 4 * j + (lane >> 4));
+    }
+    for (int c = 0; c < d.cout; ++c) dst[G::data(l) + c] = L.host_shift[c];
+    dst += G::packet(l);
+  }
+  // final 1x129 layer, CH -> 1, Toeplitz A-fragments: [s][m][lane][e] then tail [m][lane]
+  constexpr int CH = N::kFinalCh;
+  using FG = chain::FinalGeo<CH>;
+  const rced_layer_dev& lf = m->layers[N::kLayers];
+  fin->assign(FG::kPack, 0.f);
+  auto fv = [&](int i, int mt, int k) {
+    const int f = 16 * mt + i, fp = k / CH, ci = k % CH, tap = fp - f + 64;
+    return (k < FG::kK && f < 129 && tap >= 0 && tap < 129) ? wq(lf, tap, ci, 0, CH) : 0.f;
+  };
+  for (int s = 0; s < FG::kNB64; ++s)
+    for (int mt = 0; mt < FG::kMT; ++mt)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 2; ++e)
+          (*fin)[((size_t)s * FG::kMT + mt) * 128 + lane * 2 + e] = fv(lane & 15, mt, 8 * s + 2 * (lane >> 4) + e);
+  for (int mt = 0; mt < FG::kMT; ++mt)
+    for (int lane = 0; lane < 64; ++lane)
+      (*fin)[(size_t)FG::kNB64 * FG::kMT * 128 + mt * 64 + lane] = fv(lane & 15, mt, 8 * FG::kNB64 + (lane >> 4));
+  *fin_bias = lf.host_shift[0];
+}
+
+template <class N>
+int chain_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
+  using G = chain::Geo<N>;
+  chain::Params P;
+  P.x = x;
+  P.h = f->h;
+  P.wpack = f->wpack;
+  P.scratch = f->scratch;
+  P.N = Nb;
+  P.T = T;
+  P.tiles_per_utt = (T + N::kTF - 1) / N::kTF;
+  P.total_tiles = Nb * P.tiles_per_utt;
+  const int cus = f->grid_limit > 0 ? std::min(f->grid_limit, m->num_cus) : m->num_cus;   // scratch is sized for #CUs
+  const int grid = std::min(P.total_tiles, cus);
+  m->prof_begin(RCED_K_FUSED, st);
+  hipLaunchKernelGGL(chain::fused_chain_kernel<N>, dim3(grid), dim3(chain::kThreads), G::kLdsBytes, st, P);
+  m->prof_end(RCED_K_FUSED, st);
+  HIP_TRY(hipGetLastError());
+  const int frames = Nb * T;
+  m->prof_begin(RCED_K_FINAL, st);
+  hipLaunchKernelGGL(chain::final_gemm_kernel<N::kFinalCh>, dim3((frames + chain::kFinFrames - 1) / chain::kFinFrames),
+                     dim3(chain::kFinThreads), 0, st, (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y,
+                     frames);
+  m->prof_end(RCED_K_FINAL, st);
+  HIP_TRY(hipGetLastError());
+  return RCED_OK;
+}
+
+template <class N>
+int chain_create(rced_model* m, rced_fused* f) {
+  using G = chain::Geo<N>;
+  std::vector<float> wpack, fin;
+  pack_chain<N>(m, &wpack, &fin, &f->fin_bias);
+  int rc = upload(&f->wpack, wpack);
+  if (!rc) rc = upload(&f->fin_apack, fin);
+  if (rc) return rc;
+  f->scratch_bytes = (size_t)m->num_cus * G::kScratchFloatsPerWg * sizeof(float);
+  HIP_TRY(hipMalloc(&f->scratch, f->scratch_bytes));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain::fused_chain_kernel<N>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+  return RCED_OK;
+}
+
 int upload(float** dev, const std::vector<float>& host) {
   HIP_TRY(hipMalloc(dev, host.size() * sizeof(float)));
   HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -141,8 +244,13 @@ int upload(float** dev, const std::vector<float>& host) {
 
 int fused_create(rced_model* m) {
   m->fused = nullptr;
-  if (m->variant != RCED_V3) return RCED_OK;  // V1 / V2 run layerwise for now
   rced_fused* f = new rced_fused();
+  if (m->variant != RCED_V3) {
+    m->fused = f;
+    const int rc = m->variant == RCED_V1 ? chain_create<chain::NetV1>(m, f) : chain_create<chain::NetV2>(m, f);
+    if (rc) fused_destroy(m);
+    return rc;
+  }
   std::vector<float> wpack, fin;
   pack_v3(m, &wpack, &fin, &f->fin_bias);
   int rc = upload(&f->wpack, wpack);
@@ -169,13 +277,15 @@ void fused_destroy(rced_model* m) {
   if (f->wpack) (void)hipFree(f->wpack);
   if (f->fin_apack) (void)hipFree(f->fin_apack);
   if (f->h) (void)hipFree(f->h);
+  if (f->scratch) (void)hipFree(f->scratch);
   delete f;
   m->fused = nullptr;
 }
 
 int fused_reserve(rced_model* m, int N, int T) {
   rced_fused* f = m->fused;
-  const size_t need = (size_t)N * T * v3::kF * v3::kHCh * sizeof(float);
+  const int ch = m->variant == RCED_V3 ? v3::kHCh : (m->variant == RCED_V1 ? chain::NetV1::kFinalCh : chain::NetV2::kFinalCh);
+  const size_t need = (size_t)N * T * v3::kF * ch * sizeof(float);
   if (need <= f->h_bytes) return RCED_OK;
   if (f->h) {
     HIP_TRY(hipDeviceSynchronize());
@@ -191,6 +301,8 @@ int fused_reserve(rced_model* m, int N, int T) {
 int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStream_t st) {
   rced_fused* f = m->fused;
   if (int rc = fused_reserve(m, N, T)) return rc;
+  if (m->variant == RCED_V1) return chain_forward<chain::NetV1>(m, f, x, y, N, T, st);
+  if (m->variant == RCED_V2) return chain_forward<chain::NetV2>(m, f, x, y, N, T, st);
   v3::Params P;
   P.x = x;
   P.h = f->h;

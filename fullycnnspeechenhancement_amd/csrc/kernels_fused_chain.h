@@ -1,0 +1,502 @@
+// Fused R-CED (V1: model_utils/model.py:6-29, V2: model.py:32-61) forward: every layer but the last
+// 1x129 one in ONE kernel, fp32 MFMA; generic over a compile-time layer table.
+//
+// Same construction as the CR-CED kernel (kernels_fused_v3.h, which carries the long explanation):
+// a tile of frames lives in LDS as [pixel][channel] with the channel stride equal to the (even-padded)
+// channel count, a 1xk conv is an implicit GEMM whose B operand is a ds_read_b64 out of that buffer,
+// cout sits on the 16-row MFMA M axis, weights arrive as pre-packed A-fragment packets by LDS-DMA
+// one layer ahead.  Differences:
+//   * the nets are plain encoder/decoder chains, so activations ping-pong between two buffers;
+//   * module.py:30-31 skips (decoder layer += encoder output, BEFORE the ReLU) are too many to hold in
+//     registers (V2: 114 channels), so an encoder layer that feeds a skip also stores its output
+//     fragments, in MFMA D-layout order, to a per-workgroup scratch in global memory (L2/MALL
+//     resident, fully coalesced 1 KiB per wave-store); the matching decoder layer has the same cout,
+//     hence the same tile -> wave map and fragment layout, and simply loads them back (issued at the
+//     start of the layer, consumed in its epilogue).  A wave only ever re-reads its own stores.
+//   * no pixel-phase tricks (cout 10..32 fills one or two M-tiles reasonably).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rced {
+namespace chain {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kF = 129;
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kMaxLayers = 15;
+
+struct LayerDesc {
+  int cin, cinp;    // true / even-padded input channels (cinp = channel stride of the input buffer)
+  int taps;         // kernel width along frequency
+  int cout, coutp;  // true / even-padded output channels
+  int skip_from;    // layer whose output is added before the ReLU, or -1
+  int saves_skip;   // 1 if a later layer adds this layer's output
+};
+
+constexpr int even(int c) { return (c + 1) & ~1; }
+
+// ---- the two nets (first layer: 8 x taps kernel on the 1-channel input) ------------------------
+struct NetV1 {
+  static constexpr int kVariant = 1;
+  static constexpr int kLayers = 9;          // decode_5 (1x129) is the separate final GEMM
+  static constexpr int kTF = 3;              // frames per tile
+  static constexpr int kGap = 6;             // >= half width of the widest kernel (13)
+  static constexpr int kFinalCh = 12;
+  static constexpr LayerDesc layer[kMaxLayers] = {
+      {1, 1, 13, 12, 12, -1, 1},  {12, 12, 11, 16, 16, -1, 1}, {16, 16, 9, 20, 20, -1, 1},
+      {20, 20, 7, 24, 24, -1, 1}, {24, 24, 7, 32, 32, -1, 0},  {32, 32, 7, 24, 24, 3, 0},
+      {24, 24, 9, 20, 20, 2, 0},  {20, 20, 11, 16, 16, 1, 0},  {16, 16, 13, 12, 12, 0, 0}};
+};
+struct NetV2 {
+  static constexpr int kVariant = 2;
+  static constexpr int kLayers = 15;         // decode_8 (1x129) is the separate final GEMM
+  static constexpr int kTF = 3;
+  static constexpr int kGap = 5;             // widest kernel 11
+  static constexpr int kFinalCh = 10;
+  static constexpr LayerDesc layer[kMaxLayers] = {
+      {1, 1, 11, 10, 10, -1, 1},   {10, 10, 7, 12, 12, -1, 1},  {12, 12, 5, 14, 14, -1, 1},
+      {14, 14, 5, 15, 16, -1, 1},  {15, 16, 5, 19, 20, -1, 1},  {19, 20, 5, 21, 22, -1, 1},
+      {21, 22, 7, 23, 24, -1, 1},  {23, 24, 11, 25, 26, -1, 0}, {25, 26, 7, 23, 24, 6, 0},
+      {23, 24, 5, 21, 22, 5, 0},   {21, 22, 5, 19, 20, 4, 0},   {19, 20, 5, 15, 16, 3, 0},
+      {15, 16, 5, 14, 14, 2, 0},   {14, 14, 7, 12, 12, 1, 0},   {12, 12, 11, 10, 10, 0, 0}};
+};
+
+// ---- derived geometry ------------------------------------------------------------------------
+template <class N>
+struct Geo {
+  static constexpr int kS = kF + N::kGap;                 // pixel stride of a frame
+  static constexpr int kNPX = N::kTF * kS;                // pixels per tile
+  static constexpr int kTiles = (kNPX + 15) / 16;         // every pixel of the tile is (re)written each layer
+  static constexpr int kRegular = kTiles / kWaves;        // slots every wave has
+  static constexpr int kExtra = kTiles - kRegular * kWaves;   // waves 0..kExtra-1 have one more
+  static_assert(kExtra <= 4, "extra tiles go to waves 0..3 (one per SIMD)");
+  static constexpr int kPad = N::kGap;                    // leading zero rows of each buffer
+  static constexpr int kRows = kPad + 16 * kTiles;        // pixels -pad .. 16*tiles-1 (reads past land in the next buffer)
+  static_assert(kPad == (N::layer[0].taps - 1) / 2, "X0 indexing assumes pad == half width of the first kernel");
+  static constexpr int chmax(int parity) {
+    int m = 0;
+    for (int l = parity; l < N::kLayers; l += 2) m = N::layer[l].coutp > m ? N::layer[l].coutp : m;
+    return m;
+  }
+  static constexpr int kChX = chmax(0), kChY = chmax(1);  // buffer X holds outputs of even layers
+  static constexpr int kXOff = 0;
+  static constexpr int kYOff = kXOff + kRows * kChX;
+  static constexpr int kWOff = ((kYOff + kRows * kChY + 3) / 4) * 4;
+  // packet of layer l (floats): b64 steps, b32 tails, 32 shifts
+  static constexpr int K(int l) { return (l == 0 ? 8 : 1) * N::layer[l].taps * N::layer[l].cinp; }
+  static constexpr int MT(int l) { return (N::layer[l].cout + 15) / 16; }
+  static constexpr int NB64(int l) { return l == 0 ? 0 : K(l) / 8; }
+  static constexpr int NTAIL(int l) { return l == 0 ? 2 * N::layer[0].taps : (K(l) % 8 + 3) / 4; }   // b32 steps
+  static constexpr int data(int l) { return NB64(l) * MT(l) * 128 + NTAIL(l) * MT(l) * 64; }
+  static constexpr int packet(int l) { return data(l) + 32; }
+  static constexpr int packet_off(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += packet(i);
+    return o;
+  }
+  static constexpr int kWTotal = packet_off(N::kLayers);
+  static constexpr int maxpacket() {
+    int m = 0;
+    for (int l = 0; l < N::kLayers; ++l) m = packet(l) > m ? packet(l) : m;
+    return m;
+  }
+  static constexpr int kWRegion = ((maxpacket() + 3) / 4) * 4;
+  static constexpr int kLdsFloats = kWOff + 2 * kWRegion;
+  static constexpr int kLdsBytes = kLdsFloats * 4;
+  static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+  // input rows of the first layer alias buffer Y (dead until layer 1 writes it)
+  static constexpr int kX0Rows = N::kTF + 7;
+  static constexpr int kX0Floats = ((kX0Rows * kS + 32 + 3) / 4) * 4;
+  static constexpr int kX0Off = kYOff + kPad * kChY;
+  static_assert(kX0Floats <= 4 * kThreads, "XStage holds 4 floats per thread");
+  static_assert(kX0Floats <= kRows * kChY - kPad * kChY, "X0 fits in buffer Y");
+  // skip scratch: units = (layer that saves, slot, mt), each kThreads x float4
+  static constexpr int skip_unit(int l) {   // first unit index of saving layer l
+    int u = 0;
+    for (int i = 0; i < l; ++i)
+      if (N::layer[i].saves_skip) u += (kRegular + 1) * MT(i);
+    return u;
+  }
+  static constexpr int kSkipUnits = skip_unit(N::kLayers);
+  static constexpr size_t kScratchFloatsPerWg = (size_t)kSkipUnits * kThreads * 4;
+};
+
+struct Params {
+  const float* x;       // [N, T, 129]
+  float* h;             // [N*T, 129, kFinalCh]: input of the final 1x129 layer
+  const float* wpack;   // Geo::kWTotal floats
+  float* scratch;       // gridDim.x * Geo::kScratchFloatsPerWg floats (skip fragments)
+  int N, T;
+  int tiles_per_utt;
+  int total_tiles;
+};
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ float relu1(float v) {   // integer max: see kernels_fused_v3.h relu1
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
+
+template <int NFLOATS>
+__device__ __forceinline__ void packet_dma(const float* __restrict__ src, float* dst, int wave, int lane) {
+  constexpr int n4 = NFLOATS / 4;
+  constexpr int chunks = (n4 + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < (chunks + kWaves - 1) / kWaves; ++i) {
+    const int c = wave + i * kWaves;
+    if (c < chunks) {
+      const int idx = c * 64 + lane;
+      if (idx < n4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)idx * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
+    }
+  }
+}
+__device__ __forceinline__ void layer_end_sync() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// Implicit-GEMM pass: NB64 b64 steps (k = 8s + 2kq + e) then NTAIL b32 steps (k = 8*NB64 + 4j + kq),
+// NT = NR regular slots (offsets off0 + t*STRIDE) + NX extra slot (offx), every M-tile.
+// Lanes whose tail k is past K re-read in-window data (their weights are zero).
+template <int NR, int NX, int MT, int K, int STRIDE, int DEPTH>
+__device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, const float* w, int lane,
+                                          f32x4 (&acc)[NR + NX][MT]) {
+  constexpr int NT = NR + NX, RING = DEPTH + 1;
+  constexpr int NB64 = K / 8, NTAIL = (K % 8 + 3) / 4;
+  const int kq = lane >> 4;
+  const f32x2* wp = reinterpret_cast<const f32x2*>(w) + lane;
+  const float* wt = w + NB64 * MT * 128 + lane;
+  f32x2 a[RING][MT], b[RING][NT];
+  float at[NTAIL == 0 ? 1 : NTAIL][MT], bt[NTAIL == 0 ? 1 : NTAIL][NT];
+#pragma unroll
+  for (int j = 0; j < NTAIL; ++j) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int valid = K - 8 * NB64 - 4 * j;                  // real k in this tail step (1..4, or more)
+    const int kqe = valid >= 4 ? kq : (kq < valid ? kq : valid - 1);
+    const int d = 8 * NB64 + 4 * j + kqe - 2 * kq;            // off0 already carries + 2*kq
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) at[j][mt] = wt[(j * MT + mt) * 64];
+#pragma unroll
+    for (int t = 0; t < NR; ++t) bt[j][t] = act[off0 + t * STRIDE + d];
+    if constexpr (NX > 0) bt[j][NR] = act[offx + d];
+  }
+  auto load = [&](int s, f32x2(&as)[MT], f32x2(&bs)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) as[mt] = wp[(s * MT + mt) * 64];
+#pragma unroll
+    for (int t = 0; t < NR; ++t) bs[t] = *reinterpret_cast<const f32x2*>(act + off0 + t * STRIDE + 8 * s);
+    if constexpr (NX > 0) bs[NR] = *reinterpret_cast<const f32x2*>(act + offx + 8 * s);
+  };
+#pragma unroll
+  for (int s = 0; s < DEPTH && s < NB64; ++s) load(s, a[s % RING], b[s % RING]);
+#pragma unroll
+  for (int s = 0; s < NB64; ++s) {
+    if (s + DEPTH < NB64) load(s + DEPTH, a[(s + DEPTH) % RING], b[(s + DEPTH) % RING]);
+    pin();
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(a[s % RING][mt][e], b[s % RING][t][e], acc[t][mt]);
+    pin();
+  }
+#pragma unroll
+  for (int j = 0; j < NTAIL; ++j)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(at[j][mt], bt[j][t], acc[t][mt]);
+}
+
+// First layer: 8 x TAPS kernel on the 1-channel input, b32 steps; step s = ih*TAPS + j, lane kq <->
+// time tap 4*ih + kq.  x0 index of (input row r, bin f') is PADL + r*S + f'  =>  pixel + ti*S + j.
+template <int NR, int NX, int TAPS, int S, int DEPTH>
+__device__ __forceinline__ void first_pass(const float* x0, int off0, int offx, const float* w, int lane,
+                                           f32x4 (&acc)[NR + NX][1]) {
+  constexpr int NT = NR + NX, RING = DEPTH + 1, STEPS = 2 * TAPS;
+  const float* wp = w + lane;
+  float a[RING], b[RING][NT];
+  auto load = [&](int s, int buf) {
+    a[buf] = wp[s * 64];
+    const int d = (s / TAPS) * 4 * S + (s % TAPS);
+#pragma unroll
+    for (int t = 0; t < NR; ++t) b[buf][t] = x0[off0 + t * 128 + d];
+    if constexpr (NX > 0) b[buf][NR] = x0[offx + d];
+  };
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s) load(s, s % RING);
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    if (s + DEPTH < STEPS) load(s + DEPTH, (s + DEPTH) % RING);
+    pin();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][0] = mfma(a[s % RING], b[s % RING][t], acc[t][0]);
+    pin();
+  }
+}
+
+template <class N>
+__device__ __forceinline__ bool px_valid(int px) {
+  using G = Geo<N>;
+  const int fr = px / G::kS;
+  return px < G::kNPX && (px - fr * G::kS) < kF;
+}
+template <class N>
+__device__ __forceinline__ bool span_has_gap(int p0, int len) {   // wave-uniform arguments
+  using G = Geo<N>;
+  const int fr = p0 / G::kS;
+  return p0 + len > G::kNPX || (p0 - fr * G::kS) + len > kF;
+}
+
+struct XStage {
+  float v0, v1, v2, v3;
+};
+template <class N>
+__device__ __forceinline__ float xstage_one(const Params& P, bool live, const float* xu, int t0, int e) {
+  using G = Geo<N>;
+  const int q = e - G::kPad;
+  const int r = q >= 0 ? q / G::kS : -1;
+  const int f = q - r * G::kS;
+  const int tt = t0 + r - 3;
+  float v = 0.f;
+  if (live && e < G::kX0Floats && q >= 0 && r < G::kX0Rows && f < kF && tt >= 0 && tt < P.T)
+    v = xu[(size_t)tt * kF + f];
+  return v;
+}
+template <class N>
+__device__ __forceinline__ XStage xstage_load(const Params& P, int tile, int tid) {
+  const bool live = tile < P.total_tiles;
+  const int utt = live ? tile / P.tiles_per_utt : 0;
+  const int t0 = live ? (tile - utt * P.tiles_per_utt) * N::kTF : 0;
+  const float* xu = P.x + (size_t)utt * P.T * kF;
+  XStage st;
+  st.v0 = xstage_one<N>(P, live, xu, t0, tid);
+  st.v1 = xstage_one<N>(P, live, xu, t0, tid + kThreads);
+  st.v2 = xstage_one<N>(P, live, xu, t0, tid + 2 * kThreads);
+  st.v3 = xstage_one<N>(P, live, xu, t0, tid + 3 * kThreads);
+  return st;
+}
+template <class N>
+__device__ __forceinline__ void xstage_store(const XStage& st, float* x0, int tid) {
+  using G = Geo<N>;
+  x0[tid] = st.v0;
+  if (tid + kThreads < G::kX0Floats) x0[tid + kThreads] = st.v1;
+  if (tid + 2 * kThreads < G::kX0Floats) x0[tid + 2 * kThreads] = st.v2;
+  if (tid + 3 * kThreads < G::kX0Floats) x0[tid + 3 * kThreads] = st.v3;
+}
+
+// One layer for one wave.  NX = 1 for the waves that own an extra tile.
+template <class N, int L, int NX>
+__device__ __forceinline__ void run_layer(const Params& P, float* lds, const float* w, __amdgpu_buffer_rsrc_t scratch,
+                                          int wave, int lane, int tid, int utt, int t0) {
+  using G = Geo<N>;
+  constexpr LayerDesc D = N::layer[L];
+  constexpr int NR = G::kRegular, NT = NR + NX, MT = G::MT(L);
+  constexpr bool kLast = (L == N::kLayers - 1);
+  // Re-derive the lane coordinates behind an opaque barrier in EVERY layer: otherwise hipcc hoists the
+  // address arithmetic of all 9-15 layers out of the tile loop, keeps ~100 values live and spills.
+  asm volatile("" : "+v"(lane), "+v"(tid));
+  const int n = lane & 15, kq = lane >> 4;
+  float* bufx = lds + G::kXOff + G::kPad * G::kChX;
+  float* bufy = lds + G::kYOff + G::kPad * G::kChY;
+  const float* in = (L % 2 == 1) ? bufx : bufy;          // layer L reads what layer L-1 wrote
+  float* out = (L % 2 == 0) ? bufx : bufy;
+  const int xtile = G::kRegular * kWaves + wave;          // extra tile of waves 0..kExtra-1
+  const int px0 = 16 * wave + n, pxx = 16 * xtile + n;
+
+  // skip fragments of the matching encoder layer: issue the loads now, use them in the epilogue
+  f32x4 skip[D.skip_from >= 0 ? NT : 1][D.skip_from >= 0 ? MT : 1];
+  if constexpr (D.skip_from >= 0) {
+    static_assert(N::layer[D.skip_from >= 0 ? D.skip_from : 0].cout == D.cout, "skip shapes match");
+    // buffer loads: one descriptor (SGPRs) + tid*16 (one VGPR) + a scalar unit offset; plain pointers
+    // made hipcc keep a 64-bit address per unit live across the whole tile loop and spill them
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        skip[t][mt] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                       scratch, tid * 16, (G::skip_unit(D.skip_from) + t * MT + mt) * kThreads * 16, 0));
+  }
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(w + G::data(L) + 16 * mt + 4 * kq);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][mt] = sh;
+  }
+  if constexpr (L == 0) {
+    first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc);
+  } else {
+    constexpr int padl = (D.taps - 1) / 2;
+    gemm_pass<NR, NX, MT, G::K(L), 128 * D.cinp, 1>(in, (px0 - padl) * D.cinp + 2 * kq,
+                                                    (pxx - padl) * D.cinp + 2 * kq, w, lane, acc);
+  }
+  // ---- epilogue: (+skip) -> ReLU -> zero the gap pixels -> LDS (or the hand-off tensor)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tile = t < NR ? wave + kWaves * t : xtile;
+    const int px = t < NR ? px0 + 128 * t : pxx;
+    const bool gap = span_has_gap<N>(16 * tile, 16);
+    const bool ok = gap ? px_valid<N>(px) : true;
+    const int fr = px / G::kS, f = px - fr * G::kS;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 v = acc[t][mt];
+      if constexpr (D.skip_from >= 0) v += skip[t][mt];   // module.py:30-31: before the ReLU
+      v = relu4(v);
+      if (gap && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (D.saves_skip)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), scratch, tid * 16,
+                                               (G::skip_unit(L) + t * MT + mt) * kThreads * 16, 0);
+      const int co0 = 16 * mt + 4 * kq;
+      if constexpr (!kLast) {
+        float* p = out + px * D.coutp + co0;
+        if (co0 + 1 < D.coutp) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
+        if (co0 + 3 < D.coutp) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
+      } else if (ok && px < G::kNPX && f < kF && t0 + fr < P.T) {
+        float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * N::kFinalCh + co0;
+        if (co0 + 1 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp) = f32x2{v.x, v.y};
+        if (co0 + 3 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp + 2) = f32x2{v.z, v.w};
+      }
+    }
+  }
+}
+
+template <class N, int L>
+__device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu_buffer_rsrc_t scratch, int& wcur, XStage& xst,
+                                           int tile, int wave, int lane, int tid, int utt, int t0) {
+  using G = Geo<N>;
+  if constexpr (L < N::kLayers) {
+    float* const wbase = lds + G::kWOff;
+    // next packet: layer L+1, or layer 0 for the next tile (the stream wraps)
+    constexpr int nxt = (L + 1 < N::kLayers) ? L + 1 : 0;
+    packet_dma<G::packet(nxt)>(P.wpack + G::packet_off(nxt), wbase + (wcur ^ 1) * G::kWRegion, wave, lane);
+    if constexpr (L == N::kLayers - 1) xst = xstage_load<N>(P, tile + gridDim.x, tid);
+    const float* w = wbase + wcur * G::kWRegion;
+    if (wave < G::kExtra) run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+    else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+    wcur ^= 1;
+    layer_end_sync();
+    run_layers<N, L + 1>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0);
+  }
+}
+
+template <class N>
+__global__ __launch_bounds__(kThreads) void fused_chain_kernel(Params P) {
+  using G = Geo<N>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < G::kLdsFloats; e += kThreads) lds[e] = 0.f;
+  __syncthreads();
+  packet_dma<G::packet(0)>(P.wpack, lds + G::kWOff, wave, lane);
+  int wcur = 0;
+  XStage xst = xstage_load<N>(P, blockIdx.x, tid);
+  const __amdgpu_buffer_rsrc_t scratch = __builtin_amdgcn_make_buffer_rsrc(
+      P.scratch + (size_t)blockIdx.x * G::kScratchFloatsPerWg, 0, (int)(G::kScratchFloatsPerWg * 4), 0x00020000);
+  layer_end_sync();
+  for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
+    const int utt = tile / P.tiles_per_utt;
+    const int t0 = (tile - utt * P.tiles_per_utt) * N::kTF;
+    xstage_store<N>(xst, lds + G::kX0Off, tid);   // buffer Y is dead: its last reader finished before the last barrier
+    __syncthreads();
+    run_layers<N, 0>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Final 1x129 layer (decode_5 / decode_8: CH -> 1, no BN, no ReLU) as a Toeplitz GEMM, see
+// v3::final_gemm_kernel.  K = 129*CH = 8*NB64 + one b32 tail step.
+// ---------------------------------------------------------------------------------------------
+template <int CH>
+struct FinalGeo {
+  static constexpr int kK = kF * CH;
+  static constexpr int kNB64 = kK / 8;
+  static constexpr int kTailValid = kK - 8 * kNB64;   // 4 (CH = 12) or 2 (CH = 10)
+  static_assert(kTailValid > 0 && kTailValid <= 4, "one b32 tail step");
+  static constexpr int kMT = 9;
+  static constexpr int kPack = kNB64 * kMT * 128 + kMT * 64;
+};
+constexpr int kFinFrames = 64;
+constexpr int kFinThreads = 192;
+
+template <int CH>
+__global__ __launch_bounds__(kFinThreads) void final_gemm_kernel(const float* __restrict__ h,
+                                                                  const float* __restrict__ apack, float bias,
+                                                                  float* __restrict__ y, int frames) {
+  using FG = FinalGeo<CH>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kq = lane >> 4;
+  const int f0 = blockIdx.x * kFinFrames;
+  const f32x2* ap = reinterpret_cast<const f32x2*>(apack) + (wave * 3) * 64 + lane;
+  const float* at = apack + FG::kNB64 * FG::kMT * 128 + (wave * 3) * 64 + lane;
+  const float* bp[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int fr = f0 + 16 * t + n;
+    if (fr >= frames) fr = frames - 1;   // clamp: computed, never stored
+    bp[t] = h + (size_t)fr * FG::kK;
+  }
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) acc[t][m] = f32x4{bias, bias, bias, bias};
+#pragma unroll 4
+  for (int s = 0; s < FG::kNB64; ++s) {
+    f32x2 a[3], b[4];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) a[m] = ap[(s * FG::kMT + m) * 64];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const f32x2*>(bp[t] + 8 * s + 2 * kq);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[t][m] = mfma(a[m][e], b[t][e], acc[t][m]);
+  }
+  {
+    const int kqe = kq < FG::kTailValid ? kq : FG::kTailValid - 1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float b = bp[t][8 * FG::kNB64 + kqe];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) acc[t][m] = mfma(at[m * 64], b, acc[t][m]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int fr = f0 + 16 * t + n;
+    if (fr >= frames) continue;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int f = 16 * (3 * wave + m) + 4 * kq;
+      float* yp = y + (size_t)fr * kF + f;
+      const f32x4 v = acc[t][m];
+      if (f + 0 < kF) yp[0] = v.x;
+      if (f + 1 < kF) yp[1] = v.y;
+      if (f + 2 < kF) yp[2] = v.z;
+      if (f + 3 < kF) yp[3] = v.w;
+    }
+  }
+}
+
+}  // namespace chain
+}  // namespace rced
