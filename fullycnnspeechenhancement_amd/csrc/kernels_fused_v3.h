@@ -147,6 +147,14 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
+// Experiment switch: re-derive lane coordinates behind an opaque barrier in every layer, so that hipcc
+// does not hoist every layer's address arithmetic out of the loops (VGPRs 238 -> 136, but the
+// recomputation costs 3 % here; the chain kernel needs it to avoid spills).
+#ifdef RCED_V3_OPAQUE
+#define OPAQUE_LANE(l) asm volatile("" : "+v"(l))
+#else
+#define OPAQUE_LANE(l)
+#endif
 
 // Stream one weight packet global -> LDS with LDS-DMA (no VGPR staging, no ds_write): wave w copies
 // the 1-KiB chunks w, w+8, w+16; lane l of a chunk moves 16 bytes.  Completion: vmcnt(0) + barrier
@@ -433,6 +441,7 @@ template <int NMR, int NMX, int NR>
 __device__ __forceinline__ void layer1(float* lds, const float* w, bool first, int wave, int lane, int xm, int xr0,
                                        int xr1) {
   constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR;
+  OPAQUE_LANE(lane);
   const int n = lane & 15, kq = lane >> 4;
   float* b8 = lds + kB8Off + kB8Pad * kB8S;
   float* b18 = lds + kB18Off + kB18Pad * 18;
@@ -481,6 +490,7 @@ __device__ unsigned long long g_fine[8][4];   // [wave][prologue, gemm, epilogue
 template <int XMT>
 __device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int lane) {
   constexpr int NX = XMT >= 0 ? 1 : 0, NT = 4 + NX;
+  OPAQUE_LANE(lane);
   const int n = lane & 15, kq = lane >> 4;
   const float* b18 = lds + kB18Off + kB18Pad * 18;
   float* b30 = lds + kB30Off + kB30Pad * 30;
@@ -532,6 +542,7 @@ __device__ __forceinline__ void layer3(const Params& P, float* lds, const float*
                                        unsigned tag, int utt, int t0, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
   constexpr int NX = ROLE == kRolePlain ? 0 : 1, NT = 2 + NX;
   constexpr int NEPI = ROLE == kRoleHelper ? 2 : NT;   // tiles this wave finishes
+  OPAQUE_LANE(lane);
   const int n = lane & 15, kq = lane >> 4;
   const float* b30 = lds + kB30Off + kB30Pad * 30;
   float* b8 = lds + kB8Off + kB8Pad * kB8S;
