@@ -33,6 +33,9 @@ SYMBOLS = {
     "rced_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
     "rced_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _c_int_p]),
     "rced_conv_bn_relu": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 9 + [_vp]),
+    "rced_stft_num_frames": (ctypes.c_int, [ctypes.c_int]),
+    "rced_stft": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
+    "rced_istft": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
     "rced_last_kernel_ms": (ctypes.c_float, [_vp]),
     "rced_profile_query": (ctypes.c_int, [_vp, ctypes.c_int, _c_float_p, _c_int_p]),
     "rced_last_error": (ctypes.c_char_p, []),

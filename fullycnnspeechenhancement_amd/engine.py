@@ -67,6 +67,20 @@ class InferenceEngine(FullyCNNTester):
     """infer.py:19-52, the forward slice: `denoise_magnitude` is infer.py:62-65 without the
     STFT/ISTFT around it."""
 
+    def denoise_pcm(self, sig, nfft=512):
+        """infer.py:54-71 end to end on the device: STFT (audio_feature.py) -> model -> rebuild (utils.py:171-183).
+        The magnitude is laid out [1, T, 129, 1] by TRANSPOSE, as the batch loader does
+        (data_loader.py:206-208); infer.py:59 itself reshapes without transposing.
+        sig: 1-D float PCM at 8 kHz.  Returns the denoised signal, same length, numpy float32."""
+        import torch
+        from . import audio
+        dev = "cuda:%d" % self.device
+        pcm = torch.as_tensor(np.asarray(sig, dtype=np.float32), device=dev)[None]
+        mag, phase = audio.stft_batch(pcm)
+        pred = self.model(mag)
+        out = audio.istft_batch(pred, phase, nfft)
+        return out[0, :len(sig)].cpu().numpy()
+
     def denoise_magnitude(self, mag):
         mag = np.asarray(mag, dtype=np.float32)
         if mag.ndim == 2:  # [T, 129] -> [1, T, 129, 1]  (a transpose-correct version of infer.py:59)

@@ -93,6 +93,30 @@ int rced_conv_bn_relu(const float* x, float* y, const float* kernel, const float
                       const float* bn, const float* skip_input, int use_act, int N, int T, int F,
                       int cin, int cout, int kh, int kw, int device, void* stream);
 
+/* ---- audio front-end / back-end around the CNN, fixed to the reference's
+ * configuration: 8 kHz, 256-sample hamming window, 128-sample stride, rfft(256) -> 129 bins. ---- */
+
+/* Frames the reference produces for a signal of `length` samples: ceil(|L-256|/128 + 1)
+ * (data_utils/audio_feature.py:70). */
+int rced_stft_num_frames(int length);
+
+/* AudioFeature.compute_spectrogram + power_spectrum + divide_phase (audio_feature.py:22-44,102-115) for a
+ * batch, laid out as DataLoader.padding_batch does (data_loader.py:198-209):
+ *   pcm_dev [N, L] float32; lengths_dev [N] int32 (device) or NULL (= L each);
+ *   mag_dev [N, T, 129] float32 (= the CNN's [N, T, 129, 1] input);
+ *   phase_dev [N, T, 129, 2] float32 (re, im of exp(j*angle)) or NULL.
+ * Frames past an utterance's own rced_stft_num_frames(length) are zero magnitude, phase 1+0j. */
+int rced_stft(const float* pcm_dev, const int* lengths_dev, int N, int L, int T, float* mag_dev,
+              float* phase_dev, int device, void* stream);
+
+/* AudioReBuild.rebuild_audio (model_utils/utils.py:171-183): merge mag*phase, irfft(n=nfft)[:256],
+ * divide by the hamming window, keep the first half of frame 0 and the second half of every frame,
+ * de-emphasis.  audio_dev [N, (T+1)*128] float32; the caller trims row n to its signal length.
+ * nfft = 512 reproduces the reference as shipped (AudioReBuild() default although the STFT used 256);
+ * nfft = 256 is the matching inverse. */
+int rced_istft(const float* mag_dev, const float* phase_dev, int N, int T, int nfft, float* audio_dev,
+               int device, void* stream);
+
 /* Average device time (ms) of the dominant kernel of the last rced_forward, measured with HIP
  * events on the launch stream when profiling is on ("profile" option = 1).  <0 if none. */
 float rced_last_kernel_ms(rced_model* m);
