@@ -10,6 +10,7 @@
 #include "../../include/rced.h"
 #include "kernels_fused_chain.h"
 #include "kernels_fused_v3.h"
+#include "kernels_fused_v3t.h"
 #include "rced_internal.h"
 
 using namespace rced;
@@ -23,6 +24,7 @@ struct rced_fused {
   float* h = nullptr;         // [frames, 129, 8] hand-off to the final layer
   size_t h_bytes = 0;
   unsigned long long* stamps = nullptr;  // diagnostic builds (RCED_STAMPS) only
+  int teams = 0;              // option "v3_teams": 1 = two-team kernel (kernels_fused_v3t.h)
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
 };
 
@@ -245,6 +247,7 @@ int upload(float** dev, const std::vector<float>& host) {
 int fused_create(rced_model* m) {
   m->fused = nullptr;
   rced_fused* f = new rced_fused();
+  if (const char* e = getenv("RCED_V3_TEAMS")) f->teams = atoi(e) != 0;   // experiment switch
   if (m->variant != RCED_V3) {
     m->fused = f;
     const int rc = m->variant == RCED_V1 ? chain_create<chain::NetV1>(m, f) : chain_create<chain::NetV2>(m, f);
@@ -259,6 +262,9 @@ int fused_create(rced_model* m) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3::fused_v3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLdsBytes);
     if (e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(LDS %d): %s", v3::kLdsBytes, hipGetErrorString(e));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3t::fused_v3t_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, v3t::kLdsBytes);
+    if (!rc && e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(v3t): %s", hipGetErrorString(e));
   }
 #if RCED_STAMPS
   if (!rc && hipMalloc(&f->stamps, (64 + 24) * sizeof(unsigned long long)) != hipSuccess) f->stamps = nullptr;
@@ -303,6 +309,30 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   if (int rc = fused_reserve(m, N, T)) return rc;
   if (m->variant == RCED_V1) return chain_forward<chain::NetV1>(m, f, x, y, N, T, st);
   if (m->variant == RCED_V2) return chain_forward<chain::NetV2>(m, f, x, y, N, T, st);
+  if (f->teams) {
+    v3t::Params Q;
+    Q.x = x;
+    Q.h = f->h;
+    Q.wpack = f->wpack;
+    Q.N = N;
+    Q.T = T;
+    Q.tiles_per_utt = (T + v3t::kTF - 1) / v3t::kTF;
+    Q.total_tiles = N * Q.tiles_per_utt;
+    const int cus2 = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
+    const int grid2 = std::min((Q.total_tiles + v3t::kTeams - 1) / v3t::kTeams, cus2);
+    m->prof_begin(RCED_K_FUSED, st);
+    hipLaunchKernelGGL(v3t::fused_v3t_kernel, dim3(grid2), dim3(v3t::kThreads), v3t::kLdsBytes, st, Q);
+    m->prof_end(RCED_K_FUSED, st);
+    HIP_TRY(hipGetLastError());
+    const int frames2 = N * T;
+    m->prof_begin(RCED_K_FINAL, st);
+    hipLaunchKernelGGL(v3::final_gemm_kernel, dim3((frames2 + v3::kFinFrames - 1) / v3::kFinFrames),
+                       dim3(v3::kFinThreads), 0, st, (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y,
+                       frames2);
+    m->prof_end(RCED_K_FINAL, st);
+    HIP_TRY(hipGetLastError());
+    return RCED_OK;
+  }
   v3::Params P;
   P.x = x;
   P.h = f->h;
@@ -335,6 +365,10 @@ int fused_set_option(rced_model* m, const char* key, int value) {
     m->fused->grid_limit = value;
     return RCED_OK;
   }
+  if (!strcmp(key, "v3_teams") && m->variant == RCED_V3) {
+    m->fused->teams = value != 0;
+    return RCED_OK;
+  }
   return RCED_ERR_ARG;
 }
 
@@ -352,6 +386,10 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
 #endif
   if (!strcmp(key, "fused_grid")) {
     *value = m->fused->grid_limit;
+    return RCED_OK;
+  }
+  if (!strcmp(key, "v3_teams")) {
+    *value = m->fused->teams;
     return RCED_OK;
   }
   return RCED_ERR_ARG;

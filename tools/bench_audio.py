@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Times the STFT front-end, the CNN and the ISTFT rebuild at BASELINE config-3 scale
+(256 utterances x 512 frames = 65,664 samples each), device-resident, with torch.cuda events."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from fullycnnspeechenhancement_amd import audio, build_model
+from oracle import rced_np
+
+N, T = 256, 512
+L = (T - 1) * 128 + 256
+pcm = torch.randn((N, L), device="cuda") * 0.1
+model = build_model("FullyCNNV3", False, weights=rced_np.make_weights("FullyCNNV3"))
+
+
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        out = fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps, out
+
+
+t_stft, (mag, ph) = timed(lambda: audio.stft_batch(pcm))
+assert mag.shape[1] == T
+t_cnn, pred = timed(lambda: model(mag))
+t_istft, _ = timed(lambda: audio.istft_batch(pred, ph))
+frames = N * T
+flop_dft = 2 * 256 * 258
+print(json.dumps({"frames": frames, "stft_ms": t_stft, "cnn_ms": t_cnn, "istft_ms": t_istft,
+                  "stft_tflops": frames * flop_dft / t_stft / 1e9, "istft_tflops": frames * flop_dft / t_istft / 1e9,
+                  "stft_gbps_algorithmic": (N * L * 4 + frames * 129 * 12) / t_stft / 1e6,
+                  "istft_gbps_algorithmic": (frames * 129 * 12 + N * (T + 1) * 128 * 4) / t_istft / 1e6,
+                  "pipeline_frames_per_s": frames / ((t_stft + t_cnn + t_istft) * 1e-3)}))
