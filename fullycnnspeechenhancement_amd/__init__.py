@@ -9,7 +9,8 @@ package as the Python host side that keeps the reference's `Model(is_training)(x
 from .model import (FullyCNNSEModel, FullyCNNSEModelV2, FullyCNNSEModelV3, build_model,  # noqa: F401
                     conv_bn_relu)
 from .engine import FullyCNNTester, InferenceEngine  # noqa: F401
+from .trainer import FullyCNNTrainer  # noqa: F401
 from . import audio, spec, weights  # noqa: F401
 
 __all__ = ["FullyCNNSEModel", "FullyCNNSEModelV2", "FullyCNNSEModelV3", "build_model", "conv_bn_relu",
-           "FullyCNNTester", "InferenceEngine", "audio", "spec", "weights"]
+           "FullyCNNTester", "InferenceEngine", "FullyCNNTrainer", "audio", "spec", "weights"]

@@ -36,6 +36,14 @@ SYMBOLS = {
     "rced_stft_num_frames": (ctypes.c_int, [ctypes.c_int]),
     "rced_stft": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
     "rced_istft": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    "rced_train_create": (ctypes.c_int, [ctypes.c_int, _c_float_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(_vp)]),
+    "rced_train_destroy": (None, [_vp]),
+    "rced_train_step": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                       ctypes.POINTER(ctypes.c_double), _vp]),
+    "rced_train_global_step": (ctypes.c_longlong, [_vp]),
+    "rced_train_get_variables": (ctypes.c_int, [_vp, _c_float_p, ctypes.c_size_t]),
+    "rced_train_get_gradients": (ctypes.c_int, [_vp, _c_float_p, ctypes.c_size_t]),
     "rced_last_kernel_ms": (ctypes.c_float, [_vp]),
     "rced_profile_query": (ctypes.c_int, [_vp, ctypes.c_int, _c_float_p, _c_int_p]),
     "rced_last_error": (ctypes.c_char_p, []),

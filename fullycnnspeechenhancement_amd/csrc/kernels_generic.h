@@ -16,15 +16,16 @@ constexpr int kGenericThreads = 256;
 
 // x [N,T,F,cin], w [kh,kw,cin,cout4] (cout padded to a multiple of 4, zero filled),
 // shift [cout4], y [N,T,F,cout].
-__global__ __launch_bounds__(kGenericThreads) void conv_layer_generic(
+static __global__ __launch_bounds__(kGenericThreads) void conv_layer_generic(
     const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w,
     const float* __restrict__ shift, const float* __restrict__ skip_pre,
     const float* __restrict__ skip_post, int T, int F, int cin, int cout, int cout4, int kh,
-    int kw, int use_act) {
+    int kw, int use_act, int pt, int pl) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [kh][F + kw - 1][cin]
   const int frame = blockIdx.x;  // n*T + t
   const int n = frame / T, t = frame - n * T;
-  const int pt = (kh - 1) / 2, pl = (kw - 1) / 2;  // TF SAME: floor half before
+  // pt / pl: zero rows / columns before the window.  TF SAME forward: floor((k-1)/2); the transposed
+  // (dgrad) use of this kernel passes the other half.
   const int W = F + kw - 1;
   const int row_elems = W * cin;
   // stage: rows t-pt .. t-pt+kh-1, zero outside [0,T) and in the frequency halo

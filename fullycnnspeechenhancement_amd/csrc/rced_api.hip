@@ -101,7 +101,7 @@ int launch_generic(const float* x, float* y, const float* w, const float* shift,
   if (lds > 64 * 1024) return fail(RCED_ERR_ARG, "generic layer needs %zu B of LDS (> 64 KiB)", lds);
   if (frames <= 0) return RCED_OK;
   hipLaunchKernelGGL(conv_layer_generic, dim3(frames), dim3(kGenericThreads), lds, st, x, y, w, shift,
-                     skip_pre, skip_post, T, F, cin, cout, cout4, kh, kw, use_act);
+                     skip_pre, skip_post, T, F, cin, cout, cout4, kh, kw, use_act, (kh - 1) / 2, (kw - 1) / 2);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
 }

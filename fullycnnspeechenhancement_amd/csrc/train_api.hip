@@ -1,0 +1,341 @@
+// C ABI of the training step (include/rced.h, "training" section): host-side orchestration.
+// Replaces FullyCNNTrainer.creat_graph + train_step (model_utils/trainer.py:156-192): forward with
+// train-mode BatchNorm, loss = sum((target - pred)^2) / batch_size, backward, TF-form Adam, moving
+// statistics update.  Layer by layer; see kernels_train.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rced.h"
+#include "kernels_generic.h"
+#include "kernels_train.h"
+#include "rced_internal.h"
+#include "rced_spec.h"
+
+using namespace rced;
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return rced_fail(e_ == hipErrorOutOfMemory ? RCED_ERR_ALLOC : RCED_ERR_HIP, "%s: %s", #expr, \
+                       hipGetErrorString(e_));                                                 \
+  } while (0)
+
+namespace {
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+    ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+constexpr int kReduceGrid = 512;
+constexpr float kAdamB1 = 0.9f, kAdamB2 = 0.999f, kAdamEps = 1e-8f;   // tf.train.AdamOptimizer defaults
+constexpr float kBnMomentum = 0.99f;                                  // tf.layers.batch_normalization default
+
+struct LayerOff {   // float offsets into the variable blob
+  size_t kernel, bias, gamma, beta, mmean, mvar;
+  int cin, cout, cout4, cin4, K;
+};
+}  // namespace
+
+struct rced_trainer {
+  int variant = 0, device = 0, batch_size = 1;
+  const NetSpec* net = nullptr;
+  size_t nvars = 0;
+  std::vector<LayerOff> off;
+  float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
+  unsigned char* trainable = nullptr;
+  std::vector<float*> wf, wt, bias4, mu, rstd;   // per layer
+  float* zero32 = nullptr;
+  double *part = nullptr, *sums = nullptr;
+  // activations for P pixels
+  size_t cap_px = 0;
+  std::vector<float*> out, z, G;   // out/G indexed by tensor id (0 unused), z by layer
+  float* D = nullptr;
+  long long global_step = 0;
+  ~rced_trainer() {
+    DeviceGuard g(device);
+    auto fr = [](void* p) { if (p) (void)hipFree(p); };
+    fr(params); fr(grads); fr(m); fr(v); fr(trainable); fr(zero32); fr(part); fr(sums); fr(D);
+    for (auto* p : wf) fr(p);
+    for (auto* p : wt) fr(p);
+    for (auto* p : bias4) fr(p);
+    for (auto* p : mu) fr(p);
+    for (auto* p : rstd) fr(p);
+    free_acts();
+  }
+  void free_acts() {
+    for (size_t i = 1; i < out.size(); ++i)
+      if (out[i] && out[i] != z[i - 1]) (void)hipFree(out[i]);   // a plain conv layer's output aliases its z
+    for (auto* p : z) if (p) (void)hipFree(p);
+    for (auto* p : G) if (p) (void)hipFree(p);
+    out.clear(); z.clear(); G.clear();
+    cap_px = 0;
+  }
+};
+
+namespace {
+
+int ensure_acts(rced_trainer* t, size_t P) {
+  if (P <= t->cap_px) return RCED_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  t->free_acts();
+  if (t->D) { (void)hipFree(t->D); t->D = nullptr; }
+  const NetSpec& net = *t->net;
+  const int L = net.n_layers;
+  t->out.assign(L + 1, nullptr);
+  t->G.assign(L + 1, nullptr);
+  t->z.assign(L, nullptr);
+  int maxc = 1;
+  for (int l = 0; l < L; ++l) {
+    const int c = net.layer[l].cout;
+    maxc = std::max(maxc, c);
+    HIP_TRY(hipMalloc(&t->z[l], P * c * sizeof(float)));
+    if (net.layer[l].use_norm || net.layer[l].use_act || net.layer[l].skip_pre >= 0 || net.layer[l].skip_post >= 0)
+      HIP_TRY(hipMalloc(&t->out[l + 1], P * c * sizeof(float)));
+    else
+      t->out[l + 1] = t->z[l];   // plain conv layer (decode_final): its output IS z
+    HIP_TRY(hipMalloc(&t->G[l + 1], P * c * sizeof(float)));
+  }
+  HIP_TRY(hipMalloc(&t->D, P * maxc * sizeof(float)));
+  t->cap_px = P;
+  return RCED_OK;
+}
+
+int launch_conv(const float* x, float* y, const float* w, const float* shift, const float* skip, int frames, int T, int F,
+                int cin, int cout, int cout4, int kh, int kw, int pt, int pl, hipStream_t st) {
+  const size_t lds = (size_t)kh * (F + kw - 1) * cin * sizeof(float);
+  if (lds > 64 * 1024) return rced_fail(RCED_ERR_ARG, "layer needs %zu B of LDS", lds);
+  hipLaunchKernelGGL(conv_layer_generic, dim3(frames), dim3(kGenericThreads), lds, st, x, y, w, shift, skip,
+                     (const float*)nullptr, T, F, cin, cout, cout4, kh, kw, 0, pt, pl);
+  HIP_TRY(hipGetLastError());
+  return RCED_OK;
+}
+
+int reduce_channels(rced_trainer* t, const float* a, const float* b, const float* mu, const float* rstd, size_t P, int C,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(train::chan_reduce, dim3(kReduceGrid), dim3(train::kThreads), 0, st, a, b, mu, rstd, P, C, t->part);
+  hipLaunchKernelGGL(train::reduce_finish, dim3(1), dim3(64), 0, st, (const double*)t->part, kReduceGrid, C, t->sums);
+  HIP_TRY(hipGetLastError());
+  return RCED_OK;
+}
+
+__global__ void sums_to_float(const double* __restrict__ sums, int C, int which, float* __restrict__ dst) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) dst[c] = (float)sums[2 * c + which];
+}
+
+}  // namespace
+
+extern "C" {
+
+int rced_train_create(int variant, const float* blob, size_t n_floats, int batch_size, int device, rced_trainer** out) {
+  if (!out) return rced_fail(RCED_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  const NetSpec* net = net_spec(variant);
+  if (!net) return rced_fail(RCED_ERR_ARG, "unknown variant %d", variant);
+  if (!blob || n_floats != net_num_weights(*net)) return rced_fail(RCED_ERR_ARG, "blob must hold %zu floats", net_num_weights(*net));
+  if (batch_size <= 0) return rced_fail(RCED_ERR_ARG, "batch_size must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return rced_fail(RCED_ERR_HIP, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return rced_fail(RCED_ERR_ARG, "device %d out of range", device);
+  DeviceGuard g(device);
+  if (!g.ok) return rced_fail(RCED_ERR_HIP, "hipSetDevice(%d) failed", device);
+  rced_trainer* t = new rced_trainer();
+  t->variant = variant;
+  t->device = device;
+  t->net = net;
+  t->batch_size = batch_size;
+  t->nvars = n_floats;
+  const int L = net->n_layers;
+  std::vector<unsigned char> mask(n_floats, 0);
+  size_t o = 0;
+  t->off.resize(L);
+  for (int l = 0; l < L; ++l) {
+    const LayerSpec& s = net->layer[l];
+    LayerOff& f = t->off[l];
+    f.cin = layer_cin(*net, l);
+    f.cout = s.cout;
+    f.cout4 = (s.cout + 3) & ~3;
+    f.cin4 = (f.cin + 3) & ~3;
+    f.K = s.kh * s.kw * f.cin;
+    f.kernel = o; o += (size_t)f.K * s.cout;
+    f.bias = o; o += s.cout;
+    std::fill(mask.begin() + f.kernel, mask.begin() + o, 1);
+    if (s.use_norm) {
+      f.gamma = o; o += s.cout;
+      f.beta = o; o += s.cout;
+      std::fill(mask.begin() + f.gamma, mask.begin() + o, 1);
+      f.mmean = o; o += s.cout;
+      f.mvar = o; o += s.cout;
+    } else {
+      f.gamma = f.beta = f.mmean = f.mvar = 0;
+    }
+  }
+  auto fail_free = [&](int rc) { delete t; return rc; };
+#define TRY_OR_FREE(expr)                                                      \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) return fail_free(rced_fail(RCED_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+  const size_t bytes = n_floats * sizeof(float);
+  TRY_OR_FREE(hipMalloc(&t->params, bytes));
+  TRY_OR_FREE(hipMalloc(&t->grads, bytes));
+  TRY_OR_FREE(hipMalloc(&t->m, bytes));
+  TRY_OR_FREE(hipMalloc(&t->v, bytes));
+  TRY_OR_FREE(hipMalloc(&t->trainable, n_floats));
+  TRY_OR_FREE(hipMemcpy(t->params, blob, bytes, hipMemcpyHostToDevice));
+  TRY_OR_FREE(hipMemset(t->m, 0, bytes));
+  TRY_OR_FREE(hipMemset(t->v, 0, bytes));
+  TRY_OR_FREE(hipMemcpy(t->trainable, mask.data(), n_floats, hipMemcpyHostToDevice));
+  TRY_OR_FREE(hipMalloc(&t->zero32, 64 * sizeof(float)));
+  TRY_OR_FREE(hipMemset(t->zero32, 0, 64 * sizeof(float)));
+  TRY_OR_FREE(hipMalloc(&t->part, (size_t)kReduceGrid * train::kMaxC * 2 * sizeof(double)));
+  TRY_OR_FREE(hipMalloc(&t->sums, train::kMaxC * 2 * sizeof(double)));
+  t->wf.assign(L, nullptr); t->wt.assign(L, nullptr); t->bias4.assign(L, nullptr);
+  t->mu.assign(L, nullptr); t->rstd.assign(L, nullptr);
+  for (int l = 0; l < L; ++l) {
+    const LayerSpec& s = net->layer[l];
+    const LayerOff& f = t->off[l];
+    TRY_OR_FREE(hipMalloc(&t->wf[l], (size_t)f.K * f.cout4 * sizeof(float)));
+    TRY_OR_FREE(hipMalloc(&t->wt[l], (size_t)s.kh * s.kw * s.cout * f.cin4 * sizeof(float)));
+    TRY_OR_FREE(hipMalloc(&t->bias4[l], 64 * sizeof(float)));
+    TRY_OR_FREE(hipMalloc(&t->mu[l], 64 * sizeof(float)));
+    TRY_OR_FREE(hipMalloc(&t->rstd[l], 64 * sizeof(float)));
+  }
+#undef TRY_OR_FREE
+  *out = t;
+  return RCED_OK;
+}
+
+void rced_train_destroy(rced_trainer* t) { delete t; }
+
+long long rced_train_global_step(rced_trainer* t) { return t ? t->global_step : -1; }
+
+int rced_train_get_variables(rced_trainer* t, float* blob_host, size_t n_floats) {
+  if (!t || !blob_host || n_floats != t->nvars) return rced_fail(RCED_ERR_ARG, "bad arguments");
+  DeviceGuard g(t->device);
+  HIP_TRY(hipMemcpy(blob_host, t->params, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return RCED_OK;
+}
+
+int rced_train_get_gradients(rced_trainer* t, float* blob_host, size_t n_floats) {
+  if (!t || !blob_host || n_floats != t->nvars) return rced_fail(RCED_ERR_ARG, "bad arguments");
+  DeviceGuard g(t->device);
+  HIP_TRY(hipMemcpy(blob_host, t->grads, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return RCED_OK;
+}
+
+int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int N, int T, float lr, double* loss_out,
+                    void* stream) {
+  if (!t) return rced_fail(RCED_ERR_ARG, "trainer is NULL");
+  if (N <= 0 || T <= 0 || !x_dev || !y_dev) return rced_fail(RCED_ERR_ARG, "bad batch");
+  DeviceGuard g(t->device);
+  if (!g.ok) return rced_fail(RCED_ERR_HIP, "hipSetDevice(%d) failed", t->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const NetSpec& net = *t->net;
+  const int L = net.n_layers, F = kFeatureDim, frames = N * T;
+  const size_t P = (size_t)frames * F;
+  if (int rc = ensure_acts(t, P)) return rc;
+  auto blocks = [](size_t n) { return dim3((unsigned)std::min<size_t>((n + train::kThreads - 1) / train::kThreads, 65535)); };
+  auto tensor = [&](int id) -> const float* { return id < 0 ? nullptr : (id == 0 ? x_dev : t->out[id]); };
+
+  // ---- weights in the layouts the conv kernel wants
+  for (int l = 0; l < L; ++l) {
+    const LayerSpec& s = net.layer[l];
+    const LayerOff& f = t->off[l];
+    hipLaunchKernelGGL(train::repack_fwd, dim3((f.K * f.cout4 + 255) / 256), dim3(256), 0, st, t->params + f.kernel, f.K,
+                       s.cout, f.cout4, t->wf[l]);
+    hipLaunchKernelGGL(train::repack_fwd, dim3(1), dim3(64), 0, st, t->params + f.bias, 1, s.cout, f.cout4, t->bias4[l]);
+    const int nt = s.kh * s.kw * s.cout * f.cin4;
+    hipLaunchKernelGGL(train::repack_dgrad, dim3((nt + 255) / 256), dim3(256), 0, st, t->params + f.kernel, s.kh, s.kw,
+                       f.cin, s.cout, f.cin4, t->wt[l]);
+  }
+  // ---- forward (is_training=True)
+  for (int l = 0; l < L; ++l) {
+    const LayerSpec& s = net.layer[l];
+    const LayerOff& f = t->off[l];
+    if (int rc = launch_conv(tensor(s.src), t->z[l], t->wf[l], t->bias4[l], nullptr, frames, T, F, f.cin, s.cout, f.cout4,
+                             s.kh, s.kw, (s.kh - 1) / 2, (s.kw - 1) / 2, st))
+      return rc;
+    const size_t n = P * s.cout;
+    if (s.use_norm) {
+      if (int rc = reduce_channels(t, t->z[l], t->z[l], nullptr, nullptr, P, s.cout, st)) return rc;
+      hipLaunchKernelGGL(train::bn_stats_finish, dim3(1), dim3(64), 0, st, (const double*)t->sums, (double)P, s.cout,
+                         kBnEps, kBnMomentum, t->mu[l], t->rstd[l], t->params + f.mmean, t->params + f.mvar);
+    }
+    if (t->out[l + 1] != t->z[l])
+      hipLaunchKernelGGL(train::bn_act_fwd, blocks(n), dim3(train::kThreads), 0, st, (const float*)t->z[l],
+                         s.use_norm ? (const float*)t->mu[l] : nullptr, (const float*)t->rstd[l],
+                         (const float*)(t->params + f.gamma), (const float*)(t->params + f.beta), tensor(s.skip_pre),
+                         tensor(s.skip_post), s.use_act, n, s.cout, t->out[l + 1]);
+  }
+  HIP_TRY(hipGetLastError());
+  // ---- loss and its gradient (trainer.py:146-147,153)
+  hipLaunchKernelGGL(train::loss_fwd_bwd, dim3(kReduceGrid), dim3(train::kThreads), 0, st, (const float*)t->out[L], y_dev,
+                     P, 1.f / (float)t->batch_size, t->G[L], t->part);
+  std::vector<double> hp(kReduceGrid);
+  HIP_TRY(hipMemcpyAsync(hp.data(), t->part, kReduceGrid * sizeof(double), hipMemcpyDeviceToHost, st));
+  // ---- backward
+  HIP_TRY(hipMemsetAsync(t->grads, 0, t->nvars * sizeof(float), st));
+  for (int id = 1; id < L; ++id) HIP_TRY(hipMemsetAsync(t->G[id], 0, P * net.layer[id - 1].cout * sizeof(float), st));
+  for (int l = L - 1; l >= 0; --l) {
+    const LayerSpec& s = net.layer[l];
+    const LayerOff& f = t->off[l];
+    const size_t n = P * s.cout;
+    const float* mu = s.use_norm ? t->mu[l] : nullptr;
+    hipLaunchKernelGGL(train::bwd_route, blocks(n), dim3(train::kThreads), 0, st, (const float*)t->G[l + 1],
+                       (const float*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
+                       (const float*)(t->params + f.beta), tensor(s.skip_pre), s.use_act, n, s.cout,
+                       s.skip_pre > 0 ? t->G[s.skip_pre] : nullptr, s.skip_post > 0 ? t->G[s.skip_post] : nullptr, t->D);
+    if (s.use_norm) {
+      if (int rc = reduce_channels(t, t->D, t->z[l], mu, t->rstd[l], P, s.cout, st)) return rc;
+      hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.beta);
+      hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 1, t->grads + f.gamma);
+      hipLaunchKernelGGL(train::bn_bwd_apply, blocks(n), dim3(train::kThreads), 0, st, t->D, (const float*)t->z[l], mu,
+                         (const float*)t->rstd[l], (const float*)(t->params + f.gamma), (const double*)t->sums, (double)P, n,
+                         s.cout);
+    }
+    // dbias = sum dz
+    if (int rc = reduce_channels(t, t->D, t->D, nullptr, nullptr, P, s.cout, st)) return rc;
+    hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.bias);
+    // dW
+    {
+      const int fpw = 16;
+      const size_t lds = ((size_t)s.kh * (F + s.kw - 1) * f.cin + (size_t)F * s.cout) * sizeof(float);
+      if (f.K * s.cout > train::kWgradMaxOut * train::kThreads || lds > 64 * 1024)
+        return rced_fail(RCED_ERR_ARG, "layer %d too large for conv_wgrad", l);
+      hipLaunchKernelGGL(train::conv_wgrad, dim3((frames + fpw - 1) / fpw), dim3(train::kThreads), lds, st, tensor(s.src),
+                         (const float*)t->D, T, F, f.cin, s.cout, s.kh, s.kw, frames, fpw, t->grads + f.kernel);
+    }
+    // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
+    if (s.src > 0) {
+      if (int rc = launch_conv(t->D, t->G[s.src], t->wt[l], t->zero32, t->G[s.src], frames, T, F, s.cout, f.cin, f.cin4, s.kh,
+                               s.kw, (s.kh - 1) - (s.kh - 1) / 2, (s.kw - 1) - (s.kw - 1) / 2, st))
+        return rc;
+    }
+  }
+  // ---- Adam (TF form), trainer.py:175-179
+  t->global_step += 1;
+  const double tt = (double)t->global_step;
+  const float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)kAdamB2, tt)) / (1.0 - std::pow((double)kAdamB1, tt)));
+  hipLaunchKernelGGL(train::adam_step, dim3((unsigned)((t->nvars + train::kThreads - 1) / train::kThreads)),
+                     dim3(train::kThreads), 0, st, t->params, (const float*)t->grads, t->m, t->v,
+                     (const unsigned char*)t->trainable, t->nvars, lr_t, kAdamB1, kAdamB2, kAdamEps);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  double loss = 0.0;
+  for (double v : hp) loss += v;
+  if (loss_out) *loss_out = loss / (double)t->batch_size;
+  return RCED_OK;
+}
+
+}  // extern "C"

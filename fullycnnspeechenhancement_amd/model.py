@@ -31,8 +31,8 @@ class _RcedNet(object):
         if is_training:
             # trainer.py:156-179 builds the same graph with is_training=True (batch-stat BN + Adam);
             # that is SURVEY 8(f) N3, not part of the forward hot path.
-            raise NotImplementedError("is_training=True (train-mode BatchNorm / backward) is not built; "
-                                      "use is_training=False for the forward pass")
+            raise NotImplementedError("Model(is_training=True) only exists inside the training step: use "
+                                      "fullycnnspeechenhancement_amd.FullyCNNTrainer (rced_train_step)")
         self.is_training = False
         self.device = int(device)
         self._handle = None

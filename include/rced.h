@@ -117,6 +117,29 @@ int rced_stft(const float* pcm_dev, const int* lengths_dev, int N, int L, int T,
 int rced_istft(const float* mag_dev, const float* phase_dev, int N, int T, int nfft, float* audio_dev,
                int device, void* stream);
 
+/* ---- training step: FullyCNNTrainer.creat_graph + train_step,
+ * model_utils/trainer.py:156-192, over Model(is_training=True).  Layer-by-layer, correctness first. ---- */
+typedef struct rced_trainer rced_trainer;
+
+/* blob: the same TF-variable blob rced_create takes (initial values, incl. BN moving statistics);
+ * batch_size: the CONFIGURED batch size the loss divides by (trainer.py:146-147), not the dynamic N. */
+int rced_train_create(int variant, const float* blob, size_t n_floats, int batch_size, int device,
+                      rced_trainer** out);
+void rced_train_destroy(rced_trainer* t);
+
+/* sess.run([loss, global_step, train_op]) (trainer.py:181-192) with the UPDATE_OPS: forward with batch
+ * statistics, loss = sum((y - pred)^2) / batch_size, backward, tf.train.AdamOptimizer(lr) step in TF's
+ * form (beta1 0.9, beta2 0.999, eps 1e-8), moving mean / variance update (momentum 0.99).
+ * x_dev, y_dev: DEVICE [N, T, 129, 1] float32.  lr: the value fed to the learning-rate placeholder.
+ * *loss_out (host) receives the batch loss.  Synchronises the stream. */
+int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int N, int T, float lr,
+                    double* loss_out, void* stream);
+
+long long rced_train_global_step(rced_trainer* t);
+/* Current variables / last gradients, in blob order (gradients of moving statistics are 0). */
+int rced_train_get_variables(rced_trainer* t, float* blob_host, size_t n_floats);
+int rced_train_get_gradients(rced_trainer* t, float* blob_host, size_t n_floats);
+
 /* Average device time (ms) of the dominant kernel of the last rced_forward, measured with HIP
  * events on the launch stream when profiling is on ("profile" option = 1).  <0 if none. */
 float rced_last_kernel_ms(rced_model* m);

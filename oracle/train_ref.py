@@ -1,0 +1,99 @@
+"""ORACLE (test infrastructure, NOT product code): one training step of the reference trainer,
+restated on PyTorch-CPU autograd.
+
+PARITY UNPINNED: restates model_utils/trainer.py:143-192 (loss, optimizer, train_step) and :68-76 (Noam
+learning rate) over the train-mode graph (is_training=True: BatchNorm normalises with the batch mean and
+the biased batch variance and moves its statistics with momentum 0.99) from the reference source plus
+TensorFlow-1.14 defaults; TensorFlow cannot run here.  TF specifics hard-coded:
+  * loss = sum((target - pred)^2) / batch_size   with the CONFIGURED batch size (trainer.py:146-147,153)
+  * tf.train.AdamOptimizer defaults beta1 0.9, beta2 0.999, eps 1e-8 in TF's form
+        lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  theta -= lr_t * m / (sqrt(v) + eps)
+  * moving_variance is updated with the UNBIASED batch variance (TF fused batch-norm), moving_mean
+    with the batch mean, both `moving = 0.99 * moving + 0.01 * batch`  (cannot be confirmed here).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+from . import layers as L
+
+BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-8
+
+
+def noam_lr(init_lr, global_step, warmup_steps):
+    """trainer.py:68-76."""
+    step = global_step + 1
+    return init_lr * warmup_steps ** 0.5 * min(step * warmup_steps ** -1.5, step ** -0.5)
+
+
+def trainable_names(net_work):
+    return [n for n, _ in L.variable_shapes(L.layers_for(net_work)) if "moving_" not in n]
+
+
+class TrainRef:
+    def __init__(self, net_work, weights, batch_size, dtype=torch.float64):
+        self.layers = L.layers_for(net_work)
+        self.net_work = net_work
+        self.batch_size = batch_size
+        self.dtype = dtype
+        self.vars = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in weights.items()}
+        for k in trainable_names(net_work):
+            self.vars[k].requires_grad_(True)
+        self.m = {k: torch.zeros_like(self.vars[k]) for k in trainable_names(net_work)}
+        self.v = {k: torch.zeros_like(self.vars[k]) for k in trainable_names(net_work)}
+        self.global_step = 0
+
+    def forward_train(self, x):
+        """model(x) with is_training=True; returns (pred, list of (scope, batch_mean, batch_var_biased, count))."""
+        tens = [torch.as_tensor(x).to(self.dtype).permute(0, 3, 1, 2)]
+        stats = []
+        for l in self.layers:
+            k = self.vars[l.scope + "/kernel"].permute(3, 2, 0, 1).contiguous()   # HWIO -> OIHW
+            pt, pb = (l.kh - 1) // 2, (l.kh - 1) - (l.kh - 1) // 2
+            pl, pr = (l.kw - 1) // 2, (l.kw - 1) - (l.kw - 1) // 2
+            y = Fn.conv2d(Fn.pad(tens[l.src], (pl, pr, pt, pb)), k, self.vars[l.scope + "/bias"])
+            if l.use_norm:
+                p = l.scope + "/batch_norm/"
+                mean = y.mean(dim=(0, 2, 3), keepdim=True)
+                var = ((y - mean) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+                y = (y - mean) / torch.sqrt(var + L.BN_EPS) * self.vars[p + "gamma"].view(1, -1, 1, 1) + \
+                    self.vars[p + "beta"].view(1, -1, 1, 1)
+                stats.append((l.scope, mean.detach().flatten(), var.detach().flatten(), y.numel() // y.shape[1]))
+            if l.skip_pre >= 0:
+                y = y + tens[l.skip_pre]
+            if l.use_act:
+                y = torch.relu(y)
+            if l.skip_post >= 0:
+                y = y + tens[l.skip_post]
+            tens.append(y)
+        return tens[-1].permute(0, 2, 3, 1), stats
+
+    def loss_and_grads(self, x, target):
+        for k in self.m:
+            self.vars[k].grad = None
+        pred, stats = self.forward_train(x)
+        loss = ((torch.as_tensor(target).to(self.dtype) - pred) ** 2).sum() / self.batch_size
+        loss.backward()
+        return loss.item(), {k: self.vars[k].grad.clone() for k in self.m}, stats
+
+    def train_step(self, x, target, lr):
+        """trainer.py:181-192 (+ UPDATE_OPS): returns (batch_loss, global_step after the step)."""
+        loss, grads, stats = self.loss_and_grads(x, target)
+        self.global_step += 1
+        t = self.global_step
+        lr_t = lr * np.sqrt(1 - BETA2 ** t) / (1 - BETA1 ** t)
+        with torch.no_grad():
+            for k, g in grads.items():
+                self.m[k].mul_(BETA1).add_(g, alpha=1 - BETA1)
+                self.v[k].mul_(BETA2).addcmul_(g, g, value=1 - BETA2)
+                self.vars[k].sub_(lr_t * self.m[k] / (self.v[k].sqrt() + ADAM_EPS))
+            for scope, mean, var, n in stats:
+                p = scope + "/batch_norm/"
+                self.vars[p + "moving_mean"].mul_(L.BN_MOMENTUM).add_(mean, alpha=1 - L.BN_MOMENTUM)
+                self.vars[p + "moving_variance"].mul_(L.BN_MOMENTUM).add_(var * n / max(n - 1, 1), alpha=1 - L.BN_MOMENTUM)
+        return loss, self.global_step
+
+    def weights(self):
+        return {k: v.detach().numpy().copy() for k, v in self.vars.items()}
