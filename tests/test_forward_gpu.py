@@ -209,6 +209,35 @@ def test_engine_test_step_surface(built):
     assert isinstance(out, np.ndarray) and rel_err(out, g["y_small"]) < RTOL
 
 
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_forward_is_capturable_into_a_hip_graph(net_work, tag, variant, built):
+    """rced.h: after rced_reserve, rced_forward allocates nothing and can be stream-captured."""
+    import torch
+    w, g = load_golden(tag)
+    m = make_model(variant, w)
+    x = torch.from_numpy(g["x_long"]).cuda()
+    m.reserve(x.shape[0], x.shape[1])
+    y_eager = m(x).clone()
+    static_x = x.clone()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        m(static_x)                      # warm-up on the side stream
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(graph):
+        static_y = m(static_x)
+    for scale in (1.0, 0.5):
+        static_x.copy_(x * scale)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_y, m(static_x))
+    static_x.copy_(x)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_y, y_eager)
+
+
 def test_restore_swaps_weights(built):
     w1 = rced_np.make_weights("FullyCNN", seed=1)
     w2 = rced_np.make_weights("FullyCNN", seed=2)
