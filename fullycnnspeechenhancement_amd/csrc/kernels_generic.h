@@ -20,56 +20,104 @@ static __global__ __launch_bounds__(kGenericThreads) void conv_layer_generic(
     const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w,
     const float* __restrict__ shift, const float* __restrict__ skip_pre,
     const float* __restrict__ skip_post, int T, int F, int cin, int cout, int cout4, int kh,
-    int kw, int use_act, int pt, int pl) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [kh][F + kw - 1][cin]
-  const int frame = blockIdx.x;  // n*T + t
-  const int n = frame / T, t = frame - n * T;
+    int kw, int use_act, int pt, int pl, int fpw, int frames) {
+  // fpw = frames per workgroup (> 1 only for kh == 1 layers with few output channels, to keep the
+  // 256 threads busy: a frame offers ceil(129/4) * ceil(cout/4) work items)
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [fpw][kh][F + kw - 1][cin]
+  const int frame0 = blockIdx.x * fpw;
   // pt / pl: zero rows / columns before the window.  TF SAME forward: floor((k-1)/2); the transposed
   // (dgrad) use of this kernel passes the other half.
   const int W = F + kw - 1;
   const int row_elems = W * cin;
-  // stage: rows t-pt .. t-pt+kh-1, zero outside [0,T) and in the frequency halo
-  for (int e = threadIdx.x; e < kh * row_elems; e += kGenericThreads) {
-    const int i = e / row_elems, r = e - i * row_elems;
+  // stage: per frame rows t-pt .. t-pt+kh-1, zero outside [0,T) and in the frequency halo
+  for (int e = threadIdx.x; e < fpw * kh * row_elems; e += kGenericThreads) {
+    const int fl = e / (kh * row_elems), e1 = e - fl * (kh * row_elems);
+    const int i = e1 / row_elems, r = e1 - i * row_elems;
     const int fw = r / cin, ci = r - fw * cin;
+    const int frame = frame0 + fl;
+    const int n = frame / T, t = frame - n * T;
     const int tt = t + i - pt, ff = fw - pl;
     float v = 0.f;
-    if (tt >= 0 && tt < T && ff >= 0 && ff < F) v = x[(((size_t)n * T + tt) * F + ff) * cin + ci];
+    if (frame < frames && tt >= 0 && tt < T && ff >= 0 && ff < F) v = x[(((size_t)n * T + tt) * F + ff) * cin + ci];
     lds[e] = v;
   }
   __syncthreads();
+  // Work item = 4 adjacent bins x 4 output channels (16 accumulators).  Loop order (row i, input
+  // channel ci, chunk of 8 taps): the 4 + 8 - 1 = 11 input values a chunk touches are read from LDS once
+  // and slid over the taps in registers, so there are ~19 loads per 128 FMAs instead of 2 per 4.
   const int groups = cout4 >> 2;
-  const int items = F * groups;
+  const int fgroups = (F + 3) >> 2;
+  const int per_frame = fgroups * groups;
+  const int items = fpw * per_frame;
   for (int it = threadIdx.x; it < items; it += kGenericThreads) {
-    const int f = it / groups, g = it - f * groups;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int fl = it / per_frame, it1 = it - fl * per_frame;
+    const int fg = it1 / groups, g = it1 - fg * groups;
+    const int f0 = fg * 4;
+    const int frame = frame0 + fl;
+    if (frame >= frames) continue;
+    float acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
     for (int i = 0; i < kh; ++i) {
-      const float* xr = lds + i * row_elems + f * cin;         // window start (f - pl + pl)
-      const float* wr = w + (size_t)i * kw * cin * cout4 + g * 4;
-      const int klen = kw * cin;                                // contiguous (tap, ci) window
-      for (int k = 0; k < klen; ++k) {
-        const float xv = xr[k];
-        const float4 wv = *reinterpret_cast<const float4*>(wr + (size_t)k * cout4);
-        a0 = fmaf(xv, wv.x, a0);
-        a1 = fmaf(xv, wv.y, a1);
-        a2 = fmaf(xv, wv.z, a2);
-        a3 = fmaf(xv, wv.w, a3);
+      const float* xrow = lds + (fl * kh + i) * row_elems;
+      const float* wrow = w + (size_t)i * kw * cin * cout4 + g * 4;
+      for (int ci = 0; ci < cin; ++ci) {
+        for (int j0 = 0; j0 < kw; j0 += 8) {
+          float xw[11];
+#pragma unroll
+          for (int q = 0; q < 11; ++q) {
+            const int fw = f0 + j0 + q;                 // column of the padded row
+            xw[q] = fw < W ? xrow[fw * cin + ci] : 0.f;
+          }
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            if (j0 + jj < kw) {
+              const float4 wv = *reinterpret_cast<const float4*>(wrow + (size_t)((j0 + jj) * cin + ci) * cout4);
+#pragma unroll
+              for (int p = 0; p < 4; ++p) {
+                acc[p][0] = fmaf(xw[jj + p], wv.x, acc[p][0]);
+                acc[p][1] = fmaf(xw[jj + p], wv.y, acc[p][1]);
+                acc[p][2] = fmaf(xw[jj + p], wv.z, acc[p][2]);
+                acc[p][3] = fmaf(xw[jj + p], wv.w, acc[p][3]);
+              }
+            }
+          }
+        }
       }
     }
     const float4 sh = *reinterpret_cast<const float4*>(shift + g * 4);
-    float v[4] = {a0 + sh.x, a1 + sh.y, a2 + sh.z, a3 + sh.w};
-    const size_t o = ((size_t)frame * F + f) * cout + g * 4;
+    const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (g * 4 + c < cout) {
-        float r = v[c];
-        if (skip_pre) r += skip_pre[o + c];
-        if (use_act) r = fmaxf(r, 0.f);
-        if (skip_post) r += skip_post[o + c];
-        y[o + c] = r;
+    for (int p = 0; p < 4; ++p) {
+      const int f = f0 + p;
+      if (f >= F) continue;
+      const size_t o = ((size_t)frame * F + f) * cout + g * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (g * 4 + c < cout) {
+          float r = acc[p][c] + shv[c];
+          if (skip_pre) r += skip_pre[o + c];
+          if (use_act) r = fmaxf(r, 0.f);
+          if (skip_post) r += skip_post[o + c];
+          y[o + c] = r;
+        }
       }
     }
   }
+}
+
+// frames per workgroup: enough (bins/4 x couts/4) items for 256 threads, within 64 KiB of LDS
+inline int generic_frames_per_wg(int F, int cout4, int kh, size_t row_bytes) {
+  // Measured: packing several frames per workgroup to fill idle threads (cout 8 -> 66 items) is 5 % SLOWER
+  // (occupancy drops with the LDS footprint); one frame per workgroup stays.
+  if (kh != 1 || true) return 1;
+  const int per_frame = ((F + 3) / 4) * (cout4 / 4);
+  int fpw = (kGenericThreads + per_frame - 1) / per_frame;
+  if (fpw > 8) fpw = 8;
+  while (fpw > 1 && row_bytes * fpw > 64 * 1024) --fpw;
+  return fpw < 1 ? 1 : fpw;
 }
 
 }  // namespace rced

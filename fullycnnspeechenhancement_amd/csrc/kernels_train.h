@@ -27,11 +27,24 @@ __global__ __launch_bounds__(kThreads) void chan_reduce(const float* __restrict_
   if (tid < lanes) {
     const float m = mu ? mu[c] : 0.f, r = rstd ? rstd[c] : 1.f;
     const size_t rows_per_iter = (size_t)(lanes / C) * gridDim.x;
-    for (size_t p = (size_t)blockIdx.x * (lanes / C) + tid / C; p < P; p += rows_per_iter) {
-      const float av = a[p * C + c], bv = b[p * C + c];
-      acc1 += (double)av;
-      acc2 += (double)av * (double)((bv - m) * r);
+    size_t p = (size_t)blockIdx.x * (lanes / C) + tid / C;
+    double b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};   // four rows in flight per thread
+    for (; p + 3 * rows_per_iter < P; p += 4 * rows_per_iter) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t q = (p + u * rows_per_iter) * C + c;
+        const float av = a[q], bv = b[q];
+        b1[u] += (double)av;
+        b2[u] += (double)av * (double)((bv - m) * r);
+      }
     }
+    for (; p < P; p += rows_per_iter) {
+      const float av = a[p * C + c], bv = b[p * C + c];
+      b1[0] += (double)av;
+      b2[0] += (double)av * (double)((bv - m) * r);
+    }
+    acc1 = (b1[0] + b1[1]) + (b1[2] + b1[3]);
+    acc2 = (b2[0] + b2[1]) + (b2[2] + b2[3]);
   }
   s1[tid] = acc1;
   s2[tid] = acc2;
@@ -45,12 +58,21 @@ __global__ __launch_bounds__(kThreads) void chan_reduce(const float* __restrict_
 }
 
 // sums[c][2] = sum over partials
-__global__ void reduce_finish(const double* __restrict__ part, int nparts, int C, double* __restrict__ sums) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C) return;
+__global__ __launch_bounds__(kThreads) void reduce_finish(const double* __restrict__ part, int nparts, int C,
+                                                           double* __restrict__ sums) {
+  __shared__ double s[kThreads];
+  const int tid = threadIdx.x, n = 2 * C;            // n <= 64 outputs
+  const int lanes = (kThreads / n) * n, i = tid % n, j0 = tid / n, stride = lanes / n;
   double t = 0.0;
-  for (int k = 0; k < nparts; ++k) t += part[(size_t)k * 2 * C + i];
-  sums[i] = t;
+  if (tid < lanes)
+    for (int k = j0; k < nparts; k += stride) t += part[(size_t)k * n + i];   // coalesced across i
+  s[tid] = t;
+  __syncthreads();
+  if (tid < n) {
+    double r = 0.0;
+    for (int j = tid; j < lanes; j += n) r += s[j];
+    sums[tid] = r;
+  }
 }
 
 // Batch statistics from (sum z, sum z^2): mu, rstd = 1/sqrt(var_biased + eps); moving statistics with

@@ -97,11 +97,13 @@ void fold_layer(const NetSpec& net, int i, const float* p, std::vector<float>* w
 int launch_generic(const float* x, float* y, const float* w, const float* shift, const float* skip_pre,
                    const float* skip_post, int frames, int T, int F, int cin, int cout, int cout4, int kh,
                    int kw, int use_act, hipStream_t st) {
-  const size_t lds = (size_t)kh * (F + kw - 1) * cin * sizeof(float);
-  if (lds > 64 * 1024) return fail(RCED_ERR_ARG, "generic layer needs %zu B of LDS (> 64 KiB)", lds);
+  const size_t row = (size_t)kh * (F + kw - 1) * cin * sizeof(float);
+  if (row > 64 * 1024) return fail(RCED_ERR_ARG, "generic layer needs %zu B of LDS (> 64 KiB)", row);
   if (frames <= 0) return RCED_OK;
-  hipLaunchKernelGGL(conv_layer_generic, dim3(frames), dim3(kGenericThreads), lds, st, x, y, w, shift,
-                     skip_pre, skip_post, T, F, cin, cout, cout4, kh, kw, use_act, (kh - 1) / 2, (kw - 1) / 2);
+  const int fpw = generic_frames_per_wg(F, cout4, kh, row);
+  hipLaunchKernelGGL(conv_layer_generic, dim3((frames + fpw - 1) / fpw), dim3(kGenericThreads), row * fpw, st, x, y, w,
+                     shift, skip_pre, skip_post, T, F, cin, cout, cout4, kh, kw, use_act, (kh - 1) / 2, (kw - 1) / 2,
+                     fpw, frames);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
 }

@@ -111,10 +111,11 @@ int ensure_acts(rced_trainer* t, size_t P) {
 
 int launch_conv(const float* x, float* y, const float* w, const float* shift, const float* skip, int frames, int T, int F,
                 int cin, int cout, int cout4, int kh, int kw, int pt, int pl, hipStream_t st) {
-  const size_t lds = (size_t)kh * (F + kw - 1) * cin * sizeof(float);
-  if (lds > 64 * 1024) return rced_fail(RCED_ERR_ARG, "layer needs %zu B of LDS", lds);
-  hipLaunchKernelGGL(conv_layer_generic, dim3(frames), dim3(kGenericThreads), lds, st, x, y, w, shift, skip,
-                     (const float*)nullptr, T, F, cin, cout, cout4, kh, kw, 0, pt, pl);
+  const size_t row = (size_t)kh * (F + kw - 1) * cin * sizeof(float);
+  if (row > 64 * 1024) return rced_fail(RCED_ERR_ARG, "layer needs %zu B of LDS", row);
+  const int fpw = generic_frames_per_wg(F, cout4, kh, row);
+  hipLaunchKernelGGL(conv_layer_generic, dim3((frames + fpw - 1) / fpw), dim3(kGenericThreads), row * fpw, st, x, y, w,
+                     shift, skip, (const float*)nullptr, T, F, cin, cout, cout4, kh, kw, 0, pt, pl, fpw, frames);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
 }
@@ -122,7 +123,7 @@ int launch_conv(const float* x, float* y, const float* w, const float* shift, co
 int reduce_channels(rced_trainer* t, const float* a, const float* b, const float* mu, const float* rstd, size_t P, int C,
                     hipStream_t st) {
   hipLaunchKernelGGL(train::chan_reduce, dim3(kReduceGrid), dim3(train::kThreads), 0, st, a, b, mu, rstd, P, C, t->part);
-  hipLaunchKernelGGL(train::reduce_finish, dim3(1), dim3(64), 0, st, (const double*)t->part, kReduceGrid, C, t->sums);
+  hipLaunchKernelGGL(train::reduce_finish, dim3(1), dim3(train::kThreads), 0, st, (const double*)t->part, kReduceGrid, C, t->sums);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
 }
