@@ -6,12 +6,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "../../include/rced.h"
 #include "kernels_generic.h"
 #include "kernels_train.h"
+#include "kernels_train_mfma.h"
 #include "rced_internal.h"
 #include "rced_spec.h"
 
@@ -46,13 +48,15 @@ struct LayerOff {   // float offsets into the variable blob
 }  // namespace
 
 struct rced_trainer {
-  int variant = 0, device = 0, batch_size = 1;
+  int variant = 0, device = 0, batch_size = 1, num_cus = 256;
   const NetSpec* net = nullptr;
   size_t nvars = 0;
   std::vector<LayerOff> off;
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
   unsigned char* trainable = nullptr;
   std::vector<float*> wf, wt, bias4, mu, rstd;   // per layer
+  std::vector<float*> pk_fwd, pk_bwd;            // per layer: MFMA A-fragment packets (1xk layers with an MFMA kernel)
+  int use_mfma = 1;
   float* zero32 = nullptr;
   double *part = nullptr, *sums = nullptr;
   // activations for P pixels
@@ -69,6 +73,8 @@ struct rced_trainer {
     for (auto* p : bias4) fr(p);
     for (auto* p : mu) fr(p);
     for (auto* p : rstd) fr(p);
+    for (auto* p : pk_fwd) fr(p);
+    for (auto* p : pk_bwd) fr(p);
     free_acts();
   }
   void free_acts() {
@@ -128,6 +134,77 @@ int reduce_channels(rced_trainer* t, const float* a, const float* b, const float
   return RCED_OK;
 }
 
+// ---- MFMA paths for the 1xk layers (kernels_train_mfma.h): one instantiation per (cin, taps, cout) ----
+#define RCED_TM_SHAPES(X) X(8, 9, 18) X(18, 5, 30) X(30, 9, 8) X(18, 9, 8) X(30, 5, 18) X(8, 9, 30) X(1, 129, 8)
+
+size_t tm_packet_floats(int cin, int taps, int cout) {
+  const int cinp = (cin + 1) & ~1, K = taps * cinp, MT = (cout + 15) / 16;
+  return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + 32;
+}
+
+template <int CIN, int TAPS, int COUT>
+int tm_conv_launch(bool accum, const float* in, const float* packet, float* out, int frames, int cus, hipStream_t st) {
+  using G = tmm::Geo<CIN, TAPS, COUT>;
+  const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
+  const int grid = std::min(ntiles, cus * 4);
+  const size_t lds = G::kLdsFloats * sizeof(float);
+  if (accum) {
+    static bool attr = false;
+    if (!attr && lds > 48 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, true>), dim3(grid), dim3(tmm::kThreads), lds, st, in, packet, out, frames);
+  } else {
+    static bool attr = false;
+    if (!attr && lds > 48 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, false>), dim3(grid), dim3(tmm::kThreads), lds, st, in, packet, out, frames);
+  }
+  return 1;
+}
+
+// returns 1 if an MFMA kernel exists for this shape (and was launched), 0 otherwise
+int tm_conv(int cin, int taps, int cout, bool accum, const float* in, const float* packet, float* out, int frames, int cus,
+            hipStream_t st) {
+#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_conv_launch<CI, TP, CO>(accum, in, packet, out, frames, cus, st);
+  RCED_TM_SHAPES(X)
+#undef X
+  return 0;
+}
+bool tm_has(int cin, int taps, int cout) {
+#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return true;
+  RCED_TM_SHAPES(X)
+#undef X
+  return false;
+}
+
+template <int CIN, int TAPS, int COUT>
+int tm_wgrad_launch(const float* x, const float* dz, float* dW, int frames, int cus, hipStream_t st) {
+  using G = tmm::Geo<CIN, TAPS, COUT>;
+  const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
+  const int grid = std::min(ntiles, cus * 2);
+  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32) * sizeof(float);
+  static bool attr = false;
+  if (!attr && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW, frames);
+  return 1;
+}
+int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float* dW, int frames, int cus, hipStream_t st) {
+#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_wgrad_launch<CI, TP, CO>(x, dz, dW, frames, cus, st);
+  X(8, 9, 18) X(18, 5, 30) X(30, 9, 8)
+#undef X
+  return 0;
+}
+
 __global__ void sums_to_float(const double* __restrict__ sums, int C, int which, float* __restrict__ dst) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) dst[c] = (float)sums[2 * c + which];
@@ -156,6 +233,11 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
   t->net = net;
   t->batch_size = batch_size;
   t->nvars = n_floats;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) t->num_cus = prop.multiProcessorCount;
+    if (const char* e = getenv("RCED_TRAIN_MFMA")) t->use_mfma = atoi(e);
+  }
   const int L = net->n_layers;
   std::vector<unsigned char> mask(n_floats, 0);
   size_t o = 0;
@@ -203,6 +285,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
   TRY_OR_FREE(hipMalloc(&t->sums, train::kMaxC * 2 * sizeof(double)));
   t->wf.assign(L, nullptr); t->wt.assign(L, nullptr); t->bias4.assign(L, nullptr);
   t->mu.assign(L, nullptr); t->rstd.assign(L, nullptr);
+  t->pk_fwd.assign(L, nullptr); t->pk_bwd.assign(L, nullptr);
   for (int l = 0; l < L; ++l) {
     const LayerSpec& s = net->layer[l];
     const LayerOff& f = t->off[l];
@@ -211,6 +294,8 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     TRY_OR_FREE(hipMalloc(&t->bias4[l], 64 * sizeof(float)));
     TRY_OR_FREE(hipMalloc(&t->mu[l], 64 * sizeof(float)));
     TRY_OR_FREE(hipMalloc(&t->rstd[l], 64 * sizeof(float)));
+    if (s.kh == 1 && tm_has(f.cin, s.kw, s.cout)) TRY_OR_FREE(hipMalloc(&t->pk_fwd[l], tm_packet_floats(f.cin, s.kw, s.cout) * sizeof(float)));
+    if (s.kh == 1 && tm_has(s.cout, s.kw, f.cin)) TRY_OR_FREE(hipMalloc(&t->pk_bwd[l], tm_packet_floats(s.cout, s.kw, f.cin) * sizeof(float)));
   }
 #undef TRY_OR_FREE
   *out = t;
@@ -260,13 +345,32 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     hipLaunchKernelGGL(train::repack_dgrad, dim3((nt + 255) / 256), dim3(256), 0, st, t->params + f.kernel, s.kh, s.kw,
                        f.cin, s.cout, f.cin4, t->wt[l]);
   }
+  if (t->use_mfma)
+    for (int l = 0; l < L; ++l) {
+      const LayerSpec& s = net.layer[l];
+      const LayerOff& f = t->off[l];
+      if (t->pk_fwd[l]) {
+        const int n = (int)tm_packet_floats(f.cin, s.kw, s.cout);
+        hipLaunchKernelGGL(tmm::pack_packet, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
+                           (const float*)(t->params + f.bias), s.kw, f.cin, s.cout, 0, t->pk_fwd[l]);
+      }
+      if (t->pk_bwd[l]) {
+        const int n = (int)tm_packet_floats(s.cout, s.kw, f.cin);
+        hipLaunchKernelGGL(tmm::pack_packet, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
+                           (const float*)nullptr, s.kw, s.cout, f.cin, 1, t->pk_bwd[l]);
+      }
+    }
   // ---- forward (is_training=True)
   for (int l = 0; l < L; ++l) {
     const LayerSpec& s = net.layer[l];
     const LayerOff& f = t->off[l];
-    if (int rc = launch_conv(tensor(s.src), t->z[l], t->wf[l], t->bias4[l], nullptr, frames, T, F, f.cin, s.cout, f.cout4,
-                             s.kh, s.kw, (s.kh - 1) / 2, (s.kw - 1) / 2, st))
+    if (t->use_mfma && t->pk_fwd[l] &&
+        tm_conv(f.cin, s.kw, s.cout, false, tensor(s.src), t->pk_fwd[l], t->z[l], frames, t->num_cus, st)) {
+      // MFMA path (kernels_train_mfma.h)
+    } else if (int rc = launch_conv(tensor(s.src), t->z[l], t->wf[l], t->bias4[l], nullptr, frames, T, F, f.cin, s.cout,
+                                    f.cout4, s.kh, s.kw, (s.kh - 1) / 2, (s.kw - 1) / 2, st)) {
       return rc;
+    }
     const size_t n = P * s.cout;
     if (s.use_norm) {
       if (int rc = reduce_channels(t, t->z[l], t->z[l], nullptr, nullptr, P, s.cout, st)) return rc;
@@ -309,7 +413,10 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     if (int rc = reduce_channels(t, t->D, t->D, nullptr, nullptr, P, s.cout, st)) return rc;
     hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.bias);
     // dW
-    {
+    if (t->use_mfma && s.kh == 1 &&
+        tm_wgrad(f.cin, s.kw, s.cout, tensor(s.src), t->D, t->grads + f.kernel, frames, t->num_cus, st)) {
+      // MFMA path
+    } else {
       const int fpw = 16;
       const size_t lds = ((size_t)s.kh * (F + s.kw - 1) * f.cin + (size_t)F * s.cout) * sizeof(float);
       if (f.K * s.cout > train::kWgradMaxOut * train::kThreads || lds > 64 * 1024)
@@ -319,9 +426,13 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     }
     // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
     if (s.src > 0) {
-      if (int rc = launch_conv(t->D, t->G[s.src], t->wt[l], t->zero32, t->G[s.src], frames, T, F, s.cout, f.cin, f.cin4, s.kh,
-                               s.kw, (s.kh - 1) - (s.kh - 1) / 2, (s.kw - 1) - (s.kw - 1) / 2, st))
+      if (t->use_mfma && t->pk_bwd[l] &&
+          tm_conv(s.cout, s.kw, f.cin, true, t->D, t->pk_bwd[l], t->G[s.src], frames, t->num_cus, st)) {
+        // MFMA path
+      } else if (int rc = launch_conv(t->D, t->G[s.src], t->wt[l], t->zero32, t->G[s.src], frames, T, F, s.cout, f.cin,
+                                      f.cin4, s.kh, s.kw, (s.kh - 1) - (s.kh - 1) / 2, (s.kw - 1) - (s.kw - 1) / 2, st)) {
         return rc;
+      }
     }
   }
   // ---- Adam (TF form), trainer.py:175-179
