@@ -17,6 +17,7 @@ namespace tmm {
 using chain::f32x2;
 using chain::f32x4;
 using chain::mfma;
+using chain::pin;
 
 constexpr int kF = 129;
 constexpr int kTF = 2;                 // frames per tile
@@ -73,6 +74,58 @@ __global__ void pack_packet(const float* __restrict__ w, const float* __restrict
     v = transpose ? w[((taps - 1 - tap) * cout + co) * cin + ci]    // w[tap_l][ci_l = co][co_l = ci], layer dims (cout, cin)
                   : w[(tap * cin + ci) * cout + co];
   packet[e] = v;
+}
+
+
+// ---- tile staging: kTF frames are contiguous in global ([frame][bin][C], C even => 16-byte aligned tile start and
+// a whole number of float4).  A thread keeps PER float4 in flight (fetch), and writes them to LDS later (commit) as
+// float2 pieces, which never straddle a frame or a pixel because C is even.  The fetch of the NEXT tile is issued
+// before the MFMA work of the current one so HBM latency hides behind it.
+template <int C>
+struct Stage {
+  static constexpr int kFrame = kF * C, kElems = kTF * kFrame, kVec = kElems / 4;
+  static constexpr int kPer = (kVec + kThreads - 1) / kThreads;
+  static_assert(C % 2 == 0 && kElems % 4 == 0, "wide staging needs an even channel count");
+};
+template <int C>
+__device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int frame0, int frames, int tid,
+                                           f32x4 (&pre)[Stage<C>::kPer]) {
+  using St = Stage<C>;
+  const float* src = base + (size_t)frame0 * St::kFrame;
+  const int left = frames - frame0;
+  const int nvalid = (left < kTF ? left : kTF) * St::kFrame;
+#pragma unroll
+  for (int i = 0; i < St::kPer; ++i) {
+    const int q = tid + i * kThreads;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < St::kVec) {
+      if (4 * q + 4 <= nvalid) {
+        v = *reinterpret_cast<const f32x4*>(src + 4 * q);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * q + j < nvalid) v[j] = src[4 * q + j];
+      }
+    }
+    pre[i] = v;
+  }
+}
+// dst index of element (frame fr, offset r inside the frame) = base_row(fr) * ROWSTRIDE-style mapping given by MAP
+template <int C, class MAP>
+__device__ __forceinline__ void tile_commit(float* lds, int tid, const f32x4 (&pre)[Stage<C>::kPer], MAP map) {
+  using St = Stage<C>;
+#pragma unroll
+  for (int i = 0; i < St::kPer; ++i) {
+    const int q = tid + i * kThreads;
+    if (q < St::kVec) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 4 * q + 2 * h;
+        const int fr = e / St::kFrame, r = e - fr * St::kFrame;
+        *reinterpret_cast<f32x2*>(lds + map(fr, r)) = f32x2{pre[i][2 * h], pre[i][2 * h + 1]};
+      }
+    }
+  }
 }
 
 template <int CIN, int TAPS, int COUT, bool ACCUM, int NX>
@@ -142,18 +195,33 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
   for (int e = tid; e < G::kLdsFloats; e += kThreads) lds[e] = e < G::kInFloats ? 0.f : packet[e - G::kInFloats];
   __syncthreads();
   const int ntiles = (frames + kTF - 1) / kTF;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int frame0 = tile * kTF;
-    // stage kTF frames: [fr][f][ci] (contiguous in global) -> LDS pixel fr*S + f, channel stride CinP
-    const float* src = in + (size_t)frame0 * kF * CIN;
-    for (int e = tid; e < kTF * kF * CIN; e += kThreads) {
-      const int fr = e / (kF * CIN), r = e - fr * (kF * CIN), f = r / CIN, ci = r - f * CIN;
-      lin[(G::kG + fr * G::kS + f) * G::kCinP + ci] = (frame0 + fr < frames) ? src[e] : 0.f;
+  if constexpr (CIN % 2 == 0) {
+    f32x4 pre[Stage<CIN>::kPer];
+    if ((int)blockIdx.x < ntiles) tile_fetch<CIN>(in, blockIdx.x * kTF, frames, tid, pre);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int frame0 = tile * kTF;
+      tile_commit<CIN>(lin, tid, pre, [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; });
+      __syncthreads();
+      if (tile + (int)gridDim.x < ntiles) tile_fetch<CIN>(in, (tile + gridDim.x) * kTF, frames, tid, pre);
+      pin();
+      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, 1>(lin, lw, out, frame0, frames, wave, lane);
+      else conv_tile<CIN, TAPS, COUT, ACCUM, 0>(lin, lw, out, frame0, frames, wave, lane);
+      __syncthreads();
     }
-    __syncthreads();
-    if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, 1>(lin, lw, out, frame0, frames, wave, lane);
-    else conv_tile<CIN, TAPS, COUT, ACCUM, 0>(lin, lw, out, frame0, frames, wave, lane);
-    __syncthreads();
+  } else {
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int frame0 = tile * kTF;
+      // odd channel count (the 1-channel dz of decode_final): element-wise staging, channel stride CinP
+      const float* src = in + (size_t)frame0 * kF * CIN;
+      for (int e = tid; e < kTF * kF * CIN; e += kThreads) {
+        const int fr = e / (kF * CIN), r = e - fr * (kF * CIN), f = r / CIN, ci = r - f * CIN;
+        lin[(G::kG + fr * G::kS + f) * G::kCinP + ci] = (frame0 + fr < frames) ? src[e] : 0.f;
+      }
+      __syncthreads();
+      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, 1>(lin, lw, out, frame0, frames, wave, lane);
+      else conv_tile<CIN, TAPS, COUT, ACCUM, 0>(lin, lw, out, frame0, frames, wave, lane);
+      __syncthreads();
+    }
   }
 }
 
@@ -167,9 +235,12 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int TAPS, int COUT>
 __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restrict__ x, const float* __restrict__ dz,
-                                                           float* __restrict__ dW, int frames) {
+                                                           float* __restrict__ dW, float* __restrict__ dbias, int frames) {
   using G = Geo<CIN, TAPS, COUT>;
-  constexpr int KT = (G::kK + 15) / 16, NTo = G::kMT;
+  static_assert(CIN % 2 == 0 && COUT % 2 == 0, "wgrad1xk_mfma stages float4 / float2 pieces");
+  // one spare k row carries a constant 1, so its output row is sum_px dz = dbias
+  constexpr int KT = (G::kK + 1 + 15) / 16, NTo = G::kMT;
+  constexpr int kOneTile = G::kK / 16, kOneRow = G::kK % 16;
   constexpr int kDzRows = 16 * G::kTiles + 4;
   constexpr int kDzStride = 32;                        // floats per pixel row of the dz tile (>= 16*NTo, bank friendly)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -179,34 +250,39 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
   for (int e = tid; e < G::kInFloats + 64 + kDzRows * kDzStride; e += kThreads) lds[e] = 0.f;
-  __syncthreads();
   f32x4 acc[KT][NTo];
 #pragma unroll
   for (int a = 0; a < KT; ++a)
 #pragma unroll
     for (int b = 0; b < NTo; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (frames + kTF - 1) / kTF;
+  f32x4 prex[Stage<CIN>::kPer], prez[Stage<COUT>::kPer];
+  if ((int)blockIdx.x < ntiles) {
+    tile_fetch<CIN>(x, blockIdx.x * kTF, frames, tid, prex);
+    tile_fetch<COUT>(dz, blockIdx.x * kTF, frames, tid, prez);
+  }
+  __syncthreads();
+  const float* ain = lin + kq * G::kCinP + i;          // window start of pixel (px0 + kq) is row (px0 + kq) of lin
+  const float* bin = ldz + kq * kDzStride + i;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int frame0 = tile * kTF;
-    const float* xs = x + (size_t)frame0 * kF * CIN;
-    const float* ds = dz + (size_t)frame0 * kF * COUT;
+    tile_commit<CIN>(lin, tid, prex, [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; });
+    tile_commit<COUT>(ldz, tid, prez, [](int fr, int r) {
+      const int f = r / COUT, co = r - f * COUT;
+      return (fr * G::kS + f) * kDzStride + co;
+    });
     __syncthreads();
-    for (int e = tid; e < kTF * kF * CIN; e += kThreads) {
-      const int fr = e / (kF * CIN), r = e - fr * (kF * CIN), f = r / CIN, ci = r - f * CIN;
-      lin[(G::kG + fr * G::kS + f) * G::kCinP + ci] = (frame0 + fr < frames) ? xs[e] : 0.f;
+    if (tile + (int)gridDim.x < ntiles) {
+      tile_fetch<CIN>(x, (tile + gridDim.x) * kTF, frames, tid, prex);
+      tile_fetch<COUT>(dz, (tile + gridDim.x) * kTF, frames, tid, prez);
     }
-    for (int e = tid; e < kTF * kF * COUT; e += kThreads) {
-      const int fr = e / (kF * COUT), r = e - fr * (kF * COUT), f = r / COUT, co = r - f * COUT;
-      ldz[(fr * G::kS + f) * kDzStride + co] = (frame0 + fr < frames) ? ds[e] : 0.f;
-    }
-    __syncthreads();
-    const float* ain = lin + kq * G::kCinP + i;        // window start of pixel (px0 + kq) is row (px0 + kq) of lin
-    const float* bin = ldz + kq * kDzStride + i;
+    pin();
+#pragma unroll 2
     for (int g = wave; g < G::kNPX / 4 + 1; g += kWaves) {
       const int px0 = 4 * g;
       float a[KT], b[NTo];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) a[kt] = ain[px0 * G::kCinP + 16 * kt];
+      if (i == kOneRow) a[kOneTile] = 1.f;
 #pragma unroll
       for (int nt = 0; nt < NTo; ++nt) b[nt] = bin[px0 * kDzStride + 16 * nt];
 #pragma unroll
@@ -214,6 +290,7 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
 #pragma unroll
         for (int nt = 0; nt < NTo; ++nt) acc[kt][nt] = mfma(a[kt], b[nt], acc[kt][nt]);
     }
+    __syncthreads();
   }
   // D row = k = 16*kt + 4*kq + r, column = co = 16*nt + i
 #pragma unroll
@@ -227,9 +304,10 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
         const int k = 16 * kt + 4 * kq + r;
         const int tap = k / G::kCinP, ci = k - tap * G::kCinP;
         if (k < G::kK && ci < CIN && co < COUT) atomicAdd(dW + (tap * CIN + ci) * COUT + co, vv[r]);
+        if (k == G::kK && co < COUT && dbias) atomicAdd(dbias + co, vv[r]);
       }
     }
 }
 
-}  // namespace tm
+}  // namespace tmm
 }  // namespace rced

@@ -184,7 +184,7 @@ bool tm_has(int cin, int taps, int cout) {
 }
 
 template <int CIN, int TAPS, int COUT>
-int tm_wgrad_launch(const float* x, const float* dz, float* dW, int frames, int cus, hipStream_t st) {
+int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, hipStream_t st) {
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const int grid = std::min(ntiles, cus * 2);
@@ -195,11 +195,12 @@ int tm_wgrad_launch(const float* x, const float* dz, float* dW, int frames, int 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW, frames);
+  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW, dbias, frames);
   return 1;
 }
-int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float* dW, int frames, int cus, hipStream_t st) {
-#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_wgrad_launch<CI, TP, CO>(x, dz, dW, frames, cus, st);
+int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
+             hipStream_t st) {
+#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_wgrad_launch<CI, TP, CO>(x, dz, dW, dbias, frames, cus, st);
   X(8, 9, 18) X(18, 5, 30) X(30, 9, 8)
 #undef X
   return 0;
@@ -391,7 +392,24 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
   HIP_TRY(hipMemcpyAsync(hp.data(), t->part, kReduceGrid * sizeof(double), hipMemcpyDeviceToHost, st));
   // ---- backward
   HIP_TRY(hipMemsetAsync(t->grads, 0, t->nvars * sizeof(float), st));
-  for (int id = 1; id < L; ++id) HIP_TRY(hipMemsetAsync(t->G[id], 0, P * net.layer[id - 1].cout * sizeof(float), st));
+  // G[id] collects d loss / d tensor id from every consumer (the conv reading it, skip adds).  A tensor with one
+  // consumer is written (=) by that consumer's dgrad; the others are zeroed here and accumulated into (+=).
+  std::vector<int> consumers(L + 1, 0);
+  for (int l = 0; l < L; ++l) {
+    if (net.layer[l].src > 0) ++consumers[net.layer[l].src];
+    if (net.layer[l].skip_pre > 0) ++consumers[net.layer[l].skip_pre];
+    if (net.layer[l].skip_post > 0) ++consumers[net.layer[l].skip_post];
+  }
+  auto overwrite = [&](int l) {   // layer l's dgrad may overwrite G[src] (MFMA path only; the generic kernel always +=)
+    const LayerSpec& s = net.layer[l];
+    return t->use_mfma && t->pk_bwd[l] != nullptr && s.src > 0 && consumers[s.src] == 1;
+  };
+  {
+    std::vector<char> plain(L + 1, 0);
+    for (int l = 0; l < L; ++l) if (overwrite(l)) plain[net.layer[l].src] = 1;
+    for (int id = 1; id < L; ++id)
+      if (!plain[id]) HIP_TRY(hipMemsetAsync(t->G[id], 0, P * net.layer[id - 1].cout * sizeof(float), st));
+  }
   for (int l = L - 1; l >= 0; --l) {
     const LayerSpec& s = net.layer[l];
     const LayerOff& f = t->off[l];
@@ -409,14 +427,13 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
                          (const float*)t->rstd[l], (const float*)(t->params + f.gamma), (const double*)t->sums, (double)P, n,
                          s.cout);
     }
-    // dbias = sum dz
-    if (int rc = reduce_channels(t, t->D, t->D, nullptr, nullptr, P, s.cout, st)) return rc;
-    hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.bias);
-    // dW
-    if (t->use_mfma && s.kh == 1 &&
-        tm_wgrad(f.cin, s.kw, s.cout, tensor(s.src), t->D, t->grads + f.kernel, frames, t->num_cus, st)) {
+    // dW and dbias = sum dz (the MFMA wgrad kernel produces both)
+    if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, tensor(s.src), t->D, t->grads + f.kernel,
+                                             t->grads + f.bias, frames, t->num_cus, st)) {
       // MFMA path
     } else {
+      if (int rc = reduce_channels(t, t->D, t->D, nullptr, nullptr, P, s.cout, st)) return rc;
+      hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.bias);
       const int fpw = 16;
       const size_t lds = ((size_t)s.kh * (F + s.kw - 1) * f.cin + (size_t)F * s.cout) * sizeof(float);
       if (f.K * s.cout > train::kWgradMaxOut * train::kThreads || lds > 64 * 1024)
@@ -427,7 +444,7 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
     if (s.src > 0) {
       if (t->use_mfma && t->pk_bwd[l] &&
-          tm_conv(s.cout, s.kw, f.cin, true, t->D, t->pk_bwd[l], t->G[s.src], frames, t->num_cus, st)) {
+          tm_conv(s.cout, s.kw, f.cin, !overwrite(l), t->D, t->pk_bwd[l], t->G[s.src], frames, t->num_cus, st)) {
         // MFMA path
       } else if (int rc = launch_conv(t->D, t->G[s.src], t->wt[l], t->zero32, t->G[s.src], frames, T, F, s.cout, f.cin,
                                       f.cin4, s.kh, s.kw, (s.kh - 1) - (s.kh - 1) / 2, (s.kw - 1) - (s.kw - 1) / 2, st)) {
