@@ -167,6 +167,161 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply(float* __restrict__ d, 
   }
 }
 
+// ---- channel-aligned float2 variants of the three elementwise kernels (even C) ----------------------
+// A thread owns one channel pair, c2 = tid % (C/2), and walks pixels row = tid / (C/2) + k * rows: no
+// per-element modulo, 8-byte accesses, the per-channel constants live in registers, and the BN-backward
+// sums (S1 = sum d_u, S2 = sum d_u * zhat) fall out of bwd_route2 without another pass over d and z.
+constexpr int kPairUnroll = 4;   // pixels in flight per thread
+
+struct PairLane {
+  int C2, c2, row, rows;
+  bool active;
+  __device__ PairLane(int C, int tid) : C2(C >> 1), c2(tid % (C >> 1)), row(tid / (C >> 1)), rows(kThreads / (C >> 1)) {
+    active = row < rows;
+  }
+};
+
+__global__ __launch_bounds__(kThreads) void bn_act_fwd2(const float2* __restrict__ z, const float* __restrict__ mu,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float2* __restrict__ skip_pre,
+                                                         const float2* __restrict__ skip_post, int use_act, size_t P, int C,
+                                                         float2* __restrict__ out) {
+  const PairLane L(C, threadIdx.x);
+  if (!L.active) return;
+  float m[2] = {0.f, 0.f}, r[2] = {1.f, 1.f}, ga[2] = {1.f, 1.f}, be[2] = {0.f, 0.f};
+  if (mu)
+    for (int k = 0; k < 2; ++k) { const int c = 2 * L.c2 + k; m[k] = mu[c]; r[k] = rstd[c]; ga[k] = gamma[c]; be[k] = beta[c]; }
+  const size_t stride = (size_t)gridDim.x * L.rows;
+  for (size_t p = (size_t)blockIdx.x * L.rows + L.row; p < P; p += kPairUnroll * stride) {
+    float2 zv[kPairUnroll], s1[kPairUnroll], s2[kPairUnroll];
+#pragma unroll
+    for (int u = 0; u < kPairUnroll; ++u) {
+      const size_t q = (p + u * stride) * L.C2 + L.c2;
+      const bool ok = p + u * stride < P;
+      zv[u] = ok ? z[q] : float2{0.f, 0.f};
+      s1[u] = (ok && skip_pre) ? skip_pre[q] : float2{0.f, 0.f};
+      s2[u] = (ok && skip_post) ? skip_post[q] : float2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < kPairUnroll; ++u) {
+      if (p + u * stride >= P) break;
+      float v[2] = {zv[u].x, zv[u].y};
+      const float a1[2] = {s1[u].x, s1[u].y}, a2[2] = {s2[u].x, s2[u].y};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (mu) v[k] = ga[k] * ((v[k] - m[k]) * r[k]) + be[k];
+        if (skip_pre) v[k] += a1[k];
+        if (use_act) v[k] = fmaxf(v[k], 0.f);
+        if (skip_post) v[k] += a2[k];
+      }
+      out[(p + u * stride) * L.C2 + L.c2] = float2{v[0], v[1]};
+    }
+  }
+}
+
+// part [grid][C][2] doubles (as chan_reduce); pass part = nullptr for layers without BN
+__global__ __launch_bounds__(kThreads) void bwd_route2(const float2* __restrict__ g_out, const float2* __restrict__ z,
+                                                        const float* __restrict__ mu, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float2* __restrict__ skip_pre, int use_act, size_t P, int C,
+                                                        float2* __restrict__ g_skip_pre, float2* __restrict__ g_skip_post,
+                                                        float2* __restrict__ d, double* __restrict__ part) {
+  __shared__ double red[kThreads * 4];
+  const PairLane L(C, threadIdx.x);
+  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [k][S1, S2]
+  if (L.active) {
+    float m[2] = {0.f, 0.f}, r[2] = {1.f, 1.f}, ga[2] = {1.f, 1.f}, be[2] = {0.f, 0.f};
+    if (mu)
+      for (int k = 0; k < 2; ++k) { const int c = 2 * L.c2 + k; m[k] = mu[c]; r[k] = rstd[c]; ga[k] = gamma[c]; be[k] = beta[c]; }
+    const size_t stride = (size_t)gridDim.x * L.rows;
+    for (size_t p = (size_t)blockIdx.x * L.rows + L.row; p < P; p += kPairUnroll * stride) {
+      float2 gv[kPairUnroll], zv[kPairUnroll], sp[kPairUnroll], gp[kPairUnroll], gq[kPairUnroll];
+#pragma unroll
+      for (int u = 0; u < kPairUnroll; ++u) {
+        const size_t q = (p + u * stride) * L.C2 + L.c2;
+        const bool ok = p + u * stride < P;
+        gv[u] = ok ? g_out[q] : float2{0.f, 0.f};
+        zv[u] = ok ? z[q] : float2{0.f, 0.f};
+        sp[u] = (ok && skip_pre) ? skip_pre[q] : float2{0.f, 0.f};
+        gp[u] = (ok && g_skip_pre) ? g_skip_pre[q] : float2{0.f, 0.f};
+        gq[u] = (ok && g_skip_post) ? g_skip_post[q] : float2{0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < kPairUnroll; ++u) {
+        if (p + u * stride >= P) break;
+        const size_t q = (p + u * stride) * L.C2 + L.c2;
+        const float go[2] = {gv[u].x, gv[u].y}, zz[2] = {zv[u].x, zv[u].y}, sk[2] = {sp[u].x, sp[u].y};
+        float du[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          du[k] = go[k];
+          if (use_act) {
+            float v = zz[k];
+            if (mu) v = ga[k] * ((v - m[k]) * r[k]) + be[k];
+            if (skip_pre) v += sk[k];
+            du[k] = v > 0.f ? go[k] : 0.f;
+          }
+          acc[k][0] += (double)du[k];
+          acc[k][1] += (double)du[k] * (double)((zz[k] - m[k]) * r[k]);
+        }
+        if (g_skip_post) g_skip_post[q] = float2{gq[u].x + go[0], gq[u].y + go[1]};
+        if (g_skip_pre) g_skip_pre[q] = float2{gp[u].x + du[0], gp[u].y + du[1]};
+        d[q] = float2{du[0], du[1]};
+      }
+    }
+  }
+  if (!part) return;
+  red[threadIdx.x * 4 + 0] = acc[0][0];
+  red[threadIdx.x * 4 + 1] = acc[0][1];
+  red[threadIdx.x * 4 + 2] = acc[1][0];
+  red[threadIdx.x * 4 + 3] = acc[1][1];
+  __syncthreads();
+  if ((int)threadIdx.x < L.C2) {
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int rr = 0; rr < L.rows; ++rr)
+      for (int j = 0; j < 4; ++j) t[j] += red[(rr * L.C2 + threadIdx.x) * 4 + j];
+    double* o = part + ((size_t)blockIdx.x * C + 2 * threadIdx.x) * 2;   // channels 2*c2, 2*c2+1: (S1, S2) each
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply2(float2* __restrict__ d, const float2* __restrict__ z,
+                                                           const float* __restrict__ mu, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                           double P, size_t Ppx, int C) {
+  const PairLane L(C, threadIdx.x);
+  if (!L.active) return;
+  float m[2], r[2], gr[2], m1[2], m2[2];
+  for (int k = 0; k < 2; ++k) {
+    const int c = 2 * L.c2 + k;
+    m[k] = mu[c]; r[k] = rstd[c]; gr[k] = gamma[c] * rstd[c];
+    m1[k] = (float)(sums[2 * c] / P); m2[k] = (float)(sums[2 * c + 1] / P);
+  }
+  const size_t stride = (size_t)gridDim.x * L.rows;
+  for (size_t p = (size_t)blockIdx.x * L.rows + L.row; p < Ppx; p += kPairUnroll * stride) {
+    float2 dv[kPairUnroll], zv[kPairUnroll];
+#pragma unroll
+    for (int u = 0; u < kPairUnroll; ++u) {
+      const size_t q = (p + u * stride) * L.C2 + L.c2;
+      const bool ok = p + u * stride < Ppx;
+      dv[u] = ok ? d[q] : float2{0.f, 0.f};
+      zv[u] = ok ? z[q] : float2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < kPairUnroll; ++u) {
+      if (p + u * stride >= Ppx) break;
+      const float dd[2] = {dv[u].x, dv[u].y}, zz[2] = {zv[u].x, zv[u].y};
+      float o[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float zh = (zz[k] - m[k]) * r[k];
+        o[k] = gr[k] * (dd[k] - m1[k] - zh * m2[k]);
+      }
+      d[(p + u * stride) * L.C2 + L.c2] = float2{o[0], o[1]};
+    }
+  }
+}
+
 // ---- weight gradient: dW[i,j,ci,co] = sum_p x[p + (i,j) - pad, ci] * dz[p, co]  (+= via atomics) ----
 // One workgroup per group of `frames_per_wg` frames; per frame the kh input rows and the dz row are
 // staged in LDS; thread o owns outputs o, o+256, ... of the [kh*kw*cin][cout] gradient and walks the

@@ -128,9 +128,10 @@ __device__ __forceinline__ void tile_commit(float* lds, int tid, const f32x4 (&p
   }
 }
 
-template <int CIN, int TAPS, int COUT, bool ACCUM, int NX>
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX>
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
-                                          int frames, int wave, int lane) {
+                                          int frames, int wave, int lane,
+                                          double (&st1)[Geo<CIN, TAPS, COUT>::kMT][4], double (&st2)[Geo<CIN, TAPS, COUT>::kMT][4]) {
   using G = Geo<CIN, TAPS, COUT>;
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMT;
   const int n = lane & 15, kq = lane >> 4;
@@ -146,11 +147,28 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
   }
   chain::gemm_pass<NR, NX, MT, G::kK, 64 * G::kCinP, 2>(in, (px0 - G::kG) * G::kCinP + 2 * kq,
                                                         (pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc);
+  float p1[MT][4], p2[MT][4];   // this tile's share of sum z, sum z^2 (<= NT values each, fp32)
+  if constexpr (STATS) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p1[mt][j] = p2[mt][j] = 0.f;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int px = t < NR ? px0 + 64 * t : pxx;
     const int fr = px / G::kS, f = px - fr * G::kS;
     if (px >= G::kNPX || f >= kF || frame0 + fr >= frames) continue;
+    if constexpr (STATS) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[t][mt][j];
+          p1[mt][j] += v;
+          p2[mt][j] = fmaf(v, v, p2[mt][j]);
+        }
+    }
     float* op = out + ((size_t)(frame0 + fr) * kF + f) * COUT;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -180,12 +198,23 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
       }
     }
   }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        st1[mt][j] += (double)p1[mt][j];
+        st2[mt][j] += (double)p2[mt][j];
+      }
+  }
 }
 
 // in [frames][129][CIN], out [frames][129][COUT].  Persistent over tiles of kTF frames.
-template <int CIN, int TAPS, int COUT, bool ACCUM>
+// STATS: also emit this workgroup's per-channel (sum z, sum z^2) of what it wrote, as doubles, into
+// part[blockIdx.x][COUT][2] -- the batch-norm statistics, without another pass over z.
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS>
 __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict__ in, const float* __restrict__ packet,
-                                                          float* __restrict__ out, int frames) {
+                                                          float* __restrict__ out, int frames, double* __restrict__ part) {
   using G = Geo<CIN, TAPS, COUT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lin = lds;
@@ -194,6 +223,11 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int e = tid; e < G::kLdsFloats; e += kThreads) lds[e] = e < G::kInFloats ? 0.f : packet[e - G::kInFloats];
   __syncthreads();
+  double st1[G::kMT][4], st2[G::kMT][4];
+#pragma unroll
+  for (int mt = 0; mt < G::kMT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st1[mt][j] = st2[mt][j] = 0.0;
   const int ntiles = (frames + kTF - 1) / kTF;
   if constexpr (CIN % 2 == 0) {
     f32x4 pre[Stage<CIN>::kPer];
@@ -204,8 +238,8 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
       __syncthreads();
       if (tile + (int)gridDim.x < ntiles) tile_fetch<CIN>(in, (tile + gridDim.x) * kTF, frames, tid, pre);
       pin();
-      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, 1>(lin, lw, out, frame0, frames, wave, lane);
-      else conv_tile<CIN, TAPS, COUT, ACCUM, 0>(lin, lw, out, frame0, frames, wave, lane);
+      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1>(lin, lw, out, frame0, frames, wave, lane, st1, st2);
+      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0>(lin, lw, out, frame0, frames, wave, lane, st1, st2);
       __syncthreads();
     }
   } else {
@@ -218,9 +252,36 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
         lin[(G::kG + fr * G::kS + f) * G::kCinP + ci] = (frame0 + fr < frames) ? src[e] : 0.f;
       }
       __syncthreads();
-      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, 1>(lin, lw, out, frame0, frames, wave, lane);
-      else conv_tile<CIN, TAPS, COUT, ACCUM, 0>(lin, lw, out, frame0, frames, wave, lane);
+      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1>(lin, lw, out, frame0, frames, wave, lane, st1, st2);
+      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0>(lin, lw, out, frame0, frames, wave, lane, st1, st2);
       __syncthreads();
+    }
+  }
+  if constexpr (STATS) {
+    // lane (n, kq) holds channels 16*mt + 4*kq + j of its pixels: add over the 16 pixel lanes, then over the waves
+    double* red = reinterpret_cast<double*>(lds);             // [wave][32 channels][2]; the tile loop is over
+#pragma unroll
+    for (int mt = 0; mt < G::kMT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double a = st1[mt][j], b = st2[mt][j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        if ((lane & 15) == 0) {
+          const int c = 16 * mt + 4 * (lane >> 4) + j;
+          red[(wave * 32 + c) * 2 + 0] = a;
+          red[(wave * 32 + c) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+      const int c = tid >> 1, k = tid & 1;
+      double t = 0.0;
+      for (int w = 0; w < kWaves; ++w) t += red[(w * 32 + c) * 2 + k];
+      part[((size_t)blockIdx.x * COUT + c) * 2 + k] = t;
     }
   }
 }
@@ -276,7 +337,6 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
       tile_fetch<COUT>(dz, (tile + gridDim.x) * kTF, frames, tid, prez);
     }
     pin();
-#pragma unroll 2
     for (int g = wave; g < G::kNPX / 4 + 1; g += kWaves) {
       const int px0 = 4 * g;
       float a[KT], b[NTo];

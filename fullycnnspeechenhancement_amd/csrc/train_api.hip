@@ -38,6 +38,7 @@ struct DeviceGuard {
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 constexpr int kReduceGrid = 512;
+constexpr int kPairGrid = 2048;     // workgroups of the channel-aligned elementwise kernels (and their partial sums)
 constexpr float kAdamB1 = 0.9f, kAdamB2 = 0.999f, kAdamEps = 1e-8f;   // tf.train.AdamOptimizer defaults
 constexpr float kBnMomentum = 0.99f;                                  // tf.layers.batch_normalization default
 
@@ -142,36 +143,37 @@ size_t tm_packet_floats(int cin, int taps, int cout) {
   return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + 32;
 }
 
-template <int CIN, int TAPS, int COUT>
-int tm_conv_launch(bool accum, const float* in, const float* packet, float* out, int frames, int cus, hipStream_t st) {
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS>
+int tm_conv_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part, hipStream_t st) {
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
-  const int grid = std::min(ntiles, cus * 4);
+  const int grid = std::min(ntiles, std::min(cus * 4, kPairGrid));
   const size_t lds = G::kLdsFloats * sizeof(float);
-  if (accum) {
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr = true;
-    }
-    hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, true>), dim3(grid), dim3(tmm::kThreads), lds, st, in, packet, out, frames);
-  } else {
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr = true;
-    }
-    hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, false>), dim3(grid), dim3(tmm::kThreads), lds, st, in, packet, out, frames);
+  static bool attr = false;
+  if (!attr && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
   }
-  return 1;
+  hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS>), dim3(grid), dim3(tmm::kThreads), lds, st, in, packet,
+                     out, frames, part);
+  return grid;
+}
+// mode 0: out = conv + shift;  1: out += conv;  2: as 0 and per-workgroup (sum, sum of squares) into part.
+// Returns the grid size (= number of partial-sum records for mode 2).
+template <int CIN, int TAPS, int COUT>
+int tm_conv_launch(int mode, const float* in, const float* packet, float* out, int frames, int cus, double* part,
+                   hipStream_t st) {
+  if (mode == 1) return tm_conv_launch1<CIN, TAPS, COUT, true, false>(in, packet, out, frames, cus, nullptr, st);
+  if (mode == 2) return tm_conv_launch1<CIN, TAPS, COUT, false, true>(in, packet, out, frames, cus, part, st);
+  return tm_conv_launch1<CIN, TAPS, COUT, false, false>(in, packet, out, frames, cus, nullptr, st);
 }
 
-// returns 1 if an MFMA kernel exists for this shape (and was launched), 0 otherwise
-int tm_conv(int cin, int taps, int cout, bool accum, const float* in, const float* packet, float* out, int frames, int cus,
-            hipStream_t st) {
-#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_conv_launch<CI, TP, CO>(accum, in, packet, out, frames, cus, st);
+// returns the grid size if an MFMA kernel exists for this shape (and was launched), 0 otherwise
+int tm_conv(int cin, int taps, int cout, int mode, const float* in, const float* packet, float* out, int frames, int cus,
+            double* part, hipStream_t st) {
+#define X(CI, TP, CO) \
+  if (cin == CI && taps == TP && cout == CO) return tm_conv_launch<CI, TP, CO>(mode, in, packet, out, frames, cus, part, st);
   RCED_TM_SHAPES(X)
 #undef X
   return 0;
@@ -282,7 +284,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
   TRY_OR_FREE(hipMemcpy(t->trainable, mask.data(), n_floats, hipMemcpyHostToDevice));
   TRY_OR_FREE(hipMalloc(&t->zero32, 64 * sizeof(float)));
   TRY_OR_FREE(hipMemset(t->zero32, 0, 64 * sizeof(float)));
-  TRY_OR_FREE(hipMalloc(&t->part, (size_t)kReduceGrid * train::kMaxC * 2 * sizeof(double)));
+  TRY_OR_FREE(hipMalloc(&t->part, (size_t)std::max(kReduceGrid, kPairGrid) * train::kMaxC * 2 * sizeof(double)));
   TRY_OR_FREE(hipMalloc(&t->sums, train::kMaxC * 2 * sizeof(double)));
   t->wf.assign(L, nullptr); t->wt.assign(L, nullptr); t->bias4.assign(L, nullptr);
   t->mu.assign(L, nullptr); t->rstd.assign(L, nullptr);
@@ -333,6 +335,10 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
   const size_t P = (size_t)frames * F;
   if (int rc = ensure_acts(t, P)) return rc;
   auto blocks = [](size_t n) { return dim3((unsigned)std::min<size_t>((n + train::kThreads - 1) / train::kThreads, 65535)); };
+  auto pair_grid = [&](int C) {   // channel-aligned kernels: rows = 256 / (C/2) pixels per workgroup pass
+    const size_t rows = train::kThreads / (C / 2);
+    return dim3((unsigned)std::min<size_t>((P + rows - 1) / rows, kPairGrid));
+  };
   auto tensor = [&](int id) -> const float* { return id < 0 ? nullptr : (id == 0 ? x_dev : t->out[id]); };
 
   // ---- weights in the layouts the conv kernel wants
@@ -365,24 +371,38 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
   for (int l = 0; l < L; ++l) {
     const LayerSpec& s = net.layer[l];
     const LayerOff& f = t->off[l];
+    int stat_parts = 0;   // > 0: the conv kernel already left that many (sum z, sum z^2) records in t->part
     if (t->use_mfma && t->pk_fwd[l] &&
-        tm_conv(f.cin, s.kw, s.cout, false, tensor(s.src), t->pk_fwd[l], t->z[l], frames, t->num_cus, st)) {
-      // MFMA path (kernels_train_mfma.h)
+        (stat_parts = tm_conv(f.cin, s.kw, s.cout, s.use_norm ? 2 : 0, tensor(s.src), t->pk_fwd[l], t->z[l], frames,
+                              t->num_cus, t->part, st)) > 0) {
+      if (!s.use_norm) stat_parts = 0;
     } else if (int rc = launch_conv(tensor(s.src), t->z[l], t->wf[l], t->bias4[l], nullptr, frames, T, F, f.cin, s.cout,
                                     f.cout4, s.kh, s.kw, (s.kh - 1) / 2, (s.kw - 1) / 2, st)) {
       return rc;
     }
     const size_t n = P * s.cout;
     if (s.use_norm) {
-      if (int rc = reduce_channels(t, t->z[l], t->z[l], nullptr, nullptr, P, s.cout, st)) return rc;
+      if (stat_parts > 0)
+        hipLaunchKernelGGL(train::reduce_finish, dim3(1), dim3(train::kThreads), 0, st, (const double*)t->part, stat_parts,
+                           s.cout, t->sums);
+      else if (int rc = reduce_channels(t, t->z[l], t->z[l], nullptr, nullptr, P, s.cout, st))
+        return rc;
       hipLaunchKernelGGL(train::bn_stats_finish, dim3(1), dim3(64), 0, st, (const double*)t->sums, (double)P, s.cout,
                          kBnEps, kBnMomentum, t->mu[l], t->rstd[l], t->params + f.mmean, t->params + f.mvar);
     }
-    if (t->out[l + 1] != t->z[l])
-      hipLaunchKernelGGL(train::bn_act_fwd, blocks(n), dim3(train::kThreads), 0, st, (const float*)t->z[l],
-                         s.use_norm ? (const float*)t->mu[l] : nullptr, (const float*)t->rstd[l],
-                         (const float*)(t->params + f.gamma), (const float*)(t->params + f.beta), tensor(s.skip_pre),
-                         tensor(s.skip_post), s.use_act, n, s.cout, t->out[l + 1]);
+    if (t->out[l + 1] != t->z[l]) {
+      if (s.cout % 2 == 0)
+        hipLaunchKernelGGL(train::bn_act_fwd2, pair_grid(s.cout), dim3(train::kThreads), 0, st, (const float2*)t->z[l],
+                           s.use_norm ? (const float*)t->mu[l] : nullptr, (const float*)t->rstd[l],
+                           (const float*)(t->params + f.gamma), (const float*)(t->params + f.beta),
+                           (const float2*)tensor(s.skip_pre), (const float2*)tensor(s.skip_post), s.use_act, P, s.cout,
+                           (float2*)t->out[l + 1]);
+      else
+        hipLaunchKernelGGL(train::bn_act_fwd, blocks(n), dim3(train::kThreads), 0, st, (const float*)t->z[l],
+                           s.use_norm ? (const float*)t->mu[l] : nullptr, (const float*)t->rstd[l],
+                           (const float*)(t->params + f.gamma), (const float*)(t->params + f.beta), tensor(s.skip_pre),
+                           tensor(s.skip_post), s.use_act, n, s.cout, t->out[l + 1]);
+    }
   }
   HIP_TRY(hipGetLastError());
   // ---- loss and its gradient (trainer.py:146-147,153)
@@ -415,17 +435,37 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     const LayerOff& f = t->off[l];
     const size_t n = P * s.cout;
     const float* mu = s.use_norm ? t->mu[l] : nullptr;
-    hipLaunchKernelGGL(train::bwd_route, blocks(n), dim3(train::kThreads), 0, st, (const float*)t->G[l + 1],
-                       (const float*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
-                       (const float*)(t->params + f.beta), tensor(s.skip_pre), s.use_act, n, s.cout,
-                       s.skip_pre > 0 ? t->G[s.skip_pre] : nullptr, s.skip_post > 0 ? t->G[s.skip_post] : nullptr, t->D);
+    const bool pairs = s.cout % 2 == 0;
+    if (pairs) {
+      const dim3 grid = pair_grid(s.cout);
+      hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
+                         (const float2*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
+                         (const float*)(t->params + f.beta), (const float2*)tensor(s.skip_pre), s.use_act, P, s.cout,
+                         (float2*)(s.skip_pre > 0 ? t->G[s.skip_pre] : nullptr),
+                         (float2*)(s.skip_post > 0 ? t->G[s.skip_post] : nullptr), (float2*)t->D,
+                         s.use_norm ? t->part : (double*)nullptr);
+      if (s.use_norm)
+        hipLaunchKernelGGL(train::reduce_finish, dim3(1), dim3(train::kThreads), 0, st, (const double*)t->part, (int)grid.x,
+                           s.cout, t->sums);
+    } else {
+      hipLaunchKernelGGL(train::bwd_route, blocks(n), dim3(train::kThreads), 0, st, (const float*)t->G[l + 1],
+                         (const float*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
+                         (const float*)(t->params + f.beta), tensor(s.skip_pre), s.use_act, n, s.cout,
+                         s.skip_pre > 0 ? t->G[s.skip_pre] : nullptr, s.skip_post > 0 ? t->G[s.skip_post] : nullptr, t->D);
+      if (s.use_norm)
+        if (int rc = reduce_channels(t, t->D, t->z[l], mu, t->rstd[l], P, s.cout, st)) return rc;
+    }
     if (s.use_norm) {
-      if (int rc = reduce_channels(t, t->D, t->z[l], mu, t->rstd[l], P, s.cout, st)) return rc;
       hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.beta);
       hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 1, t->grads + f.gamma);
-      hipLaunchKernelGGL(train::bn_bwd_apply, blocks(n), dim3(train::kThreads), 0, st, t->D, (const float*)t->z[l], mu,
-                         (const float*)t->rstd[l], (const float*)(t->params + f.gamma), (const double*)t->sums, (double)P, n,
-                         s.cout);
+      if (pairs)
+        hipLaunchKernelGGL(train::bn_bwd_apply2, pair_grid(s.cout), dim3(train::kThreads), 0, st, (float2*)t->D,
+                           (const float2*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
+                           (const double*)t->sums, (double)P, P, s.cout);
+      else
+        hipLaunchKernelGGL(train::bn_bwd_apply, blocks(n), dim3(train::kThreads), 0, st, t->D, (const float*)t->z[l], mu,
+                           (const float*)t->rstd[l], (const float*)(t->params + f.gamma), (const double*)t->sums, (double)P, n,
+                           s.cout);
     }
     // dW and dbias = sum dz (the MFMA wgrad kernel produces both)
     if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, tensor(s.src), t->D, t->grads + f.kernel,
@@ -444,7 +484,7 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
     if (s.src > 0) {
       if (t->use_mfma && t->pk_bwd[l] &&
-          tm_conv(s.cout, s.kw, f.cin, !overwrite(l), t->D, t->pk_bwd[l], t->G[s.src], frames, t->num_cus, st)) {
+          tm_conv(s.cout, s.kw, f.cin, overwrite(l) ? 0 : 1, t->D, t->pk_bwd[l], t->G[s.src], frames, t->num_cus, nullptr, st)) {
         // MFMA path
       } else if (int rc = launch_conv(t->D, t->G[s.src], t->wt[l], t->zero32, t->G[s.src], frames, T, F, s.cout, f.cin,
                                       f.cin4, s.kh, s.kw, (s.kh - 1) - (s.kh - 1) / 2, (s.kw - 1) - (s.kw - 1) / 2, st)) {
