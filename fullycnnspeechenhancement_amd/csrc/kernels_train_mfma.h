@@ -369,5 +369,167 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The 1x129, CH -> 1 output layer (decode_5 / decode_8 / decode_final; model.py:24,56,89).
+// Forward: dense Toeplitz GEMM as in the inference kernels,
+//   y[frame, f] = b + sum_{f', ci} h[frame, f', ci] * W[f' - f + 64, ci],  D[f (9 M-tiles), frame (N)], k = f'*CH + ci;
+// the Toeplitz-expanded A fragments are rebuilt on the device every step (the weights move).
+// ---------------------------------------------------------------------------------------------
+template <int CH>
+struct FinGeo {
+  static constexpr int kK = kF * CH;
+  static constexpr int kNB64 = kK / 8, kTail = kK - 8 * kNB64;    // tail: 0 (CH 8), 4 (CH 12), 2 (CH 10)
+  static_assert(kTail <= 4 && CH % 2 == 0 && CH <= 14, "one b32 tail step at most; CH even, one spare N column");
+  static constexpr int kMT = 9;
+  static constexpr int kMain = kNB64 * kMT * 128;
+  static constexpr int kPack = kMain + (kTail ? kMT * 64 : 0);
+};
+constexpr int kFinFrames = 64, kFinThreads = 192;
+
+// w [129][CH] (TF [1,129,CH,1]) -> pack [s][mt][lane][e] (+ tail [mt][lane]); row f = 16*mt + i
+__global__ void pack_final_fwd(const float* __restrict__ w, int CH, float* __restrict__ pack) {
+  const int K = kF * CH, NB = K / 8, main = NB * 9 * 128, total = main + ((K % 8) ? 9 * 64 : 0);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  int k, f;
+  if (e < main) {
+    const int s = e / (9 * 128), r = e - s * 9 * 128, mt = r / 128, q = r - mt * 128, lane = q >> 1;
+    k = 8 * s + 2 * (lane >> 4) + (q & 1);
+    f = 16 * mt + (lane & 15);
+  } else {
+    const int r = e - main, mt = r / 64, lane = r - mt * 64;
+    k = 8 * NB + (lane >> 4);
+    f = 16 * mt + (lane & 15);
+  }
+  const int fp = k / CH, ci = k - fp * CH, tap = fp - f + 64;
+  pack[e] = (k < K && f < kF && tap >= 0 && tap < kF) ? w[tap * CH + ci] : 0.f;
+}
+
+template <int CH>
+__global__ __launch_bounds__(kFinThreads) void final_fwd(const float* __restrict__ h, const float* __restrict__ apack,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int frames) {
+  using FG = FinGeo<CH>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kq = lane >> 4;
+  const int f0 = blockIdx.x * kFinFrames;
+  const f32x2* ap = reinterpret_cast<const f32x2*>(apack) + (wave * 3) * 64 + lane;
+  const float* bp[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int fr = f0 + 16 * t + n;
+    if (fr >= frames) fr = frames - 1;   // clamp: computed, never stored
+    bp[t] = h + (size_t)fr * FG::kK;
+  }
+  const float b0 = bias[0];
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) acc[t][m] = f32x4{b0, b0, b0, b0};
+#pragma unroll 4
+  for (int s = 0; s < FG::kNB64; ++s) {
+    f32x2 a[3], b[4];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) a[m] = ap[(s * FG::kMT + m) * 64];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const f32x2*>(bp[t] + 8 * s + 2 * kq);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[t][m] = mfma(a[m][e], b[t][e], acc[t][m]);
+  }
+  if constexpr (FG::kTail > 0) {
+    const float* at = apack + FG::kMain + (wave * 3) * 64 + lane;
+    const int kqe = kq < FG::kTail ? kq : FG::kTail - 1;      // rows past K carry zero weights
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float b = bp[t][8 * FG::kNB64 + kqe];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) acc[t][m] = mfma(at[m * 64], b, acc[t][m]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int fr = f0 + 16 * t + n;
+    if (fr >= frames) continue;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int f = 16 * (3 * wave + m) + 4 * kq;
+      float* yp = y + (size_t)fr * kF + f;
+      const f32x4 v = acc[t][m];
+      if (f + 0 < kF) yp[0] = v.x;
+      if (f + 1 < kF) yp[1] = v.y;
+      if (f + 2 < kF) yp[2] = v.z;
+      if (f + 3 < kF) yp[3] = v.w;
+    }
+  }
+}
+
+// Output-layer wgrad: dW[tap, ci] = sum_{frame, q} x[frame, q, ci] * dz[frame, q + 64 - tap]  (q = f + tap - 64).
+// MFMA roles: M = tap (9 tiles), N = ci (one tile; column CH carries ones, so D[64][CH] = sum dz = dbias),
+// K = q (4 bins per MFMA, 33 steps per frame).  A[i][kq] = dzpad[q0 + kq + 64 - (16 mt + i)] from a zero-padded
+// per-wave LDS copy of the frame's dz row; B[kq][j] = x[frame, q0 + kq, j] straight from global (the 4 bins of a
+// step are 4*CH contiguous floats).  A wave owns frames; the workgroup's waves add up through LDS, then atomics.
+constexpr int kFwPad = 80, kFwRow = 288;   // dzpad index = 80 + bin, reads span [-79, 195] around it
+template <int CH>
+__global__ __launch_bounds__(kThreads) void final_wgrad(const float* __restrict__ x, const float* __restrict__ dz,
+                                                         float* __restrict__ dW, float* __restrict__ dbias, int frames) {
+  __shared__ float rows[kWaves][kFwRow];
+  __shared__ float red[9 * 16 * 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  float* row = rows[wave];
+  for (int e = lane; e < kFwRow; e += 64) row[e] = 0.f;
+  for (int e = tid; e < 9 * 256; e += kThreads) red[e] = 0.f;
+  __syncthreads();
+  f32x4 acc[9];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int kSteps = (kF + 3) / 4;   // 33
+  const float* ap = row + kFwPad + 64 + kq - i;
+  const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
+  for (int fr = gw; fr < frames; fr += nw) {
+    const float* xr = x + (size_t)fr * kF * CH;
+    const float* dr = dz + (size_t)fr * kF;
+    float b[kSteps];
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+      const int q = 4 * s + kq;
+      b[s] = (i < CH && q < kF) ? xr[q * CH + i] : (i == CH && q < kF ? 1.f : 0.f);
+    }
+    // the previous frame's MFMA reads of `row` are complete (same wave, in order): overwrite it
+    const float d0 = dr[lane], d1 = dr[64 + lane], d2 = lane == 0 ? dr[128] : 0.f;
+    row[kFwPad + lane] = d0;
+    row[kFwPad + 64 + lane] = d1;
+    if (lane == 0) row[kFwPad + 128] = d2;
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+      float a[9];
+#pragma unroll
+      for (int m = 0; m < 9; ++m) a[m] = ap[4 * s - 16 * m];
+#pragma unroll
+      for (int m = 0; m < 9; ++m) acc[m] = mfma(a[m], b[s], acc[m]);
+    }
+  }
+  // D row = tap = 16*m + 4*kq + r, column = i (ci, or the ones column)
+#pragma unroll
+  for (int m = 0; m < 9; ++m) {
+    const float vv[4] = {acc[m].x, acc[m].y, acc[m].z, acc[m].w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * m + 4 * kq + r) * 16 + i], vv[r]);
+  }
+  __syncthreads();
+  for (int e = tid; e < 9 * 256; e += kThreads) {
+    const int tap = e >> 4, c = e & 15;
+    if (tap < kF && c < CH) atomicAdd(dW + tap * CH + c, red[e]);
+    if (tap == 64 && c == CH && dbias) atomicAdd(dbias, red[e]);
+  }
+}
+
 }  // namespace tmm
 }  // namespace rced

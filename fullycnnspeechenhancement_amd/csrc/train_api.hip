@@ -58,6 +58,7 @@ struct rced_trainer {
   std::vector<float*> wf, wt, bias4, mu, rstd;   // per layer
   std::vector<float*> pk_fwd, pk_bwd;            // per layer: MFMA A-fragment packets (1xk layers with an MFMA kernel)
   int use_mfma = 1;
+  float* pk_fin = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
   float* zero32 = nullptr;
   double *part = nullptr, *sums = nullptr;
   // activations for P pixels
@@ -76,6 +77,7 @@ struct rced_trainer {
     for (auto* p : rstd) fr(p);
     for (auto* p : pk_fwd) fr(p);
     for (auto* p : pk_bwd) fr(p);
+    fr(pk_fin);
     free_acts();
   }
   void free_acts() {
@@ -208,6 +210,38 @@ int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float
   return 0;
 }
 
+
+// ---- output layer (1x129, CH -> 1): Toeplitz forward + MFMA wgrad (kernels_train_mfma.h) ----
+#define RCED_FIN_CH(X) X(8) X(10) X(12)
+size_t fin_pack_floats(int ch) {
+#define X(CH) if (ch == CH) return tmm::FinGeo<CH>::kPack;
+  RCED_FIN_CH(X)
+#undef X
+  return 0;
+}
+bool is_output_layer(const LayerSpec& s, int cin) {
+  return s.kh == 1 && s.kw == kFeatureDim && s.cout == 1 && !s.use_norm && !s.use_act && s.skip_pre < 0 && s.skip_post < 0 &&
+         fin_pack_floats(cin) > 0;
+}
+int fin_forward(int ch, const float* h, const float* w, const float* bias, float* pack, float* y, int frames, hipStream_t st) {
+  const int total = (int)fin_pack_floats(ch);
+  hipLaunchKernelGGL(tmm::pack_final_fwd, dim3((total + 255) / 256), dim3(256), 0, st, w, ch, pack);
+  const dim3 grid((frames + tmm::kFinFrames - 1) / tmm::kFinFrames);
+#define X(CH) \
+  if (ch == CH) hipLaunchKernelGGL((tmm::final_fwd<CH>), grid, dim3(tmm::kFinThreads), 0, st, h, (const float*)pack, bias, y, frames);
+  RCED_FIN_CH(X)
+#undef X
+  return 1;
+}
+int fin_wgrad(int ch, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, hipStream_t st) {
+  const dim3 grid(std::min((frames + tmm::kWaves - 1) / tmm::kWaves, cus * 2));
+#define X(CH) \
+  if (ch == CH) hipLaunchKernelGGL((tmm::final_wgrad<CH>), grid, dim3(tmm::kThreads), 0, st, x, dz, dW, dbias, frames);
+  RCED_FIN_CH(X)
+#undef X
+  return 1;
+}
+
 __global__ void sums_to_float(const double* __restrict__ sums, int C, int which, float* __restrict__ dst) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) dst[c] = (float)sums[2 * c + which];
@@ -297,6 +331,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     TRY_OR_FREE(hipMalloc(&t->bias4[l], 64 * sizeof(float)));
     TRY_OR_FREE(hipMalloc(&t->mu[l], 64 * sizeof(float)));
     TRY_OR_FREE(hipMalloc(&t->rstd[l], 64 * sizeof(float)));
+    if (is_output_layer(s, f.cin) && !t->pk_fin) TRY_OR_FREE(hipMalloc(&t->pk_fin, fin_pack_floats(f.cin) * sizeof(float)));
     if (s.kh == 1 && tm_has(f.cin, s.kw, s.cout)) TRY_OR_FREE(hipMalloc(&t->pk_fwd[l], tm_packet_floats(f.cin, s.kw, s.cout) * sizeof(float)));
     if (s.kh == 1 && tm_has(s.cout, s.kw, f.cin)) TRY_OR_FREE(hipMalloc(&t->pk_bwd[l], tm_packet_floats(s.cout, s.kw, f.cin) * sizeof(float)));
   }
@@ -376,6 +411,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
         (stat_parts = tm_conv(f.cin, s.kw, s.cout, s.use_norm ? 2 : 0, tensor(s.src), t->pk_fwd[l], t->z[l], frames,
                               t->num_cus, t->part, st)) > 0) {
       if (!s.use_norm) stat_parts = 0;
+    } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
+      fin_forward(f.cin, tensor(s.src), t->params + f.kernel, t->params + f.bias, t->pk_fin, t->z[l], frames, st);
     } else if (int rc = launch_conv(tensor(s.src), t->z[l], t->wf[l], t->bias4[l], nullptr, frames, T, F, f.cin, s.cout,
                                     f.cout4, s.kh, s.kw, (s.kh - 1) / 2, (s.kw - 1) / 2, st)) {
       return rc;
@@ -471,6 +508,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, tensor(s.src), t->D, t->grads + f.kernel,
                                              t->grads + f.bias, frames, t->num_cus, st)) {
       // MFMA path
+    } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
+      fin_wgrad(f.cin, tensor(s.src), t->D, t->grads + f.kernel, t->grads + f.bias, frames, t->num_cus, st);
     } else {
       if (int rc = reduce_channels(t, t->D, t->D, nullptr, nullptr, P, s.cout, st)) return rc;
       hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.bias);
