@@ -57,22 +57,20 @@ __global__ __launch_bounds__(kThreads) void chan_reduce(const float* __restrict_
   }
 }
 
-// sums[c][2] = sum over partials
+// sums[c][2] = sum over partials.  One workgroup per output (launch with 2*C workgroups).
 __global__ __launch_bounds__(kThreads) void reduce_finish(const double* __restrict__ part, int nparts, int C,
                                                            double* __restrict__ sums) {
   __shared__ double s[kThreads];
-  const int tid = threadIdx.x, n = 2 * C;            // n <= 64 outputs
-  const int lanes = (kThreads / n) * n, i = tid % n, j0 = tid / n, stride = lanes / n;
+  const int tid = threadIdx.x, n = 2 * C, i = blockIdx.x;
   double t = 0.0;
-  if (tid < lanes)
-    for (int k = j0; k < nparts; k += stride) t += part[(size_t)k * n + i];   // coalesced across i
+  for (int k = tid; k < nparts; k += kThreads) t += part[(size_t)k * n + i];
   s[tid] = t;
   __syncthreads();
-  if (tid < n) {
-    double r = 0.0;
-    for (int j = tid; j < lanes; j += n) r += s[j];
-    sums[tid] = r;
+  for (int k = kThreads / 2; k > 0; k >>= 1) {
+    if (tid < k) s[tid] += s[tid + k];
+    __syncthreads();
   }
+  if (tid == 0) sums[i] = s[0];
 }
 
 // Batch statistics from (sum z, sum z^2): mu, rstd = 1/sqrt(var_biased + eps); moving statistics with

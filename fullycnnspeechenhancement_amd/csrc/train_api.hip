@@ -132,7 +132,7 @@ int launch_conv(const float* x, float* y, const float* w, const float* shift, co
 int reduce_channels(rced_trainer* t, const float* a, const float* b, const float* mu, const float* rstd, size_t P, int C,
                     hipStream_t st) {
   hipLaunchKernelGGL(train::chan_reduce, dim3(kReduceGrid), dim3(train::kThreads), 0, st, a, b, mu, rstd, P, C, t->part);
-  hipLaunchKernelGGL(train::reduce_finish, dim3(1), dim3(train::kThreads), 0, st, (const double*)t->part, kReduceGrid, C, t->sums);
+  hipLaunchKernelGGL(train::reduce_finish, dim3(2 * C), dim3(train::kThreads), 0, st, (const double*)t->part, kReduceGrid, C, t->sums);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
 }
@@ -420,7 +420,7 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     const size_t n = P * s.cout;
     if (s.use_norm) {
       if (stat_parts > 0)
-        hipLaunchKernelGGL(train::reduce_finish, dim3(1), dim3(train::kThreads), 0, st, (const double*)t->part, stat_parts,
+        hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part, stat_parts,
                            s.cout, t->sums);
       else if (int rc = reduce_channels(t, t->z[l], t->z[l], nullptr, nullptr, P, s.cout, st))
         return rc;
@@ -482,7 +482,7 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
                          (float2*)(s.skip_post > 0 ? t->G[s.skip_post] : nullptr), (float2*)t->D,
                          s.use_norm ? t->part : (double*)nullptr);
       if (s.use_norm)
-        hipLaunchKernelGGL(train::reduce_finish, dim3(1), dim3(train::kThreads), 0, st, (const double*)t->part, (int)grid.x,
+        hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part, (int)grid.x,
                            s.cout, t->sums);
     } else {
       hipLaunchKernelGGL(train::bwd_route, blocks(n), dim3(train::kThreads), 0, st, (const float*)t->G[l + 1],
