@@ -15,7 +15,7 @@ class FullyCNNTester(object):
     """test_config: a configparser-like object (config.py:9-12) or None with keyword overrides.
 
     Keys read, as the reference does: [model] net_work (tester.py:21-22), [testing]
-    checkpoint_filepath (tester.py:20) -- here a .npz of TF variables --, [data] feature_dim
+    checkpoint_filepath (tester.py:20) -- a TF V2 checkpoint prefix, a frozen .pb or a .npz of TF variables --, [data] feature_dim
     (tester.py:54).  The shipped infer cfgs name the section [inference]: both are accepted.
     """
 
@@ -49,7 +49,7 @@ class FullyCNNTester(object):
         if self._weights is not None:
             self.model.restore(self._weights)
         elif self.checkpoint_file:
-            self.model.restore(_weights.load_npz(self.checkpoint_file))
+            self.model.restore(_weights.load(self.checkpoint_file, self.model.variant))
             print("recover from checkpoint_file: {}".format(self.checkpoint_file))
 
     def param_count(self):

@@ -80,6 +80,16 @@ class FullyCNNTrainer(object):
     def gradients(self):
         return self._blob(_lib.load().rced_train_get_gradients)
 
+    def save_checkpoint(self, prefix):
+        """Write the model variables + global_step as a TF V2 checkpoint (trainer.py:98-104 naming is the
+        caller's).  The reference's test / infer / freeze graphs restore exactly these variables
+        (tester.py:36-39); Adam slots are not exported, so the reference *trainer* cannot continue from it."""
+        from . import tf_checkpoint
+        tensors = dict(self.variables())
+        tensors["global_step"] = np.asarray(self.global_step, np.int64)
+        tf_checkpoint.write_checkpoint(prefix, tensors)
+        return prefix
+
     def close(self):
         if self._h is not None:
             _lib.load().rced_train_destroy(self._h)

@@ -51,6 +51,15 @@ def pack_blob(variant, weights):
     return blob
 
 
+def load(path, variant):
+    """What `Saver.restore(sess, checkpoint_file)` does for the reference (tester.py:36-39): accepts a
+    TF V2 checkpoint prefix (or its .index), a frozen .pb (freeze.py) or the .npz interchange file."""
+    from . import tf_checkpoint
+    w = tf_checkpoint.load_reference_weights(path, variant)
+    validate(variant, w)
+    return w
+
+
 def load_npz(path):
     with np.load(path) as z:
         return {k: z[k] for k in z.files}
