@@ -8,11 +8,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rced.h"
@@ -120,6 +122,7 @@ rced_model::~rced_model() {
     if (l.shift) (void)hipFree(l.shift);
   }
   if (workspace) (void)hipFree(workspace);
+  for (auto st : host_streams) if (st) (void)hipStreamDestroy(st);
   if (stage_x) (void)hipFree(stage_x);
   if (stage_y) (void)hipFree(stage_y);
   if (fused) fused_destroy(this);
@@ -346,6 +349,11 @@ int rced_set_option(rced_model* m, const char* key, int value) {
     m->profile = value != 0;
     return RCED_OK;
   }
+  if (!strcmp(key, "host_chunks")) {  // rced_forward_host pipeline depth: 0 = default (8), 1 = no overlap
+    if (value < 0 || value > 64) return fail(RCED_ERR_ARG, "host_chunks must be 0..64");
+    m->host_chunks = value;
+    return RCED_OK;
+  }
   if (fused_set_option(m, key, value) == RCED_OK) return RCED_OK;
   return fail(RCED_ERR_ARG, "unknown option '%s'", key);
 }
@@ -356,6 +364,7 @@ int rced_get_option(rced_model* m, const char* key, int* value) {
   if (!strcmp(key, "profile")) { *value = m->profile; return RCED_OK; }
   if (!strcmp(key, "has_fused")) { *value = m->fused != nullptr; return RCED_OK; }
   if (!strcmp(key, "num_cus")) { *value = m->num_cus; return RCED_OK; }
+  if (!strcmp(key, "host_chunks")) { *value = m->host_chunks; return RCED_OK; }
   if (fused_get_option(m, key, value) == RCED_OK) return RCED_OK;
   return fail(RCED_ERR_ARG, "unknown option '%s'", key);
 }
@@ -405,9 +414,65 @@ int rced_forward_host(rced_model* m, const float* x_host, float* y_host, int N, 
     HIP_TRY(hipMalloc(&m->stage_y, bytes));
     m->stage_bytes = bytes;
   }
-  HIP_TRY(hipMemcpy(m->stage_x, x_host, bytes, hipMemcpyHostToDevice));
-  if (int rc = rced_forward(m, (const float*)m->stage_x, (float*)m->stage_y, N, T, nullptr)) return rc;
-  HIP_TRY(hipMemcpy(y_host, m->stage_y, bytes, hipMemcpyDeviceToHost));  // synchronises
+  // Small batches: copy in, run, copy out.  Large ones: split the utterances into chunks and overlap the three
+  // legs -- this thread uploads chunk i+1 while chunk i computes, a helper thread downloads chunk i-1 (copies
+  // from/to pageable numpy memory block their caller, so the two directions need two callers).
+  const size_t utt_bytes = (size_t)T * kFeatureDim * sizeof(float);
+  int chunks = m->host_chunks > 0 ? m->host_chunks : 8;
+  if (chunks > N) chunks = N;
+  if (bytes < ((size_t)8 << 20) || chunks <= 1) {
+    HIP_TRY(hipMemcpy(m->stage_x, x_host, bytes, hipMemcpyHostToDevice));
+    if (int rc = rced_forward(m, (const float*)m->stage_x, (float*)m->stage_y, N, T, nullptr)) return rc;
+    HIP_TRY(hipMemcpy(y_host, m->stage_y, bytes, hipMemcpyDeviceToHost));  // synchronises
+    return RCED_OK;
+  }
+  if (!m->host_streams[0]) {
+    for (auto& st : m->host_streams) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  }
+  hipStream_t s_in = m->host_streams[0], s_run = m->host_streams[1], s_out = m->host_streams[2];
+  std::vector<hipEvent_t> ev_in(chunks), ev_done(chunks);
+  for (int i = 0; i < chunks; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
+  }
+  auto first = [&](int i) { return (int)((long long)N * i / chunks); };
+  std::atomic<int> launched{0};
+  std::atomic<bool> abort_flag{false};
+  hipError_t out_err = hipSuccess;
+  std::thread downloader([&] {
+    if (hipSetDevice(m->device) != hipSuccess) { out_err = hipErrorInvalidDevice; return; }
+    for (int i = 0; i < chunks; ++i) {
+      while (launched.load(std::memory_order_acquire) <= i) {
+        if (abort_flag.load()) return;
+        std::this_thread::yield();
+      }
+      const size_t off = (size_t)first(i) * utt_bytes, len = (size_t)(first(i + 1) - first(i)) * utt_bytes;
+      hipError_t e = hipStreamWaitEvent(s_out, ev_done[i], 0);
+      if (e == hipSuccess) e = hipMemcpyAsync((char*)y_host + off, (const char*)m->stage_y + off, len, hipMemcpyDeviceToHost, s_out);
+      if (e != hipSuccess) { out_err = e; return; }
+    }
+    out_err = hipStreamSynchronize(s_out);
+  });
+  int rc = RCED_OK;
+  hipError_t in_err = hipSuccess;
+  for (int i = 0; i < chunks && rc == RCED_OK && in_err == hipSuccess; ++i) {
+    const int n0 = first(i), n1 = first(i + 1);
+    const size_t off = (size_t)n0 * utt_bytes;
+    in_err = hipMemcpyAsync((char*)m->stage_x + off, (const char*)x_host + off, (size_t)(n1 - n0) * utt_bytes, hipMemcpyHostToDevice, s_in);
+    if (in_err == hipSuccess) in_err = hipEventRecord(ev_in[i], s_in);
+    if (in_err == hipSuccess) in_err = hipStreamWaitEvent(s_run, ev_in[i], 0);
+    if (in_err != hipSuccess) break;
+    rc = rced_forward(m, (const float*)((const char*)m->stage_x + off), (float*)((char*)m->stage_y + off), n1 - n0, T, s_run);
+    if (rc == RCED_OK) in_err = hipEventRecord(ev_done[i], s_run);
+    if (rc == RCED_OK && in_err == hipSuccess) launched.store(i + 1, std::memory_order_release);
+  }
+  if (rc != RCED_OK || in_err != hipSuccess) abort_flag.store(true);
+  downloader.join();
+  (void)hipStreamSynchronize(s_run);
+  for (int i = 0; i < chunks; ++i) { (void)hipEventDestroy(ev_in[i]); (void)hipEventDestroy(ev_done[i]); }
+  if (rc != RCED_OK) return rc;
+  if (in_err != hipSuccess) return fail(RCED_ERR_HIP, "host path upload: %s", hipGetErrorString(in_err));
+  if (out_err != hipSuccess) return fail(RCED_ERR_HIP, "host path download: %s", hipGetErrorString(out_err));
   return RCED_OK;
 }
 

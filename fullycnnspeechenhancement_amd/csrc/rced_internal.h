@@ -36,6 +36,8 @@ struct rced_model {
   // rced_forward_host staging
   void *stage_x = nullptr, *stage_y = nullptr;
   size_t stage_bytes = 0;
+  hipStream_t host_streams[3] = {nullptr, nullptr, nullptr};   // rced_forward_host: upload, compute, download
+  int host_chunks = 0;                                         // option "host_chunks" (0 = default 8)
   // options
   int path = 0;
   bool profile = false;

@@ -74,6 +74,23 @@ def test_device_resident_path_equals_host_path(net_work, tag, variant, built):
     assert np.array_equal(y2.cpu().numpy(), y_host)
 
 
+@pytest.mark.parametrize("chunks", [0, 1, 3, 64])
+def test_pipelined_host_path_equals_resident_path(chunks, built):
+    """rced_forward_host splits batches >= 8 MB into utterance chunks and overlaps upload / compute / download;
+    the result must not depend on the split (13 utterances: ragged chunks; 64 chunks > N clamps to N)."""
+    import torch
+    w, _ = load_golden("v3")
+    m = make_model(3, w)
+    x = np.abs(np.random.default_rng(7).standard_normal((13, 1300, 129, 1))).astype(np.float32)   # 8.7 MB
+    ref = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    m.set_option("host_chunks", chunks)
+    assert m.get_option("host_chunks") == chunks
+    for _ in range(2):
+        assert np.array_equal(m(x), ref)
+    with pytest.raises(Exception):
+        m.set_option("host_chunks", 65)
+
+
 def test_empty_and_degenerate_batches(built):
     w, _ = load_golden("v3")
     m = make_model(3, w)
