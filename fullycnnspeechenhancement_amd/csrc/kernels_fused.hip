@@ -318,6 +318,7 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
     Q.T = T;
     Q.tiles_per_utt = (T + v3t::kTF - 1) / v3t::kTF;
     Q.total_tiles = N * Q.tiles_per_utt;
+    Q.stamps = f->stamps;
     const int cus2 = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
     const int grid2 = std::min((Q.total_tiles + v3t::kTeams - 1) / v3t::kTeams, cus2);
     m->prof_begin(RCED_K_FUSED, st);

@@ -24,6 +24,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef RCED_EXP_NOEPI
+#define RCED_EXP_NOEPI 0  // timing experiments only: bit0/1/2 drop the epilogue (ReLU + LDS stores) of L1/L2/L3 (results wrong)
+#endif
 #ifndef RCED_EXP_SKIP
 #define RCED_EXP_SKIP 0   // timing experiments only: bit0 skip L1 math, bit1 L2, bit2 L3 (results wrong)
 #endif
@@ -147,9 +150,25 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
+
+// Volatile accesses to LDS words used for wave-to-wave signalling.  Through a generic pointer hipcc emits
+// flat_load/flat_store (both memory pipes, s_waitcnt vmcnt(0) in every poll); typed as LDS they are ds_read/ds_write.
+__device__ __forceinline__ unsigned lds_peek(const void* p) {
+  return *(volatile __attribute__((address_space(3))) const unsigned*)p;
+}
+__device__ __forceinline__ void lds_poke(void* p, unsigned v) {
+  *(volatile __attribute__((address_space(3))) unsigned*)p = v;
+}
+
 // Experiment switch: re-derive lane coordinates behind an opaque barrier in every layer, so that hipcc
 // does not hoist every layer's address arithmetic out of the loops (VGPRs 238 -> 136, but the
 // recomputation costs 3 % here; the chain kernel needs it to avoid spills).
+// Always-on variant for the few values only the split-tile code needs: recomputed where used (3-4 VALU)
+// instead of being hoisted out of the tile loop by LICM and kept live in VGPRs across all fifteen layers.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 #ifdef RCED_V3_OPAQUE
 #define OPAQUE_LANE(l) asm volatile("" : "+v"(l))
 #else
@@ -472,12 +491,16 @@ __device__ __forceinline__ void layer1(float* lds, const float* w, bool first, i
     }
   }
 #pragma unroll
-  for (int t = 0; t < NMR; ++t) store_p1<1, 18>(b18, accm[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
-  if constexpr (NMX > 0) store_p1<1, 18>(b18, accm[NMR], pxx, kq, span_has_gap(16 * xm, 16));
+  for (int t = 0; t < NMR; ++t)
+    if (!(RCED_EXP_NOEPI & 1) || accm[t][0].x == 12345.678f)
+      store_p1<1, 18>(b18, accm[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
+  if constexpr (NMX > 0)
+    if (!(RCED_EXP_NOEPI & 1) || accm[NMR][0].x == 12345.678f) store_p1<1, 18>(b18, accm[NMR], pxx, kq, span_has_gap(16 * xm, 16));
   if constexpr (NR > 0) {
 #pragma unroll
     for (int t = 0; t < NR; ++t)
-      store_rem(b18, accr[t][0] + accr[t][1], pxr[t], kq, span_has_gap(128 * (t == 0 ? xr0 : xr1), 128));
+      if (!(RCED_EXP_NOEPI & 1) || accr[t][0].x + accr[t][1].x == 12345.678f)
+        store_rem(b18, accr[t][0] + accr[t][1], pxr[t], kq, span_has_gap(128 * (t == 0 ? xr0 : xr1), 128));
   }
 }
 
@@ -485,11 +508,22 @@ __device__ __forceinline__ void layer1(float* lds, const float* w, bool first, i
 __device__ unsigned long long g_fine[8][4];   // [wave][prologue, gemm, epilogue, -] of layer 2, workgroup 0
 #endif
 
-// Layer 2.  XMT < 0: four regular tiles.  XMT = 0/1: plus M-tile XMT of tile 32 (its two M-tiles go
-// to two waves on different SIMDs).
-template <int XMT>
-__device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int lane) {
-  constexpr int NX = XMT >= 0 ? 1 : 0, NT = 4 + NX;
+// Layer 2.  Every wave has four regular tiles.  Tile 32 (pixels 512..527) is cut in four equal pieces, one per
+// SIMD, so that the layer's MFMA count is the same on every SIMD: M-tile XMT x K-half.  Waves 0 / 1 are the
+// helpers (steps [0, kL2Cut) of M-tile 0 / 1), waves 2 / 3 the reducers (steps [kL2Cut, 11) + tail of M-tile
+// 0 / 1; they add the helper's partial sums and own the epilogue).  Hand-off as in layer 3, through scratch
+// in the B8 buffer, which is dead during layer 2 (layer 3 rewrites every real pixel of it).
+constexpr int kL2Cut = 6;
+constexpr int kScratch2Off = kB8Off + kB8Pad * kB8S + 8 * kB8S;   // B8 rows 8.. of frame 0 (2 x 256 floats + 2 flags)
+constexpr int kFlag2Off = kScratch2Off + 2 * 256;
+static_assert((kScratch2Off * 4) % 16 == 0, "scratch is read/written with b128");
+static_assert(8 + (2 * 256 + 2 + kB8S - 1) / kB8S <= kF, "layer-2 scratch stays inside frame 0's real pixels");
+constexpr int kL2Plain = 0, kL2Reducer = 1, kL2Helper = 2;
+
+template <int ROLE, int XMTP>   // XMTP: the M-tile of tile 32 this wave works on (plain: unused)
+__device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int lane, unsigned tag) {
+  constexpr int NX = ROLE == kL2Plain ? 0 : 1, NT = 4 + NX;
+  constexpr int XMT = ROLE == kL2Plain ? -1 : XMTP;
   OPAQUE_LANE(lane);
   const int n = lane & 15, kq = lane >> 4;
   const float* b18 = lds + kB18Off + kB18Pad * 18;
@@ -497,26 +531,49 @@ __device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int
 #if RCED_STAMPS
   const unsigned long long f0 = stamp();
 #endif
-  const int px0 = 16 * wave + n, pxx = 16 * 32 + n;
+  const int lx = NX > 0 ? opaque(lane) : lane;   // lane copy for the split tile's addresses (see opaque())
+  const int px0 = 16 * wave + n, pxx = 16 * 32 + (lx & 15), kqx = lx >> 4;
   f32x4 acc[NT][2];
   f32x4 sh[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) sh[mt] = *reinterpret_cast<const f32x4*>(w + kW2Data + 16 * mt + 4 * kq);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { acc[t][0] = sh[0]; acc[t][1] = sh[1]; }
+  for (int t = 0; t < NT; ++t) {
+    const bool partial = t == 4 && ROLE == kL2Helper;   // the helper's share starts from zero, the reducer's from the shift
+    acc[t][0] = partial ? f32x4{0.f, 0.f, 0.f, 0.f} : sh[0];
+    acc[t][1] = partial ? f32x4{0.f, 0.f, 0.f, 0.f} : sh[1];
+  }
   const int tailoff = (kq < 1 ? kq : 1) - 2 * kq;   // K = 90: tail k = 88 + kq is real for kq < 2
 #if RCED_STAMPS
   const unsigned long long f1 = stamp();
 #endif
-  if (!(RCED_EXP_SKIP & 2))
-    gemm_pass<4, NX, 2, XMT, kL2Steps, 0, kL2Steps, true, 128 * 18, RCED_D2>(
-        b18, (px0 - 2) * 18 + 2 * kq, (pxx - 2) * 18 + 2 * kq, tailoff, w, lane, acc);
+  if (!(RCED_EXP_SKIP & 2)) {
+    constexpr int XS0 = ROLE == kL2Reducer ? kL2Cut : 0;
+    constexpr int XS1 = ROLE == kL2Helper ? kL2Cut : kL2Steps;
+    gemm_pass<4, NX, 2, XMT, kL2Steps, XS0, XS1, ROLE == kL2Reducer, 128 * 18, RCED_D2>(
+        b18, (px0 - 2) * 18 + 2 * kq, (pxx - 2) * 18 + 2 * kqx, tailoff, w, lane, acc);
+  }
 #if RCED_STAMPS
   const unsigned long long f2 = stamp();
 #endif
+  if constexpr (ROLE == kL2Helper) {
+    *reinterpret_cast<f32x4*>(lds + kScratch2Off + XMTP * 256 + 4 * lx) = acc[4][XMTP];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lx == 0) lds_poke(lds + kFlag2Off + XMTP, tag);
+  }
 #pragma unroll
-  for (int t = 0; t < 4; ++t) store_p1<2, 30>(b30, acc[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
-  if constexpr (NX > 0) store_p1_mt<30>(b30, acc[4][XMT], pxx, kq, XMT);
+  for (int t = 0; t < 4; ++t)
+    if (!(RCED_EXP_NOEPI & 2) || acc[t][0].x + acc[t][1].x == 12345.678f)
+      store_p1<2, 30>(b30, acc[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
+  if constexpr (ROLE == kL2Reducer) {   // after the own tiles' epilogue: the helper has had time to finish
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      if (__builtin_amdgcn_readfirstlane(lds_peek(lds + kFlag2Off + XMTP)) == tag) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const f32x4 v = acc[4][XMTP] + *reinterpret_cast<const f32x4*>(lds + kScratch2Off + XMTP * 256 + 4 * lx);
+    store_p1_mt<30>(b30, v, pxx, kqx, XMTP);
+  }
 #if RCED_STAMPS
   const unsigned long long f3 = stamp();
   if (blockIdx.x == 0 && lane == 0) {
@@ -527,17 +584,20 @@ __device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int
 #endif
 }
 
-// Layer 3 roles: every wave has two regular pair tiles; pair tile 16 is split ALONG K between a
-// reducer wave (steps [0,19), owns the epilogue and the skip registers) and a helper wave on another
-// SIMD (steps [19,37) + tail), which hands its partial sums over through a 1-KiB scratch in the
-// (dead during layer 3) B18 buffer and a tagged flag word -- a pairwise hand-off, no extra barrier.
+// Layer 3 roles: every wave has two regular pair tiles; pair tile 16 is split ALONG K in four, one part per
+// SIMD (waves 0..3), so that every SIMD carries the same MFMA count in this layer (the barrier that ends the
+// layer waits for the most loaded SIMD): the reducer (wave 0: steps [0,10), owns the epilogue and the skip
+// registers) and three helpers (waves 1..3: steps [10,19), [19,28), [28,37) + tail), which hand their partial
+// sums over through 1-KiB scratch areas in the (dead during layer 3) B18 buffer and tagged flag words --
+// pairwise hand-offs, no extra barrier.
 constexpr int kRolePlain = 0, kRoleReducer = 1, kRoleHelper = 2;
-constexpr int kL3Split = 19;
-constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;   // pixels 8..22 of frame 0: always rewritten by layer 1
-constexpr int kFlagOff = kScratchOff + 256;
+constexpr int kL3Cut1 = 10, kL3Cut2 = 19, kL3Cut3 = 28;
+constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;   // pixels 8..51 of frame 0: always rewritten by layer 1
+constexpr int kFlagOff = kScratchOff + 3 * 256;
 static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
+static_assert(8 + (3 * 256 + 3 + 17) / 18 <= kF, "scratch + flags stay inside frame 0's real pixels");
 
-template <int ROLE>
+template <int ROLE, int HID>   // HID: helper number 1..3 (0 otherwise)
 __device__ __forceinline__ void layer3(const Params& P, float* lds, const float* w, int blk, int wave, int lane,
                                        unsigned tag, int utt, int t0, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
   constexpr int NX = ROLE == kRolePlain ? 0 : 1, NT = 2 + NX;
@@ -546,41 +606,41 @@ __device__ __forceinline__ void layer3(const Params& P, float* lds, const float*
   const int n = lane & 15, kq = lane >> 4;
   const float* b30 = lds + kB30Off + kB30Pad * 30;
   float* b8 = lds + kB8Off + kB8Pad * kB8S;
-  const int q0 = 16 * wave + n, qx = 16 * 16 + n;   // pixel pair indices
+  const int lx = NX > 0 ? opaque(lane) : lane;   // lane copy for the split tile's addresses (see opaque())
+  const int q0 = 16 * wave + n, qx = 16 * 16 + (lx & 15), kqx = lx >> 4;   // pixel pair indices
   f32x4 acc[NT][1];
   const f32x4 sh = *reinterpret_cast<const f32x4*>(w + kW3Data + 4 * (kq & 1));
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t][0] = (t == 2 && ROLE == kRoleHelper) ? f32x4{0.f, 0.f, 0.f, 0.f} : sh;
   const int tailoff = -kq;   // K = 300: tail k = 296 + kq, all four real
   if (!(RCED_EXP_SKIP & 4)) {
-#ifdef RCED_EXP_NOSPLIT   // experiment: reducer does the whole tile, helper publishes zeros
-    constexpr int XS0 = ROLE == kRoleHelper ? kL3Steps : 0;
-    constexpr int XS1 = kL3Steps;
-    constexpr bool XT = ROLE == kRoleReducer;
-#else
-    constexpr int XS0 = ROLE == kRoleHelper ? kL3Split : 0;
-    constexpr int XS1 = ROLE == kRoleReducer ? kL3Split : kL3Steps;
-    constexpr bool XT = ROLE == kRoleHelper;
-#endif
+    constexpr int XS0 = ROLE != kRoleHelper ? 0 : HID == 1 ? kL3Cut1 : HID == 2 ? kL3Cut2 : kL3Cut3;
+    constexpr int XS1 = ROLE == kRoleReducer ? kL3Cut1 : ROLE != kRoleHelper ? kL3Steps
+                        : HID == 1 ? kL3Cut2 : HID == 2 ? kL3Cut3 : kL3Steps;
+    constexpr bool XT = ROLE == kRoleHelper && HID == 3;
     gemm_pass<2, NX, 1, -1, kL3Steps, XS0, XS1, XT, 128 * 60, RCED_D3>(
-        b30, (2 * q0 - 4) * 30 + 2 * kq, (2 * qx - 4) * 30 + 2 * kq, tailoff, w, lane, acc);
+        b30, (2 * q0 - 4) * 30 + 2 * kq, (2 * qx - 4) * 30 + 2 * kqx, tailoff, w, lane, acc);
   }
   if constexpr (ROLE == kRoleHelper) {   // publish the partial sums of pair tile 16
-    *reinterpret_cast<f32x4*>(lds + kScratchOff + 4 * lane) = acc[2][0];
+    *reinterpret_cast<f32x4*>(lds + kScratchOff + (HID - 1) * 256 + 4 * lx) = acc[2][0];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) *reinterpret_cast<volatile unsigned*>(lds + kFlagOff) = tag;
+    if (lx == 0) lds_poke(lds + kFlagOff + (HID - 1), tag);
   }
-  if constexpr (ROLE == kRoleReducer) {  // collect them (bounded spin: both waves are resident)
-    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(lds + kFlagOff);
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-      if (__builtin_amdgcn_readfirstlane(*flag) == tag) break;
-      __builtin_amdgcn_s_sleep(1);
+  if constexpr (ROLE == kRoleReducer) {  // collect them (bounded spins: all waves are resident)
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__builtin_amdgcn_readfirstlane(lds_peek(lds + kFlagOff + h)) == tag) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    acc[2][0] += *reinterpret_cast<const f32x4*>(lds + kScratchOff + 4 * lane);
+#pragma unroll
+    for (int h = 0; h < 3; ++h) acc[2][0] += *reinterpret_cast<const f32x4*>(lds + kScratchOff + h * 256 + 4 * lx);
   }
 #pragma unroll
   for (int t = 0; t < NEPI; ++t) {
+    if ((RCED_EXP_NOEPI & 4) && acc[t][0].x != 12345.678f) continue;
     const int q = (t < 2) ? q0 + 128 * t : qx;
     const int px = 2 * q + (kq >> 1);   // this lane's output pixel (phase = kq >> 1)
     f32x4 v = relu4(acc[t][0]);
@@ -666,9 +726,12 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         STAMP_BEGIN();
         if (!RCED_EXP_WGLOBAL) packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane);
         const float* w = RCED_EXP_WGLOBAL ? wsrc + kW1 : WREG(wcur);
-        if (wave == 2) layer2<0>(lds, w, wave, lane);
-        else if (wave == 3) layer2<1>(lds, w, wave, lane);
-        else layer2<-1>(lds, w, wave, lane);
+        const unsigned tag2 = 0xC0000000u | (epoch + 1u);   // distinct from layer 3's tags (0x8.......)
+        if (wave == 0) layer2<kL2Helper, 0>(lds, w, wave, lane, tag2);
+        else if (wave == 1) layer2<kL2Helper, 1>(lds, w, wave, lane, tag2);
+        else if (wave == 2) layer2<kL2Reducer, 0>(lds, w, wave, lane, tag2);
+        else if (wave == 3) layer2<kL2Reducer, 1>(lds, w, wave, lane, tag2);
+        else layer2<kL2Plain, 0>(lds, w, wave, lane, tag2);
         wcur ^= 1;
         STAMP_MATH(1);
         layer_end_sync();
@@ -682,9 +745,11 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         const float* w = RCED_EXP_WGLOBAL ? wsrc + kW1 + kW2 : WREG(wcur);
         ++epoch;
         const unsigned tag = 0x80000000u | epoch;   // sign bit set: never the bits of a ReLU output
-        if (wave == 0) layer3<kRoleReducer>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
-        else if (wave == 1) layer3<kRoleHelper>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
-        else layer3<kRolePlain>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        if (wave == 0) layer3<kRoleReducer, 0>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        else if (wave == 1) layer3<kRoleHelper, 1>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        else if (wave == 2) layer3<kRoleHelper, 2>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        else if (wave == 3) layer3<kRoleHelper, 3>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        else layer3<kRolePlain, 0>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
         wcur ^= 1;
         STAMP_MATH(2);
         layer_end_sync();

@@ -8,12 +8,20 @@
 // drift out of phase, so one team's sync bubble is filled by the other team's MFMAs.
 //
 // What had to change to make two teams fit:
-//   * LDS: 2 x (B8 + B18 + B30 for 266 pixels) = 125 KB leaves no room for weight packets, so the MFMA
-//     A operand (pre-packed weights) is read from global memory (L2-resident, 224 KB for the whole
-//     net) straight into registers, prefetched kDepthA steps ahead; shifts (15 x 32 floats) sit in LDS.
+//   * LDS: 2 x (B8 + B18 + B30 for 266 pixels) = 125 KB leaves 38.7 KB: exactly one ping-pong of the largest
+//     weight packet (2 x 19.3 KB), SHARED by the two teams.  Both teams run the same layer sequence, so layer
+//     number L (counted per team over all its tiles) lives in slot L & 1.  Protocol (two LDS words per slot):
+//       fin[slot]  every wave adds 1 after its last read of the slot's packet; the wave that makes it a
+//                  multiple of 8 knows all eight are done with layer L and streams layer L+2 into the slot
+//                  by LDS-DMA (<= 19 instructions), waits for it to land, and sets
+//       rdy[slot]  = L + 3 ("layer L+2 is here"); a wave entering layer L spins until rdy[L & 1] >= L + 1.
+//     So a team can run at most one layer ahead of the other, and the refill stall is taken by the wave (and
+//     team) that is behind, while the team that is ahead keeps the MFMA pipes busy.
 //   * tiles: 17 sixteen-pixel tiles, 9 pair tiles and 3 remainder tiles per team, dealt over 4 waves;
 //     team 1 plays the roles rotated by two waves so that the heavier roles of the two teams land on
 //     different SIMDs.
+//   * both teams of a workgroup run the same number of tile iterations (a team without a tile computes on
+//     zeros and stores nothing), so the slot protocol never waits for a team that has left.
 // Packet layout, pass structure, epilogues and the K-split hand-off are those of kernels_fused_v3.h.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -28,6 +36,8 @@ using v3::f32x4;
 using v3::kF;
 using v3::kHCh;
 using v3::kS;
+using v3::lds_peek;
+using v3::lds_poke;
 using v3::mfma;
 using v3::pin;
 using v3::relu4;
@@ -43,21 +53,21 @@ constexpr int kB8Off = 0;
 constexpr int kB18Off = kB8Off + kB8Rows * kB8S;
 constexpr int kB30Off = kB18Off + kB18Rows * 18;
 constexpr int kTeamFloats = ((kB30Off + kB30Rows * 30 + 3) / 4) * 4;    // 15,624
-constexpr int kShiftOff = kTeams * kTeamFloats;                         // 15 x 32 shifts, shared
-constexpr int kCtrOff = kShiftOff + 15 * 32;                            // per team: barrier counter (+16 floats apart)
-constexpr int kLdsFloats = kCtrOff + 64;
+constexpr int kWOff = kTeams * kTeamFloats;                             // shared weight ping-pong
+constexpr int kWRegion = v3::kWRegion;
+constexpr int kSyncOff = kWOff + 2 * kWRegion;                          // unsigned words: see sync_word()
+constexpr int kLdsFloats = kSyncOff + 16;
 constexpr int kLdsBytes = kLdsFloats * 4;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+static_assert((kWOff * 4) % 16 == 0 && (kWRegion * 4) % 16 == 0, "LDS-DMA destinations are 16-byte aligned");
+enum { kSyncCtr0 = 0, kSyncCtr1 = 4, kSyncFin = 8, kSyncRdy = 12 };     // ctr[team], fin[slot], rdy[slot]
 constexpr int kX0Rows = kTF + 7;
 constexpr int kX0Floats = ((kX0Rows * kS + 24 + 3) / 4) * 4;            // 1224
 constexpr int kX0Off = kB30Off + kB30Pad * 30;
 static_assert(kX0Floats <= 5 * kTeamThreads && kX0Floats <= 44 * 30, "X0 staging");
 constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;            // K-split hand-off, in the team's B18
 constexpr int kFlagOff = kScratchOff + 256;
-#ifndef RCED_T_DEPTHA
-#define RCED_T_DEPTHA 4
-#endif
-constexpr int kDepthA = RCED_T_DEPTHA;                                  // global A prefetch depth (steps)
+constexpr int kDepthA = 2;                                              // A-fragment (LDS) prefetch depth, steps
 
 using v3::kL2Steps;
 using v3::kL3Steps;
@@ -77,6 +87,7 @@ struct Params {
   int N, T;
   int tiles_per_utt;   // ceil(T / 2)
   int total_tiles;
+  unsigned long long* stamps;   // diagnostic builds only (RCED_STAMPS): [wave][8] cycle sums of workgroup 0
 };
 
 __device__ __forceinline__ bool px_valid(int px) {
@@ -93,18 +104,17 @@ __device__ __forceinline__ void team_barrier(unsigned* ctr, unsigned& phase, int
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   phase += kTeamWaves;
   if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  volatile unsigned* c = ctr;
   for (int spin = 0; spin < (1 << 24); ++spin) {
-    if ((int)(__builtin_amdgcn_readfirstlane(*c) - phase) >= 0) break;
+    if ((int)(__builtin_amdgcn_readfirstlane(lds_peek(ctr)) - phase) >= 0) break;
     __builtin_amdgcn_s_sleep(1);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// Implicit-GEMM pass as v3::gemm_pass, with the A operand read from GLOBAL memory kDepthA steps ahead
-// and the B operand from LDS DEPTH steps ahead.
+// Implicit-GEMM pass as v3::gemm_pass: A operand (packet in the shared LDS slot) kDepthA steps ahead, B operand
+// (the team's activations) DEPTH steps ahead.
 template <int NR, int NX, int MT, int XMT, int NB64, int XS0, int XS1, bool XTAIL, int STRIDE, int DEPTH>
-__device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, int tailoff, const float* __restrict__ w,
+__device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, int tailoff, const float* w,
                                           int lane, f32x4 (&acc)[NR + NX][MT]) {
   constexpr int NT = NR + NX, RING = DEPTH + 1, RA = kDepthA + 1;
   const f32x2* wp = reinterpret_cast<const f32x2*>(w) + lane;
@@ -115,11 +125,7 @@ __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, 
   auto xmt = [](int mt) { return XMT < 0 || mt == XMT; };
   auto loadA = [&](int s) {
 #pragma unroll
-#ifdef RCED_T_FAKEA   // timing experiment (wrong results): every step re-reads step 0's fragment (always L1-hot)
-    for (int mt = 0; mt < MT; ++mt) a[s % RA][mt] = wp[(0 * s * MT + mt) * 64];
-#else
     for (int mt = 0; mt < MT; ++mt) a[s % RA][mt] = wp[(s * MT + mt) * 64];
-#endif
   };
   auto loadB = [&](int s) {
 #pragma unroll
@@ -168,9 +174,9 @@ __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, 
 }
 
 // Layer 1 main (NMR regular + NMX extra tiles, 9 b64 steps) and remainder (NR tiles, 16 b64 steps)
-// interleaved, A from global.  FIRST: block 0 (8x9 kernel on the input rows, b32 steps: 18 / 32).
+// interleaved.  FIRST: block 0 (8x9 kernel on the input rows, b32 steps: 18 / 32).
 template <int NMR, int NMX, int NR, bool FIRST>
-__device__ __forceinline__ void l1_pass(const float* in, int offm0, int offmx, int offr, const float* __restrict__ w,
+__device__ __forceinline__ void l1_pass(const float* in, int offm0, int offmx, int offr, const float* w,
                                         int lane, f32x4 (&accm)[NMR + NMX][1], f32x4 (&accr)[2]) {
   constexpr int NM = NMR + NMX;
   constexpr int MAIN = FIRST ? 18 : 9, REM = FIRST ? 32 : 16;
@@ -261,8 +267,8 @@ __device__ __forceinline__ float xstage_one(const Params& P, bool live, const fl
 //   layer 2: roles 0,1 = 4 tiles + one M-tile of tile 16                           (207 / 184)
 //   layer 3: roles 2,3 = 2 pair tiles + half of pair tile 8 along K                (188 / 150)
 template <int NMX, int NR>
-__device__ __forceinline__ void layer1(float* tb, const float* lds_shift, const float* __restrict__ w, bool first,
-                                       int role, int lane) {
+__device__ __forceinline__ void layer1(float* tb, const float* w, bool first, int role, int lane) {
+  const float* lds_shift = w + kW1Data;
   constexpr int NM = 4 + NMX;
   const int n = lane & 15, kq = lane >> 4;
   float* b8 = tb + kB8Off + kB8Pad * kB8S;
@@ -295,8 +301,8 @@ __device__ __forceinline__ void layer1(float* tb, const float* lds_shift, const 
 }
 
 template <int XMT>
-__device__ __forceinline__ void layer2(float* tb, const float* lds_shift, const float* __restrict__ w, int role,
-                                       int lane) {
+__device__ __forceinline__ void layer2(float* tb, const float* w, int role, int lane) {
+  const float* lds_shift = w + kW2Data;
   constexpr int NX = XMT >= 0 ? 1 : 0, NT = 4 + NX;
   const int n = lane & 15, kq = lane >> 4;
   const float* b18 = tb + kB18Off + kB18Pad * 18;
@@ -331,9 +337,10 @@ constexpr int kRolePlain = 0, kRoleReducer = 1, kRoleHelper = 2;
 constexpr int kL3Split = 19;
 
 template <int ROLE>
-__device__ __forceinline__ void layer3(const Params& P, float* tb, const float* lds_shift, const float* __restrict__ w,
-                                       int blk, int role, int lane, unsigned tag, int utt, int t0,
-                                       f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
+__device__ __forceinline__ void layer3(const Params& P, float* tb, const float* w, int blk, int role, int lane,
+                                       unsigned tag, bool live, int utt, int t0, f32x4 (&skip_ce1)[3],
+                                       f32x4 (&skip_ce2)[3]) {
+  const float* lds_shift = w + kW3Data;
   constexpr int NX = ROLE == kRolePlain ? 0 : 1, NT = 2 + NX;
   constexpr int NEPI = ROLE == kRoleHelper ? 2 : NT;
   const int n = lane & 15, kq = lane >> 4;
@@ -351,12 +358,11 @@ __device__ __forceinline__ void layer3(const Params& P, float* tb, const float* 
   if constexpr (ROLE == kRoleHelper) {
     *reinterpret_cast<f32x4*>(tb + kScratchOff + 4 * lane) = acc[2][0];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) *reinterpret_cast<volatile unsigned*>(tb + kFlagOff) = tag;
+    if (lane == 0) lds_poke(tb + kFlagOff, tag);
   }
   if constexpr (ROLE == kRoleReducer) {
-    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(tb + kFlagOff);
     for (int spin = 0; spin < (1 << 22); ++spin) {
-      if (__builtin_amdgcn_readfirstlane(*flag) == tag) break;
+      if (__builtin_amdgcn_readfirstlane(lds_peek(tb + kFlagOff)) == tag) break;
       __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -380,11 +386,32 @@ __device__ __forceinline__ void layer3(const Params& P, float* tb, const float* 
       float* bp = b8 + px * kB8S + 4 * (kq & 1);
       *reinterpret_cast<f32x2*>(bp) = f32x2{v.x, v.y};
       *reinterpret_cast<f32x2*>(bp + 2) = f32x2{v.z, v.w};
-    } else if (ok && t0 + fr < P.T) {
+    } else if (live && ok && t0 + fr < P.T) {
       float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * kHCh + 4 * (kq & 1);
       *reinterpret_cast<f32x4*>(hp) = v;
     }
   }
+}
+
+// One wave streams a whole packet global -> LDS (LDS-DMA, 1 KiB per instruction).
+template <int NFLOATS>
+__device__ __forceinline__ void wave_dma(const float* __restrict__ src, float* dst, int lane) {
+  constexpr int n4 = NFLOATS / 4, chunks = (n4 + 63) / 64;
+#pragma unroll
+  for (int c = 0; c < chunks; ++c) {
+    const int idx = c * 64 + lane;
+    if (idx < n4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)idx * 4),
+                                       (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
+  }
+}
+// Packet of layer number l (any team's count): layer l % 15 of the net.
+__device__ __forceinline__ void refill(const float* __restrict__ wpack, float* dst, unsigned l, int lane) {
+  const unsigned li = l % 15u, blk = li / 3u, j = li - 3u * blk;
+  const float* src = wpack + blk * kWBlock;
+  if (j == 0) wave_dma<kW1>(src, dst, lane);
+  else if (j == 1) wave_dma<kW2>(src + kW1, dst, lane);
+  else wave_dma<kW3>(src + kW1 + kW2, dst, lane);
 }
 
 __global__ __launch_bounds__(kThreads) void fused_v3t_kernel(Params P) {
@@ -397,29 +424,49 @@ __global__ __launch_bounds__(kThreads) void fused_v3t_kernel(Params P) {
   const int ttid = tid & (kTeamThreads - 1);
   for (int e = tid; e < kLdsFloats; e += kThreads) lds[e] = 0.f;
   __syncthreads();
-  for (int e = tid; e < 15 * 32; e += kThreads) {   // shifts of all 15 layers (packet tails) -> LDS, once
-    const int l = e >> 5, blk = l / 3, j = l - 3 * blk;
-    const float* pk = P.wpack + blk * kWBlock + (j == 0 ? kW1Data : j == 1 ? kW1 + kW2Data : kW1 + kW2 + kW3Data);
-    lds[kShiftOff + e] = pk[e & 31];
-  }
-  __syncthreads();   // last workgroup-wide barrier: from here on the two teams run independently
+  unsigned* sync = reinterpret_cast<unsigned*>(lds + kSyncOff);
+  // layers 0 and 1 of the first tile into the two slots
+  if (wave == 0) refill(P.wpack, lds + kWOff, 0, lane);
+  if (wave == 1) refill(P.wpack, lds + kWOff + kWRegion, 1, lane);
+  if (tid == 0) { sync[kSyncRdy + 0] = 1; sync[kSyncRdy + 1] = 2; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // last workgroup-wide barrier: from here on the two teams only meet through fin / rdy
 
   float* tb = lds + team * kTeamFloats;
-  unsigned* ctr = reinterpret_cast<unsigned*>(lds + kCtrOff + 16 * team);
+  unsigned* ctr = sync + (team ? kSyncCtr1 : kSyncCtr0);
   unsigned phase = 0, epoch = 0;
-#ifdef RCED_T_SOLO   // experiment: team 0 alone does every tile of the workgroup
-  if (team != 0) return;
-  const int tstride = gridDim.x;
-  int tile = blockIdx.x;
+  unsigned L = 0;   // this team's layer count (identical sequence in both teams)
+#if RCED_STAMPS
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // enter wait, math L1/L2/L3, leave, team barrier
+  unsigned long long tq = v3::stamp();
+#define TSTAMP(i) { const unsigned long long tn_ = v3::stamp(); ts[i] += tn_ - tq; tq = tn_; }
 #else
-  const int tstride = gridDim.x * kTeams;
-  int tile = blockIdx.x * kTeams + team;
+#define TSTAMP(i)
 #endif
 
-#ifdef RCED_T_STAGGER   // experiment: start team 1 late so that the teams' sync bubbles do not coincide
-  if (team == 1)
-    for (int i = 0; i < RCED_T_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);   // ~1 k cycles each
-#endif
+  // enter layer L: its packet must have landed in slot L & 1
+  auto enter = [&]() -> const float* {
+    for (int spin = 0; spin < (1 << 24); ++spin) {
+      if ((int)(__builtin_amdgcn_readfirstlane(lds_peek(sync + kSyncRdy + (L & 1u))) - (L + 1u)) >= 0) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return lds + kWOff + (L & 1u) * kWRegion;
+  };
+  // leave layer L: this wave no longer reads the slot; the last of the 8 waves refills it with layer L + 2
+  auto leave = [&]() {
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(sync + kSyncFin + (L & 1u), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if ((old & 7u) == 7u) {
+      refill(P.wpack, lds + kWOff + (L & 1u) * kWRegion, L + 2u, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) lds_poke(sync + kSyncRdy + (L & 1u), L + 3u);
+    }
+    ++L;
+  };
+
   XStage xst;
   auto xload = [&](int tl) {
     const bool live = tl < P.total_tiles;
@@ -429,11 +476,15 @@ __global__ __launch_bounds__(kThreads) void fused_v3t_kernel(Params P) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) xst.v[i] = xstage_one(P, live, xu, t0, ttid + i * kTeamThreads);
   };
+  const int tstride = gridDim.x * kTeams;
+  int tile = blockIdx.x * kTeams + team;
   xload(tile);
 
-  for (; tile < P.total_tiles; tile += tstride) {
-    const int utt = tile / P.tiles_per_utt;
-    const int t0 = (tile - utt * P.tiles_per_utt) * kTF;
+  // both teams iterate while the workgroup's FIRST tile of the round exists (team 1's may be missing: dummy)
+  for (; tile - team < P.total_tiles; tile += tstride) {
+    const bool live = tile < P.total_tiles;
+    const int utt = live ? tile / P.tiles_per_utt : 0;
+    const int t0 = live ? (tile - utt * P.tiles_per_utt) * kTF : 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
       if (ttid + i * kTeamThreads < kX0Floats) tb[kX0Off + ttid + i * kTeamThreads] = xst.v[i];
@@ -442,33 +493,57 @@ __global__ __launch_bounds__(kThreads) void fused_v3t_kernel(Params P) {
     f32x4 skip_ce1[3], skip_ce2[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) skip_ce1[t] = skip_ce2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* wsrc = P.wpack;
-    const float* shf = lds + kShiftOff;
 
 #pragma unroll 1
     for (int blk = 0; blk < 5; ++blk) {
-      if (role == 0) layer1<1, 0>(tb, shf, wsrc, blk == 0, role, lane);
-      else layer1<0, 1>(tb, shf, wsrc, blk == 0, role, lane);
-      team_barrier(ctr, phase, lane);
-
-      if (role == 0) layer2<0>(tb, shf + 32, wsrc + kW1, role, lane);
-      else if (role == 1) layer2<1>(tb, shf + 32, wsrc + kW1, role, lane);
-      else layer2<-1>(tb, shf + 32, wsrc + kW1, role, lane);
-      team_barrier(ctr, phase, lane);
-
-      if (blk == 4) xload(tile + tstride);   // next tile's input rows, one layer ahead
-      ++epoch;
-      const unsigned tag = 0x80000000u | epoch;
-      const float* w3 = wsrc + kW1 + kW2;
-      if (role == 2) layer3<kRoleReducer>(P, tb, shf + 64, w3, blk, role, lane, tag, utt, t0, skip_ce1, skip_ce2);
-      else if (role == 3) layer3<kRoleHelper>(P, tb, shf + 64, w3, blk, role, lane, tag, utt, t0, skip_ce1, skip_ce2);
-      else layer3<kRolePlain>(P, tb, shf + 64, w3, blk, role, lane, tag, utt, t0, skip_ce1, skip_ce2);
-      team_barrier(ctr, phase, lane);
-
-      wsrc += kWBlock;
-      shf += 96;
+      {
+        TSTAMP(7);
+        const float* w = enter();
+        TSTAMP(0);
+        if (role == 0) layer1<1, 0>(tb, w, blk == 0, role, lane);
+        else layer1<0, 1>(tb, w, blk == 0, role, lane);
+        TSTAMP(1);
+        leave();
+        TSTAMP(4);
+        team_barrier(ctr, phase, lane);
+        TSTAMP(5);
+      }
+      {
+        const float* w = enter();
+        TSTAMP(0);
+        if (role == 0) layer2<0>(tb, w, role, lane);
+        else if (role == 1) layer2<1>(tb, w, role, lane);
+        else layer2<-1>(tb, w, role, lane);
+        TSTAMP(2);
+        leave();
+        TSTAMP(4);
+        team_barrier(ctr, phase, lane);
+        TSTAMP(5);
+      }
+      {
+        if (blk == 4) xload(tile + tstride);   // next tile's input rows, one layer ahead
+        ++epoch;
+        const unsigned tag = 0x80000000u | epoch;
+        TSTAMP(7);
+        const float* w = enter();
+        TSTAMP(0);
+        if (role == 2) layer3<kRoleReducer>(P, tb, w, blk, role, lane, tag, live, utt, t0, skip_ce1, skip_ce2);
+        else if (role == 3) layer3<kRoleHelper>(P, tb, w, blk, role, lane, tag, live, utt, t0, skip_ce1, skip_ce2);
+        else layer3<kRolePlain>(P, tb, w, blk, role, lane, tag, live, utt, t0, skip_ce1, skip_ce2);
+        TSTAMP(3);
+        leave();
+        TSTAMP(4);
+        team_barrier(ctr, phase, lane);
+        TSTAMP(5);
+      }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a refill issued for layers nobody will run
+#if RCED_STAMPS
+  if (P.stamps && blockIdx.x == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) P.stamps[wave * 8 + i] = ts[i];
+#endif
+#undef TSTAMP
 }
 
 }  // namespace v3t
