@@ -109,3 +109,31 @@ def test_training_reduces_the_loss_and_moves_bn_statistics(built):
     v = tr.variables()
     assert np.abs(v["encode_1/batch_norm/moving_mean"] - w["encode_1/batch_norm/moving_mean"]).max() > 1e-4
     assert tr.global_step == 8
+
+
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_mfma_and_generic_training_kernels_agree(net_work, tag, variant, built, monkeypatch):
+    """RCED_TRAIN_MFMA=0 keeps the direct-convolution kernels for every layer; the MFMA kernels
+    (kernels_train_mfma.h) must give the same step.  Ragged shape: 5 x 7 = 35 frames (odd: half-empty tile)."""
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer
+    w = rced_np.make_weights(net_work, seed=17)
+    x = rced_np.make_input(5, 7, seed=31)
+    y = rced_np.make_input(5, 7, seed=32)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RCED_TRAIN_MFMA", mode)
+        tr = FullyCNNTrainer(net_work, batch_size=5, lr=1e-3, weights=w)
+        loss, _, _ = tr.train_step(x, y)
+        out[mode] = (loss, tr.gradients(), tr.variables())
+        tr.close()
+    assert abs(out["0"][0] - out["1"][0]) <= 1e-6 * abs(out["0"][0])
+    last = net_layers_last(net_work)
+    for name, g0 in out["0"][1].items():
+        g1 = out["1"][1][name]
+        if "moving_" in name or (name.endswith("/bias") and not name.startswith(last)):
+            continue                                   # not trainable / rounding noise in front of BatchNorm (see above)
+        assert rel(g1, g0) < (TIGHT if name.startswith(last) else LOOSE), name
+        assert cosine(g1, g0) > COS, name
+    for name in out["0"][2]:
+        if "moving_" in name:
+            assert rel(out["1"][2][name], out["0"][2][name]) < 1e-5, name
