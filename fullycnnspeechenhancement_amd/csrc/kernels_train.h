@@ -186,9 +186,9 @@ __global__ __launch_bounds__(kThreads) void bn_act_fwd2(const float2* __restrict
                                                          float2* __restrict__ out) {
   const PairLane L(C, threadIdx.x);
   if (!L.active) return;
-  float m[2] = {0.f, 0.f}, r[2] = {1.f, 1.f}, ga[2] = {1.f, 1.f}, be[2] = {0.f, 0.f};
+  float fa[2] = {1.f, 1.f}, fb[2] = {0.f, 0.f};   // folded BatchNorm: a*z + b (the form every consumer of z uses)
   if (mu)
-    for (int k = 0; k < 2; ++k) { const int c = 2 * L.c2 + k; m[k] = mu[c]; r[k] = rstd[c]; ga[k] = gamma[c]; be[k] = beta[c]; }
+    for (int k = 0; k < 2; ++k) { const int c = 2 * L.c2 + k; fa[k] = gamma[c] * rstd[c]; fb[k] = beta[c] - fa[k] * mu[c]; }
   const size_t stride = (size_t)gridDim.x * L.rows;
   for (size_t p = (size_t)blockIdx.x * L.rows + L.row; p < P; p += kPairUnroll * stride) {
     float2 zv[kPairUnroll], s1[kPairUnroll], s2[kPairUnroll];
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void bn_act_fwd2(const float2* __restrict
       const float a1[2] = {s1[u].x, s1[u].y}, a2[2] = {s2[u].x, s2[u].y};
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        if (mu) v[k] = ga[k] * ((v[k] - m[k]) * r[k]) + be[k];
+        if (mu) v[k] = fmaf(fa[k], v[k], fb[k]);
         if (skip_pre) v[k] += a1[k];
         if (use_act) v[k] = fmaxf(v[k], 0.f);
         if (skip_post) v[k] += a2[k];
@@ -228,9 +228,13 @@ __global__ __launch_bounds__(kThreads) void bwd_route2(const float2* __restrict_
   const PairLane L(C, threadIdx.x);
   double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [k][S1, S2]
   if (L.active) {
-    float m[2] = {0.f, 0.f}, r[2] = {1.f, 1.f}, ga[2] = {1.f, 1.f}, be[2] = {0.f, 0.f};
+    float m[2] = {0.f, 0.f}, r[2] = {1.f, 1.f}, fa[2] = {1.f, 1.f}, fb[2] = {0.f, 0.f};
     if (mu)
-      for (int k = 0; k < 2; ++k) { const int c = 2 * L.c2 + k; m[k] = mu[c]; r[k] = rstd[c]; ga[k] = gamma[c]; be[k] = beta[c]; }
+      for (int k = 0; k < 2; ++k) {
+        const int c = 2 * L.c2 + k;
+        m[k] = mu[c]; r[k] = rstd[c];
+        fa[k] = gamma[c] * rstd[c]; fb[k] = beta[c] - fa[k] * mu[c];   // folded form, as in the forward
+      }
     const size_t stride = (size_t)gridDim.x * L.rows;
     for (size_t p = (size_t)blockIdx.x * L.rows + L.row; p < P; p += kPairUnroll * stride) {
       float2 gv[kPairUnroll], zv[kPairUnroll], sp[kPairUnroll], gp[kPairUnroll], gq[kPairUnroll];
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void bwd_route2(const float2* __restrict_
           du[k] = go[k];
           if (use_act) {
             float v = zz[k];
-            if (mu) v = ga[k] * ((v - m[k]) * r[k]) + be[k];
+            if (mu) v = fmaf(fa[k], v, fb[k]);
             if (skip_pre) v += sk[k];
             du[k] = v > 0.f ? go[k] : 0.f;
           }

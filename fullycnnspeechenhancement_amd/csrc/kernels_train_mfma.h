@@ -111,6 +111,21 @@ __device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int f
   }
 }
 // dst index of element (frame fr, offset r inside the frame) = base_row(fr) * ROWSTRIDE-style mapping given by MAP
+// Input transform applied while committing a tile: the producer layer's BatchNorm + ReLU (module.py:28-33),
+//   act = relu(a * z + b),   a = gamma * rstd,  b = beta - a * mu   (per channel; bn_act_fwd2 / bwd_route2 use the
+// same folded form, so the forward value and the backward ReLU mask always agree),
+// so that a plain conv+BN+ReLU layer's activation never has to be written to / read from HBM: its consumers
+// (the next layer's forward conv and wgrad) read z and rebuild it here.  table = [a | b][C] in LDS.
+template <int C>
+__device__ __forceinline__ void xform_table_fill(float* table, const float* mu, const float* rstd, const float* gamma,
+                                                 const float* beta, int tid) {
+  if (tid < C) {
+    const float a = gamma[tid] * rstd[tid];
+    table[tid] = a;
+    table[C + tid] = beta[tid] - a * mu[tid];
+  }
+}
+
 template <int C, class MAP>
 __device__ __forceinline__ void tile_commit(float* lds, int tid, const f32x4 (&pre)[Stage<C>::kPer], MAP map) {
   using St = Stage<C>;
@@ -125,6 +140,35 @@ __device__ __forceinline__ void tile_commit(float* lds, int tid, const f32x4 (&p
         *reinterpret_cast<f32x2*>(lds + map(fr, r)) = f32x2{pre[i][2 * h], pre[i][2 * h + 1]};
       }
     }
+  }
+}
+// The same with the BatchNorm + ReLU transform.  The channel of a thread's i-th float4 advances by a constant
+// (4 * kThreads mod C), so it is tracked incrementally instead of by a modulo per element.
+template <int C, class MAP>
+__device__ __forceinline__ void tile_commit_bnrelu(float* lds, int tid, const f32x4 (&pre)[Stage<C>::kPer], MAP map,
+                                                   const float* table, int frame0, int frames) {
+  using St = Stage<C>;
+  static_assert(St::kFrame % C == 0 && C % 2 == 0, "frames start at channel 0; float2 pieces stay inside a pixel");
+  constexpr int kStep = (4 * kThreads) % C;
+  int c = (4 * tid) % C;
+#pragma unroll
+  for (int i = 0; i < St::kPer; ++i) {
+    const int q = tid + i * kThreads;
+    if (q < St::kVec) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 4 * q + 2 * h;
+        const int fr = e / St::kFrame, r = e - fr * St::kFrame;
+        int ch = c + 2 * h;
+        if (ch >= C) ch -= C;
+        const f32x2 a = *reinterpret_cast<const f32x2*>(table + ch), b = *reinterpret_cast<const f32x2*>(table + C + ch);
+        f32x2 v = {fmaxf(fmaf(a.x, pre[i][2 * h], b.x), 0.f), fmaxf(fmaf(a.y, pre[i][2 * h + 1], b.y), 0.f)};
+        if (frame0 + fr >= frames) v = f32x2{0.f, 0.f};      // frames past the batch stay zero
+        *reinterpret_cast<f32x2*>(lds + map(fr, r)) = v;
+      }
+    }
+    c += kStep;
+    if (c >= C) c -= C;
   }
 }
 
@@ -212,9 +256,14 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 // in [frames][129][CIN], out [frames][129][COUT].  Persistent over tiles of kTF frames.
 // STATS: also emit this workgroup's per-channel (sum z, sum z^2) of what it wrote, as doubles, into
 // part[blockIdx.x][COUT][2] -- the batch-norm statistics, without another pass over z.
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS>
+// XF: `in` is the producer's pre-BatchNorm z and xa its statistics / affine parameters (see tile_commit_bnrelu).
+struct XformArgs {
+  const float *mu, *rstd, *gamma, *beta;
+};
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, bool XF>
 __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict__ in, const float* __restrict__ packet,
-                                                          float* __restrict__ out, int frames, double* __restrict__ part) {
+                                                          float* __restrict__ out, int frames, double* __restrict__ part,
+                                                          XformArgs xa) {
   using G = Geo<CIN, TAPS, COUT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lin = lds;
@@ -222,6 +271,8 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int e = tid; e < G::kLdsFloats; e += kThreads) lds[e] = e < G::kInFloats ? 0.f : packet[e - G::kInFloats];
+  float* xt = lds + G::kLdsFloats;                      // [2][CIN], only with XF
+  if constexpr (XF) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
   __syncthreads();
   double st1[G::kMT][4], st2[G::kMT][4];
 #pragma unroll
@@ -234,7 +285,9 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
     if ((int)blockIdx.x < ntiles) tile_fetch<CIN>(in, blockIdx.x * kTF, frames, tid, pre);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int frame0 = tile * kTF;
-      tile_commit<CIN>(lin, tid, pre, [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; });
+      auto where = [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; };
+      if constexpr (XF) tile_commit_bnrelu<CIN>(lin, tid, pre, where, xt, frame0, frames);
+      else tile_commit<CIN>(lin, tid, pre, where);
       __syncthreads();
       if (tile + (int)gridDim.x < ntiles) tile_fetch<CIN>(in, (tile + gridDim.x) * kTF, frames, tid, pre);
       pin();
@@ -294,9 +347,10 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
 // Each wave walks the pixel groups g = wave, wave+4, ... of every tile the workgroup owns, keeps the
 // whole [K][COUT] partial in accumulators, and the workgroup adds it to dW with atomics at the end.
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int TAPS, int COUT>
+template <int CIN, int TAPS, int COUT, bool XF>
 __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restrict__ x, const float* __restrict__ dz,
-                                                           float* __restrict__ dW, float* __restrict__ dbias, int frames) {
+                                                           float* __restrict__ dW, float* __restrict__ dbias, int frames,
+                                                           XformArgs xa) {
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(CIN % 2 == 0 && COUT % 2 == 0, "wgrad1xk_mfma stages float4 / float2 pieces");
   // one spare k row carries a constant 1, so its output row is sum_px dz = dbias
@@ -311,6 +365,8 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
   for (int e = tid; e < G::kInFloats + 64 + kDzRows * kDzStride; e += kThreads) lds[e] = 0.f;
+  float* xt = lds + G::kInFloats + 64 + kDzRows * kDzStride;   // [2][CIN], only with XF
+  if constexpr (XF) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
   f32x4 acc[KT][NTo];
 #pragma unroll
   for (int a = 0; a < KT; ++a)
@@ -326,7 +382,9 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
   const float* ain = lin + kq * G::kCinP + i;          // window start of pixel (px0 + kq) is row (px0 + kq) of lin
   const float* bin = ldz + kq * kDzStride + i;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    tile_commit<CIN>(lin, tid, prex, [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; });
+    auto where = [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; };
+    if constexpr (XF) tile_commit_bnrelu<CIN>(lin, tid, prex, where, xt, tile * kTF, frames);
+    else tile_commit<CIN>(lin, tid, prex, where);
     tile_commit<COUT>(ldz, tid, prez, [](int fr, int r) {
       const int f = r / COUT, co = r - f * COUT;
       return (fr * G::kS + f) * kDzStride + co;

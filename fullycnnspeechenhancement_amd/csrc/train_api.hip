@@ -58,6 +58,7 @@ struct rced_trainer {
   std::vector<float*> wf, wt, bias4, mu, rstd;   // per layer
   std::vector<float*> pk_fwd, pk_bwd;            // per layer: MFMA A-fragment packets (1xk layers with an MFMA kernel)
   int use_mfma = 1;
+  std::vector<char> virt;      // virt[id]: tensor id (= relu(bn(z[id-1]))) is never materialised; its consumer rebuilds it
   float* pk_fin = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
   float* zero32 = nullptr;
   double *part = nullptr, *sums = nullptr;
@@ -107,7 +108,9 @@ int ensure_acts(rced_trainer* t, size_t P) {
     const int c = net.layer[l].cout;
     maxc = std::max(maxc, c);
     HIP_TRY(hipMalloc(&t->z[l], P * c * sizeof(float)));
-    if (net.layer[l].use_norm || net.layer[l].use_act || net.layer[l].skip_pre >= 0 || net.layer[l].skip_post >= 0)
+    if (!t->virt.empty() && t->virt[l + 1])
+      t->out[l + 1] = nullptr;   // rebuilt from z by its consumer (BnReluXform)
+    else if (net.layer[l].use_norm || net.layer[l].use_act || net.layer[l].skip_pre >= 0 || net.layer[l].skip_post >= 0)
       HIP_TRY(hipMalloc(&t->out[l + 1], P * c * sizeof(float)));
     else
       t->out[l + 1] = t->z[l];   // plain conv layer (decode_final): its output IS z
@@ -145,37 +148,44 @@ size_t tm_packet_floats(int cin, int taps, int cout) {
   return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + 32;
 }
 
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS>
-int tm_conv_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part, hipStream_t st) {
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, bool XF>
+int tm_conv_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part,
+                    tmm::XformArgs xa, hipStream_t st) {
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const int grid = std::min(ntiles, std::min(cus * 4, kPairGrid));
-  const size_t lds = G::kLdsFloats * sizeof(float);
+  const size_t lds = (G::kLdsFloats + (XF ? 2 * CIN : 0)) * sizeof(float);
   static bool attr = false;
   if (!attr && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS>), dim3(grid), dim3(tmm::kThreads), lds, st, in, packet,
-                     out, frames, part);
+  hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), dim3(grid), dim3(tmm::kThreads), lds, st, in,
+                     packet, out, frames, part, xa);
   return grid;
 }
 // mode 0: out = conv + shift;  1: out += conv;  2: as 0 and per-workgroup (sum, sum of squares) into part.
+// xa != null (modes 0, 2; even CIN): `in` is the producer's z, rebuilt to relu(bn(z)) while staging.
 // Returns the grid size (= number of partial-sum records for mode 2).
 template <int CIN, int TAPS, int COUT>
 int tm_conv_launch(int mode, const float* in, const float* packet, float* out, int frames, int cus, double* part,
-                   hipStream_t st) {
-  if (mode == 1) return tm_conv_launch1<CIN, TAPS, COUT, true, false>(in, packet, out, frames, cus, nullptr, st);
-  if (mode == 2) return tm_conv_launch1<CIN, TAPS, COUT, false, true>(in, packet, out, frames, cus, part, st);
-  return tm_conv_launch1<CIN, TAPS, COUT, false, false>(in, packet, out, frames, cus, nullptr, st);
+                   const tmm::XformArgs* xa, hipStream_t st) {
+  const tmm::XformArgs none{nullptr, nullptr, nullptr, nullptr};
+  if constexpr (CIN % 2 == 0) {
+    if (xa && mode == 2) return tm_conv_launch1<CIN, TAPS, COUT, false, true, true>(in, packet, out, frames, cus, part, *xa, st);
+    if (xa && mode == 0) return tm_conv_launch1<CIN, TAPS, COUT, false, false, true>(in, packet, out, frames, cus, nullptr, *xa, st);
+  }
+  if (mode == 1) return tm_conv_launch1<CIN, TAPS, COUT, true, false, false>(in, packet, out, frames, cus, nullptr, none, st);
+  if (mode == 2) return tm_conv_launch1<CIN, TAPS, COUT, false, true, false>(in, packet, out, frames, cus, part, none, st);
+  return tm_conv_launch1<CIN, TAPS, COUT, false, false, false>(in, packet, out, frames, cus, nullptr, none, st);
 }
 
 // returns the grid size if an MFMA kernel exists for this shape (and was launched), 0 otherwise
 int tm_conv(int cin, int taps, int cout, int mode, const float* in, const float* packet, float* out, int frames, int cus,
-            double* part, hipStream_t st) {
+            double* part, const tmm::XformArgs* xa, hipStream_t st) {
 #define X(CI, TP, CO) \
-  if (cin == CI && taps == TP && cout == CO) return tm_conv_launch<CI, TP, CO>(mode, in, packet, out, frames, cus, part, st);
+  if (cin == CI && taps == TP && cout == CO) return tm_conv_launch<CI, TP, CO>(mode, in, packet, out, frames, cus, part, xa, st);
   RCED_TM_SHAPES(X)
 #undef X
   return 0;
@@ -187,24 +197,35 @@ bool tm_has(int cin, int taps, int cout) {
   return false;
 }
 
-template <int CIN, int TAPS, int COUT>
-int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, hipStream_t st) {
+template <int CIN, int TAPS, int COUT, bool XF>
+int tm_wgrad_launch1(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, tmm::XformArgs xa,
+                     hipStream_t st) {
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const int grid = std::min(ntiles, cus * 2);
-  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32) * sizeof(float);
+  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32 + (XF ? 2 * CIN : 0)) * sizeof(float);
   static bool attr = false;
   if (!attr && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW, dbias, frames);
+  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW, dbias,
+                     frames, xa);
   return 1;
 }
+template <int CIN, int TAPS, int COUT>
+int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, const tmm::XformArgs* xa,
+                    hipStream_t st) {
+  if constexpr (CIN % 2 == 0 && COUT % 2 == 0) {
+    if (xa) return tm_wgrad_launch1<CIN, TAPS, COUT, true>(x, dz, dW, dbias, frames, cus, *xa, st);
+    return tm_wgrad_launch1<CIN, TAPS, COUT, false>(x, dz, dW, dbias, frames, cus, tmm::XformArgs{nullptr, nullptr, nullptr, nullptr}, st);
+  }
+  return 0;
+}
 int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
-             hipStream_t st) {
-#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_wgrad_launch<CI, TP, CO>(x, dz, dW, dbias, frames, cus, st);
+             const tmm::XformArgs* xa, hipStream_t st) {
+#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_wgrad_launch<CI, TP, CO>(x, dz, dW, dbias, frames, cus, xa, st);
   X(8, 9, 18) X(18, 5, 30) X(30, 9, 8)
 #undef X
   return 0;
@@ -335,6 +356,28 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     if (s.kh == 1 && tm_has(f.cin, s.kw, s.cout)) TRY_OR_FREE(hipMalloc(&t->pk_fwd[l], tm_packet_floats(f.cin, s.kw, s.cout) * sizeof(float)));
     if (s.kh == 1 && tm_has(s.cout, s.kw, f.cin)) TRY_OR_FREE(hipMalloc(&t->pk_bwd[l], tm_packet_floats(s.cout, s.kw, f.cin) * sizeof(float)));
   }
+  // Tensors that need not exist in HBM: output of a plain conv+BN+ReLU layer (no skip in or out) whose only
+  // consumer is a 1xk layer with MFMA forward and wgrad kernels.  RCED_TRAIN_FUSE_ACT=0 turns this off.
+  t->virt.assign(L + 1, 0);
+  {
+    const char* e = getenv("RCED_TRAIN_FUSE_ACT");
+    const bool fuse = t->use_mfma && !(e && atoi(e) == 0);
+    std::vector<int> uses(L + 1, 0), conv_user(L + 1, -1);
+    for (int l = 0; l < L; ++l) {
+      const LayerSpec& s = t->net->layer[l];
+      if (s.src > 0) { ++uses[s.src]; conv_user[s.src] = l; }
+      if (s.skip_pre > 0) uses[s.skip_pre] += 2;     // a skip use disqualifies
+      if (s.skip_post > 0) uses[s.skip_post] += 2;
+    }
+    for (int id = 1; fuse && id < L; ++id) {
+      const LayerSpec& p = t->net->layer[id - 1];
+      const int c = conv_user[id];
+      if (uses[id] != 1 || c < 0) continue;
+      const LayerSpec& q = t->net->layer[c];
+      t->virt[id] = p.use_norm && p.use_act && p.skip_pre < 0 && p.skip_post < 0 && p.cout % 2 == 0 && q.kh == 1 &&
+                    q.cout % 2 == 0 && t->pk_fwd[c] != nullptr && tm_has(p.cout, q.kw, q.cout);
+    }
+  }
 #undef TRY_OR_FREE
   *out = t;
   return RCED_OK;
@@ -374,6 +417,15 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     const size_t rows = train::kThreads / (C / 2);
     return dim3((unsigned)std::min<size_t>((P + rows - 1) / rows, kPairGrid));
   };
+  // a virtual tensor is read as its producer's z plus that layer's BatchNorm parameters (BnReluXform)
+  tmm::XformArgs xa_tmp{nullptr, nullptr, nullptr, nullptr};
+  auto conv_in = [&](int id) -> const float* { return id == 0 ? x_dev : (t->virt[id] ? t->z[id - 1] : t->out[id]); };
+  auto xform_of = [&](int id, tmm::XformArgs* xa) -> const tmm::XformArgs* {
+    if (id <= 0 || !t->virt[id]) return nullptr;
+    const LayerOff& pf = t->off[id - 1];
+    *xa = tmm::XformArgs{t->mu[id - 1], t->rstd[id - 1], t->params + pf.gamma, t->params + pf.beta};
+    return xa;
+  };
   auto tensor = [&](int id) -> const float* { return id < 0 ? nullptr : (id == 0 ? x_dev : t->out[id]); };
 
   // ---- weights in the layouts the conv kernel wants
@@ -408,8 +460,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     const LayerOff& f = t->off[l];
     int stat_parts = 0;   // > 0: the conv kernel already left that many (sum z, sum z^2) records in t->part
     if (t->use_mfma && t->pk_fwd[l] &&
-        (stat_parts = tm_conv(f.cin, s.kw, s.cout, s.use_norm ? 2 : 0, tensor(s.src), t->pk_fwd[l], t->z[l], frames,
-                              t->num_cus, t->part, st)) > 0) {
+        (stat_parts = tm_conv(f.cin, s.kw, s.cout, s.use_norm ? 2 : 0, conv_in(s.src), t->pk_fwd[l], t->z[l], frames,
+                              t->num_cus, t->part, xform_of(s.src, &xa_tmp), st)) > 0) {
       if (!s.use_norm) stat_parts = 0;
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
       fin_forward(f.cin, tensor(s.src), t->params + f.kernel, t->params + f.bias, t->pk_fin, t->z[l], frames, st);
@@ -427,7 +479,7 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
       hipLaunchKernelGGL(train::bn_stats_finish, dim3(1), dim3(64), 0, st, (const double*)t->sums, (double)P, s.cout,
                          kBnEps, kBnMomentum, t->mu[l], t->rstd[l], t->params + f.mmean, t->params + f.mvar);
     }
-    if (t->out[l + 1] != t->z[l]) {
+    if (t->out[l + 1] != t->z[l] && !t->virt[l + 1]) {
       if (s.cout % 2 == 0)
         hipLaunchKernelGGL(train::bn_act_fwd2, pair_grid(s.cout), dim3(train::kThreads), 0, st, (const float2*)t->z[l],
                            s.use_norm ? (const float*)t->mu[l] : nullptr, (const float*)t->rstd[l],
@@ -505,8 +557,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
                            s.cout);
     }
     // dW and dbias = sum dz (the MFMA wgrad kernel produces both)
-    if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, tensor(s.src), t->D, t->grads + f.kernel,
-                                             t->grads + f.bias, frames, t->num_cus, st)) {
+    if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, conv_in(s.src), t->D, t->grads + f.kernel,
+                                             t->grads + f.bias, frames, t->num_cus, xform_of(s.src, &xa_tmp), st)) {
       // MFMA path
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
       fin_wgrad(f.cin, tensor(s.src), t->D, t->grads + f.kernel, t->grads + f.bias, frames, t->num_cus, st);
@@ -523,7 +575,7 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
     if (s.src > 0) {
       if (t->use_mfma && t->pk_bwd[l] &&
-          tm_conv(s.cout, s.kw, f.cin, overwrite(l) ? 0 : 1, t->D, t->pk_bwd[l], t->G[s.src], frames, t->num_cus, nullptr, st)) {
+          tm_conv(s.cout, s.kw, f.cin, overwrite(l) ? 0 : 1, t->D, t->pk_bwd[l], t->G[s.src], frames, t->num_cus, nullptr, nullptr, st)) {
         // MFMA path
       } else if (int rc = launch_conv(t->D, t->G[s.src], t->wt[l], t->zero32, t->G[s.src], frames, T, F, s.cout, f.cin,
                                       f.cin4, s.kh, s.kw, (s.kh - 1) - (s.kh - 1) / 2, (s.kw - 1) - (s.kw - 1) / 2, st)) {
