@@ -172,6 +172,58 @@ __device__ __forceinline__ void tile_commit_bnrelu(float* lds, int tid, const f3
   }
 }
 
+// BatchNorm backward applied while committing a tile of d_u (the gradient w.r.t. the BN output, after the ReLU
+// mask): dz = gamma*rstd * (d_u - S1/P - zhat * S2/P), zhat = (z - mu)*rstd, S1 = sum d_u, S2 = sum d_u*zhat
+// (bn_bwd_apply2), folded per channel into  dz = A*d_u + B*z + C.  table = [A | B | C][C] in LDS.  With it the
+// dz tensor never exists in HBM: the two kernels that consume it (wgrad, dgrad) read d_u and z instead.
+struct BnBwdArgs {
+  const float* z;          // pre-BatchNorm output of the layer, same layout as d_u
+  const float *mu, *rstd, *gamma;
+  const double* sums;      // [C][2] = (S1, S2)
+  double P;                // pixels in the batch
+};
+template <int C>
+__device__ __forceinline__ void bnbwd_table_fill(float* table, const BnBwdArgs& a, int tid) {
+  if (tid < C) {
+    const float gr = a.gamma[tid] * a.rstd[tid];
+    const float m1 = (float)(a.sums[2 * tid] / a.P), m2 = (float)(a.sums[2 * tid + 1] / a.P);
+    const float B = -gr * m2 * a.rstd[tid];
+    table[tid] = gr;
+    table[C + tid] = B;
+    table[2 * C + tid] = -gr * m1 - B * a.mu[tid];
+  }
+}
+template <int C, class MAP>
+__device__ __forceinline__ void tile_commit_bnbwd(float* lds, int tid, const f32x4 (&pd)[Stage<C>::kPer],
+                                                  const f32x4 (&pz)[Stage<C>::kPer], MAP map, const float* table,
+                                                  int frame0, int frames) {
+  using St = Stage<C>;
+  static_assert(St::kFrame % C == 0 && C % 2 == 0, "frames start at channel 0; float2 pieces stay inside a pixel");
+  constexpr int kStep = (4 * kThreads) % C;
+  int c = (4 * tid) % C;
+#pragma unroll
+  for (int i = 0; i < St::kPer; ++i) {
+    const int q = tid + i * kThreads;
+    if (q < St::kVec) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 4 * q + 2 * h;
+        const int fr = e / St::kFrame, r = e - fr * St::kFrame;
+        int ch = c + 2 * h;
+        if (ch >= C) ch -= C;
+        const f32x2 A = *reinterpret_cast<const f32x2*>(table + ch), B = *reinterpret_cast<const f32x2*>(table + C + ch);
+        const f32x2 K = *reinterpret_cast<const f32x2*>(table + 2 * C + ch);
+        f32x2 v = {fmaf(A.x, pd[i][2 * h], fmaf(B.x, pz[i][2 * h], K.x)),
+                   fmaf(A.y, pd[i][2 * h + 1], fmaf(B.y, pz[i][2 * h + 1], K.y))};
+        if (frame0 + fr >= frames) v = f32x2{0.f, 0.f};      // frames past the batch stay zero
+        *reinterpret_cast<f32x2*>(lds + map(fr, r)) = v;
+      }
+    }
+    c += kStep;
+    if (c >= C) c -= C;
+  }
+}
+
 template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX>
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
                                           int frames, int wave, int lane,
@@ -260,10 +312,11 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 struct XformArgs {
   const float *mu, *rstd, *gamma, *beta;
 };
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, bool XF>
+constexpr int kXfNone = 0, kXfBnRelu = 1, kXfBnBwd = 2;
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF>
 __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict__ in, const float* __restrict__ packet,
                                                           float* __restrict__ out, int frames, double* __restrict__ part,
-                                                          XformArgs xa) {
+                                                          XformArgs xa, BnBwdArgs ba) {
   using G = Geo<CIN, TAPS, COUT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lin = lds;
@@ -271,8 +324,9 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int e = tid; e < G::kLdsFloats; e += kThreads) lds[e] = e < G::kInFloats ? 0.f : packet[e - G::kInFloats];
-  float* xt = lds + G::kLdsFloats;                      // [2][CIN], only with XF
-  if constexpr (XF) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
+  float* xt = lds + G::kLdsFloats;                      // [2 or 3][CIN], only with XF
+  if constexpr (XF == kXfBnRelu) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
+  if constexpr (XF == kXfBnBwd) bnbwd_table_fill<CIN>(xt, ba, tid);
   __syncthreads();
   double st1[G::kMT][4], st2[G::kMT][4];
 #pragma unroll
@@ -281,15 +335,22 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
     for (int j = 0; j < 4; ++j) st1[mt][j] = st2[mt][j] = 0.0;
   const int ntiles = (frames + kTF - 1) / kTF;
   if constexpr (CIN % 2 == 0) {
-    f32x4 pre[Stage<CIN>::kPer];
-    if ((int)blockIdx.x < ntiles) tile_fetch<CIN>(in, blockIdx.x * kTF, frames, tid, pre);
+    f32x4 pre[Stage<CIN>::kPer], pre2[XF == kXfBnBwd ? Stage<CIN>::kPer : 1];
+    if ((int)blockIdx.x < ntiles) {
+      tile_fetch<CIN>(in, blockIdx.x * kTF, frames, tid, pre);
+      if constexpr (XF == kXfBnBwd) tile_fetch<CIN>(ba.z, blockIdx.x * kTF, frames, tid, pre2);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int frame0 = tile * kTF;
       auto where = [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; };
-      if constexpr (XF) tile_commit_bnrelu<CIN>(lin, tid, pre, where, xt, frame0, frames);
+      if constexpr (XF == kXfBnRelu) tile_commit_bnrelu<CIN>(lin, tid, pre, where, xt, frame0, frames);
+      else if constexpr (XF == kXfBnBwd) tile_commit_bnbwd<CIN>(lin, tid, pre, pre2, where, xt, frame0, frames);
       else tile_commit<CIN>(lin, tid, pre, where);
       __syncthreads();
-      if (tile + (int)gridDim.x < ntiles) tile_fetch<CIN>(in, (tile + gridDim.x) * kTF, frames, tid, pre);
+      if (tile + (int)gridDim.x < ntiles) {
+        tile_fetch<CIN>(in, (tile + gridDim.x) * kTF, frames, tid, pre);
+        if constexpr (XF == kXfBnBwd) tile_fetch<CIN>(ba.z, (tile + gridDim.x) * kTF, frames, tid, pre2);
+      }
       pin();
       if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1>(lin, lw, out, frame0, frames, wave, lane, st1, st2);
       else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0>(lin, lw, out, frame0, frames, wave, lane, st1, st2);
@@ -347,10 +408,11 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
 // Each wave walks the pixel groups g = wave, wave+4, ... of every tile the workgroup owns, keeps the
 // whole [K][COUT] partial in accumulators, and the workgroup adds it to dW with atomics at the end.
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int TAPS, int COUT, bool XF>
+// XF: x is the producer's z (rebuilt to relu(bn(z)));  DZF: dz is d_u (rebuilt to the BatchNorm-backward dz).
+template <int CIN, int TAPS, int COUT, bool XF, bool DZF>
 __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restrict__ x, const float* __restrict__ dz,
                                                            float* __restrict__ dW, float* __restrict__ dbias, int frames,
-                                                           XformArgs xa) {
+                                                           XformArgs xa, BnBwdArgs ba) {
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(CIN % 2 == 0 && COUT % 2 == 0, "wgrad1xk_mfma stages float4 / float2 pieces");
   // one spare k row carries a constant 1, so its output row is sum_px dz = dbias
@@ -365,18 +427,21 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
   for (int e = tid; e < G::kInFloats + 64 + kDzRows * kDzStride; e += kThreads) lds[e] = 0.f;
-  float* xt = lds + G::kInFloats + 64 + kDzRows * kDzStride;   // [2][CIN], only with XF
+  float* xt = lds + G::kInFloats + 64 + kDzRows * kDzStride;   // [2][CIN] with XF, then [3][COUT] with DZF
+  float* dt = xt + 2 * CIN;
   if constexpr (XF) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
+  if constexpr (DZF) bnbwd_table_fill<COUT>(dt, ba, tid);
   f32x4 acc[KT][NTo];
 #pragma unroll
   for (int a = 0; a < KT; ++a)
 #pragma unroll
     for (int b = 0; b < NTo; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (frames + kTF - 1) / kTF;
-  f32x4 prex[Stage<CIN>::kPer], prez[Stage<COUT>::kPer];
+  f32x4 prex[Stage<CIN>::kPer], prez[Stage<COUT>::kPer], prez2[DZF ? Stage<COUT>::kPer : 1];
   if ((int)blockIdx.x < ntiles) {
     tile_fetch<CIN>(x, blockIdx.x * kTF, frames, tid, prex);
     tile_fetch<COUT>(dz, blockIdx.x * kTF, frames, tid, prez);
+    if constexpr (DZF) tile_fetch<COUT>(ba.z, blockIdx.x * kTF, frames, tid, prez2);
   }
   __syncthreads();
   const float* ain = lin + kq * G::kCinP + i;          // window start of pixel (px0 + kq) is row (px0 + kq) of lin
@@ -385,14 +450,17 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
     auto where = [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; };
     if constexpr (XF) tile_commit_bnrelu<CIN>(lin, tid, prex, where, xt, tile * kTF, frames);
     else tile_commit<CIN>(lin, tid, prex, where);
-    tile_commit<COUT>(ldz, tid, prez, [](int fr, int r) {
+    auto where_dz = [](int fr, int r) {
       const int f = r / COUT, co = r - f * COUT;
       return (fr * G::kS + f) * kDzStride + co;
-    });
+    };
+    if constexpr (DZF) tile_commit_bnbwd<COUT>(ldz, tid, prez, prez2, where_dz, dt, tile * kTF, frames);
+    else tile_commit<COUT>(ldz, tid, prez, where_dz);
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) {
       tile_fetch<CIN>(x, (tile + gridDim.x) * kTF, frames, tid, prex);
       tile_fetch<COUT>(dz, (tile + gridDim.x) * kTF, frames, tid, prez);
+      if constexpr (DZF) tile_fetch<COUT>(ba.z, (tile + gridDim.x) * kTF, frames, tid, prez2);
     }
     pin();
     for (int g = wave; g < G::kNPX / 4 + 1; g += kWaves) {

@@ -58,6 +58,7 @@ struct rced_trainer {
   std::vector<float*> wf, wt, bias4, mu, rstd;   // per layer
   std::vector<float*> pk_fwd, pk_bwd;            // per layer: MFMA A-fragment packets (1xk layers with an MFMA kernel)
   int use_mfma = 1;
+  bool fuse_dz = true;         // RCED_TRAIN_FUSE_DZ=0: always materialise dz with bn_bwd_apply
   std::vector<char> virt;      // virt[id]: tensor id (= relu(bn(z[id-1]))) is never materialised; its consumer rebuilds it
   float* pk_fin = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
   float* zero32 = nullptr;
@@ -141,20 +142,19 @@ int reduce_channels(rced_trainer* t, const float* a, const float* b, const float
 }
 
 // ---- MFMA paths for the 1xk layers (kernels_train_mfma.h): one instantiation per (cin, taps, cout) ----
-#define RCED_TM_SHAPES(X) X(8, 9, 18) X(18, 5, 30) X(30, 9, 8) X(18, 9, 8) X(30, 5, 18) X(8, 9, 30) X(1, 129, 8)
 
 size_t tm_packet_floats(int cin, int taps, int cout) {
   const int cinp = (cin + 1) & ~1, K = taps * cinp, MT = (cout + 15) / 16;
   return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + 32;
 }
 
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, bool XF>
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF>
 int tm_conv_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part,
-                    tmm::XformArgs xa, hipStream_t st) {
+                    tmm::XformArgs xa, tmm::BnBwdArgs ba, hipStream_t st) {
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const int grid = std::min(ntiles, std::min(cus * 4, kPairGrid));
-  const size_t lds = (G::kLdsFloats + (XF ? 2 * CIN : 0)) * sizeof(float);
+  const size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 3 * CIN : 0)) * sizeof(float);
   static bool attr = false;
   if (!attr && lds > 48 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>),
@@ -162,70 +162,99 @@ int tm_conv_launch1(const float* in, const float* packet, float* out, int frames
     attr = true;
   }
   hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), dim3(grid), dim3(tmm::kThreads), lds, st, in,
-                     packet, out, frames, part, xa);
+                     packet, out, frames, part, xa, ba);
   return grid;
 }
-// mode 0: out = conv + shift;  1: out += conv;  2: as 0 and per-workgroup (sum, sum of squares) into part.
-// xa != null (modes 0, 2; even CIN): `in` is the producer's z, rebuilt to relu(bn(z)) while staging.
-// Returns the grid size (= number of partial-sum records for mode 2).
-template <int CIN, int TAPS, int COUT>
-int tm_conv_launch(int mode, const float* in, const float* packet, float* out, int frames, int cus, double* part,
-                   const tmm::XformArgs* xa, hipStream_t st) {
-  const tmm::XformArgs none{nullptr, nullptr, nullptr, nullptr};
-  if constexpr (CIN % 2 == 0) {
-    if (xa && mode == 2) return tm_conv_launch1<CIN, TAPS, COUT, false, true, true>(in, packet, out, frames, cus, part, *xa, st);
-    if (xa && mode == 0) return tm_conv_launch1<CIN, TAPS, COUT, false, false, true>(in, packet, out, frames, cus, nullptr, *xa, st);
+// One 1xk convolution on the MFMA kernels.  The shape decides the role: a layer's forward shape gets
+//   out = conv(in) + shift, optionally with the per-workgroup (sum, sum of squares) records in `part` (stats) and
+//   optionally with in = relu(bn(z)) rebuilt from the producer's z (xa);
+// a dgrad shape gets  out (=|+=) conv(in)  with in = dz, optionally rebuilt from (d_u, z) (ba).
+// Returns the grid size (= number of partial-sum records when stats), 0 if no kernel was built for the request.
+template <int CIN, int TAPS, int COUT, bool FWD>
+int tm_conv_launch(bool accum, bool stats, const float* in, const float* packet, float* out, int frames, int cus,
+                   double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
+  const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
+  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0};
+  if constexpr (FWD) {
+    if (accum || ba) return 0;
+    if (xa) {
+      if constexpr (CIN % 2 == 0) {
+        if (stats) return tm_conv_launch1<CIN, TAPS, COUT, false, true, tmm::kXfBnRelu>(in, packet, out, frames, cus, part, *xa, nb, st);
+        return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfBnRelu>(in, packet, out, frames, cus, nullptr, *xa, nb, st);
+      }
+      return 0;
+    }
+    if (stats) return tm_conv_launch1<CIN, TAPS, COUT, false, true, tmm::kXfNone>(in, packet, out, frames, cus, part, nx, nb, st);
+    return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
+  } else {
+    if (stats || xa) return 0;
+    if (ba) {
+      if constexpr (CIN % 2 == 0) {
+        if (accum) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfBnBwd>(in, packet, out, frames, cus, nullptr, nx, *ba, st);
+        return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfBnBwd>(in, packet, out, frames, cus, nullptr, nx, *ba, st);
+      }
+      return 0;
+    }
+    if (accum) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
+    return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
   }
-  if (mode == 1) return tm_conv_launch1<CIN, TAPS, COUT, true, false, false>(in, packet, out, frames, cus, nullptr, none, st);
-  if (mode == 2) return tm_conv_launch1<CIN, TAPS, COUT, false, true, false>(in, packet, out, frames, cus, part, none, st);
-  return tm_conv_launch1<CIN, TAPS, COUT, false, false, false>(in, packet, out, frames, cus, nullptr, none, st);
 }
 
-// returns the grid size if an MFMA kernel exists for this shape (and was launched), 0 otherwise
-int tm_conv(int cin, int taps, int cout, int mode, const float* in, const float* packet, float* out, int frames, int cus,
-            double* part, const tmm::XformArgs* xa, hipStream_t st) {
-#define X(CI, TP, CO) \
-  if (cin == CI && taps == TP && cout == CO) return tm_conv_launch<CI, TP, CO>(mode, in, packet, out, frames, cus, part, xa, st);
-  RCED_TM_SHAPES(X)
+// forward shapes (cin, taps, cout) of CR-CED's 1xk layers, and the shapes of their dgrad convolutions
+#define RCED_TM_FWD(X) X(8, 9, 18) X(18, 5, 30) X(30, 9, 8)
+#define RCED_TM_BWD(X) X(18, 9, 8) X(30, 5, 18) X(8, 9, 30) X(1, 129, 8)
+int tm_conv(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet, float* out,
+            int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
+#define X(CI, TP, CO)                                                                                                   \
+  if (fwd && cin == CI && taps == TP && cout == CO)                                                                      \
+    return tm_conv_launch<CI, TP, CO, true>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
+  RCED_TM_FWD(X)
+#undef X
+#define X(CI, TP, CO)                                                                                                   \
+  if (!fwd && cin == CI && taps == TP && cout == CO)                                                                     \
+    return tm_conv_launch<CI, TP, CO, false>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
+  RCED_TM_BWD(X)
 #undef X
   return 0;
 }
-bool tm_has(int cin, int taps, int cout) {
+bool tm_has(bool fwd, int cin, int taps, int cout) {
 #define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return true;
-  RCED_TM_SHAPES(X)
+  if (fwd) { RCED_TM_FWD(X) } else { RCED_TM_BWD(X) }
 #undef X
   return false;
 }
 
-template <int CIN, int TAPS, int COUT, bool XF>
+template <int CIN, int TAPS, int COUT, bool XF, bool DZF>
 int tm_wgrad_launch1(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, tmm::XformArgs xa,
-                     hipStream_t st) {
+                     tmm::BnBwdArgs ba, hipStream_t st) {
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const int grid = std::min(ntiles, cus * 2);
-  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32 + (XF ? 2 * CIN : 0)) * sizeof(float);
+  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32 + 2 * CIN + 3 * COUT) * sizeof(float);
   static bool attr = false;
   if (!attr && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW, dbias,
-                     frames, xa);
+  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW,
+                     dbias, frames, xa, ba);
   return 1;
 }
+// xa: x is the producer's z (see tm_conv); ba: dz is d_u, rebuilt through BatchNorm backward from (d_u, z)
 template <int CIN, int TAPS, int COUT>
 int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, const tmm::XformArgs* xa,
-                    hipStream_t st) {
-  if constexpr (CIN % 2 == 0 && COUT % 2 == 0) {
-    if (xa) return tm_wgrad_launch1<CIN, TAPS, COUT, true>(x, dz, dW, dbias, frames, cus, *xa, st);
-    return tm_wgrad_launch1<CIN, TAPS, COUT, false>(x, dz, dW, dbias, frames, cus, tmm::XformArgs{nullptr, nullptr, nullptr, nullptr}, st);
-  }
-  return 0;
+                    const tmm::BnBwdArgs* ba, hipStream_t st) {
+  const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
+  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0};
+  if (xa && ba) return tm_wgrad_launch1<CIN, TAPS, COUT, true, true>(x, dz, dW, dbias, frames, cus, *xa, *ba, st);
+  if (xa) return tm_wgrad_launch1<CIN, TAPS, COUT, true, false>(x, dz, dW, dbias, frames, cus, *xa, nb, st);
+  if (ba) return tm_wgrad_launch1<CIN, TAPS, COUT, false, true>(x, dz, dW, dbias, frames, cus, nx, *ba, st);
+  return tm_wgrad_launch1<CIN, TAPS, COUT, false, false>(x, dz, dW, dbias, frames, cus, nx, nb, st);
 }
 int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
-             const tmm::XformArgs* xa, hipStream_t st) {
-#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_wgrad_launch<CI, TP, CO>(x, dz, dW, dbias, frames, cus, xa, st);
+             const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
+#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_wgrad_launch<CI, TP, CO>(x, dz, dW, dbias, frames, cus, xa, ba, st);
   X(8, 9, 18) X(18, 5, 30) X(30, 9, 8)
 #undef X
   return 0;
@@ -295,6 +324,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) t->num_cus = prop.multiProcessorCount;
     if (const char* e = getenv("RCED_TRAIN_MFMA")) t->use_mfma = atoi(e);
+    if (const char* e = getenv("RCED_TRAIN_FUSE_DZ")) t->fuse_dz = atoi(e) != 0;
   }
   const int L = net->n_layers;
   std::vector<unsigned char> mask(n_floats, 0);
@@ -353,8 +383,8 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     TRY_OR_FREE(hipMalloc(&t->mu[l], 64 * sizeof(float)));
     TRY_OR_FREE(hipMalloc(&t->rstd[l], 64 * sizeof(float)));
     if (is_output_layer(s, f.cin) && !t->pk_fin) TRY_OR_FREE(hipMalloc(&t->pk_fin, fin_pack_floats(f.cin) * sizeof(float)));
-    if (s.kh == 1 && tm_has(f.cin, s.kw, s.cout)) TRY_OR_FREE(hipMalloc(&t->pk_fwd[l], tm_packet_floats(f.cin, s.kw, s.cout) * sizeof(float)));
-    if (s.kh == 1 && tm_has(s.cout, s.kw, f.cin)) TRY_OR_FREE(hipMalloc(&t->pk_bwd[l], tm_packet_floats(s.cout, s.kw, f.cin) * sizeof(float)));
+    if (s.kh == 1 && tm_has(true, f.cin, s.kw, s.cout)) TRY_OR_FREE(hipMalloc(&t->pk_fwd[l], tm_packet_floats(f.cin, s.kw, s.cout) * sizeof(float)));
+    if (s.kh == 1 && tm_has(false, s.cout, s.kw, f.cin)) TRY_OR_FREE(hipMalloc(&t->pk_bwd[l], tm_packet_floats(s.cout, s.kw, f.cin) * sizeof(float)));
   }
   // Tensors that need not exist in HBM: output of a plain conv+BN+ReLU layer (no skip in or out) whose only
   // consumer is a 1xk layer with MFMA forward and wgrad kernels.  RCED_TRAIN_FUSE_ACT=0 turns this off.
@@ -375,7 +405,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
       if (uses[id] != 1 || c < 0) continue;
       const LayerSpec& q = t->net->layer[c];
       t->virt[id] = p.use_norm && p.use_act && p.skip_pre < 0 && p.skip_post < 0 && p.cout % 2 == 0 && q.kh == 1 &&
-                    q.cout % 2 == 0 && t->pk_fwd[c] != nullptr && tm_has(p.cout, q.kw, q.cout);
+                    q.cout % 2 == 0 && t->pk_fwd[c] != nullptr && tm_has(true, p.cout, q.kw, q.cout);
     }
   }
 #undef TRY_OR_FREE
@@ -460,8 +490,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     const LayerOff& f = t->off[l];
     int stat_parts = 0;   // > 0: the conv kernel already left that many (sum z, sum z^2) records in t->part
     if (t->use_mfma && t->pk_fwd[l] &&
-        (stat_parts = tm_conv(f.cin, s.kw, s.cout, s.use_norm ? 2 : 0, conv_in(s.src), t->pk_fwd[l], t->z[l], frames,
-                              t->num_cus, t->part, xform_of(s.src, &xa_tmp), st)) > 0) {
+        (stat_parts = tm_conv(true, f.cin, s.kw, s.cout, false, s.use_norm != 0, conv_in(s.src), t->pk_fwd[l], t->z[l],
+                              frames, t->num_cus, t->part, xform_of(s.src, &xa_tmp), nullptr, st)) > 0) {
       if (!s.use_norm) stat_parts = 0;
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
       fin_forward(f.cin, tensor(s.src), t->params + f.kernel, t->params + f.bias, t->pk_fin, t->z[l], frames, st);
@@ -544,10 +574,18 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
       if (s.use_norm)
         if (int rc = reduce_channels(t, t->D, t->z[l], mu, t->rstd[l], P, s.cout, st)) return rc;
     }
+    // BatchNorm backward: either applied in place on D (bn_bwd_apply*), or -- when both consumers of dz are MFMA
+    // kernels -- folded into their staging, which reads (d_u, z) and never materialises dz (tile_commit_bnbwd)
+    const bool fuse_dz = t->fuse_dz && t->use_mfma && s.use_norm && pairs && s.kh == 1 && f.cin % 2 == 0 &&
+                         tm_has(true, f.cin, s.kw, s.cout) && (s.src == 0 || t->pk_bwd[l] != nullptr);
+    const tmm::BnBwdArgs ba_l{t->z[l], mu, t->rstd[l], t->params + f.gamma, t->sums, (double)P};
+    const tmm::BnBwdArgs* ba = fuse_dz ? &ba_l : nullptr;
     if (s.use_norm) {
       hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.beta);
       hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 1, t->grads + f.gamma);
-      if (pairs)
+      if (fuse_dz) {
+        // nothing: wgrad and dgrad below rebuild dz from D = d_u and z
+      } else if (pairs)
         hipLaunchKernelGGL(train::bn_bwd_apply2, pair_grid(s.cout), dim3(train::kThreads), 0, st, (float2*)t->D,
                            (const float2*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
                            (const double*)t->sums, (double)P, P, s.cout);
@@ -558,7 +596,7 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     }
     // dW and dbias = sum dz (the MFMA wgrad kernel produces both)
     if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, conv_in(s.src), t->D, t->grads + f.kernel,
-                                             t->grads + f.bias, frames, t->num_cus, xform_of(s.src, &xa_tmp), st)) {
+                                             t->grads + f.bias, frames, t->num_cus, xform_of(s.src, &xa_tmp), ba, st)) {
       // MFMA path
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
       fin_wgrad(f.cin, tensor(s.src), t->D, t->grads + f.kernel, t->grads + f.bias, frames, t->num_cus, st);
@@ -575,7 +613,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
     if (s.src > 0) {
       if (t->use_mfma && t->pk_bwd[l] &&
-          tm_conv(s.cout, s.kw, f.cin, overwrite(l) ? 0 : 1, t->D, t->pk_bwd[l], t->G[s.src], frames, t->num_cus, nullptr, nullptr, st)) {
+          tm_conv(false, s.cout, s.kw, f.cin, !overwrite(l), false, t->D, t->pk_bwd[l], t->G[s.src], frames, t->num_cus,
+                  nullptr, nullptr, ba, st)) {
         // MFMA path
       } else if (int rc = launch_conv(t->D, t->G[s.src], t->wt[l], t->zero32, t->G[s.src], frames, T, F, s.cout, f.cin,
                                       f.cin4, s.kh, s.kw, (s.kh - 1) - (s.kh - 1) / 2, (s.kw - 1) - (s.kw - 1) / 2, st)) {
