@@ -657,5 +657,120 @@ __global__ __launch_bounds__(kThreads) void final_wgrad(const float* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// First layer (8 x KW kernel on the 1-channel input; model.py:10,36,81) weight gradient:
+//   dW[i, j, co] = sum_{frame, f} x[t + i - 3, f + j - PL] * dz[frame, f, co]
+// MFMA roles as wgrad1xk_mfma: M = k = i*KW + j (one spare row carries ones -> dbias), N = co, K = pixels.
+// A tile is kTF consecutive frames; for each of them the 8 input rows t-3 .. t+4 (zero outside the utterance,
+// SAME padding 3/4) are staged with their column halo, so A[k][pixel] = rows[(fl*8 + i)*RS + f + j]; dz as in
+// wgrad1xk_mfma (optionally rebuilt from (d_u, z): DZF).
+// ---------------------------------------------------------------------------------------------
+template <int KW, int COUT, bool DZF>
+__global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict__ x, const float* __restrict__ dz,
+                                                         float* __restrict__ dW, float* __restrict__ dbias, int frames,
+                                                         int T, BnBwdArgs ba) {
+  constexpr int KH = 8, PT = 3, PL = (KW - 1) / 2, RS = kF + KW - 1, K1 = KH * KW;
+  constexpr int KT = (K1 + 1 + 15) / 16, NTo = (COUT + 15) / 16;
+  constexpr int kOneTile = K1 / 16, kOneRow = K1 % 16;
+  constexpr int kFS = 132;                              // dz rows per frame: 33 groups of 4 bins
+  constexpr int kDzStride = 32, kDzRows = kTF * kFS + 4;
+  constexpr int kRowsFloats = ((kTF * KH * RS + 32 + 3) / 4) * 4;
+  constexpr int kXElems = kTF * KH * kF, kPerX = (kXElems + kThreads - 1) / kThreads;
+  static_assert(COUT % 2 == 0, "dz is staged in float2 pieces");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* rows = lds;                                    // [kTF*8][RS] (+ slack for the k >= K1 / f >= 129 reads)
+  float* ldz = lds + kRowsFloats;                       // [kDzRows][32]
+  float* dt = ldz + kDzRows * kDzStride;                // [3][COUT] with DZF
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  for (int e = tid; e < kRowsFloats + kDzRows * kDzStride; e += kThreads) lds[e] = 0.f;
+  if constexpr (DZF) bnbwd_table_fill<COUT>(dt, ba, tid);
+  int offk[KT];                                         // this lane's window offset in every M-tile
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int k = 16 * kt + i;
+    offk[kt] = k < K1 ? (k / KW) * RS + (k % KW) : 0;
+  }
+  f32x4 acc[KT][NTo];
+#pragma unroll
+  for (int a = 0; a < KT; ++a)
+#pragma unroll
+    for (int b = 0; b < NTo; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (frames + kTF - 1) / kTF;
+  float prex[kPerX];
+  f32x4 prez[Stage<COUT>::kPer], prez2[DZF ? Stage<COUT>::kPer : 1];
+  auto fetch_rows = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < kPerX; ++u) {
+      const int e = tid + u * kThreads;
+      const int fl = e / (KH * kF), r = e - fl * (KH * kF), ih = r / kF, f = r - ih * kF;
+      const int frame = tile * kTF + fl;
+      const int n = frame / T, tt = frame - n * T + ih - PT;
+      prex[u] = (e < kXElems && frame < frames && tt >= 0 && tt < T) ? x[((size_t)n * T + tt) * kF + f] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < ntiles) {
+    fetch_rows(blockIdx.x);
+    tile_fetch<COUT>(dz, blockIdx.x * kTF, frames, tid, prez);
+    if constexpr (DZF) tile_fetch<COUT>(ba.z, blockIdx.x * kTF, frames, tid, prez2);
+  }
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < kPerX; ++u) {
+      const int e = tid + u * kThreads;
+      if (e < kXElems) {
+        const int row = e / kF, f = e - row * kF;        // row = fl*8 + ih
+        rows[row * RS + PL + f] = prex[u];
+      }
+    }
+    auto where_dz = [](int fr, int r) {
+      const int f = r / COUT, co = r - f * COUT;
+      return (fr * kFS + f) * kDzStride + co;
+    };
+    if constexpr (DZF) tile_commit_bnbwd<COUT>(ldz, tid, prez, prez2, where_dz, dt, tile * kTF, frames);
+    else tile_commit<COUT>(ldz, tid, prez, where_dz);
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) {
+      fetch_rows(tile + gridDim.x);
+      tile_fetch<COUT>(dz, (tile + gridDim.x) * kTF, frames, tid, prez);
+      if constexpr (DZF) tile_fetch<COUT>(ba.z, (tile + gridDim.x) * kTF, frames, tid, prez2);
+    }
+    pin();
+    for (int g = wave; g < kTF * 33; g += kWaves) {
+      const int fl = g / 33, f0 = 4 * (g - fl * 33);
+      const float* ap = rows + fl * KH * RS + f0 + kq;
+      const float* bp = ldz + (fl * kFS + f0 + kq) * kDzStride + i;
+      float a[KT], b[NTo];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) a[kt] = ap[offk[kt]];
+      if (i == kOneRow) a[kOneTile] = 1.f;
+#pragma unroll
+      for (int nt = 0; nt < NTo; ++nt) b[nt] = bp[16 * nt];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NTo; ++nt) acc[kt][nt] = mfma(a[kt], b[nt], acc[kt][nt]);
+    }
+    __syncthreads();
+  }
+  // D row = k = 16*kt + 4*kq + r (TF layout [8][KW][1][COUT] = k*COUT + co), column = co = 16*nt + i
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NTo; ++nt) {
+      const int co = 16 * nt + i;
+      const float vv[4] = {acc[kt][nt].x, acc[kt][nt].y, acc[kt][nt].z, acc[kt][nt].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * kt + 4 * kq + r;
+        if (k < K1 && co < COUT) atomicAdd(dW + k * COUT + co, vv[r]);
+        if (k == K1 && co < COUT && dbias) atomicAdd(dbias + co, vv[r]);
+      }
+    }
+}
+
 }  // namespace tmm
 }  // namespace rced

@@ -261,6 +261,42 @@ int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float
 }
 
 
+// ---- first layer (8 x kw on the 1-channel input): MFMA wgrad (kernels_train_mfma.h) ----
+#define RCED_FIRST(X) X(9, 18) X(13, 12) X(11, 10)
+bool first_has(const LayerSpec& s, int cin) {
+#define X(KW, CO) if (s.kh == 8 && cin == 1 && s.src == 0 && s.kw == KW && s.cout == CO) return true;
+  RCED_FIRST(X)
+#undef X
+  return false;
+}
+template <int KW, int COUT>
+int first_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, int frames, int T, int cus,
+                       const tmm::BnBwdArgs* ba, hipStream_t st) {
+  constexpr int RS = 129 + KW - 1;
+  const size_t lds = (((size_t)(tmm::kTF * 8 * RS + 32 + 3) / 4) * 4 + (size_t)(tmm::kTF * 132 + 4) * 32 + 3 * COUT) * sizeof(float);
+  const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
+  const dim3 grid(std::min(ntiles, cus * 3));
+  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0};
+  static bool attr = false;
+  if (!attr && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  if (ba) hipLaunchKernelGGL((tmm::first_wgrad<KW, COUT, true>), grid, dim3(tmm::kThreads), lds, st, x, dz, dW, dbias, frames, T, *ba);
+  else hipLaunchKernelGGL((tmm::first_wgrad<KW, COUT, false>), grid, dim3(tmm::kThreads), lds, st, x, dz, dW, dbias, frames, T, nb);
+  return 1;
+}
+int first_wgrad(const LayerSpec& s, const float* x, const float* dz, float* dW, float* dbias, int frames, int T, int cus,
+                const tmm::BnBwdArgs* ba, hipStream_t st) {
+#define X(KW, CO) if (s.kw == KW && s.cout == CO) return first_wgrad_launch<KW, CO>(x, dz, dW, dbias, frames, T, cus, ba, st);
+  RCED_FIRST(X)
+#undef X
+  return 0;
+}
+
 // ---- output layer (1x129, CH -> 1): Toeplitz forward + MFMA wgrad (kernels_train_mfma.h) ----
 #define RCED_FIN_CH(X) X(8) X(10) X(12)
 size_t fin_pack_floats(int ch) {
@@ -576,8 +612,10 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     }
     // BatchNorm backward: either applied in place on D (bn_bwd_apply*), or -- when both consumers of dz are MFMA
     // kernels -- folded into their staging, which reads (d_u, z) and never materialises dz (tile_commit_bnbwd)
-    const bool fuse_dz = t->fuse_dz && t->use_mfma && s.use_norm && pairs && s.kh == 1 && f.cin % 2 == 0 &&
-                         tm_has(true, f.cin, s.kw, s.cout) && (s.src == 0 || t->pk_bwd[l] != nullptr);
+    const bool first_mfma = t->use_mfma && first_has(s, f.cin);
+    const bool fuse_dz = t->fuse_dz && t->use_mfma && s.use_norm && pairs &&
+                         (first_mfma || (s.kh == 1 && f.cin % 2 == 0 && tm_has(true, f.cin, s.kw, s.cout) &&
+                                         (s.src == 0 || t->pk_bwd[l] != nullptr)));
     const tmm::BnBwdArgs ba_l{t->z[l], mu, t->rstd[l], t->params + f.gamma, t->sums, (double)P};
     const tmm::BnBwdArgs* ba = fuse_dz ? &ba_l : nullptr;
     if (s.use_norm) {
@@ -598,6 +636,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, conv_in(s.src), t->D, t->grads + f.kernel,
                                              t->grads + f.bias, frames, t->num_cus, xform_of(s.src, &xa_tmp), ba, st)) {
       // MFMA path
+    } else if (first_mfma && first_wgrad(s, x_dev, t->D, t->grads + f.kernel, t->grads + f.bias, frames, T, t->num_cus, ba, st)) {
+      // MFMA path, first layer
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
       fin_wgrad(f.cin, tensor(s.src), t->D, t->grads + f.kernel, t->grads + f.bias, frames, t->num_cus, st);
     } else {
