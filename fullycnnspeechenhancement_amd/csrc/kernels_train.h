@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void bwd_route2(const float2* __restrict_
         }
         if (g_skip_post) g_skip_post[q] = float2{gq[u].x + go[0], gq[u].y + go[1]};
         if (g_skip_pre) g_skip_pre[q] = float2{gp[u].x + du[0], gp[u].y + du[1]};
-        d[q] = float2{du[0], du[1]};
+        if (d) d[q] = float2{du[0], du[1]};      // d == nullptr: the consumers apply the mask themselves
       }
     }
   }

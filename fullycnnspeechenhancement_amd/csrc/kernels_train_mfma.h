@@ -181,6 +181,8 @@ struct BnBwdArgs {
   const float *mu, *rstd, *gamma;
   const double* sums;      // [C][2] = (S1, S2)
   double P;                // pixels in the batch
+  const float* beta;       // non-null: the first input is g (gradient w.r.t. the layer's OUTPUT) and the ReLU mask
+                           // [gamma*rstd*z + beta - ... > 0] is applied here too: d_u = g * [a*z + b > 0]
 };
 template <int C>
 __device__ __forceinline__ void bnbwd_table_fill(float* table, const BnBwdArgs& a, int tid) {
@@ -191,12 +193,13 @@ __device__ __forceinline__ void bnbwd_table_fill(float* table, const BnBwdArgs& 
     table[tid] = gr;
     table[C + tid] = B;
     table[2 * C + tid] = -gr * m1 - B * a.mu[tid];
+    table[3 * C + tid] = a.beta ? a.beta[tid] - gr * a.mu[tid] : 0.f;   // b of the folded forward a*z + b (a = gr)
   }
 }
 template <int C, class MAP>
 __device__ __forceinline__ void tile_commit_bnbwd(float* lds, int tid, const f32x4 (&pd)[Stage<C>::kPer],
                                                   const f32x4 (&pz)[Stage<C>::kPer], MAP map, const float* table,
-                                                  int frame0, int frames) {
+                                                  int frame0, int frames, bool mask) {
   using St = Stage<C>;
   static_assert(St::kFrame % C == 0 && C % 2 == 0, "frames start at channel 0; float2 pieces stay inside a pixel");
   constexpr int kStep = (4 * kThreads) % C;
@@ -213,8 +216,13 @@ __device__ __forceinline__ void tile_commit_bnbwd(float* lds, int tid, const f32
         if (ch >= C) ch -= C;
         const f32x2 A = *reinterpret_cast<const f32x2*>(table + ch), B = *reinterpret_cast<const f32x2*>(table + C + ch);
         const f32x2 K = *reinterpret_cast<const f32x2*>(table + 2 * C + ch);
-        f32x2 v = {fmaf(A.x, pd[i][2 * h], fmaf(B.x, pz[i][2 * h], K.x)),
-                   fmaf(A.y, pd[i][2 * h + 1], fmaf(B.y, pz[i][2 * h + 1], K.y))};
+        f32x2 d = {pd[i][2 * h], pd[i][2 * h + 1]};
+        if (mask) {   // wave-uniform: the input is g, not d_u
+          const f32x2 fb = *reinterpret_cast<const f32x2*>(table + 3 * C + ch);
+          d.x = fmaf(A.x, pz[i][2 * h], fb.x) > 0.f ? d.x : 0.f;
+          d.y = fmaf(A.y, pz[i][2 * h + 1], fb.y) > 0.f ? d.y : 0.f;
+        }
+        f32x2 v = {fmaf(A.x, d.x, fmaf(B.x, pz[i][2 * h], K.x)), fmaf(A.y, d.y, fmaf(B.y, pz[i][2 * h + 1], K.y))};
         if (frame0 + fr >= frames) v = f32x2{0.f, 0.f};      // frames past the batch stay zero
         *reinterpret_cast<f32x2*>(lds + map(fr, r)) = v;
       }
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
       const int frame0 = tile * kTF;
       auto where = [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; };
       if constexpr (XF == kXfBnRelu) tile_commit_bnrelu<CIN>(lin, tid, pre, where, xt, frame0, frames);
-      else if constexpr (XF == kXfBnBwd) tile_commit_bnbwd<CIN>(lin, tid, pre, pre2, where, xt, frame0, frames);
+      else if constexpr (XF == kXfBnBwd) tile_commit_bnbwd<CIN>(lin, tid, pre, pre2, where, xt, frame0, frames, ba.beta != nullptr);
       else tile_commit<CIN>(lin, tid, pre, where);
       __syncthreads();
       if (tile + (int)gridDim.x < ntiles) {
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
       const int f = r / COUT, co = r - f * COUT;
       return (fr * G::kS + f) * kDzStride + co;
     };
-    if constexpr (DZF) tile_commit_bnbwd<COUT>(ldz, tid, prez, prez2, where_dz, dt, tile * kTF, frames);
+    if constexpr (DZF) tile_commit_bnbwd<COUT>(ldz, tid, prez, prez2, where_dz, dt, tile * kTF, frames, ba.beta != nullptr);
     else tile_commit<COUT>(ldz, tid, prez, where_dz);
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) {
@@ -730,7 +738,7 @@ __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict_
       const int f = r / COUT, co = r - f * COUT;
       return (fr * kFS + f) * kDzStride + co;
     };
-    if constexpr (DZF) tile_commit_bnbwd<COUT>(ldz, tid, prez, prez2, where_dz, dt, tile * kTF, frames);
+    if constexpr (DZF) tile_commit_bnbwd<COUT>(ldz, tid, prez, prez2, where_dz, dt, tile * kTF, frames, ba.beta != nullptr);
     else tile_commit<COUT>(ldz, tid, prez, where_dz);
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) {

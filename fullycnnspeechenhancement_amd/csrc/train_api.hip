@@ -154,7 +154,7 @@ int tm_conv_launch1(const float* in, const float* packet, float* out, int frames
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const int grid = std::min(ntiles, std::min(cus * 4, kPairGrid));
-  const size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 3 * CIN : 0)) * sizeof(float);
+  const size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 4 * CIN : 0)) * sizeof(float);
   static bool attr = false;
   if (!attr && lds > 48 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>),
@@ -174,7 +174,7 @@ template <int CIN, int TAPS, int COUT, bool FWD>
 int tm_conv_launch(bool accum, bool stats, const float* in, const float* packet, float* out, int frames, int cus,
                    double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
   const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
-  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0};
+  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
   if constexpr (FWD) {
     if (accum || ba) return 0;
     if (xa) {
@@ -230,7 +230,7 @@ int tm_wgrad_launch1(const float* x, const float* dz, float* dW, float* dbias, i
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const int grid = std::min(ntiles, cus * 2);
-  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32 + 2 * CIN + 3 * COUT) * sizeof(float);
+  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32 + 2 * CIN + 4 * COUT) * sizeof(float);
   static bool attr = false;
   if (!attr && lds > 48 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>),
@@ -246,7 +246,7 @@ template <int CIN, int TAPS, int COUT>
 int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, const tmm::XformArgs* xa,
                     const tmm::BnBwdArgs* ba, hipStream_t st) {
   const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
-  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0};
+  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
   if (xa && ba) return tm_wgrad_launch1<CIN, TAPS, COUT, true, true>(x, dz, dW, dbias, frames, cus, *xa, *ba, st);
   if (xa) return tm_wgrad_launch1<CIN, TAPS, COUT, true, false>(x, dz, dW, dbias, frames, cus, *xa, nb, st);
   if (ba) return tm_wgrad_launch1<CIN, TAPS, COUT, false, true>(x, dz, dW, dbias, frames, cus, nx, *ba, st);
@@ -273,10 +273,10 @@ template <int KW, int COUT>
 int first_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, int frames, int T, int cus,
                        const tmm::BnBwdArgs* ba, hipStream_t st) {
   constexpr int RS = 129 + KW - 1;
-  const size_t lds = (((size_t)(tmm::kTF * 8 * RS + 32 + 3) / 4) * 4 + (size_t)(tmm::kTF * 132 + 4) * 32 + 3 * COUT) * sizeof(float);
+  const size_t lds = (((size_t)(tmm::kTF * 8 * RS + 32 + 3) / 4) * 4 + (size_t)(tmm::kTF * 132 + 4) * 32 + 4 * COUT) * sizeof(float);
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const dim3 grid(std::min(ntiles, cus * 3));
-  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0};
+  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
   static bool attr = false;
   if (!attr && lds > 48 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, true>),
@@ -591,13 +591,23 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     const size_t n = P * s.cout;
     const float* mu = s.use_norm ? t->mu[l] : nullptr;
     const bool pairs = s.cout % 2 == 0;
+    // BatchNorm backward: either applied in place on D (bn_bwd_apply*), or -- when both consumers of dz are MFMA
+    // kernels -- folded into their staging, which reads (d_u, z) and never materialises dz (tile_commit_bnbwd).
+    // For a plain conv+BN+ReLU layer (no skip in or out) d_u is not materialised either: the consumers read the
+    // incoming gradient g and apply the ReLU mask themselves; bwd_route2 then only produces the two sums.
+    const bool first_mfma = t->use_mfma && first_has(s, f.cin);
+    const bool fuse_dz = t->fuse_dz && t->use_mfma && s.use_norm && pairs &&
+                         (first_mfma || (s.kh == 1 && f.cin % 2 == 0 && tm_has(true, f.cin, s.kw, s.cout) &&
+                                         (s.src == 0 || t->pk_bwd[l] != nullptr)));
+    const bool lazy_mask = fuse_dz && s.use_act && s.skip_pre < 0 && s.skip_post < 0;
+    const float* dsrc = lazy_mask ? t->G[l + 1] : t->D;      // what wgrad / dgrad read as their "dz" input
     if (pairs) {
       const dim3 grid = pair_grid(s.cout);
       hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
                          (const float2*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
                          (const float*)(t->params + f.beta), (const float2*)tensor(s.skip_pre), s.use_act, P, s.cout,
                          (float2*)(s.skip_pre > 0 ? t->G[s.skip_pre] : nullptr),
-                         (float2*)(s.skip_post > 0 ? t->G[s.skip_post] : nullptr), (float2*)t->D,
+                         (float2*)(s.skip_post > 0 ? t->G[s.skip_post] : nullptr), (float2*)(lazy_mask ? nullptr : t->D),
                          s.use_norm ? t->part : (double*)nullptr);
       if (s.use_norm)
         hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part, (int)grid.x,
@@ -610,13 +620,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
       if (s.use_norm)
         if (int rc = reduce_channels(t, t->D, t->z[l], mu, t->rstd[l], P, s.cout, st)) return rc;
     }
-    // BatchNorm backward: either applied in place on D (bn_bwd_apply*), or -- when both consumers of dz are MFMA
-    // kernels -- folded into their staging, which reads (d_u, z) and never materialises dz (tile_commit_bnbwd)
-    const bool first_mfma = t->use_mfma && first_has(s, f.cin);
-    const bool fuse_dz = t->fuse_dz && t->use_mfma && s.use_norm && pairs &&
-                         (first_mfma || (s.kh == 1 && f.cin % 2 == 0 && tm_has(true, f.cin, s.kw, s.cout) &&
-                                         (s.src == 0 || t->pk_bwd[l] != nullptr)));
-    const tmm::BnBwdArgs ba_l{t->z[l], mu, t->rstd[l], t->params + f.gamma, t->sums, (double)P};
+    const tmm::BnBwdArgs ba_l{t->z[l], mu, t->rstd[l], t->params + f.gamma, t->sums, (double)P,
+                              lazy_mask ? t->params + f.beta : nullptr};
     const tmm::BnBwdArgs* ba = fuse_dz ? &ba_l : nullptr;
     if (s.use_norm) {
       hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.beta);
@@ -633,10 +638,10 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
                            s.cout);
     }
     // dW and dbias = sum dz (the MFMA wgrad kernel produces both)
-    if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, conv_in(s.src), t->D, t->grads + f.kernel,
+    if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, conv_in(s.src), dsrc, t->grads + f.kernel,
                                              t->grads + f.bias, frames, t->num_cus, xform_of(s.src, &xa_tmp), ba, st)) {
       // MFMA path
-    } else if (first_mfma && first_wgrad(s, x_dev, t->D, t->grads + f.kernel, t->grads + f.bias, frames, T, t->num_cus, ba, st)) {
+    } else if (first_mfma && first_wgrad(s, x_dev, dsrc, t->grads + f.kernel, t->grads + f.bias, frames, T, t->num_cus, ba, st)) {
       // MFMA path, first layer
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
       fin_wgrad(f.cin, tensor(s.src), t->D, t->grads + f.kernel, t->grads + f.bias, frames, t->num_cus, st);
@@ -653,7 +658,7 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
     if (s.src > 0) {
       if (t->use_mfma && t->pk_bwd[l] &&
-          tm_conv(false, s.cout, s.kw, f.cin, !overwrite(l), false, t->D, t->pk_bwd[l], t->G[s.src], frames, t->num_cus,
+          tm_conv(false, s.cout, s.kw, f.cin, !overwrite(l), false, dsrc, t->pk_bwd[l], t->G[s.src], frames, t->num_cus,
                   nullptr, nullptr, ba, st)) {
         // MFMA path
       } else if (int rc = launch_conv(t->D, t->G[s.src], t->wt[l], t->zero32, t->G[s.src], frames, T, F, s.cout, f.cin,
