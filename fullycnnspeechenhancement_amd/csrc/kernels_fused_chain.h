@@ -74,6 +74,10 @@ struct Geo {
   static constexpr int kRegular = kTiles / kWaves;        // slots every wave has
   static constexpr int kExtra = kTiles - kRegular * kWaves;   // waves 0..kExtra-1 have one more
   static_assert(kExtra <= 4, "extra tiles go to waves 0..3 (one per SIMD)");
+  // Layers with two M-tiles cut each extra tile in two (by M-tile) when that gives at most one piece per SIMD:
+  // piece u = wave (< 2*kExtra) is M-tile u / kExtra of extra tile u % kExtra.  The barrier that ends a layer
+  // waits for the most loaded SIMD, so 6.5 tiles on each beats 7 / 7 / 6 / 6.
+  static constexpr bool kSplitExtra = kExtra > 0 && 2 * kExtra <= 4;
   static constexpr int kPad = N::kGap;                    // leading zero rows of each buffer
   static constexpr int kRows = kPad + 16 * kTiles;        // pixels -pad .. 16*tiles-1 (reads past land in the next buffer)
   static_assert(kPad == (N::layer[0].taps - 1) / 2, "X0 indexing assumes pad == half width of the first kernel");
@@ -168,7 +172,8 @@ __device__ __forceinline__ void layer_end_sync() {
 // Implicit-GEMM pass: NB64 b64 steps (k = 8s + 2kq + e) then NTAIL b32 steps (k = 8*NB64 + 4j + kq),
 // NT = NR regular slots (offsets off0 + t*STRIDE) + NX extra slot (offx), every M-tile.
 // Lanes whose tail k is past K re-read in-window data (their weights are zero).
-template <int NR, int NX, int MT, int K, int STRIDE, int DEPTH>
+// XMT >= 0: the extra slot only computes M-tile XMT (the tile's other M-tile belongs to another wave).
+template <int NR, int NX, int MT, int K, int STRIDE, int DEPTH, int XMT = -1>
 __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, const float* w, int lane,
                                           f32x4 (&acc)[NR + NX][MT]) {
   constexpr int NT = NR + NX, RING = DEPTH + 1;
@@ -209,7 +214,8 @@ __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, 
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(a[s % RING][mt][e], b[s % RING][t][e], acc[t][mt]);
+        for (int mt = 0; mt < MT; ++mt)
+          if (t < NR || XMT < 0 || mt == XMT) acc[t][mt] = mfma(a[s % RING][mt][e], b[s % RING][t][e], acc[t][mt]);
     pin();
   }
 #pragma unroll
@@ -217,7 +223,8 @@ __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, 
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(at[j][mt], bt[j][t], acc[t][mt]);
+      for (int mt = 0; mt < MT; ++mt)
+        if (t < NR || XMT < 0 || mt == XMT) acc[t][mt] = mfma(at[j][mt], bt[j][t], acc[t][mt]);
 }
 
 // First layer: 8 x TAPS kernel on the 1-channel input, b32 steps; step s = ih*TAPS + j, lane kq <->
@@ -297,8 +304,8 @@ __device__ __forceinline__ void xstage_store(const XStage& st, float* x0, int ti
   if (tid + 3 * kThreads < G::kX0Floats) x0[tid + 3 * kThreads] = st.v3;
 }
 
-// One layer for one wave.  NX = 1 for the waves that own an extra tile.
-template <class N, int L, int NX>
+// One layer for one wave.  NX = 1 for the waves that own an extra tile (XMT < 0) or one M-tile of it (XMT = 0/1).
+template <class N, int L, int NX, int XMT = -1>
 __device__ __forceinline__ void run_layer(const Params& P, float* lds, const float* w, __amdgpu_buffer_rsrc_t scratch,
                                           int wave, int lane, int tid, int utt, int t0) {
   using G = Geo<N>;
@@ -313,7 +320,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
   float* bufy = lds + G::kYOff + G::kPad * G::kChY;
   const float* in = (L % 2 == 1) ? bufx : bufy;          // layer L reads what layer L-1 wrote
   float* out = (L % 2 == 0) ? bufx : bufy;
-  const int xtile = G::kRegular * kWaves + wave;          // extra tile of waves 0..kExtra-1
+  const int xtile = G::kRegular * kWaves + (XMT < 0 ? wave : wave % (G::kExtra > 0 ? G::kExtra : 1));   // this wave's extra tile
   const int px0 = 16 * wave + n, pxx = 16 * xtile + n;
 
   // skip fragments of the matching encoder layer: issue the loads now, use them in the epilogue
@@ -326,6 +333,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
+        if (t < NR || XMT < 0 || mt == XMT)
         skip[t][mt] = __builtin_bit_cast(
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                        scratch, tid * 16, (G::skip_unit(D.skip_from) + t * MT + mt) * kThreads * 16, 0));
@@ -342,8 +350,8 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc);
   } else {
     constexpr int padl = (D.taps - 1) / 2;
-    gemm_pass<NR, NX, MT, G::K(L), 128 * D.cinp, 1>(in, (px0 - padl) * D.cinp + 2 * kq,
-                                                    (pxx - padl) * D.cinp + 2 * kq, w, lane, acc);
+    gemm_pass<NR, NX, MT, G::K(L), 128 * D.cinp, 1, XMT>(in, (px0 - padl) * D.cinp + 2 * kq,
+                                                         (pxx - padl) * D.cinp + 2 * kq, w, lane, acc);
   }
   // ---- epilogue: (+skip) -> ReLU -> zero the gap pixels -> LDS (or the hand-off tensor)
 #pragma unroll
@@ -355,6 +363,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     const int fr = px / G::kS, f = px - fr * G::kS;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      if (t >= NR && XMT >= 0 && mt != XMT) continue;      // the other M-tile of the split extra tile is another wave's
       f32x4 v = acc[t][mt];
       if constexpr (D.skip_from >= 0) v += skip[t][mt];   // module.py:30-31: before the ReLU
       v = relu4(v);
@@ -387,8 +396,14 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
     packet_dma<G::packet(nxt)>(P.wpack + G::packet_off(nxt), wbase + (wcur ^ 1) * G::kWRegion, wave, lane);
     if constexpr (L == N::kLayers - 1) xst = xstage_load<N>(P, tile + gridDim.x, tid);
     const float* w = wbase + wcur * G::kWRegion;
-    if (wave < G::kExtra) run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0);
-    else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+    if constexpr (L > 0 && G::MT(L) == 2 && G::kSplitExtra) {
+      if (wave < G::kExtra) run_layer<N, L, 1, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+      else if (wave < 2 * G::kExtra) run_layer<N, L, 1, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+      else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+    } else {
+      if (wave < G::kExtra) run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+      else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+    }
     wcur ^= 1;
     layer_end_sync();
     run_layers<N, L + 1>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0);
