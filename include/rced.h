@@ -74,14 +74,23 @@ void rced_destroy(rced_model* m);
 int rced_forward(rced_model* m, const float* x_dev, float* y_dev, int N, int T, void* stream);
 
 /* Same with HOST pointers (the reference boundary hands numpy arrays: tester.py:85-90).
- * Copies H2D, runs, copies D2H, synchronises. */
+ * Copies H2D, runs, copies D2H, synchronises.  Batches >= 8 MB are split into "host_chunks" utterance chunks and
+ * the three legs are overlapped on internal streams (a helper thread issues the downloads). */
 int rced_forward_host(rced_model* m, const float* x_host, float* y_host, int N, int T);
 
 /* Pre-size the internal workspace for shapes up to [N,T,...] so that rced_forward performs
  * no allocation (needed before stream capture into a hipGraph). */
 int rced_reserve(rced_model* m, int N, int T);
 
-/* Options: "path" = RCED_PATH_*.  Returns RCED_ERR_ARG for unknown keys/values. */
+/* Options (set/get unless noted).  Returns RCED_ERR_ARG for unknown keys/values.
+ *   "path"        RCED_PATH_*
+ *   "profile"     1: HIP events around every kernel launch (read with rced_profile_query); set re-arms
+ *   "host_chunks" pipeline depth of rced_forward_host (0 = default 8, 1 = no overlap, <= 64)
+ *   "fused_grid"  workgroups of the persistent fused kernel (0 = one per CU)
+ *   "v3_teams"    1: experimental two-team CR-CED kernel (slower)
+ *   "has_fused", "num_cus"  get only
+ * Environment (read at create): RCED_V3_TEAMS as "v3_teams"; for rced_train_create RCED_TRAIN_MFMA=0 (direct-conv
+ * kernels only), RCED_TRAIN_FUSE_ACT=0, RCED_TRAIN_FUSE_DZ=0 (materialise activations / dz). */
 int rced_set_option(rced_model* m, const char* key, int value);
 int rced_get_option(rced_model* m, const char* key, int* value);
 
