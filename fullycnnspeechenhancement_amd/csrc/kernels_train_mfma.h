@@ -780,5 +780,245 @@ __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// First layer forward: z[frame, f, co] = bias[co] + sum_{i<8, j<KW} W[i, j, co] * x[t + i - 3, f + j - PL].
+// Same staging as first_wgrad (8 input rows per frame with their column halo).  MFMA roles: M = co, N = 16 bins of
+// one frame, K = 8*KW in b32 steps s = ih*KW + j with lane kq <-> time tap 4*ih + kq (so a step's four k values
+// are four rows at the same column).  Packet [step][mt][lane] = W[4*ih + kq][j][16*mt + i], then 32 shifts.
+// STATS as conv1xk_mfma: per-workgroup (sum z, sum z^2) records for the BatchNorm statistics.
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_first(const float* __restrict__ w, const float* __restrict__ bias, int kw, int cout,
+                           float* __restrict__ packet) {
+  const int MT = (cout + 15) / 16, steps = 2 * kw, data = steps * MT * 64;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= data + 32) return;
+  if (e >= data) {
+    const int c = e - data;
+    packet[e] = c < cout ? bias[c] : 0.f;
+    return;
+  }
+  const int s = e / (MT * 64), r = e - s * MT * 64, mt = r / 64, lane = r - mt * 64;
+  const int ih = s / kw, j = s - ih * kw, i = 4 * ih + (lane >> 4), co = 16 * mt + (lane & 15);
+  packet[e] = co < cout ? w[(i * kw + j) * cout + co] : 0.f;      // TF layout [8][kw][1][cout]
+}
+
+template <int KW, int COUT, bool STATS>
+__global__ __launch_bounds__(kThreads) void first_fwd(const float* __restrict__ x, const float* __restrict__ packet,
+                                                       float* __restrict__ z, int frames, int T, double* __restrict__ part) {
+  constexpr int KH = 8, PT = 3, PL = (KW - 1) / 2, RS = kF + KW - 1, STEPS = 2 * KW;
+  constexpr int MT = (COUT + 15) / 16, kData = STEPS * MT * 64;
+  constexpr int kRowsFloats = ((kTF * KH * RS + 32 + 3) / 4) * 4;
+  constexpr int kXElems = kTF * KH * kF, kPerX = (kXElems + kThreads - 1) / kThreads;
+  constexpr int kTilesPerFrame = (kF + 15) / 16, kTiles = kTF * kTilesPerFrame;       // 9 per frame
+  constexpr int NTW = (kTiles + kWaves - 1) / kWaves;                                  // tiles per wave (some idle slots)
+  static_assert(COUT % 2 == 0, "z is stored in float2 pieces");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* rows = lds;                       // [kTF*8][RS] + slack
+  float* lw = lds + kRowsFloats;           // packet
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kq = lane >> 4;
+  for (int e = tid; e < kRowsFloats + kData + 32; e += kThreads) lds[e] = e < kRowsFloats ? 0.f : packet[e - kRowsFloats];
+  double st1[MT][4], st2[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st1[mt][j] = st2[mt][j] = 0.0;
+  const int ntiles = (frames + kTF - 1) / kTF;
+  float prex[kPerX];
+  auto fetch_rows = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < kPerX; ++u) {
+      const int e = tid + u * kThreads;
+      const int fl = e / (KH * kF), r = e - fl * (KH * kF), ih = r / kF, f = r - ih * kF;
+      const int frame = tile * kTF + fl;
+      const int nn = frame / T, tt = frame - nn * T + ih - PT;
+      prex[u] = (e < kXElems && frame < frames && tt >= 0 && tt < T) ? x[((size_t)nn * T + tt) * kF + f] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < ntiles) fetch_rows(blockIdx.x);
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < kPerX; ++u) {
+      const int e = tid + u * kThreads;
+      if (e < kXElems) {
+        const int row = e / kF, f = e - row * kF;
+        rows[row * RS + PL + f] = prex[u];
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch_rows(tile + gridDim.x);
+    pin();
+    // tile index q = wave + 4*slot: frame fl = q / 9, bins 16*(q % 9) .. +15
+    f32x4 acc[NTW][MT];
+    int boff[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int q = wave + kWaves * t, fl = q / kTilesPerFrame, f0 = 16 * (q - fl * kTilesPerFrame);
+      boff[t] = q < kTiles ? (fl * KH + kq) * RS + f0 + n : kq * RS + n;     // idle slots re-read tile 0 (not stored)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = *reinterpret_cast<const f32x4*>(lw + kData + 16 * mt + 4 * kq);
+    }
+#pragma unroll 2
+    for (int s = 0; s < STEPS; ++s) {
+      const int ih = s / KW, j = s - ih * KW;
+      float a[MT], b[NTW];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = lw[(s * MT + mt) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) b[t] = rows[boff[t] + 4 * ih * RS + j];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(a[mt], b[t], acc[t][mt]);
+    }
+    // D row = co = 16*mt + 4*kq + r, column = bin f0 + n
+    float p1[MT][4], p2[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p1[mt][j] = p2[mt][j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int q = wave + kWaves * t, fl = q / kTilesPerFrame, f = 16 * (q - fl * kTilesPerFrame) + n;
+      const int frame = tile * kTF + fl;
+      if (q >= kTiles || f >= kF || frame >= frames) continue;
+      float* op = z + ((size_t)frame * kF + f) * COUT;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co0 = 16 * mt + 4 * kq;
+        const f32x4 v = acc[t][mt];
+        if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(op + co0) = f32x2{v.x, v.y};
+        if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(op + co0 + 2) = f32x2{v.z, v.w};
+        if constexpr (STATS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            p1[mt][j] += v[j];
+            p2[mt][j] = fmaf(v[j], v[j], p2[mt][j]);
+          }
+        }
+      }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st1[mt][j] += (double)p1[mt][j];
+          st2[mt][j] += (double)p2[mt][j];
+        }
+    }
+    __syncthreads();
+  }
+  if constexpr (STATS) {
+    double* red = reinterpret_cast<double*>(lds);             // [wave][32 channels][2]; the tile loop is over
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double a = st1[mt][j], b = st2[mt][j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        if ((lane & 15) == 0) {
+          const int c = 16 * mt + 4 * (lane >> 4) + j;
+          red[(wave * 32 + c) * 2 + 0] = a;
+          red[(wave * 32 + c) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+      const int c = tid >> 1, k = tid & 1;
+      double t = 0.0;
+      for (int w = 0; w < kWaves; ++w) t += red[(w * 32 + c) * 2 + k];
+      part[((size_t)blockIdx.x * COUT + c) * 2 + k] = t;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Output-layer dgrad (1x129, CH -> 1): dx[frame, f', ci] = sum_f dz[frame, f] * W[f' - f + 64, ci]
+// as a dense Toeplitz GEMM: D[m = f'*CH + ci (129*CH rows), frame (N)] = sum_{k = f} A[m, f] * dz[frame, f],
+// A[m, f] = W[f' - f + 64, ci] (zero outside the 129 taps), K = 129 padded to 132 (33 b32 steps).
+// A (A-fragment order, rebuilt on the device every step) streams from L2; B = the frames' dz rows staged in LDS.
+// One workgroup = 4 waves = 64 frames; wave w owns M-tiles w, w+4, ... in chunks of kDgMc accumulators.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDgSteps = 33, kDgFrames = 64, kDgMc = 3;
+// pack [mtile][step][lane] = A[16*mtile + (lane & 15), 4*step + (lane >> 4)]
+__global__ void pack_final_dgrad(const float* __restrict__ w, int CH, float* __restrict__ pack) {
+  const int M = kF * CH, MT = (M + 15) / 16, total = MT * kDgSteps * 64;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int mt = e / (kDgSteps * 64), r = e - mt * kDgSteps * 64, s = r / 64, lane = r - s * 64;
+  const int m = 16 * mt + (lane & 15), f = 4 * s + (lane >> 4);
+  const int fp = m / CH, ci = m - fp * CH, tap = fp - f + 64;
+  pack[e] = (m < M && f < kF && tap >= 0 && tap < kF) ? w[tap * CH + ci] : 0.f;
+}
+
+template <int CH>
+__global__ __launch_bounds__(kThreads) void final_dgrad(const float* __restrict__ dz, const float* __restrict__ apack,
+                                                         float* __restrict__ dx, int frames) {
+  constexpr int M = kF * CH, MT = (M + 15) / 16;            // 1032 rows -> 65 M-tiles (CH 8)
+  constexpr int kRow = 136;                                  // floats per staged dz row (132 used; 8 mod 32: no bank conflicts)
+  __shared__ float rows[kDgFrames * kRow];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kq = lane >> 4;
+  const int f0 = blockIdx.x * kDgFrames;
+  for (int e = tid; e < kDgFrames * kRow; e += kThreads) {
+    const int fr = e / kRow, f = e - fr * kRow;
+    rows[e] = (f < kF && f0 + fr < frames) ? dz[(size_t)(f0 + fr) * kF + f] : 0.f;
+  }
+  __syncthreads();
+  // B[k = 4*s + kq][frame = 16*t + n]
+  const float* bp = rows + n * kRow + kq;
+  for (int m0 = wave * kDgMc; m0 < MT; m0 += kWaves * kDgMc) {
+    f32x4 acc[kDgMc][4];
+#pragma unroll
+    for (int c = 0; c < kDgMc; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap = apack + (size_t)m0 * kDgSteps * 64 + lane;
+#pragma unroll 3
+    for (int s = 0; s < kDgSteps; ++s) {
+      float a[kDgMc], b[4];
+#pragma unroll
+      for (int c = 0; c < kDgMc; ++c) a[c] = (m0 + c < MT) ? ap[(c * kDgSteps + s) * 64] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[t] = bp[16 * t * kRow + 4 * s];
+#pragma unroll
+      for (int c = 0; c < kDgMc; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[c][t] = mfma(a[c], b[t], acc[c][t]);
+    }
+    // D row = m = 16*(m0 + c) + 4*kq + r (four consecutive floats of the frame's [129*CH] row), column = frame
+#pragma unroll
+    for (int c = 0; c < kDgMc; ++c) {
+      const int mrow = 16 * (m0 + c) + 4 * kq;
+      if (m0 + c >= MT) continue;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int fr = f0 + 16 * t + n;
+        if (fr >= frames) continue;
+        float* op = dx + (size_t)fr * M + mrow;
+        const f32x4 v = acc[c][t];
+        if (mrow + 3 < M) {
+          *reinterpret_cast<f32x2*>(op) = f32x2{v.x, v.y};          // M even (CH even): 8-byte aligned
+          *reinterpret_cast<f32x2*>(op + 2) = f32x2{v.z, v.w};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (mrow + r < M) op[r] = v[r];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace tmm
 }  // namespace rced

@@ -60,7 +60,8 @@ struct rced_trainer {
   int use_mfma = 1;
   bool fuse_dz = true;         // RCED_TRAIN_FUSE_DZ=0: always materialise dz with bn_bwd_apply
   std::vector<char> virt;      // virt[id]: tensor id (= relu(bn(z[id-1]))) is never materialised; its consumer rebuilds it
-  float* pk_fin = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
+  float* pk_first = nullptr;   // A fragments of the 8xk first layer (rebuilt every step)
+  float* pk_fin = nullptr, *pk_fin_bwd = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
   float* zero32 = nullptr;
   double *part = nullptr, *sums = nullptr;
   // activations for P pixels
@@ -80,6 +81,8 @@ struct rced_trainer {
     for (auto* p : pk_fwd) fr(p);
     for (auto* p : pk_bwd) fr(p);
     fr(pk_fin);
+    fr(pk_fin_bwd);
+    fr(pk_first);
     free_acts();
   }
   void free_acts() {
@@ -297,6 +300,28 @@ int first_wgrad(const LayerSpec& s, const float* x, const float* dz, float* dW, 
   return 0;
 }
 
+template <int KW, int COUT>
+int first_fwd_launch(const float* x, const float* w, const float* bias, float* packet, float* z, int frames, int T, int cus,
+                     bool stats, double* part, hipStream_t st) {
+  constexpr int MT = (COUT + 15) / 16, data = 2 * KW * MT * 64, RS = 129 + KW - 1;
+  hipLaunchKernelGGL(tmm::pack_first, dim3((data + 32 + 255) / 256), dim3(256), 0, st, w, bias, KW, COUT, packet);
+  const size_t lds = (((size_t)(tmm::kTF * 8 * RS + 32 + 3) / 4) * 4 + data + 32) * sizeof(float);
+  const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
+  const int grid = std::min(ntiles, std::min(cus * 4, kPairGrid));
+  if (stats) hipLaunchKernelGGL((tmm::first_fwd<KW, COUT, true>), dim3(grid), dim3(tmm::kThreads), lds, st, x, (const float*)packet, z, frames, T, part);
+  else hipLaunchKernelGGL((tmm::first_fwd<KW, COUT, false>), dim3(grid), dim3(tmm::kThreads), lds, st, x, (const float*)packet, z, frames, T, part);
+  return grid;
+}
+// returns the grid size (= partial-sum records when stats)
+int first_fwd(const LayerSpec& s, const float* x, const float* w, const float* bias, float* packet, float* z, int frames, int T,
+              int cus, bool stats, double* part, hipStream_t st) {
+#define X(KW, CO) if (s.kw == KW && s.cout == CO) return first_fwd_launch<KW, CO>(x, w, bias, packet, z, frames, T, cus, stats, part, st);
+  RCED_FIRST(X)
+#undef X
+  return 0;
+}
+size_t first_packet_floats(const LayerSpec& s) { return (size_t)2 * s.kw * ((s.cout + 15) / 16) * 64 + 32; }
+
 // ---- output layer (1x129, CH -> 1): Toeplitz forward + MFMA wgrad (kernels_train_mfma.h) ----
 #define RCED_FIN_CH(X) X(8) X(10) X(12)
 size_t fin_pack_floats(int ch) {
@@ -315,6 +340,17 @@ int fin_forward(int ch, const float* h, const float* w, const float* bias, float
   const dim3 grid((frames + tmm::kFinFrames - 1) / tmm::kFinFrames);
 #define X(CH) \
   if (ch == CH) hipLaunchKernelGGL((tmm::final_fwd<CH>), grid, dim3(tmm::kFinThreads), 0, st, h, (const float*)pack, bias, y, frames);
+  RCED_FIN_CH(X)
+#undef X
+  return 1;
+}
+size_t fin_dgrad_pack_floats(int ch) { return (size_t)((129 * ch + 15) / 16) * tmm::kDgSteps * 64; }
+int fin_dgrad(int ch, const float* dz, const float* w, float* pack, float* dx, int frames, hipStream_t st) {
+  const int total = (int)fin_dgrad_pack_floats(ch);
+  hipLaunchKernelGGL(tmm::pack_final_dgrad, dim3((total + 255) / 256), dim3(256), 0, st, w, ch, pack);
+  const dim3 grid((frames + tmm::kDgFrames - 1) / tmm::kDgFrames);
+#define X(CH) \
+  if (ch == CH) hipLaunchKernelGGL((tmm::final_dgrad<CH>), grid, dim3(tmm::kThreads), 0, st, dz, (const float*)pack, dx, frames);
   RCED_FIN_CH(X)
 #undef X
   return 1;
@@ -418,6 +454,8 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     TRY_OR_FREE(hipMalloc(&t->bias4[l], 64 * sizeof(float)));
     TRY_OR_FREE(hipMalloc(&t->mu[l], 64 * sizeof(float)));
     TRY_OR_FREE(hipMalloc(&t->rstd[l], 64 * sizeof(float)));
+    if (first_has(s, f.cin) && !t->pk_first) TRY_OR_FREE(hipMalloc(&t->pk_first, first_packet_floats(s) * sizeof(float)));
+    if (is_output_layer(s, f.cin) && !t->pk_fin_bwd) TRY_OR_FREE(hipMalloc(&t->pk_fin_bwd, fin_dgrad_pack_floats(f.cin) * sizeof(float)));
     if (is_output_layer(s, f.cin) && !t->pk_fin) TRY_OR_FREE(hipMalloc(&t->pk_fin, fin_pack_floats(f.cin) * sizeof(float)));
     if (s.kh == 1 && tm_has(true, f.cin, s.kw, s.cout)) TRY_OR_FREE(hipMalloc(&t->pk_fwd[l], tm_packet_floats(f.cin, s.kw, s.cout) * sizeof(float)));
     if (s.kh == 1 && tm_has(false, s.cout, s.kw, f.cin)) TRY_OR_FREE(hipMalloc(&t->pk_bwd[l], tm_packet_floats(s.cout, s.kw, f.cin) * sizeof(float)));
@@ -529,6 +567,10 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
         (stat_parts = tm_conv(true, f.cin, s.kw, s.cout, false, s.use_norm != 0, conv_in(s.src), t->pk_fwd[l], t->z[l],
                               frames, t->num_cus, t->part, xform_of(s.src, &xa_tmp), nullptr, st)) > 0) {
       if (!s.use_norm) stat_parts = 0;
+    } else if (t->use_mfma && t->pk_first && first_has(s, f.cin) &&
+               (stat_parts = first_fwd(s, x_dev, t->params + f.kernel, t->params + f.bias, t->pk_first, t->z[l], frames, T,
+                                       t->num_cus, s.use_norm != 0, t->part, st)) > 0) {
+      if (!s.use_norm) stat_parts = 0;
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
       fin_forward(f.cin, tensor(s.src), t->params + f.kernel, t->params + f.bias, t->pk_fin, t->z[l], frames, st);
     } else if (int rc = launch_conv(tensor(s.src), t->z[l], t->wf[l], t->bias4[l], nullptr, frames, T, F, f.cin, s.cout,
@@ -577,7 +619,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
   }
   auto overwrite = [&](int l) {   // layer l's dgrad may overwrite G[src] (MFMA path only; the generic kernel always +=)
     const LayerSpec& s = net.layer[l];
-    return t->use_mfma && t->pk_bwd[l] != nullptr && s.src > 0 && consumers[s.src] == 1;
+    const bool mfma_dgrad = t->pk_bwd[l] != nullptr || (t->pk_fin_bwd != nullptr && is_output_layer(s, t->off[l].cin));
+    return t->use_mfma && mfma_dgrad && s.src > 0 && consumers[s.src] == 1;
   };
   {
     std::vector<char> plain(L + 1, 0);
@@ -657,7 +700,9 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     }
     // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
     if (s.src > 0) {
-      if (t->use_mfma && t->pk_bwd[l] &&
+      if (t->use_mfma && t->pk_fin_bwd && is_output_layer(s, f.cin) && consumers[s.src] == 1) {
+        fin_dgrad(f.cin, t->D, t->params + f.kernel, t->pk_fin_bwd, t->G[s.src], frames, st);   // overwrites G[src]
+      } else if (t->use_mfma && t->pk_bwd[l] &&
           tm_conv(false, s.cout, s.kw, f.cin, !overwrite(l), false, dsrc, t->pk_bwd[l], t->G[s.src], frames, t->num_cus,
                   nullptr, nullptr, ba, st)) {
         // MFMA path
