@@ -110,11 +110,11 @@ def main():
         ge.build_hip()
     if world > 1:
         dist.barrier()
-    from fullycnnspeechenhancement_amd import _lib, build_model, spec
-    from oracle import rced_np  # synthetic weights/inputs generator + cpu_baseline only
+    from fullycnnspeechenhancement_amd import _lib, build_model, spec, weights as _weights
+    # (oracle/ is imported only inside cpu_baseline(): it is the checker / CPU baseline, never the measured path)
 
     variant = args.variant
-    weights = rced_np.make_weights(NET_WORK[variant], seed=42)          # random-init, SURVEY 8(d2)
+    weights = _weights.synthetic_weights(variant, seed=42)                # random-init, SURVEY 8(d2)
     model = build_model(NET_WORK[variant], False, weights=weights, device=local_rank)
     model.set_path(args.path)
     B, T = args.batch, args.frames

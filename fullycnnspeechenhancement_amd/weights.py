@@ -30,6 +30,25 @@ def initial_weights(variant, seed=None):
     return w
 
 
+def synthetic_weights(variant, seed=42):
+    """Random weights for benchmarks and smoke runs: glorot-uniform kernels, bias U(-0.1, 0.1),
+    non-trivial BatchNorm (gamma U(0.5, 1.5), beta U(-0.1, 0.1), moving_mean N(0, 0.1), moving_variance
+    U(0.5, 1.5)) so that a folding bug changes the result.  Draw order = variable order, one generator."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for l in spec.layers(variant):
+        lim = np.sqrt(6.0 / (l.kh * l.kw * l.cin + l.kh * l.kw * l.cout))
+        w[l.scope + "/kernel"] = rng.uniform(-lim, lim, (l.kh, l.kw, l.cin, l.cout)).astype(np.float32)
+        w[l.scope + "/bias"] = rng.uniform(-0.1, 0.1, l.cout).astype(np.float32)
+        if l.use_norm:
+            p = l.scope + "/batch_norm/"
+            w[p + "gamma"] = rng.uniform(0.5, 1.5, l.cout).astype(np.float32)
+            w[p + "beta"] = rng.uniform(-0.1, 0.1, l.cout).astype(np.float32)
+            w[p + "moving_mean"] = rng.normal(0, 0.1, l.cout).astype(np.float32)
+            w[p + "moving_variance"] = rng.uniform(0.5, 1.5, l.cout).astype(np.float32)
+    return w
+
+
 def validate(variant, weights):
     """Shape / dtype / finiteness check with reference-style messages (TF raises on restore mismatch)."""
     for name, shape in spec.variable_shapes(variant):

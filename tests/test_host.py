@@ -68,3 +68,16 @@ def test_shape_check_messages(built):
     for bad in ((4, 7, 129), (4, 7, 128, 1), (4, 129, 7, 1), (4, 7, 129, 2)):
         with pytest.raises(ValueError):
             _RcedNet._check_shape(bad)
+
+
+def test_package_synthetic_weights_match_the_oracle_generator():
+    """bench.py draws its random weights from the package (the product path never imports oracle/); the oracle's
+    generator, which made the golden vectors, must stay the same recipe."""
+    from fullycnnspeechenhancement_amd import spec, weights
+    from oracle import rced_np
+    for net_work in ("FullyCNN", "FullyCNNV2", "FullyCNNV3"):
+        a = weights.synthetic_weights(spec.variant_of(net_work), seed=42)
+        b = rced_np.make_weights(net_work, seed=42)
+        assert set(a) == set(b)
+        for k in a:
+            assert a[k].dtype == np.float32 and np.array_equal(a[k], b[k]), k
