@@ -11,6 +11,7 @@
 #include "kernels_fused_chain.h"
 #include "kernels_fused_v3.h"
 #include "kernels_fused_v3t.h"
+#include "kernels_fused_v3w.h"
 #include "rced_internal.h"
 
 using namespace rced;
@@ -25,6 +26,7 @@ struct rced_fused {
   size_t h_bytes = 0;
   unsigned long long* stamps = nullptr;  // diagnostic builds (RCED_STAMPS) only
   int teams = 0;              // option "v3_teams": 1 = two-team kernel (kernels_fused_v3t.h)
+  int wide = 0;               // option "v3_wide": 1 = sixteen-wave kernel (kernels_fused_v3w.h)
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
 };
 
@@ -248,6 +250,7 @@ int fused_create(rced_model* m) {
   m->fused = nullptr;
   rced_fused* f = new rced_fused();
   if (const char* e = getenv("RCED_V3_TEAMS")) f->teams = atoi(e) != 0;   // experiment switch
+  if (const char* e = getenv("RCED_V3_WIDE")) f->wide = atoi(e) != 0;
   if (m->variant != RCED_V3) {
     m->fused = f;
     const int rc = m->variant == RCED_V1 ? chain_create<chain::NetV1>(m, f) : chain_create<chain::NetV2>(m, f);
@@ -262,6 +265,9 @@ int fused_create(rced_model* m) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3::fused_v3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLdsBytes);
     if (e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(LDS %d): %s", v3::kLdsBytes, hipGetErrorString(e));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3w::fused_v3w_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, v3w::kLdsBytes);
+    if (!rc && e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(v3w): %s", hipGetErrorString(e));
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3t::fused_v3t_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, v3t::kLdsBytes);
     if (!rc && e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(v3t): %s", hipGetErrorString(e));
@@ -346,7 +352,8 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   const int cus = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
   const int grid = std::min(P.total_tiles, cus);
   m->prof_begin(RCED_K_FUSED, st);
-  hipLaunchKernelGGL(v3::fused_v3_kernel, dim3(grid), dim3(v3::kThreads), v3::kLdsBytes, st, P);
+  if (f->wide) hipLaunchKernelGGL(v3w::fused_v3w_kernel, dim3(grid), dim3(v3w::kThreads), v3w::kLdsBytes, st, P);
+  else hipLaunchKernelGGL(v3::fused_v3_kernel, dim3(grid), dim3(v3::kThreads), v3::kLdsBytes, st, P);
   m->prof_end(RCED_K_FUSED, st);
   HIP_TRY(hipGetLastError());
   const int frames = N * T;
@@ -364,6 +371,10 @@ int fused_set_option(rced_model* m, const char* key, int value) {
   if (!strcmp(key, "fused_grid")) {
     if (value < 0) return RCED_ERR_ARG;
     m->fused->grid_limit = value;
+    return RCED_OK;
+  }
+  if (!strcmp(key, "v3_wide") && m->variant == RCED_V3) {
+    m->fused->wide = value != 0;
     return RCED_OK;
   }
   if (!strcmp(key, "v3_teams") && m->variant == RCED_V3) {
@@ -387,6 +398,10 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
 #endif
   if (!strcmp(key, "fused_grid")) {
     *value = m->fused->grid_limit;
+    return RCED_OK;
+  }
+  if (!strcmp(key, "v3_wide")) {
+    *value = m->fused->wide;
     return RCED_OK;
   }
   if (!strcmp(key, "v3_teams")) {

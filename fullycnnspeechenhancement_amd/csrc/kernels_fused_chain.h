@@ -17,6 +17,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "lds_dma.h"
+
 namespace rced {
 namespace chain {
 
@@ -159,8 +161,7 @@ __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float*
     if (c < chunks) {
       const int idx = c * 64 + lane;
       if (idx < n4)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)idx * 4),
-                                         (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
+        lds_dma16(src + (size_t)idx * 4, dst + c * 256);
     }
   }
 }

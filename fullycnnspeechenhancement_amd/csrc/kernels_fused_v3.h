@@ -24,6 +24,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "lds_dma.h"
+
+#ifndef RCED_EXP_NOBAR
+#define RCED_EXP_NOBAR 0  // timing experiment only (results wrong): 1 = no per-layer barrier, no hand-off waits (waves drift
+                          // freely inside a tile); >= 2 = no barrier at all and waves 4..7 start ~4 k cycles * value late
+#endif
 #ifndef RCED_EXP_NOEPI
 #define RCED_EXP_NOEPI 0  // timing experiments only: bit0/1/2 drop the epilogue (ReLU + LDS stores) of L1/L2/L3 (results wrong)
 #endif
@@ -188,15 +194,13 @@ __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float*
     if (c < chunks) {
       const int idx = c * 64 + lane;
       if (idx < n4)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + (size_t)idx * 4),
-            (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
+        lds_dma16(src + (size_t)idx * 4, dst + c * 256);
     }
   }
 }
 __device__ __forceinline__ void layer_end_sync() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
-  __syncthreads();
+  if (!RCED_EXP_NOBAR) __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -566,7 +570,7 @@ __device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int
     if (!(RCED_EXP_NOEPI & 2) || acc[t][0].x + acc[t][1].x == 12345.678f)
       store_p1<2, 30>(b30, acc[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
   if constexpr (ROLE == kL2Reducer) {   // after the own tiles' epilogue: the helper has had time to finish
-    for (int spin = 0; spin < (1 << 22); ++spin) {
+    for (int spin = 0; spin < (RCED_EXP_NOBAR ? 0 : (1 << 22)); ++spin) {
       if (__builtin_amdgcn_readfirstlane(lds_peek(lds + kFlag2Off + XMTP)) == tag) break;
       __builtin_amdgcn_s_sleep(1);
     }
@@ -629,7 +633,7 @@ __device__ __forceinline__ void layer3(const Params& P, float* lds, const float*
   if constexpr (ROLE == kRoleReducer) {  // collect them (bounded spins: all waves are resident)
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
-      for (int spin = 0; spin < (1 << 22); ++spin) {
+      for (int spin = 0; spin < (RCED_EXP_NOBAR ? 0 : (1 << 22)); ++spin) {
         if (__builtin_amdgcn_readfirstlane(lds_peek(lds + kFlagOff + h)) == tag) break;
         __builtin_amdgcn_s_sleep(1);
       }
@@ -689,13 +693,15 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   const int xm = wave == 0 ? 32 : 31;                           // layer 1 main, waves 0 and 1
   const int xr0 = wave == 7 ? 3 : wave - 4, xr1 = 4;            // layer 1 remainder, waves 4..7
 
+  if (RCED_EXP_NOBAR >= 2 && wave >= 4)   // experiment: put the second wave of every SIMD half a layer behind the first
+    for (int i = 0; i < RCED_EXP_NOBAR; ++i) __builtin_amdgcn_s_sleep(64);   // ~4 k cycles each
   for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
     const int utt = tile / P.tiles_per_utt;
     const int t0 = (tile - utt * P.tiles_per_utt) * kTF;   // first frame of the tile
     // input rows prefetched during the previous tile -> X0 (B30 is dead: its last reader finished
     // before the barrier that ended the previous tile)
     xstage_store(xst, lds + kX0Off, tid);
-    __syncthreads();
+    if (RCED_EXP_NOBAR < 2) __syncthreads();
 
     f32x4 skip_ce1[3], skip_ce2[3];
 #pragma unroll

@@ -26,6 +26,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "lds_dma.h"
+
 #include "kernels_fused_v3.h"
 
 namespace rced {
@@ -401,8 +403,7 @@ __device__ __forceinline__ void wave_dma(const float* __restrict__ src, float* d
   for (int c = 0; c < chunks; ++c) {
     const int idx = c * 64 + lane;
     if (idx < n4)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)idx * 4),
-                                       (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
+      lds_dma16(src + (size_t)idx * 4, dst + c * 256);
   }
 }
 // Packet of layer number l (any team's count): layer l % 15 of the net.

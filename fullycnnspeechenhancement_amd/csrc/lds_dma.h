@@ -1,0 +1,21 @@
+// LDS-DMA (global -> LDS without VGPR staging) issued from inline assembly.
+//
+// Why not __builtin_amdgcn_global_load_lds: hipcc's waitcnt insertion models the builtin as a FLAT-family access that
+// may return through LGKM_CNT, so while one is in flight it treats that counter as out of order and turns EVERY
+// s_waitcnt for an LDS read into lgkmcnt(0).  The fused kernels keep the next layer's weight packet in flight during
+// the whole current layer, so every "wait for the operands of step s" also drained the prefetches of steps s+1..s+D
+// that had just been issued -- the software pipeline of the MFMA passes was silently serialised (one full LDS
+// round trip per group of steps).  Issued from asm the transfer is invisible to that pass: LDS waits get exact
+// counts again, and completion is awaited explicitly (s_waitcnt vmcnt(0) in layer_end_sync) as it already was.
+// global_load_lds_dwordx4: lane i moves 16 bytes from its address to LDS byte address M0 + 16*i.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rced {
+
+__device__ __forceinline__ void lds_dma16(const float* gsrc_lane, float* lds_dst_wave) {
+  const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_dst_wave;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(m0v) : "memory", "m0");
+}
+
+}  // namespace rced
