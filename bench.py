@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X dense fp32, vector = matrix (MI355X_MICROARCH.md chip table)
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (same table); only for --dtype bf16
 NET_WORK = {1: "FullyCNN", 2: "FullyCNNV2", 3: "FullyCNNV3"}
 
 
@@ -86,6 +87,8 @@ def main():
     ap.add_argument("--path", default="auto", choices=("auto", "layerwise", "fused"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not time the dominant kernel with HIP events")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
+                    help="bf16: R-CED V1/V2 only (BASELINE config 2); never the default, never the headline")
     args = ap.parse_args()
 
     import numpy as np
@@ -115,7 +118,8 @@ def main():
 
     variant = args.variant
     weights = _weights.synthetic_weights(variant, seed=42)                # random-init, SURVEY 8(d2)
-    model = build_model(NET_WORK[variant], False, weights=weights, device=local_rank)
+    model = build_model(NET_WORK[variant], False, weights=weights, device=local_rank,
+                        dtype="bfloat16" if args.dtype == "bf16" else "float32")
     model.set_path(args.path)
     B, T = args.batch, args.frames
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
@@ -156,10 +160,10 @@ def main():
                   "spectrogram frames/sec (%s fwd, 129-bin)" % NET_WORK[variant],
         "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "CR-CED V3 (16-layer, skip connections) forward, batch %d per GPU, 129x%d, fp32 "
                                "(BASELINE configs[2])" % (B, T) if variant == 3 else
-                               "%s forward, batch %d per GPU, 129x%d, fp32" % (NET_WORK[variant], B, T),
+                               "%s forward, batch %d per GPU, 129x%d, %s" % (NET_WORK[variant], B, T, "fp32" if args.dtype == "f32" else "bf16 activations/weights, fp32 accumulation"),
                    "variant": NET_WORK[variant], "batch_per_gpu": B, "frames": T, "bins": spec.FEATURE_DIM,
                    "global_batch": world * B, "path": {0: "auto", 1: "layerwise", 2: "fused"}[model.get_option("path")],
                    "fused_available": bool(model.get_option("has_fused")), "parallelism": "batch-shard x%d" % world,
@@ -181,8 +185,9 @@ def main():
                     kflops = final if dom == _lib.K_FINAL else flops_frame - final
                 achieved = kflops * B * T * args.steps / (ms * 1e-3) / 1e12
                 traffic = pmc_traffic(variant, B, T, kinds[dom])
-                roof = {"bound": "mfma", "kernel": kinds[dom], "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
+                peak = FP32_PEAK_TFLOPS if args.dtype == "f32" else BF16_PEAK_TFLOPS
+                roof = {"bound": "mfma", "kernel": kinds[dom], "achieved": achieved, "peak": peak,
+                        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE "
                                         "(profiles/r01_pmc_traffic.json); algorithmic bytes per launch = %d" % (1032 * B * T),
                         "avg_launch_ms": ms / launches, "launches": launches,

@@ -10,6 +10,7 @@
 #include "../../include/rced.h"
 #include "kernels_fused_chain.h"
 #include "kernels_fused_v3.h"
+#include "kernels_fused_chain16.h"
 #include "kernels_fused_v3t.h"
 #include "kernels_fused_v3w.h"
 #include "rced_internal.h"
@@ -27,6 +28,10 @@ struct rced_fused {
   unsigned long long* stamps = nullptr;  // diagnostic builds (RCED_STAMPS) only
   int teams = 0;              // option "v3_teams": 1 = two-team kernel (kernels_fused_v3t.h)
   int wide = 0;               // option "v3_wide": 1 = sixteen-wave kernel (kernels_fused_v3w.h)
+  int bf16 = 0;               // option "bf16" (V1/V2): bf16 activations + weights (kernels_fused_chain16.h)
+  float* wpack16 = nullptr;   // its packet stream (built when the option is first set)
+  float* scratch16 = nullptr; // skip fragments for 2 workgroups per CU
+  int bf16_wgs_per_cu = 1;
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
 };
 
@@ -238,6 +243,92 @@ int chain_create(rced_model* m, rced_fused* f) {
   return RCED_OK;
 }
 
+// ---- bf16 variant (kernels_fused_chain16.h) ----------------------------------------------------
+inline unsigned short bf16_rne(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+template <class N>
+void pack_chain16(const rced_model* m, std::vector<float>* wpack) {
+  using G = chain16::Geo<N>;
+  using G32 = chain::Geo<N>;
+  wpack->assign(G::kWTotal, 0.f);
+  float* dst = wpack->data();
+  for (int l = 0; l < N::kLayers; ++l) {
+    const rced_layer_dev& L = m->layers[l];
+    const chain::LayerDesc d = N::layer[l];
+    const int MT = G::MT(l);
+    if (l == 0) {   // fp32, as pack_chain
+      for (int s = 0; s < 2 * d.taps; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, ih = s / d.taps, j = s % d.taps, ti = 4 * ih + kq;
+          dst[s * 64 + lane] = i < d.cout ? wq(L, ti * d.taps + j, 0, i, 1) : 0.f;
+        }
+      static_assert(G::data(0) == G32::data(0), "layer 0 packet is the fp32 one");
+    } else {
+      const int cpi = G::cp(l - 1), K = G::K(l);
+      unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+      for (int s = 0; s < G::steps(l); ++s)
+        for (int mt = 0; mt < MT; ++mt)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 4; ++e) {
+              const int k = 16 * s + 4 * (lane >> 4) + e, co = 16 * mt + (lane & 15), tap = k / cpi, ci = k % cpi;
+              const float v = (k < K && co < d.cout && ci < d.cin) ? wq(L, tap, ci, co, d.cin) : 0.f;
+              d16[((size_t)(s * MT + mt) * 64 + lane) * 4 + e] = bf16_rne(v);
+            }
+    }
+    for (int c = 0; c < d.cout; ++c) dst[G::data(l) + c] = L.host_shift[c];
+    dst += G::packet(l);
+  }
+}
+template <class N>
+int chain16_enable(rced_model* m, rced_fused* f) {
+  using G = chain16::Geo<N>;
+  if (f->wpack16) return RCED_OK;
+  std::vector<float> wpack;
+  pack_chain16<N>(m, &wpack);
+  if (int rc = upload(&f->wpack16, wpack)) return rc;
+  HIP_TRY(hipMalloc(&f->scratch16, (size_t)2 * m->num_cus * G::kScratchFloatsPerWg * sizeof(float)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain16::fused_chain16_kernel<N>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+  int per_cu = 1;   // resident workgroups per CU with this LDS footprint and the kernel's register count
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(chain16::fused_chain16_kernel<N>),
+                                                   chain::kThreads, G::kLdsBytes) != hipSuccess || per_cu < 1)
+    per_cu = 1;
+  f->bf16_wgs_per_cu = per_cu > 2 ? 2 : per_cu;
+  return RCED_OK;
+}
+template <class N>
+int chain16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
+  using G = chain16::Geo<N>;
+  chain::Params P;
+  P.x = x;
+  P.h = f->h;
+  P.wpack = f->wpack16;
+  P.scratch = f->scratch16;
+  P.N = Nb;
+  P.T = T;
+  P.tiles_per_utt = (T + N::kTF - 1) / N::kTF;
+  P.total_tiles = Nb * P.tiles_per_utt;
+  const int wgs = f->bf16_wgs_per_cu * m->num_cus;       // LDS (<= 80 KB) allows two per CU; VGPRs decide (chain16_enable)
+  const int grid = std::min(P.total_tiles, f->grid_limit > 0 ? std::min(f->grid_limit, wgs) : wgs);
+  m->prof_begin(RCED_K_FUSED, st);
+  hipLaunchKernelGGL(chain16::fused_chain16_kernel<N>, dim3(grid), dim3(chain::kThreads), G::kLdsBytes, st, P);
+  m->prof_end(RCED_K_FUSED, st);
+  HIP_TRY(hipGetLastError());
+  const int frames = Nb * T;
+  m->prof_begin(RCED_K_FINAL, st);
+  hipLaunchKernelGGL(chain::final_gemm_kernel<N::kFinalCh>, dim3((frames + chain::kFinFrames - 1) / chain::kFinFrames),
+                     dim3(chain::kFinThreads), 0, st, (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y,
+                     frames);
+  m->prof_end(RCED_K_FINAL, st);
+  HIP_TRY(hipGetLastError());
+  return RCED_OK;
+}
+
 int upload(float** dev, const std::vector<float>& host) {
   HIP_TRY(hipMalloc(dev, host.size() * sizeof(float)));
   HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -287,6 +378,8 @@ void fused_destroy(rced_model* m) {
   rced_fused* f = m->fused;
   if (!f) return;
   if (f->wpack) (void)hipFree(f->wpack);
+  if (f->wpack16) (void)hipFree(f->wpack16);
+  if (f->scratch16) (void)hipFree(f->scratch16);
   if (f->fin_apack) (void)hipFree(f->fin_apack);
   if (f->h) (void)hipFree(f->h);
   if (f->scratch) (void)hipFree(f->scratch);
@@ -313,8 +406,10 @@ int fused_reserve(rced_model* m, int N, int T) {
 int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStream_t st) {
   rced_fused* f = m->fused;
   if (int rc = fused_reserve(m, N, T)) return rc;
-  if (m->variant == RCED_V1) return chain_forward<chain::NetV1>(m, f, x, y, N, T, st);
-  if (m->variant == RCED_V2) return chain_forward<chain::NetV2>(m, f, x, y, N, T, st);
+  if (m->variant == RCED_V1)
+    return f->bf16 ? chain16_forward<chain::NetV1>(m, f, x, y, N, T, st) : chain_forward<chain::NetV1>(m, f, x, y, N, T, st);
+  if (m->variant == RCED_V2)
+    return f->bf16 ? chain16_forward<chain::NetV2>(m, f, x, y, N, T, st) : chain_forward<chain::NetV2>(m, f, x, y, N, T, st);
   if (f->teams) {
     v3t::Params Q;
     Q.x = x;
@@ -377,6 +472,15 @@ int fused_set_option(rced_model* m, const char* key, int value) {
     m->fused->wide = value != 0;
     return RCED_OK;
   }
+  if (!strcmp(key, "bf16")) {
+    if (m->variant == RCED_V3) return value ? rced_fail(RCED_ERR_ARG, "bf16 is built for R-CED V1 / V2 only") : RCED_OK;
+    if (value) {
+      if (int rc = m->variant == RCED_V1 ? chain16_enable<chain::NetV1>(m, m->fused) : chain16_enable<chain::NetV2>(m, m->fused))
+        return rc;
+    }
+    m->fused->bf16 = value != 0;
+    return RCED_OK;
+  }
   if (!strcmp(key, "v3_teams") && m->variant == RCED_V3) {
     m->fused->teams = value != 0;
     return RCED_OK;
@@ -402,6 +506,10 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
   }
   if (!strcmp(key, "v3_wide")) {
     *value = m->fused->wide;
+    return RCED_OK;
+  }
+  if (!strcmp(key, "bf16")) {
+    *value = m->fused->bf16;
     return RCED_OK;
   }
   if (!strcmp(key, "v3_teams")) {

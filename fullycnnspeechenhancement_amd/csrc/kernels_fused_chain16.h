@@ -1,0 +1,241 @@
+// Fused R-CED (V1 / V2) forward with bf16 activations and weights on the bf16 MFMA (BASELINE config 2:
+// "R-CED V2 forward, batch 64, 129x512, bf16").  Same construction as kernels_fused_chain.h (read that first):
+// a tile of frames lives in LDS as [pixel][channel], a 1xk conv is an implicit GEMM whose B operand is a
+// ds_read_b64 out of that buffer, cout sits on the 16-row M axis, packets arrive by LDS-DMA one layer ahead.
+// What changes:
+//   * activations are bf16 in LDS, channel stride = cout rounded up to 4 (one ds_read_b64 = 4 consecutive k);
+//     v_mfma_f32_16x16x16_bf16 consumes K = 16 per instruction at 16 cycles (vs 4 x 32 for the fp32 MFMA);
+//   * every layer's output is rounded to bf16 (round to nearest even) after bias/BatchNorm shift (fp32), skip add and
+//     ReLU; the skip fragments kept in the global scratch and the hand-off tensor hold those rounded values;
+//   * the first layer (8 x k on the fp32 input) and the final 1x129 layer stay on the fp32 MFMA with fp32 weights
+//     (their inputs / outputs are the network's fp32 boundary); their activations on the inside are bf16 values.
+// Precision contract: see oracle/rced_np.py forward_bf16 (the emulation the GPU result is tested against) and
+// DESIGN.md -- this path is NOT within the 1e-4 fp32 bar, it exists because config 2 names bf16.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_fused_chain.h"
+
+namespace rced {
+namespace chain16 {
+
+using chain::f32x2;
+using chain::f32x4;
+using chain::kF;
+using chain::kThreads;
+using chain::kWaves;
+using chain::LayerDesc;
+using chain::Params;
+using chain::pin;
+using chain::u32x4;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int round4(int c) { return (c + 3) & ~3; }
+
+template <class N>
+struct Geo {
+  using G32 = chain::Geo<N>;
+  static constexpr int kS = G32::kS, kNPX = G32::kNPX, kTiles = G32::kTiles, kRegular = G32::kRegular, kExtra = G32::kExtra;
+  static constexpr int kPad = G32::kPad, kRows = G32::kRows;
+  static constexpr int cp(int l) { return round4(N::layer[l].cout); }        // channel stride (bf16) of layer l's output
+  static constexpr int chmax(int parity) {
+    int m = 0;
+    for (int l = parity; l < N::kLayers; l += 2) m = cp(l) > m ? cp(l) : m;
+    return m;
+  }
+  static constexpr int kChX = chmax(0), kChY = chmax(1);                      // X holds outputs of even layers
+  // LDS map in floats (4-byte units); bf16 buffers take rows * ch / 2 floats
+  static constexpr int kXFloats = ((kRows * kChX / 2 + 8 + 3) / 4) * 4;       // + slack for the K-padding reads
+  static constexpr int kYFloats = ((kRows * kChY / 2 + 8 + 3) / 4) * 4;
+  static constexpr int kXOff = 0, kYOff = kXOff + kXFloats, kWOff = kYOff + kYFloats;
+  // packets: layer 0 as in the fp32 kernel (b32 steps); layers >= 1: [step][mt][lane] x 4 bf16, then 32 shifts
+  static constexpr int K(int l) { return N::layer[l].taps * cp(l - 1); }
+  static constexpr int steps(int l) { return (K(l) + 15) / 16; }
+  static constexpr int MT(int l) { return (N::layer[l].cout + 15) / 16; }
+  static constexpr int data(int l) { return l == 0 ? G32::data(0) : steps(l) * MT(l) * 128; }
+  static constexpr int packet(int l) { return data(l) + 32; }
+  static constexpr int packet_off(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += packet(i);
+    return o;
+  }
+  static constexpr int kWTotal = packet_off(N::kLayers);
+  static constexpr int maxpacket() {
+    int m = 0;
+    for (int l = 0; l < N::kLayers; ++l) m = packet(l) > m ? packet(l) : m;
+    return m;
+  }
+  static constexpr int kWRegion = ((maxpacket() + 3) / 4) * 4;
+  static constexpr int kLdsFloats = kWOff + 2 * kWRegion;
+  static constexpr int kLdsBytes = kLdsFloats * 4;
+  static_assert(kLdsBytes <= 80 * 1024, "two workgroups per CU");
+  // fp32 input rows of the first layer alias buffer Y (dead until layer 1 writes it)
+  static constexpr int kX0Off = kYOff + (kPad * kChY) / 2;
+  static_assert((kPad * kChY) % 2 == 0 && G32::kX0Floats <= kYFloats - (kPad * kChY) / 2, "X0 fits in buffer Y");
+  static constexpr int skip_unit(int l) { return G32::skip_unit(l); }
+  static constexpr size_t kScratchFloatsPerWg = G32::kScratchFloatsPerWg;
+};
+
+__device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+// four floats -> four bf16 (round to nearest even, hardware conversion), as the 8-byte value stored in LDS
+__device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
+  const bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  return __builtin_bit_cast(s16x4, h);
+}
+__device__ __forceinline__ f32x4 from_bf16x4(s16x4 s) {
+  const bf16x4 h = __builtin_bit_cast(bf16x4, s);
+  return f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+}
+
+// Implicit-GEMM pass on bf16: STEPS steps of K = 16 (lane kq supplies k = 16 s + 4 kq .. +3), NT = NR + NX slots.
+template <int NR, int NX, int MT, int STEPS, int STRIDE, int DEPTH>
+__device__ __forceinline__ void pass16(const __bf16* act, int off0, int offx, const float* w, int lane,
+                                       f32x4 (&acc)[NR + NX][MT]) {
+  constexpr int NT = NR + NX, RING = DEPTH + 1;
+  const s16x4* wp = reinterpret_cast<const s16x4*>(w) + lane;
+  s16x4 a[RING][MT], b[RING][NT];
+  auto load = [&](int s, int buf) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[buf][mt] = wp[(s * MT + mt) * 64];
+#pragma unroll
+    for (int t = 0; t < NR; ++t) b[buf][t] = *reinterpret_cast<const s16x4*>(act + off0 + t * STRIDE + 16 * s);
+    if constexpr (NX > 0) b[buf][NR] = *reinterpret_cast<const s16x4*>(act + offx + 16 * s);
+  };
+#pragma unroll
+  for (int s = 0; s < DEPTH && s < STEPS; ++s) load(s, s % RING);
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    if (s + DEPTH < STEPS) load(s + DEPTH, (s + DEPTH) % RING);
+    pin();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma16(a[s % RING][mt], b[s % RING][t], acc[t][mt]);
+    pin();
+  }
+}
+
+template <class N, int L, int NX>
+__device__ __forceinline__ void run_layer(const Params& P, float* lds, const float* w, __amdgpu_buffer_rsrc_t scratch,
+                                          int wave, int lane, int tid, int utt, int t0) {
+  using G = Geo<N>;
+  constexpr LayerDesc D = N::layer[L];
+  constexpr int NR = G::kRegular, NT = NR + NX, MT = G::MT(L);
+  constexpr bool kLast = (L == N::kLayers - 1);
+  constexpr int cpo = G::cp(L);
+  asm volatile("" : "+v"(lane), "+v"(tid));   // see chain::run_layer: no hoisting of every layer's addresses
+  const int n = lane & 15, kq = lane >> 4;
+  __bf16* bufx = reinterpret_cast<__bf16*>(lds + G::kXOff) + G::kPad * G::kChX;
+  __bf16* bufy = reinterpret_cast<__bf16*>(lds + G::kYOff) + G::kPad * G::kChY;
+  const __bf16* in = (L % 2 == 1) ? bufx : bufy;
+  __bf16* out = (L % 2 == 0) ? bufx : bufy;
+  const int xtile = G::kRegular * kWaves + wave;
+  const int px0 = 16 * wave + n, pxx = 16 * xtile + n;
+
+  f32x4 skip[D.skip_from >= 0 ? NT : 1][D.skip_from >= 0 ? MT : 1];
+  if constexpr (D.skip_from >= 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        skip[t][mt] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                       scratch, tid * 16, (G::skip_unit(D.skip_from) + t * MT + mt) * kThreads * 16, 0));
+  }
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(w + G::data(L) + 16 * mt + 4 * kq);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][mt] = sh;
+  }
+  if constexpr (L == 0) {
+    chain::first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc);
+  } else {
+    constexpr int padl = (D.taps - 1) / 2, cpi = G::cp(L - 1);
+    pass16<NR, NX, MT, G::steps(L), 128 * cpi, 2>(in, (px0 - padl) * cpi + 4 * kq, (pxx - padl) * cpi + 4 * kq, w, lane, acc);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tile = t < NR ? wave + kWaves * t : xtile;
+    const int px = t < NR ? px0 + 128 * t : pxx;
+    const bool gap = chain::span_has_gap<N>(16 * tile, 16);
+    const bool ok = gap ? chain::px_valid<N>(px) : true;
+    const int fr = px / G::kS, f = px - fr * G::kS;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 v = acc[t][mt];
+      if constexpr (D.skip_from >= 0) v += skip[t][mt];   // module.py:30-31: before the ReLU
+      v = chain::relu4(v);
+      if (gap && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      const s16x4 h = to_bf16x4(v);                       // the layer's output IS this rounded value
+      if constexpr (D.saves_skip || kLast) v = from_bf16x4(h);
+      if constexpr (D.saves_skip)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), scratch, tid * 16,
+                                               (G::skip_unit(L) + t * MT + mt) * kThreads * 16, 0);
+      const int co0 = 16 * mt + 4 * kq;
+      if constexpr (!kLast) {
+        if (co0 < cpo) *reinterpret_cast<s16x4*>(out + px * cpo + co0) = h;
+      } else if (ok && px < G::kNPX && f < kF && t0 + fr < P.T) {
+        float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * N::kFinalCh + co0;
+        if (co0 + 1 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp) = f32x2{v.x, v.y};
+        if (co0 + 3 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp + 2) = f32x2{v.z, v.w};
+      }
+    }
+  }
+}
+
+template <int NFLOATS>
+__device__ __forceinline__ void packet_dma(const float* __restrict__ src, float* dst, int wave, int lane) {
+  chain::packet_dma<NFLOATS>(src, dst, wave, lane);
+}
+
+template <class N, int L>
+__device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu_buffer_rsrc_t scratch, int& wcur,
+                                           chain::XStage& xst, int tile, int wave, int lane, int tid, int utt, int t0) {
+  using G = Geo<N>;
+  if constexpr (L < N::kLayers) {
+    float* const wbase = lds + G::kWOff;
+    constexpr int nxt = (L + 1 < N::kLayers) ? L + 1 : 0;
+    packet_dma<G::packet(nxt)>(P.wpack + G::packet_off(nxt), wbase + (wcur ^ 1) * G::kWRegion, wave, lane);
+    if constexpr (L == N::kLayers - 1) xst = chain::xstage_load<N>(P, tile + gridDim.x, tid);
+    const float* w = wbase + wcur * G::kWRegion;
+    if (wave < G::kExtra) chain16::run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+    else chain16::run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+    wcur ^= 1;
+    chain::layer_end_sync();
+    chain16::run_layers<N, L + 1>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0);
+  }
+}
+
+template <class N>
+__global__ __launch_bounds__(kThreads, 2) void fused_chain16_kernel(Params P) {
+  using G = Geo<N>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < G::kLdsFloats; e += kThreads) lds[e] = 0.f;
+  __syncthreads();
+  packet_dma<G::packet(0)>(P.wpack, lds + G::kWOff, wave, lane);
+  int wcur = 0;
+  chain::XStage xst = chain::xstage_load<N>(P, blockIdx.x, tid);
+  const __amdgpu_buffer_rsrc_t scratch = __builtin_amdgcn_make_buffer_rsrc(
+      P.scratch + (size_t)blockIdx.x * G::kScratchFloatsPerWg, 0, (int)(G::kScratchFloatsPerWg * 4), 0x00020000);
+  chain::layer_end_sync();
+  for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
+    const int utt = tile / P.tiles_per_utt;
+    const int t0 = (tile - utt * P.tiles_per_utt) * N::kTF;
+    chain::xstage_store<N>(xst, lds + G::kX0Off, tid);
+    __syncthreads();
+    chain16::run_layers<N, 0>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0);
+  }
+}
+
+}  // namespace chain16
+}  // namespace rced

@@ -354,8 +354,12 @@ int rced_set_option(rced_model* m, const char* key, int value) {
     m->host_chunks = value;
     return RCED_OK;
   }
-  if (fused_set_option(m, key, value) == RCED_OK) return RCED_OK;
-  return fail(RCED_ERR_ARG, "unknown option '%s'", key);
+  {
+    DeviceGuard g(m->device);   // some fused options allocate / upload (e.g. "bf16")
+    const int rc = fused_set_option(m, key, value);
+    if (rc != RCED_ERR_ARG) return rc;   // RCED_OK, or a failure whose message the fused runtime already set
+  }
+  return fail(RCED_ERR_ARG, "unknown option '%s' (or a value it does not take: %d)", key, value);
 }
 
 int rced_get_option(rced_model* m, const char* key, int* value) {

@@ -156,13 +156,22 @@ class FullyCNNSEModelV3(_RcedNet):
     variant = spec.V3
 
 
-def build_model(net_work, is_training=False, **kw):
-    """The selection block of tester.py:76-82 / infer.py:45-51."""
+def build_model(net_work, is_training=False, dtype="float32", **kw):
+    """The selection block of tester.py:76-82 / infer.py:45-51.
+
+    dtype="bfloat16" (R-CED V1 / V2 only; BASELINE config 2) switches the fused kernel to bf16 activations and
+    weights -- outside the 1e-4 fp32 bar; the default is the reference's float32."""
     if net_work == "FullyCNNV2":
-        return FullyCNNSEModelV2(is_training, **kw)
-    if net_work == "FullyCNNV3":
-        return FullyCNNSEModelV3(is_training, **kw)
-    return FullyCNNSEModel(is_training, **kw)
+        m = FullyCNNSEModelV2(is_training, **kw)
+    elif net_work == "FullyCNNV3":
+        m = FullyCNNSEModelV3(is_training, **kw)
+    else:
+        m = FullyCNNSEModel(is_training, **kw)
+    if dtype in ("bfloat16", "bf16"):
+        m.set_option("bf16", 1)
+    elif dtype not in ("float32", "f32", "fp32"):
+        raise ValueError("dtype must be 'float32' or 'bfloat16', got %r" % (dtype,))
+    return m
 
 
 def conv_bn_relu(inputs, out_channels, kernel_size, stride=(1, 1), is_training=False, padding="SAME",

@@ -86,6 +86,49 @@ def forward(net_work, weights, x, dtype=np.float64, return_all=False):
     return tensors if return_all else tensors[-1]
 
 
+def bf16_round(a):
+    """Round float32 values to bfloat16 (round to nearest, ties to even), returned as float32."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32).reshape(np.shape(a))
+
+
+def forward_bf16(net_work, weights, x):
+    """Emulation of the bf16 variant of the R-CED kernels (csrc/kernels_fused_chain16.h; BASELINE config 2).
+
+    Not a statement about the reference (which is fp32): it restates what the bf16 KERNEL computes, so that the
+    kernel can be tested.  Inner layers: BatchNorm-folded kernels rounded to bf16, bf16 activations in, fp32 (here
+    fp64) accumulation, fp32 shift, (+ skip), ReLU, result rounded to bf16.  First layer: fp32 input and folded fp32
+    kernel, output rounded to bf16.  Last layer (1x129): fp32 kernel on the bf16 activations, fp32 output.
+    """
+    layers = L.layers_for(net_work)
+    tensors = [np.asarray(x, dtype=np.float64)]
+    for i, l in enumerate(layers):
+        k = np.asarray(weights[l.scope + "/kernel"], np.float64)
+        shift = np.asarray(weights[l.scope + "/bias"], np.float64)
+        if l.use_norm:
+            p = l.scope + "/batch_norm/"
+            g, b, m, v = (np.asarray(weights[p + n], np.float64) for n in ("gamma", "beta", "moving_mean", "moving_variance"))
+            s = g / np.sqrt(v + L.BN_EPS)
+            k = k * s
+            shift = (shift - m) * s + b
+        k = k.astype(np.float32)                 # the folded kernel as the library holds it
+        first, last = i == 0, i == len(layers) - 1
+        if not (first or last):
+            k = bf16_round(k)
+        y = conv2d_same(tensors[l.src], k, shift.astype(np.float32), np.float64)
+        if l.skip_pre >= 0:
+            y = y + tensors[l.skip_pre]
+        if l.use_act:
+            y = np.maximum(y, 0)
+        if l.skip_post >= 0:
+            y = y + tensors[l.skip_post]
+        if not last:
+            y = bf16_round(y.astype(np.float32)).astype(np.float64)
+        tensors.append(y)
+    return tensors[-1].astype(np.float32)
+
+
 def make_weights(net_work, seed=42, trivial_bn=False):
     """Synthetic weights of SURVEY 8(d2): glorot-uniform kernels, non-trivial bias and BN stats.
 

@@ -91,6 +91,36 @@ def test_pipelined_host_path_equals_resident_path(chunks, built):
         m.set_option("host_chunks", 65)
 
 
+@pytest.mark.parametrize("net_work,tag,variant", [n for n in NETS if n[2] in (1, 2)])
+def test_bf16_variant_matches_its_emulation(net_work, tag, variant, built):
+    """BASELINE config 2 names bf16 for R-CED V2: kernels_fused_chain16.h keeps activations and inner-layer weights
+    in bf16 (fp32 accumulation).  Checked against oracle.rced_np.forward_bf16, which rounds at the same places.
+    Tolerances (relative to the largest output): 1e-2 against the emulation -- fp32 accumulation order differs, and a
+    sum that lands on the other side of a bf16 rounding boundary moves that activation by one bf16 ulp (2^-8) --
+    and 3e-2 against the fp32 oracle, which is what 15 layers of 8-bit mantissas cost (measured ~7e-3).
+    NOT within the 1e-4 bar of the fp32 path; the fp32 kernels remain the default."""
+    from fullycnnspeechenhancement_amd import build_model
+    w, g = load_golden(tag)
+    x = rced_np.make_input(3, 20, seed=5)            # 20 frames: full tiles + a ragged one (3 frames per tile)
+    m = build_model(net_work, False, weights=w, dtype="bfloat16")
+    assert m.get_option("bf16") == 1
+    y = m(x)
+    ref16 = rced_np.forward_bf16(net_work, w, x)
+    ref32 = rced_np.forward(net_work, w, x)
+    assert rel_err(y, ref16) < 1e-2
+    assert rel_err(y, ref32) < 3e-2
+    assert np.array_equal(m(x), y)                   # deterministic
+    m.set_option("bf16", 0)                          # and back: the fp32 kernel is untouched
+    assert rel_err(m(x), ref32) < RTOL
+
+
+def test_bf16_is_refused_for_cr_ced(built):
+    from fullycnnspeechenhancement_amd import build_model
+    w, _ = load_golden("v3")
+    with pytest.raises(Exception, match="bf16"):
+        build_model("FullyCNNV3", False, weights=w, dtype="bfloat16")
+
+
 def test_empty_and_degenerate_batches(built):
     w, _ = load_golden("v3")
     m = make_model(3, w)
