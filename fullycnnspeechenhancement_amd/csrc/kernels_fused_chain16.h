@@ -16,6 +16,10 @@
 
 #include "kernels_fused_chain.h"
 
+#ifndef RCED_C16_DEPTH
+#define RCED_C16_DEPTH 1   // operand prefetch depth of the bf16 pass (steps)
+#endif
+
 namespace rced {
 namespace chain16 {
 
@@ -136,17 +140,6 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
   const int xtile = G::kRegular * kWaves + wave;
   const int px0 = 16 * wave + n, pxx = 16 * xtile + n;
 
-  f32x4 skip[D.skip_from >= 0 ? NT : 1][D.skip_from >= 0 ? MT : 1];
-  if constexpr (D.skip_from >= 0) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        skip[t][mt] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                       scratch, tid * 16, (G::skip_unit(D.skip_from) + t * MT + mt) * kThreads * 16, 0));
-  }
-
   f32x4 acc[NT][MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -158,8 +151,23 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     chain::first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc);
   } else {
     constexpr int padl = (D.taps - 1) / 2, cpi = G::cp(L - 1);
-    pass16<NR, NX, MT, G::steps(L), 128 * cpi, 2>(in, (px0 - padl) * cpi + 4 * kq, (pxx - padl) * cpi + 4 * kq, w, lane, acc);
+    pass16<NR, NX, MT, G::steps(L), 128 * cpi, RCED_C16_DEPTH>(in, (px0 - padl) * cpi + 4 * kq, (pxx - padl) * cpi + 4 * kq, w, lane, acc);
   }
+  // skip fragments of the matching encoder layer (own stores of an earlier layer; L2-resident).  Loaded here, not
+  // before the pass: 32 fewer live VGPRs during the pass keep the kernel at 128 and two workgroups on a CU, whose
+  // MFMAs hide this latency.
+  f32x4 skip[D.skip_from >= 0 ? NT : 1][D.skip_from >= 0 ? MT : 1];
+  if constexpr (D.skip_from >= 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        skip[t][mt] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                       scratch, tid * 16, (G::skip_unit(D.skip_from) + t * MT + mt) * kThreads * 16, 0));
+  }
+
+
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int tile = t < NR ? wave + kWaves * t : xtile;
@@ -214,7 +222,7 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
 }
 
 template <class N>
-__global__ __launch_bounds__(kThreads, 2) void fused_chain16_kernel(Params P) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_chain16_kernel(Params P) {
   using G = Geo<N>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;

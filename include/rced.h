@@ -87,6 +87,8 @@ int rced_reserve(rced_model* m, int N, int T);
  *   "profile"     1: HIP events around every kernel launch (read with rced_profile_query); set re-arms
  *   "host_chunks" pipeline depth of rced_forward_host (0 = default 8, 1 = no overlap, <= 64)
  *   "fused_grid"  workgroups of the persistent fused kernel (0 = one per CU)
+ *   "bf16"        R-CED V1 / V2 only: 1 = bf16 activations + inner-layer weights, fp32 accumulation (BASELINE config 2;
+ *                 ~6e-3 of the largest output away from the fp32 result -- opt-in)
  *   "v3_teams"    1: experimental two-team CR-CED kernel (slower)
  *   "v3_wide"     1: experimental sixteen-wave CR-CED kernel (slower)
  *   "has_fused", "num_cus"  get only
