@@ -139,3 +139,20 @@ def test_time_receptive_field_is_eight_frames():
         x2[0, t + 5] += 1.0
         x2[0, t - 4] += 1.0
         np.testing.assert_allclose(rced_np.forward(net_work, w, x2)[0, t], y[0, t], atol=1e-12)
+
+
+def test_bf16_emulation_rounding_and_scale():
+    """oracle.rced_np.bf16_round is round-to-nearest-even to 8 mantissa bits (checked against torch's bfloat16 cast),
+    and the bf16 emulation of R-CED stays within a percent of the fp32 restatement."""
+    import torch
+    rng = np.random.default_rng(3)
+    a = np.concatenate([rng.standard_normal(4096).astype(np.float32) * 10.0 ** rng.integers(-6, 6, 4096),
+                        np.array([0.0, -0.0, 1.0, 1.00390625, 1.01171875, 3.0e38, 1e-40], np.float32)])
+    assert np.array_equal(rced_np.bf16_round(a), torch.from_numpy(a).bfloat16().float().numpy())
+    assert np.array_equal(rced_np.bf16_round(rced_np.bf16_round(a)), rced_np.bf16_round(a))      # idempotent
+    for net_work in ("FullyCNN", "FullyCNNV2"):
+        w = rced_np.make_weights(net_work, seed=4)
+        x = rced_np.make_input(1, 10, seed=5)
+        y32, y16 = rced_np.forward(net_work, w, x), rced_np.forward_bf16(net_work, w, x)
+        err = np.abs(y16 - y32).max() / np.abs(y32).max()
+        assert 1e-4 < err < 3e-2, err          # really bf16 (not fp32), and no worse than 15 layers of 8-bit mantissas
