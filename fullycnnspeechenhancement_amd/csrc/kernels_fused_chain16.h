@@ -9,8 +9,8 @@
 //     ReLU; the skip fragments kept in the global scratch and the hand-off tensor hold those rounded values;
 //   * the first layer (8 x k on the fp32 input) and the final 1x129 layer stay on the fp32 MFMA with fp32 weights
 //     (their inputs / outputs are the network's fp32 boundary); their activations on the inside are bf16 values.
-// Precision contract: see oracle/rced_np.py forward_bf16 (the emulation the GPU result is tested against) and
-// DESIGN.md -- this path is NOT within the 1e-4 fp32 bar, it exists because config 2 names bf16.
+// Precision contract: DESIGN.md 3.4b and tests/test_forward_gpu.py (the GPU result is tested against an emulation that
+// rounds at the same places) -- this path is NOT within the 1e-4 fp32 bar, it exists because config 2 names bf16.
 #pragma once
 #include <hip/hip_runtime.h>
 
