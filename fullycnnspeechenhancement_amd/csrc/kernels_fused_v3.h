@@ -136,11 +136,14 @@ constexpr int kWTotal = 5 * kWBlock;
 // 16-pixel tiles 0..32 (pixels 0..527; 528..531 is gap): wave w owns tiles w + 8*slot, slot < 4
 // ("regular": one address register per wave, everything else immediates); tile 32 and, in layer 1,
 // tile 31 are handed out as "extra" tiles.  Pair tiles 0..16: w + 8*slot, slot < 2; extra 16.
-// Remainder tiles (128 pixels) 0..4 go one each to waves 4,5,6 and two to wave 7, which gives up
-// main tile 31.  Waves w and w+4 share a SIMD; MFMA counts per SIMD pair in layer 1:
-// 194, 194, 176, 190 (18 per main tile, 32 per remainder tile).  Layer 2: tile 32's two M-tiles go
-// to waves 2 and 3 (17,17,16,16 M-tile units per SIMD).  Layer 3: pair tile 16 is split along K
-// between waves 0 and 1 (323, 323, 304, 304 MFMAs per SIMD).
+// Waves w and w+4 share a SIMD, and the barrier that ends a layer waits for the most loaded SIMD, so
+// what is balanced is each LAYER's MFMA count per SIMD:
+//   layer 1: remainder tiles (128 pixels) 0..4 go one each to waves 4,5,6 and two to wave 7, which gives up
+//            main tile 31 (to wave 1; tile 32 to wave 0): 194, 194, 176, 190 per SIMD (18 per main tile,
+//            32 per remainder tile).
+//   layer 2: tile 32 is cut in four, M-tile x K-half, one piece on each of waves 0..3: 379.5 everywhere.
+//   layer 3: pair tile 16 is cut in four along K on waves 0..3: 318.75 everywhere.
+// The cut tiles are put back together through LDS scratch + tagged flag words (pairwise, no extra barrier).
 
 struct Params {
   const float* x;       // [N, T, 129]
