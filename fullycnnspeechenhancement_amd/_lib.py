@@ -44,6 +44,8 @@ SYMBOLS = {
     "rced_train_global_step": (ctypes.c_longlong, [_vp]),
     "rced_train_get_variables": (ctypes.c_int, [_vp, _c_float_p, ctypes.c_size_t]),
     "rced_train_get_gradients": (ctypes.c_int, [_vp, _c_float_p, ctypes.c_size_t]),
+    "rced_train_get_state": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_longlong)]),
+    "rced_train_set_state": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, ctypes.c_size_t, ctypes.c_longlong]),
     "rced_last_kernel_ms": (ctypes.c_float, [_vp]),
     "rced_profile_query": (ctypes.c_int, [_vp, ctypes.c_int, _c_float_p, _c_int_p]),
     "rced_last_error": (ctypes.c_char_p, []),

@@ -505,6 +505,26 @@ int rced_train_get_gradients(rced_trainer* t, float* blob_host, size_t n_floats)
   return RCED_OK;
 }
 
+int rced_train_get_state(rced_trainer* t, float* m_blob_host, float* v_blob_host, size_t n_floats, long long* global_step) {
+  if (!t || !m_blob_host || !v_blob_host || n_floats != t->nvars) return rced_fail(RCED_ERR_ARG, "bad arguments");
+  DeviceGuard g(t->device);
+  HIP_TRY(hipMemcpy(m_blob_host, t->m, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(v_blob_host, t->v, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  if (global_step) *global_step = t->global_step;
+  return RCED_OK;
+}
+
+int rced_train_set_state(rced_trainer* t, const float* m_blob_host, const float* v_blob_host, size_t n_floats,
+                         long long global_step) {
+  if (!t || !m_blob_host || !v_blob_host || n_floats != t->nvars || global_step < 0)
+    return rced_fail(RCED_ERR_ARG, "bad arguments");
+  DeviceGuard g(t->device);
+  HIP_TRY(hipMemcpy(t->m, m_blob_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(t->v, v_blob_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  t->global_step = global_step;
+  return RCED_OK;
+}
+
 int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int N, int T, float lr, double* loss_out,
                     void* stream) {
   if (!t) return rced_fail(RCED_ERR_ARG, "trainer is NULL");

@@ -80,15 +80,69 @@ class FullyCNNTrainer(object):
     def gradients(self):
         return self._blob(_lib.load().rced_train_get_gradients)
 
-    def save_checkpoint(self, prefix):
-        """Write the model variables + global_step as a TF V2 checkpoint (trainer.py:98-104 naming is the
-        caller's).  The reference's test / infer / freeze graphs restore exactly these variables
-        (tester.py:36-39); Adam slots are not exported, so the reference *trainer* cannot continue from it."""
+    # -- optimizer state / checkpoints (trainer.py:50-65, 232-239) ------------------------------------
+    def optimizer_state(self):
+        """(adam_m, adam_v, global_step): dicts keyed by TRAINABLE variable name (TF slots `<var>/Adam`, `<var>/Adam_1`)."""
+        n = self._blob_n
+        mb, vb = np.empty(n, np.float32), np.empty(n, np.float32)
+        step = ctypes.c_longlong()
+        fp = ctypes.POINTER(ctypes.c_float)
+        _lib.check(_lib.load().rced_train_get_state(self._h, mb.ctypes.data_as(fp), vb.ctypes.data_as(fp), n, ctypes.byref(step)))
+        m, v, o = {}, {}, 0
+        for name, shape in spec.variable_shapes(self.variant):
+            k = int(np.prod(shape))
+            if "moving_" not in name:
+                m[name], v[name] = mb[o:o + k].reshape(shape).copy(), vb[o:o + k].reshape(shape).copy()
+            o += k
+        return m, v, int(step.value)
+
+    def load_optimizer_state(self, adam_m, adam_v, global_step):
+        """Resume: set the Adam moments (dicts as returned by optimizer_state; missing names start at zero, as a
+        variable without slots would in TF) and the step counter; the next learning rate follows the Noam schedule."""
+        n = self._blob_n
+        mb, vb, o = np.zeros(n, np.float32), np.zeros(n, np.float32), 0
+        for name, shape in spec.variable_shapes(self.variant):
+            k = int(np.prod(shape))
+            for blob, src in ((mb, adam_m), (vb, adam_v)):
+                if src is not None and name in src:
+                    a = np.asarray(src[name], np.float32)
+                    if a.shape != tuple(shape):
+                        raise ValueError("optimizer slot of %r has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+                    blob[o:o + k] = a.reshape(-1)
+            o += k
+        fp = ctypes.POINTER(ctypes.c_float)
+        _lib.check(_lib.load().rced_train_set_state(self._h, mb.ctypes.data_as(fp), vb.ctypes.data_as(fp), n, int(global_step)))
+        if global_step > 0:
+            self.lr = self.noam_scheme(int(global_step), self.warmup_steps)     # what the loop would have set (trainer.py:215)
+
+    def save_checkpoint(self, prefix, with_optimizer=True):
+        """Write a TF V2 checkpoint holding what `tf.train.Saver(tf.global_variables())` stores for the reference's
+        training graph (trainer.py:50-51): the model variables, `global_step`, and -- with_optimizer -- the Adam
+        slots `<var>/Adam`, `<var>/Adam_1` and the `beta1_power` / `beta2_power` accumulators (beta^(t+1) after t
+        steps, as tf.train.AdamOptimizer keeps them).  The reference's test / infer / freeze graphs restore the model
+        variables from it (tester.py:36-39); `FullyCNNTrainer.from_checkpoint` resumes from it."""
         from . import tf_checkpoint
         tensors = dict(self.variables())
-        tensors["global_step"] = np.asarray(self.global_step, np.int64)
+        m, v, step = self.optimizer_state()
+        tensors["global_step"] = np.asarray(step, np.int64)
+        if with_optimizer:
+            for name in m:
+                tensors[name + "/Adam"] = m[name]
+                tensors[name + "/Adam_1"] = v[name]
+            tensors["beta1_power"] = np.asarray(0.9 ** (step + 1), np.float32)
+            tensors["beta2_power"] = np.asarray(0.999 ** (step + 1), np.float32)
         tf_checkpoint.write_checkpoint(prefix, tensors)
         return prefix
+
+    @classmethod
+    def from_checkpoint(cls, path, net_work="FullyCNNV3", **kw):
+        """trainer.py:52-65 `continue_train`: variables, Adam slots (if the checkpoint has them) and global_step."""
+        from . import tf_checkpoint
+        variant = spec.variant_of(net_work)
+        weights, adam_m, adam_v, step = tf_checkpoint.load_training_state(path, variant)
+        tr = cls(net_work, weights=weights, **kw)
+        tr.load_optimizer_state(adam_m, adam_v, step)
+        return tr
 
     def close(self):
         if self._h is not None:

@@ -151,6 +151,12 @@ long long rced_train_global_step(rced_trainer* t);
 /* Current variables / last gradients, in blob order (gradients of moving statistics are 0). */
 int rced_train_get_variables(rced_trainer* t, float* blob_host, size_t n_floats);
 int rced_train_get_gradients(rced_trainer* t, float* blob_host, size_t n_floats);
+/* Optimizer state, to save / resume a run as the reference does (trainer.py:50-65: tf.train.Saver(tf.global_variables())
+ * stores the Adam slots "<var>/Adam", "<var>/Adam_1" and global_step next to the model variables).  m / v: first and
+ * second moments in variable-blob order (entries of non-trainable variables are unused). */
+int rced_train_get_state(rced_trainer* t, float* m_blob_host, float* v_blob_host, size_t n_floats, long long* global_step);
+int rced_train_set_state(rced_trainer* t, const float* m_blob_host, const float* v_blob_host, size_t n_floats,
+                         long long global_step);
 
 /* Average device time (ms) of the dominant kernel of the last rced_forward, measured with HIP
  * events on the launch stream when profiling is on ("profile" option = 1).  <0 if none. */

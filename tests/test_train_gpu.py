@@ -140,3 +140,36 @@ def test_mfma_and_generic_training_kernels_agree(net_work, tag, variant, built, 
     for name in out["0"][2]:
         if "moving_" in name:
             assert rel(out["1"][2][name], out["0"][2][name]) < 1e-5, name
+
+
+def test_checkpoint_resume_continues_the_run(built, tmp_path):
+    """trainer.py:50-65 continue_train: save variables + Adam slots + global_step as a TF V2 checkpoint, resume in a
+    new trainer, and the continued run follows the uninterrupted one (fp32 atomics in wgrad make runs differ in the
+    last bits, hence tolerances, not equality)."""
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer, tf_checkpoint
+    w = rced_np.make_weights("FullyCNNV3", seed=21)
+    x, y = rced_np.make_input(4, 12, seed=22), 0.5 * rced_np.make_input(4, 12, seed=23)
+    kw = dict(batch_size=4, lr=1e-3, warmup_steps=50.0)
+    a = FullyCNNTrainer("FullyCNNV3", weights=w, **kw)
+    for _ in range(3):
+        a.fit_step(x, y)
+    prefix = a.save_checkpoint(str(tmp_path / "RCED_FullyCNNV3_0_2"))
+    stored = tf_checkpoint.read_checkpoint(prefix)
+    assert int(stored["global_step"]) == 3 and "decode_final/kernel/Adam_1" in stored
+    assert "CE1_encode_1/batch_norm/moving_mean/Adam" not in stored                # slots only for trainable variables
+    assert abs(float(stored["beta1_power"]) - 0.9 ** 4) < 1e-7
+    b = FullyCNNTrainer.from_checkpoint(prefix, "FullyCNNV3", **kw)
+    assert b.global_step == 3 and abs(b.lr - a.lr) <= 1e-12 * a.lr
+    la = [a.fit_step(x, y)[0] for _ in range(2)]
+    lb = [b.fit_step(x, y)[0] for _ in range(2)]
+    assert a.global_step == b.global_step == 5
+    for u, v in zip(la, lb):
+        assert abs(u - v) <= 2e-3 * abs(u)
+    va, vb = a.variables(), b.variables()
+    for name in va:
+        if name.endswith("/bias") and not name.startswith("decode_final"):
+            continue                                                              # rounding-noise gradients (see above)
+        assert moved_differently(vb[name], va[name], np.asarray(w[name], np.float64), 1e-3) <= max(0.05, 1.01 / va[name].size), name
+    # without the optimizer state the checkpoint still serves the reference's test / infer graphs
+    p2 = a.save_checkpoint(str(tmp_path / "weights_only"), with_optimizer=False)
+    assert "decode_final/kernel/Adam" not in tf_checkpoint.read_checkpoint(p2)
