@@ -552,16 +552,30 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
   };
   auto tensor = [&](int id) -> const float* { return id < 0 ? nullptr : (id == 0 ? x_dev : t->out[id]); };
 
-  // ---- weights in the layouts the conv kernel wants
+  // consumers[id]: how many layers read tensor id (as conv input or as a skip)
+  std::vector<int> consumers(L + 1, 0);
+  for (int l = 0; l < L; ++l) {
+    if (net.layer[l].src > 0) ++consumers[net.layer[l].src];
+    if (net.layer[l].skip_pre > 0) ++consumers[net.layer[l].skip_pre];
+    if (net.layer[l].skip_post > 0) ++consumers[net.layer[l].skip_post];
+  }
+  // ---- weights in the layouts the direct-convolution kernels want (only for layers that fall back to them)
   for (int l = 0; l < L; ++l) {
     const LayerSpec& s = net.layer[l];
     const LayerOff& f = t->off[l];
-    hipLaunchKernelGGL(train::repack_fwd, dim3((f.K * f.cout4 + 255) / 256), dim3(256), 0, st, t->params + f.kernel, f.K,
-                       s.cout, f.cout4, t->wf[l]);
-    hipLaunchKernelGGL(train::repack_fwd, dim3(1), dim3(64), 0, st, t->params + f.bias, 1, s.cout, f.cout4, t->bias4[l]);
-    const int nt = s.kh * s.kw * s.cout * f.cin4;
-    hipLaunchKernelGGL(train::repack_dgrad, dim3((nt + 255) / 256), dim3(256), 0, st, t->params + f.kernel, s.kh, s.kw,
-                       f.cin, s.cout, f.cin4, t->wt[l]);
+    const bool mfma_fwd = t->use_mfma && (t->pk_fwd[l] || (t->pk_first && first_has(s, f.cin)) || (t->pk_fin && is_output_layer(s, f.cin)));
+    const bool mfma_bwd = t->use_mfma && (s.src == 0 || t->pk_bwd[l] ||
+                                          (t->pk_fin_bwd && is_output_layer(s, f.cin) && consumers[s.src] == 1));
+    if (!mfma_fwd) {
+      hipLaunchKernelGGL(train::repack_fwd, dim3((f.K * f.cout4 + 255) / 256), dim3(256), 0, st, t->params + f.kernel, f.K,
+                         s.cout, f.cout4, t->wf[l]);
+      hipLaunchKernelGGL(train::repack_fwd, dim3(1), dim3(64), 0, st, t->params + f.bias, 1, s.cout, f.cout4, t->bias4[l]);
+    }
+    if (!mfma_bwd) {
+      const int nt = s.kh * s.kw * s.cout * f.cin4;
+      hipLaunchKernelGGL(train::repack_dgrad, dim3((nt + 255) / 256), dim3(256), 0, st, t->params + f.kernel, s.kh, s.kw,
+                         f.cin, s.cout, f.cin4, t->wt[l]);
+    }
   }
   if (t->use_mfma)
     for (int l = 0; l < L; ++l) {
@@ -631,12 +645,6 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
   HIP_TRY(hipMemsetAsync(t->grads, 0, t->nvars * sizeof(float), st));
   // G[id] collects d loss / d tensor id from every consumer (the conv reading it, skip adds).  A tensor with one
   // consumer is written (=) by that consumer's dgrad; the others are zeroed here and accumulated into (+=).
-  std::vector<int> consumers(L + 1, 0);
-  for (int l = 0; l < L; ++l) {
-    if (net.layer[l].src > 0) ++consumers[net.layer[l].src];
-    if (net.layer[l].skip_pre > 0) ++consumers[net.layer[l].skip_pre];
-    if (net.layer[l].skip_post > 0) ++consumers[net.layer[l].skip_post];
-  }
   auto overwrite = [&](int l) {   // layer l's dgrad may overwrite G[src] (MFMA path only; the generic kernel always +=)
     const LayerSpec& s = net.layer[l];
     const bool mfma_dgrad = t->pk_bwd[l] != nullptr || (t->pk_fin_bwd != nullptr && is_output_layer(s, t->off[l].cin));
