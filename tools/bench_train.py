@@ -8,10 +8,11 @@ import torch
 from fullycnnspeechenhancement_amd import FullyCNNTrainer
 from oracle import rced_np
 
+NET = os.environ.get("NET", "FullyCNNV3")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-w = rced_np.make_weights("FullyCNNV3", seed=42)
-tr = FullyCNNTrainer("FullyCNNV3", batch_size=B, lr=1e-3, warmup_steps=4000.0, weights=w)
+w = rced_np.make_weights(NET, seed=42)
+tr = FullyCNNTrainer(NET, batch_size=B, lr=1e-3, warmup_steps=4000.0, weights=w)
 g = torch.Generator(device="cuda").manual_seed(1234)
 x = torch.randn((B, T, 129, 1), generator=g, device="cuda").abs_()
 y = 0.5 * torch.randn((B, T, 129, 1), generator=g, device="cuda").abs_()
@@ -21,6 +22,6 @@ for i in range(4):
     l, _, s = tr.fit_step(x, y)
     torch.cuda.synchronize(); times.append(time.perf_counter() - t0); losses.append(l)
 flop = 3 * 8207496 * B * T          # ~3x forward
-print(json.dumps({"config": "CR-CED V3 train step, batch %d x %d" % (B, T), "ms_per_step": 1e3 * min(times[1:]),
+print(json.dumps({"config": "%s train step, batch %d x %d" % (NET, B, T), "ms_per_step": 1e3 * min(times[1:]),
                   "first_step_ms": 1e3 * times[0], "losses": losses, "approx_tflops": flop / min(times[1:]) / 1e12,
                   "mem_GB": torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9}))
