@@ -173,3 +173,26 @@ def test_checkpoint_resume_continues_the_run(built, tmp_path):
     # without the optimizer state the checkpoint still serves the reference's test / infer graphs
     p2 = a.save_checkpoint(str(tmp_path / "weights_only"), with_optimizer=False)
     assert "decode_final/kernel/Adam" not in tf_checkpoint.read_checkpoint(p2)
+
+
+def test_mfma_kernels_agree_with_generic_on_a_multi_tile_ragged_batch(built, monkeypatch):
+    """4847 frames (odd) = 2424 two-frame tiles: more tiles than persistent workgroups, so every MFMA training kernel
+    runs its prefetch-next-tile loop and ends on a half-empty tile; RCED_TRAIN_MFMA=0 is the direct-conv reference."""
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer
+    w = rced_np.make_weights("FullyCNNV3", seed=27)
+    x = rced_np.make_input(37, 131, seed=41)
+    y = rced_np.make_input(37, 131, seed=42)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RCED_TRAIN_MFMA", mode)
+        tr = FullyCNNTrainer("FullyCNNV3", batch_size=37, lr=1e-3, weights=w)
+        loss, _, _ = tr.train_step(x, y)
+        out[mode] = (loss, tr.gradients())
+        tr.close()
+    assert abs(out["0"][0] - out["1"][0]) <= 1e-6 * abs(out["0"][0])
+    for name, g0 in out["0"][1].items():
+        if "moving_" in name or (name.endswith("/bias") and not name.startswith("decode_final")):
+            continue
+        g1 = out["1"][1][name]
+        assert rel(g1, g0) < (TIGHT if name.startswith("decode_final") else 2 * LOOSE), name
+        assert cosine(g1, g0) > COS, name
