@@ -49,9 +49,12 @@ struct NetV1 {
   static constexpr int kGap = 6;             // >= half width of the widest kernel (13)
   static constexpr int kFinalCh = 12;
   static constexpr LayerDesc layer[kMaxLayers] = {
-      {1, 1, 13, 12, 12, -1, 1},  {12, 12, 11, 16, 16, -1, 1}, {16, 16, 9, 20, 20, -1, 1},
-      {20, 20, 7, 24, 24, -1, 1}, {24, 24, 7, 32, 32, -1, 0},  {32, 32, 7, 24, 24, 3, 0},
-      {24, 24, 9, 20, 20, 2, 0},  {20, 20, 11, 16, 16, 1, 0},  {16, 16, 13, 12, 12, 0, 0}};
+      // channel strides 16 and 32 would put a tile's 16 pixels on 4 resp. 2 distinct LDS bank groups (4- / 8-way
+      // conflicts on every B-operand read); 18 and 34 spread them over all banks at the price of 2 zero-weight
+      // k per tap
+      {1, 1, 13, 12, 12, -1, 1},  {12, 12, 11, 16, 18, -1, 1}, {16, 18, 9, 20, 20, -1, 1},
+      {20, 20, 7, 24, 24, -1, 1}, {24, 24, 7, 32, 34, -1, 0},  {32, 34, 7, 24, 24, 3, 0},
+      {24, 24, 9, 20, 20, 2, 0},  {20, 20, 11, 16, 18, 1, 0},  {16, 18, 13, 12, 12, 0, 0}};
 };
 struct NetV2 {
   static constexpr int kVariant = 2;

@@ -43,7 +43,10 @@ struct Geo {
   using G32 = chain::Geo<N>;
   static constexpr int kS = G32::kS, kNPX = G32::kNPX, kTiles = G32::kTiles, kRegular = G32::kRegular, kExtra = G32::kExtra;
   static constexpr int kPad = G32::kPad, kRows = G32::kRows;
-  static constexpr int cp(int l) { return round4(N::layer[l].cout); }        // channel stride (bf16) of layer l's output
+  // channel stride (bf16 elements) of layer l's output: cout rounded up to 4.  A stride of 16 (= 8 dwords) puts a
+  // tile's 16 pixels on 8 bank groups (2-way conflicts on every B read): those get 4 more, zero-weight, k per tap.
+  // (32 would deserve the same, but 36 does not leave room for two workgroups per CU.)
+  static constexpr int cp(int l) { return round4(N::layer[l].cout) == 16 ? 20 : round4(N::layer[l].cout); }
   static constexpr int chmax(int parity) {
     int m = 0;
     for (int l = parity; l < N::kLayers; l += 2) m = cp(l) > m ? cp(l) : m;
@@ -189,6 +192,12 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
       const int co0 = 16 * mt + 4 * kq;
       if constexpr (!kLast) {
         if (co0 < cpo) *reinterpret_cast<s16x4*>(out + px * cpo + co0) = h;
+        // padding channels past the last M-tile (stride 20 for 16 channels): keep them zero -- stale bits of another
+        // layer's layout could read as bf16 NaN, and NaN x 0 weight is not 0
+        if constexpr (cpo > 16 * MT) {
+          static_assert(cpo - 16 * MT == 4, "one 8-byte store clears the padding");
+          if (mt == MT - 1 && kq == 0) *reinterpret_cast<s16x4*>(out + px * cpo + 16 * MT) = s16x4{0, 0, 0, 0};
+        }
       } else if (ok && px < G::kNPX && f < kF && t0 + fr < P.T) {
         float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * N::kFinalCh + co0;
         if (co0 + 1 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp) = f32x2{v.x, v.y};
