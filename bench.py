@@ -184,12 +184,17 @@ def main():
                     final = 2 * spec.FEATURE_DIM * sum(l.kh * l.kw * l.cin * l.cout for l in spec.layers(variant)[-1:])
                     kflops = final if dom == _lib.K_FINAL else flops_frame - final
                 achieved = kflops * B * T * args.steps / (ms * 1e-3) / 1e12
+                hand_ch = spec.layers(variant)[-1].cin     # channels of the tensor handed to the final 1x129 layer
                 traffic = pmc_traffic(variant, B, T, kinds[dom])
                 peak = FP32_PEAK_TFLOPS if args.dtype == "f32" else BF16_PEAK_TFLOPS
                 roof = {"bound": "mfma", "kernel": kinds[dom], "achieved": achieved, "peak": peak,
                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE "
-                                        "(profiles/r01_pmc_traffic.json); algorithmic bytes per launch = %d" % (1032 * B * T),
+                                        "(profiles/r01_pmc_traffic.json); this kernel's algorithmic bytes per launch = %d "
+                                        "(516 B/frame in + the %d B/frame hand-off tensor the separate final-layer GEMM "
+                                        "reads); whole forward = %d" % (
+                                            (516 + 516 * hand_ch) * B * T if dom == _lib.K_FUSED else 1032 * B * T,
+                                            516 * hand_ch, 1032 * B * T),
                         "avg_launch_ms": ms / launches, "launches": launches,
                         "flop_per_frame": kflops, "frames_per_forward": B * T,
                         "other_kernels_ms_per_step": {kinds[k]: times[k][0] / args.steps for k in kinds if k != dom and times[k][1]},
