@@ -15,7 +15,16 @@ namespace rced {
 
 __device__ __forceinline__ void lds_dma16(const float* gsrc_lane, float* lds_dst_wave) {
   const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_dst_wave;
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(m0v) : "memory", "m0");
+  unsigned saved;   // m0 is saved and restored inside the statement, so the compiler's view of it stays valid
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(saved)
+      : "v"(gsrc_lane), "s"(m0v)
+      : "memory");
 }
 
 }  // namespace rced
