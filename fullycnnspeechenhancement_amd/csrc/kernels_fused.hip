@@ -407,9 +407,11 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   rced_fused* f = m->fused;
   if (int rc = fused_reserve(m, N, T)) return rc;
   if (m->variant == RCED_V1)
-    return f->bf16 ? chain16_forward<chain::NetV1>(m, f, x, y, N, T, st) : chain_forward<chain::NetV1>(m, f, x, y, N, T, st);
+    return f->bf16 ? chain16_forward<chain16::WithTF<chain::NetV1, RCED_C16_TF>>(m, f, x, y, N, T, st)
+                   : chain_forward<chain::NetV1>(m, f, x, y, N, T, st);
   if (m->variant == RCED_V2)
-    return f->bf16 ? chain16_forward<chain::NetV2>(m, f, x, y, N, T, st) : chain_forward<chain::NetV2>(m, f, x, y, N, T, st);
+    return f->bf16 ? chain16_forward<chain16::WithTF<chain::NetV2, RCED_C16_TF>>(m, f, x, y, N, T, st)
+                   : chain_forward<chain::NetV2>(m, f, x, y, N, T, st);
   if (f->teams) {
     v3t::Params Q;
     Q.x = x;
@@ -475,7 +477,7 @@ int fused_set_option(rced_model* m, const char* key, int value) {
   if (!strcmp(key, "bf16")) {
     if (m->variant == RCED_V3) return value ? rced_fail(RCED_ERR_ARG, "bf16 is built for R-CED V1 / V2 only") : RCED_OK;
     if (value) {
-      if (int rc = m->variant == RCED_V1 ? chain16_enable<chain::NetV1>(m, m->fused) : chain16_enable<chain::NetV2>(m, m->fused))
+      if (int rc = m->variant == RCED_V1 ? chain16_enable<chain16::WithTF<chain::NetV1, RCED_C16_TF>>(m, m->fused) : chain16_enable<chain16::WithTF<chain::NetV2, RCED_C16_TF>>(m, m->fused))
         return rc;
     }
     m->fused->bf16 = value != 0;

@@ -116,13 +116,13 @@ struct Geo {
   static constexpr int kWRegion = ((maxpacket() + 3) / 4) * 4;
   static constexpr int kLdsFloats = kWOff + 2 * kWRegion;
   static constexpr int kLdsBytes = kLdsFloats * 4;
-  static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+  static constexpr bool kFitsLds = kLdsBytes <= 160 * 1024;   // asserted where the fp32 kernel is instantiated
   // input rows of the first layer alias buffer Y (dead until layer 1 writes it)
   static constexpr int kX0Rows = N::kTF + 7;
   static constexpr int kX0Floats = ((kX0Rows * kS + 32 + 3) / 4) * 4;
   static constexpr int kX0Off = kYOff + kPad * kChY;
   static_assert(kX0Floats <= 4 * kThreads, "XStage holds 4 floats per thread");
-  static_assert(kX0Floats <= kRows * kChY - kPad * kChY, "X0 fits in buffer Y");
+  static constexpr bool kX0Fits = kX0Floats <= kRows * kChY - kPad * kChY;
   // skip scratch: units = (layer that saves, slot, mt), each kThreads x float4
   static constexpr int skip_unit(int l) {   // first unit index of saving layer l
     int u = 0;
@@ -417,6 +417,8 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
 template <class N>
 __global__ __launch_bounds__(kThreads) void fused_chain_kernel(Params P) {
   using G = Geo<N>;
+  static_assert(G::kFitsLds, "LDS budget");
+  static_assert(G::kX0Fits, "X0 fits in buffer Y");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;

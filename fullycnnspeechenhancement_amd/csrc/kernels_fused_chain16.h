@@ -16,6 +16,16 @@
 
 #include "kernels_fused_chain.h"
 
+#ifndef RCED_C16_TF
+#define RCED_C16_TF 3        // frames per tile of the bf16 kernel (3: two workgroups per CU; 6: one, experiment)
+#endif
+#if RCED_C16_TF == 3
+#define RCED_C16_LDS_KB 80
+#define RCED_C16_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define RCED_C16_LDS_KB 160
+#define RCED_C16_ATTR
+#endif
 #ifndef RCED_C16_DEPTH
 #define RCED_C16_DEPTH 1   // operand prefetch depth of the bf16 pass (steps)
 #endif
@@ -37,6 +47,12 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int round4(int c) { return (c + 3) & ~3; }
+
+// The same net with more frames per tile (bf16 activations need half the LDS): geometry only.
+template <class N, int TF>
+struct WithTF : N {
+  static constexpr int kTF = TF;
+};
 
 template <class N>
 struct Geo {
@@ -77,7 +93,7 @@ struct Geo {
   static constexpr int kWRegion = ((maxpacket() + 3) / 4) * 4;
   static constexpr int kLdsFloats = kWOff + 2 * kWRegion;
   static constexpr int kLdsBytes = kLdsFloats * 4;
-  static_assert(kLdsBytes <= 80 * 1024, "two workgroups per CU");
+  static_assert(kLdsBytes <= RCED_C16_LDS_KB * 1024, "LDS budget (80 KB = two workgroups per CU)");
   // fp32 input rows of the first layer alias buffer Y (dead until layer 1 writes it)
   static constexpr int kX0Off = kYOff + (kPad * kChY) / 2;
   static_assert((kPad * kChY) % 2 == 0 && G32::kX0Floats <= kYFloats - (kPad * kChY) / 2, "X0 fits in buffer Y");
@@ -231,7 +247,7 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
 }
 
 template <class N>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_chain16_kernel(Params P) {
+__global__ __launch_bounds__(kThreads) RCED_C16_ATTR void fused_chain16_kernel(Params P) {
   using G = Geo<N>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
