@@ -79,8 +79,8 @@ def pmc_traffic(variant, batch, frames, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU (config 3: 256)")
     ap.add_argument("--frames", type=int, default=512, help="time frames per utterance (config 3: 512)")
     ap.add_argument("--variant", type=int, default=3, choices=(1, 2, 3))
