@@ -258,7 +258,7 @@ int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, in
 int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
              const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
 #define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_wgrad_launch<CI, TP, CO>(x, dz, dW, dbias, frames, cus, xa, ba, st);
-  X(8, 9, 18) X(18, 5, 30) X(30, 9, 8)
+  RCED_TM_FWD(X)      // the same list tm_has(true, ...) answers from: fuse_dz / virt rely on the two agreeing
 #undef X
   return 0;
 }
@@ -607,6 +607,9 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
       if (!s.use_norm) stat_parts = 0;
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
       fin_forward(f.cin, tensor(s.src), t->params + f.kernel, t->params + f.bias, t->pk_fin, t->z[l], frames, st);
+    } else if (s.src > 0 && t->virt[s.src]) {
+      // a virtual input exists only inside the MFMA kernels' staging: never hand its (null) pointer to the direct kernel
+      return rced_fail(RCED_ERR_STATE, "layer %d: no MFMA forward kernel for a layer whose input is not materialised", l);
     } else if (int rc = launch_conv(tensor(s.src), t->z[l], t->wf[l], t->bias4[l], nullptr, frames, T, F, f.cin, s.cout,
                                     f.cout4, s.kh, s.kw, (s.kh - 1) / 2, (s.kw - 1) / 2, st)) {
       return rc;
@@ -717,6 +720,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
       fin_wgrad(f.cin, tensor(s.src), t->D, t->grads + f.kernel, t->grads + f.bias, frames, t->num_cus, st);
     } else {
+      if ((s.src > 0 && t->virt[s.src]) || fuse_dz)   // the direct kernel needs the activation and dz in HBM
+        return rced_fail(RCED_ERR_STATE, "layer %d: no MFMA wgrad kernel for a layer with fused activation / dz", l);
       if (int rc = reduce_channels(t, t->D, t->D, nullptr, nullptr, P, s.cout, st)) return rc;
       hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.bias);
       const int fpw = 16;
@@ -734,6 +739,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
           tm_conv(false, s.cout, s.kw, f.cin, !overwrite(l), false, dsrc, t->pk_bwd[l], t->G[s.src], frames, t->num_cus,
                   nullptr, nullptr, ba, st)) {
         // MFMA path
+      } else if (fuse_dz) {
+        return rced_fail(RCED_ERR_STATE, "layer %d: no MFMA dgrad kernel for a layer with fused dz", l);
       } else if (int rc = launch_conv(t->D, t->G[s.src], t->wt[l], t->zero32, t->G[s.src], frames, T, F, s.cout, f.cin,
                                       f.cin4, s.kh, s.kw, (s.kh - 1) - (s.kh - 1) / 2, (s.kw - 1) - (s.kw - 1) / 2, st)) {
         return rc;
