@@ -204,8 +204,13 @@ int tm_conv_launch(bool accum, bool stats, const float* in, const float* packet,
 }
 
 // forward shapes (cin, taps, cout) of CR-CED's 1xk layers, and the shapes of their dgrad convolutions
-#define RCED_TM_FWD(X) X(8, 9, 18) X(18, 5, 30) X(30, 9, 8)
-#define RCED_TM_BWD(X) X(18, 9, 8) X(30, 5, 18) X(8, 9, 30) X(1, 129, 8)
+// (CR-CED V3, then R-CED V1 whose channel counts are all even; V2 has odd ones and stays on the direct kernels)
+#define RCED_TM_FWD(X)                        \
+  X(8, 9, 18) X(18, 5, 30) X(30, 9, 8)        \
+  X(12, 11, 16) X(16, 9, 20) X(20, 7, 24) X(24, 7, 32) X(32, 7, 24) X(24, 9, 20) X(20, 11, 16) X(16, 13, 12)
+#define RCED_TM_BWD(X)                                   \
+  X(18, 9, 8) X(30, 5, 18) X(8, 9, 30) X(1, 129, 8)      \
+  X(16, 11, 12) X(20, 9, 16) X(24, 7, 20) X(32, 7, 24) X(24, 7, 32) X(20, 9, 24) X(16, 11, 20) X(12, 13, 16)
 int tm_conv(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet, float* out,
             int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
 #define X(CI, TP, CO)                                                                                                   \
