@@ -146,6 +146,18 @@ int reduce_channels(rced_trainer* t, const float* a, const float* b, const float
 
 // ---- MFMA paths for the 1xk layers (kernels_train_mfma.h): one instantiation per (cin, taps, cout) ----
 
+// Kernels that want more than the default dynamic LDS need the attribute once per (kernel, device): `done` is that
+// kernel's bit mask over device ordinals (a process may hold trainers on several devices).
+void allow_lds(const void* kernel, size_t lds, unsigned long long& done) {
+  if (lds <= 48 * 1024) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done & bit) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  done |= bit;
+}
+
 size_t tm_packet_floats(int cin, int taps, int cout) {
   const int cinp = (cin + 1) & ~1, K = taps * cinp, MT = (cout + 15) / 16;
   return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + 32;
@@ -158,12 +170,8 @@ int tm_conv_launch1(const float* in, const float* packet, float* out, int frames
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const int grid = std::min(ntiles, std::min(cus * 4, kPairGrid));
   const size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 4 * CIN : 0)) * sizeof(float);
-  static bool attr = false;
-  if (!attr && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static unsigned long long attr = 0;
+  allow_lds(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), lds, attr);
   hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), dim3(grid), dim3(tmm::kThreads), lds, st, in,
                      packet, out, frames, part, xa, ba);
   return grid;
@@ -239,12 +247,8 @@ int tm_wgrad_launch1(const float* x, const float* dz, float* dW, float* dbias, i
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const int grid = std::min(ntiles, cus * 2);
   const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32 + 2 * CIN + 4 * COUT) * sizeof(float);
-  static bool attr = false;
-  if (!attr && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static unsigned long long attr = 0;
+  allow_lds(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>), lds, attr);
   hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW,
                      dbias, frames, xa, ba);
   return 1;
@@ -285,14 +289,9 @@ int first_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias,
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const dim3 grid(std::min(ntiles, cus * 3));
   const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
-  static bool attr = false;
-  if (!attr && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static unsigned long long attr_t = 0, attr_f = 0;
+  allow_lds(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, true>), lds, attr_t);
+  allow_lds(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, false>), lds, attr_f);
   if (ba) hipLaunchKernelGGL((tmm::first_wgrad<KW, COUT, true>), grid, dim3(tmm::kThreads), lds, st, x, dz, dW, dbias, frames, T, *ba);
   else hipLaunchKernelGGL((tmm::first_wgrad<KW, COUT, false>), grid, dim3(tmm::kThreads), lds, st, x, dz, dW, dbias, frames, T, nb);
   return 1;
