@@ -455,9 +455,15 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   HIP_TRY(hipGetLastError());
   const int frames = N * T;
   m->prof_begin(RCED_K_FINAL, st);
-  hipLaunchKernelGGL(v3::final_gemm_kernel, dim3((frames + v3::kFinFrames - 1) / v3::kFinFrames),
-                     dim3(v3::kFinThreads), 0, st, (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y,
-                     frames);
+  // LDS-staged B operand (0.41 ms at config 3; the direct-load kernel, RCED_FINAL_LDS=0, takes 0.56 ms)
+  static const bool fin_lds = !(getenv("RCED_FINAL_LDS") && atoi(getenv("RCED_FINAL_LDS")) == 0);
+  if (fin_lds)
+    hipLaunchKernelGGL((v3::final_gemm_lds_kernel<4, 32>), dim3((frames + 63) / 64), dim3(v3::kFinThreads), 0, st,
+                       (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y, frames);
+  else
+    hipLaunchKernelGGL(v3::final_gemm_kernel, dim3((frames + v3::kFinFrames - 1) / v3::kFinFrames),
+                       dim3(v3::kFinThreads), 0, st, (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y,
+                       frames);
   m->prof_end(RCED_K_FINAL, st);
   HIP_TRY(hipGetLastError());
   return RCED_OK;

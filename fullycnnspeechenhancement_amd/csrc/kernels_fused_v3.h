@@ -842,5 +842,118 @@ __global__ __launch_bounds__(kFinThreads) void final_gemm_kernel(const float* __
   }
 }
 
+// The same GEMM with the B operand staged through LDS: the 64 frames' h rows arrive in chunks of 64 k as coalesced
+// 256-byte row pieces (read once per workgroup instead of once per wave, 16 cache lines per load before), one chunk
+// ahead in registers, into a two-buffer ping-pong with frame stride 66 floats (2 mod 32: the 16 frames of a
+// ds_read_b64 fall on 16 distinct bank pairs).  A still streams from L2, two steps ahead.
+template <int NT, int CHUNK>
+struct FinLds {
+  static constexpr int kFrames = 16 * NT;                             // frames per workgroup
+  static constexpr int kRow = CHUNK + 2;                              // 2 mod 32
+  static constexpr int kStepsPer = CHUNK / 8;
+  static constexpr int kChunks = (kFinK + CHUNK - 1) / CHUNK;
+  static constexpr int kPieces = CHUNK / 4;                           // float4 pieces per frame per chunk
+  static constexpr int kVec = kFrames * kPieces;
+  static constexpr int kPer = (kVec + kFinThreads - 1) / kFinThreads;
+  static_assert(kFinK % 4 == 0 && CHUNK % 8 == 0 && CHUNK % 32 == 0, "float4 pieces never straddle the end of a row");
+};
+
+template <int NT, int CHUNK>
+__global__ __launch_bounds__(kFinThreads) void final_gemm_lds_kernel(const float* __restrict__ h,
+                                                                      const float* __restrict__ apack, float bias,
+                                                                      float* __restrict__ y, int frames) {
+  using G = FinLds<NT, CHUNK>;
+  __shared__ __attribute__((aligned(16))) float bs[2][G::kFrames * G::kRow];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kq = lane >> 4;
+  const int f0 = blockIdx.x * G::kFrames;
+  const f32x2* ap = reinterpret_cast<const f32x2*>(apack) + (wave * 3) * 64 + lane;
+  auto fetch = [&](int chunk, f32x4(&r)[G::kPer]) {
+#pragma unroll
+    for (int i = 0; i < G::kPer; ++i) {
+      const int q = tid + i * kFinThreads;
+      const int fr = f0 + q / G::kPieces, k = chunk * CHUNK + 4 * (q % G::kPieces);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < G::kVec && fr < frames && k < kFinK) v = *reinterpret_cast<const f32x4*>(h + (size_t)fr * kFinK + k);
+      r[i] = v;
+    }
+  };
+  auto commit = [&](int buf, const f32x4(&r)[G::kPer]) {
+#pragma unroll
+    for (int i = 0; i < G::kPer; ++i) {
+      const int q = tid + i * kFinThreads;
+      if (q < G::kVec) {
+        float* d = bs[buf] + (q / G::kPieces) * G::kRow + 4 * (q % G::kPieces);
+        *reinterpret_cast<f32x2*>(d) = f32x2{r[i].x, r[i].y};
+        *reinterpret_cast<f32x2*>(d + 2) = f32x2{r[i].z, r[i].w};
+      }
+    }
+  };
+  f32x4 acc[NT][3];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) acc[t][m] = f32x4{bias, bias, bias, bias};
+  f32x4 r[G::kPer];
+  fetch(0, r);
+  commit(0, r);
+  f32x2 a[3], an[3], an2[3];            // A fragments of steps S, S+1, S+2
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    a[m] = ap[m * 64];
+    an[m] = ap[(kFinMT + m) * 64];
+  }
+  __syncthreads();
+  for (int c = 0; c < G::kChunks; ++c) {
+    if (c + 1 < G::kChunks) fetch(c + 1, r);
+    const float* bb = bs[c & 1] + n * G::kRow + 2 * kq;
+    const int left = kFinSteps - G::kStepsPer * c;
+    const int ns = left < G::kStepsPer ? left : G::kStepsPer;
+#pragma unroll
+    for (int s = 0; s < G::kStepsPer; ++s) {
+      if (s < ns) {
+        const int S = G::kStepsPer * c + s;
+        if (S + 2 < kFinSteps) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) an2[m] = ap[((S + 2) * kFinMT + m) * 64];
+        }
+        f32x2 b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x2*>(bb + 16 * t * G::kRow + 8 * s);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[t][m] = mfma(a[m][e], b[t][e], acc[t][m]);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          a[m] = an[m];
+          an[m] = an2[m];
+        }
+      }
+    }
+    if (c + 1 < G::kChunks) commit((c + 1) & 1, r);
+    __syncthreads();
+  }
+  // D row = f = 16*(3*wave+m) + 4*kq + j, column = frame
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int fr = f0 + 16 * t + n;
+    if (fr >= frames) continue;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int f = 16 * (3 * wave + m) + 4 * kq;
+      float* yp = y + (size_t)fr * kF + f;
+      const f32x4 v = acc[t][m];
+      if (f + 0 < kF) yp[0] = v.x;
+      if (f + 1 < kF) yp[1] = v.y;
+      if (f + 2 < kF) yp[2] = v.z;
+      if (f + 3 < kF) yp[3] = v.w;
+    }
+  }
+}
+
 }  // namespace v3
 }  // namespace rced
