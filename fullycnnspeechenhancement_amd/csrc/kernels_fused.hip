@@ -200,6 +200,22 @@ void pack_chain(const rced_model* m, std::vector<float>* wpack, std::vector<floa
   *fin_bias = lf.host_shift[0];
 }
 
+// RCED_FINAL_LDS=0: the last layer's GEMM without LDS staging of its B operand (the first form; kept for A/B)
+inline bool final_lds_enabled() {
+  static const bool on = !(getenv("RCED_FINAL_LDS") && atoi(getenv("RCED_FINAL_LDS")) == 0);
+  return on;
+}
+template <int CH>
+void chain_final_layer(const rced_fused* f, float* y, int frames, hipStream_t st) {
+  const dim3 grid((frames + chain::kFinFrames - 1) / chain::kFinFrames);
+  if (final_lds_enabled())
+    hipLaunchKernelGGL(chain::final_gemm_lds_kernel<CH>, grid, dim3(chain::kFinThreads), 0, st, (const float*)f->h,
+                       (const float*)f->fin_apack, f->fin_bias, y, frames);
+  else
+    hipLaunchKernelGGL(chain::final_gemm_kernel<CH>, grid, dim3(chain::kFinThreads), 0, st, (const float*)f->h,
+                       (const float*)f->fin_apack, f->fin_bias, y, frames);
+}
+
 template <class N>
 int chain_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
   using G = chain::Geo<N>;
@@ -220,9 +236,7 @@ int chain_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb
   HIP_TRY(hipGetLastError());
   const int frames = Nb * T;
   m->prof_begin(RCED_K_FINAL, st);
-  hipLaunchKernelGGL(chain::final_gemm_kernel<N::kFinalCh>, dim3((frames + chain::kFinFrames - 1) / chain::kFinFrames),
-                     dim3(chain::kFinThreads), 0, st, (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y,
-                     frames);
+  chain_final_layer<N::kFinalCh>(f, y, frames, st);
   m->prof_end(RCED_K_FINAL, st);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
@@ -321,9 +335,7 @@ int chain16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int 
   HIP_TRY(hipGetLastError());
   const int frames = Nb * T;
   m->prof_begin(RCED_K_FINAL, st);
-  hipLaunchKernelGGL(chain::final_gemm_kernel<N::kFinalCh>, dim3((frames + chain::kFinFrames - 1) / chain::kFinFrames),
-                     dim3(chain::kFinThreads), 0, st, (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y,
-                     frames);
+  chain_final_layer<N::kFinalCh>(f, y, frames, st);
   m->prof_end(RCED_K_FINAL, st);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
@@ -456,8 +468,7 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   const int frames = N * T;
   m->prof_begin(RCED_K_FINAL, st);
   // LDS-staged B operand (0.41 ms at config 3; the direct-load kernel, RCED_FINAL_LDS=0, takes 0.56 ms)
-  static const bool fin_lds = !(getenv("RCED_FINAL_LDS") && atoi(getenv("RCED_FINAL_LDS")) == 0);
-  if (fin_lds)
+  if (final_lds_enabled())
     hipLaunchKernelGGL((v3::final_gemm_lds_kernel<4, 32>), dim3((frames + 63) / 64), dim3(v3::kFinThreads), 0, st,
                        (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y, frames);
   else

@@ -519,5 +519,137 @@ __global__ __launch_bounds__(kFinThreads) void final_gemm_kernel(const float* __
   }
 }
 
+// The same GEMM with the B operand staged through LDS (see v3::final_gemm_lds_kernel): the 64 frames' h rows arrive in
+// chunks of 32 k as coalesced pieces, one chunk ahead in registers, into a ping-pong with frame stride 34 floats;
+// A streams from L2 two steps ahead.  k >= K is staged as zero, so the b32 tail step needs no lane clamp.
+template <int CH>
+struct FinalLds {
+  using FG = FinalGeo<CH>;
+  static constexpr int kChunk = 32, kRow = kChunk + 2, kStepsPer = kChunk / 8;
+  static constexpr int kPiece = FG::kK % 4 == 0 ? 4 : 2;              // floats per global load: rows are 16- or 8-byte aligned
+  static constexpr int kPieces = kChunk / kPiece;
+  static constexpr int kVec = kFinFrames * kPieces;
+  static constexpr int kPer = (kVec + kFinThreads - 1) / kFinThreads;
+  static constexpr int kTailChunk = (8 * FG::kNB64) / kChunk;          // chunk that holds the tail step's k
+  static constexpr int kTailOff = 8 * FG::kNB64 - kTailChunk * kChunk; // its offset inside that chunk
+  static constexpr int kChunks = kTailChunk + 1;
+  static_assert(FG::kK % kPiece == 0 && kTailOff + 4 <= kChunk, "pieces end with the row; the tail step sits in one chunk");
+};
+
+template <int CH>
+__global__ __launch_bounds__(kFinThreads) void final_gemm_lds_kernel(const float* __restrict__ h,
+                                                                      const float* __restrict__ apack, float bias,
+                                                                      float* __restrict__ y, int frames) {
+  using FG = FinalGeo<CH>;
+  using G = FinalLds<CH>;
+  __shared__ __attribute__((aligned(16))) float bs[2][kFinFrames * G::kRow];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kq = lane >> 4;
+  const int f0 = blockIdx.x * kFinFrames;
+  const f32x2* ap = reinterpret_cast<const f32x2*>(apack) + (wave * 3) * 64 + lane;
+  const float* at = apack + FG::kNB64 * FG::kMT * 128 + (wave * 3) * 64 + lane;
+  auto fetch = [&](int chunk, f32x4(&r)[G::kPer]) {
+#pragma unroll
+    for (int i = 0; i < G::kPer; ++i) {
+      const int q = tid + i * kFinThreads;
+      const int fr = f0 + q / G::kPieces, k = chunk * G::kChunk + G::kPiece * (q % G::kPieces);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < G::kVec && fr < frames && k < FG::kK) {
+        const float* src = h + (size_t)fr * FG::kK + k;
+        if constexpr (G::kPiece == 4) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+          const f32x2 w = *reinterpret_cast<const f32x2*>(src);
+          v.x = w.x;
+          v.y = w.y;
+        }
+      }
+      r[i] = v;
+    }
+  };
+  auto commit = [&](int buf, const f32x4(&r)[G::kPer]) {
+#pragma unroll
+    for (int i = 0; i < G::kPer; ++i) {
+      const int q = tid + i * kFinThreads;
+      if (q < G::kVec) {
+        float* d = bs[buf] + (q / G::kPieces) * G::kRow + G::kPiece * (q % G::kPieces);
+        *reinterpret_cast<f32x2*>(d) = f32x2{r[i].x, r[i].y};
+        if constexpr (G::kPiece == 4) *reinterpret_cast<f32x2*>(d + 2) = f32x2{r[i].z, r[i].w};
+      }
+    }
+  };
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) acc[t][m] = f32x4{bias, bias, bias, bias};
+  f32x4 r[G::kPer];
+  fetch(0, r);
+  commit(0, r);
+  f32x2 a[3], an[3], an2[3];            // A fragments of steps S, S+1, S+2
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    a[m] = ap[m * 64];
+    an[m] = ap[(FG::kMT + m) * 64];
+  }
+  __syncthreads();
+  for (int c = 0; c < G::kChunks; ++c) {
+    if (c + 1 < G::kChunks) fetch(c + 1, r);
+    const float* bb = bs[c & 1] + n * G::kRow;
+    const int left = FG::kNB64 - G::kStepsPer * c;
+    const int ns = left < G::kStepsPer ? left : G::kStepsPer;
+#pragma unroll
+    for (int s = 0; s < G::kStepsPer; ++s) {
+      if (s < ns) {
+        const int S = G::kStepsPer * c + s;
+        if (S + 2 < FG::kNB64) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) an2[m] = ap[((S + 2) * FG::kMT + m) * 64];
+        }
+        f32x2 b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const f32x2*>(bb + 16 * t * G::kRow + 8 * s + 2 * kq);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[t][m] = mfma(a[m][e], b[t][e], acc[t][m]);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          a[m] = an[m];
+          an[m] = an2[m];
+        }
+      }
+    }
+    if (c == G::kTailChunk) {   // b32 step: lane kq <-> k = 8*NB64 + kq (zero past K)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float b = bb[16 * t * G::kRow + G::kTailOff + kq];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[t][m] = mfma(at[m * 64], b, acc[t][m]);
+      }
+    }
+    if (c + 1 < G::kChunks) commit((c + 1) & 1, r);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int fr = f0 + 16 * t + n;
+    if (fr >= frames) continue;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int f = 16 * (3 * wave + m) + 4 * kq;
+      float* yp = y + (size_t)fr * kF + f;
+      const f32x4 v = acc[t][m];
+      if (f + 0 < kF) yp[0] = v.x;
+      if (f + 1 < kF) yp[1] = v.y;
+      if (f + 2 < kF) yp[2] = v.z;
+      if (f + 3 < kF) yp[3] = v.w;
+    }
+  }
+}
+
 }  // namespace chain
 }  // namespace rced
