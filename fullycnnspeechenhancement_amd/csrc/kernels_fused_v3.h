@@ -858,32 +858,17 @@ struct FinLds {
   static_assert(kFinK % 4 == 0 && CHUNK % 8 == 0 && CHUNK % 32 == 0, "float4 pieces never straddle the end of a row");
 };
 
-// Band structure: output bin f only sees input bins f' in [f-64, f+64], so M-tile mt (bins 16mt .. 16mt+15) has
-// all-zero A fragments outside the steps s = f' in [16mt-64, 16mt+79] (one b64 step per input bin: 8 channels).
-// Those steps are skipped (22 % of the MFMAs), and the nine M-tiles are dealt {0,4,8} / {1,3,7} / {2,5,6} so the
-// three waves carry 274 / 305 / 322 tile-steps instead of 387 each.
 template <int NT, int CHUNK>
 __global__ __launch_bounds__(kFinThreads) void final_gemm_lds_kernel(const float* __restrict__ h,
                                                                       const float* __restrict__ apack, float bias,
                                                                       float* __restrict__ y, int frames) {
   using G = FinLds<NT, CHUNK>;
-  static_assert(kHCh == 8, "step index = input bin");
   __shared__ __attribute__((aligned(16))) float bs[2][G::kFrames * G::kRow];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, kq = lane >> 4;
   const int f0 = blockIdx.x * G::kFrames;
-  int mt[3], lo[3], hi[3];
-  mt[0] = wave;                                   // 0 1 2
-  mt[1] = wave == 0 ? 4 : wave == 1 ? 3 : 5;
-  mt[2] = wave == 0 ? 8 : wave == 1 ? 7 : 6;
-  const f32x2* ap[3];
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    lo[m] = 16 * mt[m] - 64 < 0 ? 0 : 16 * mt[m] - 64;
-    hi[m] = 16 * mt[m] + 79 > kF - 1 ? kF - 1 : 16 * mt[m] + 79;
-    ap[m] = reinterpret_cast<const f32x2*>(apack) + mt[m] * 64 + lane;
-  }
+  const f32x2* ap = reinterpret_cast<const f32x2*>(apack) + (wave * 3) * 64 + lane;
   auto fetch = [&](int chunk, f32x4(&r)[G::kPer]) {
 #pragma unroll
     for (int i = 0; i < G::kPer; ++i) {
@@ -913,12 +898,11 @@ __global__ __launch_bounds__(kFinThreads) void final_gemm_lds_kernel(const float
   f32x4 r[G::kPer];
   fetch(0, r);
   commit(0, r);
-  f32x2 a[3], an[3], an2[3];            // A fragments of steps S, S+1, S+2 (only loaded inside the tile's band)
+  f32x2 a[3], an[3], an2[3];            // A fragments of steps S, S+1, S+2
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
-    a[m] = ap[m][0];
-    an[m] = ap[m][kFinMT * 64];
-    an2[m] = an[m];
+    a[m] = ap[m * 64];
+    an[m] = ap[(kFinMT + m) * 64];
   }
   __syncthreads();
   for (int c = 0; c < G::kChunks; ++c) {
@@ -930,20 +914,19 @@ __global__ __launch_bounds__(kFinThreads) void final_gemm_lds_kernel(const float
     for (int s = 0; s < G::kStepsPer; ++s) {
       if (s < ns) {
         const int S = G::kStepsPer * c + s;
+        if (S + 2 < kFinSteps) {
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
-          if (S + 2 >= lo[m] && S + 2 <= hi[m]) an2[m] = ap[m][(S + 2) * kFinMT * 64];
+          for (int m = 0; m < 3; ++m) an2[m] = ap[((S + 2) * kFinMT + m) * 64];
+        }
         f32x2 b[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x2*>(bb + 16 * t * G::kRow + 8 * s);
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
-          if (S >= lo[m] && S <= hi[m]) {
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+          for (int t = 0; t < NT; ++t)
 #pragma unroll
-              for (int t = 0; t < NT; ++t) acc[t][m] = mfma(a[m][e], b[t][e], acc[t][m]);
-          }
+            for (int m = 0; m < 3; ++m) acc[t][m] = mfma(a[m][e], b[t][e], acc[t][m]);
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
           a[m] = an[m];
@@ -954,14 +937,14 @@ __global__ __launch_bounds__(kFinThreads) void final_gemm_lds_kernel(const float
     if (c + 1 < G::kChunks) commit((c + 1) & 1, r);
     __syncthreads();
   }
-  // D row = f = 16*mt + 4*kq + j, column = frame
+  // D row = f = 16*(3*wave+m) + 4*kq + j, column = frame
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int fr = f0 + 16 * t + n;
     if (fr >= frames) continue;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      const int f = 16 * mt[m] + 4 * kq;
+      const int f = 16 * (3 * wave + m) + 4 * kq;
       float* yp = y + (size_t)fr * kF + f;
       const f32x4 v = acc[t][m];
       if (f + 0 < kF) yp[0] = v.x;
