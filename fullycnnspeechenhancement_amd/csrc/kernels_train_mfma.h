@@ -47,7 +47,7 @@ struct Geo {
 // transpose = 1: dgrad    (rows = CIN_L outputs; the packet is for a conv whose input has COUT_L channels:
 //                          W_t[tap'][co_l][ci_l] = w[TAPS-1-tap'][ci_l][co_l]).
 // cin / cout below are those of the conv being PACKED (dgrad: cin = COUT_L, cout = CIN_L).
-__global__ void pack_packet(const float* __restrict__ w, const float* __restrict__ shift, int taps, int cin, int cout,
+static __global__ void pack_packet(const float* __restrict__ w, const float* __restrict__ shift, int taps, int cin, int cout,
                             int transpose, float* __restrict__ packet) {
   const int cinp = (cin + 1) & ~1, K = taps * cinp, MT = (cout + 15) / 16;
   const int NB = K / 8, NTL = (K % 8 + 3) / 4, data = NB * MT * 128 + NTL * MT * 64;
@@ -522,7 +522,7 @@ struct FinGeo {
 constexpr int kFinFrames = 64, kFinThreads = 192;
 
 // w [129][CH] (TF [1,129,CH,1]) -> pack [s][mt][lane][e] (+ tail [mt][lane]); row f = 16*mt + i
-__global__ void pack_final_fwd(const float* __restrict__ w, int CH, float* __restrict__ pack) {
+static __global__ void pack_final_fwd(const float* __restrict__ w, int CH, float* __restrict__ pack) {
   const int K = kF * CH, NB = K / 8, main = NB * 9 * 128, total = main + ((K % 8) ? 9 * 64 : 0);
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict_
 // are four rows at the same column).  Packet [step][mt][lane] = W[4*ih + kq][j][16*mt + i], then 32 shifts.
 // STATS as conv1xk_mfma: per-workgroup (sum z, sum z^2) records for the BatchNorm statistics.
 // ---------------------------------------------------------------------------------------------
-__global__ void pack_first(const float* __restrict__ w, const float* __restrict__ bias, int kw, int cout,
+static __global__ void pack_first(const float* __restrict__ w, const float* __restrict__ bias, int kw, int cout,
                            float* __restrict__ packet) {
   const int MT = (cout + 15) / 16, steps = 2 * kw, data = steps * MT * 64;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(kThreads) void first_fwd(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 constexpr int kDgSteps = 33, kDgFrames = 64, kDgMc = 3;
 // pack [mtile][step][lane] = A[16*mtile + (lane & 15), 4*step + (lane >> 4)]
-__global__ void pack_final_dgrad(const float* __restrict__ w, int CH, float* __restrict__ pack) {
+static __global__ void pack_final_dgrad(const float* __restrict__ w, int CH, float* __restrict__ pack) {
   const int M = kF * CH, MT = (M + 15) / 16, total = MT * kDgSteps * 64;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;

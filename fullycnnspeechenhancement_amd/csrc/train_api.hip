@@ -14,6 +14,7 @@
 #include "kernels_generic.h"
 #include "kernels_train.h"
 #include "kernels_train_mfma.h"
+#include "train_mfma_dispatch.h"
 #include "rced_internal.h"
 #include "rced_spec.h"
 
@@ -38,7 +39,9 @@ struct DeviceGuard {
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 constexpr int kReduceGrid = 512;
-constexpr int kPairGrid = 2048;     // workgroups of the channel-aligned elementwise kernels (and their partial sums)
+using rced::tmd::kPairGrid;
+using rced::tmd::allow_lds;
+using rced::tmd::tm_packet_floats;
 constexpr float kAdamB1 = 0.9f, kAdamB2 = 0.999f, kAdamEps = 1e-8f;   // tf.train.AdamOptimizer defaults
 constexpr float kBnMomentum = 0.99f;                                  // tf.layers.batch_normalization default
 
@@ -50,8 +53,15 @@ struct LayerOff {   // float offsets into the variable blob
 
 struct rced_trainer {
   int variant = 0, device = 0, batch_size = 1, num_cus = 256;
-  const NetSpec* net = nullptr;
-  size_t nvars = 0;
+  // The MFMA kernels stage channel pairs, so odd channel counts (R-CED V2: 15, 19, 21, 23, 25) are trained in an
+  // even-padded internal layout: `inet` = the net with every hidden cout rounded up to even.  A phantom channel has
+  // zero kernel / bias / gamma / beta, so it is 0 after conv, BatchNorm and ReLU, contributes nothing downstream,
+  // receives zero gradients and is not trainable; variables cross the ABI in the reference's own (unpadded) layout.
+  const NetSpec* net = nullptr;   // = &inet
+  NetSpec inet{};
+  size_t nvars = 0;               // floats in the internal blob
+  size_t xvars = 0;               // floats in the external (reference) blob
+  std::vector<int> x2i;           // external float index -> internal float index
   std::vector<LayerOff> off;
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
   unsigned char* trainable = nullptr;
@@ -144,134 +154,37 @@ int reduce_channels(rced_trainer* t, const float* a, const float* b, const float
   return RCED_OK;
 }
 
-// ---- MFMA paths for the 1xk layers (kernels_train_mfma.h): one instantiation per (cin, taps, cout) ----
-
-// Kernels that want more than the default dynamic LDS need the attribute once per (kernel, device): `done` is that
-// kernel's bit mask over device ordinals (a process may hold trainers on several devices).
-void allow_lds(const void* kernel, size_t lds, unsigned long long& done) {
-  if (lds <= 48 * 1024) return;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (done & bit) return;
-  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  done |= bit;
-}
-
-size_t tm_packet_floats(int cin, int taps, int cout) {
-  const int cinp = (cin + 1) & ~1, K = taps * cinp, MT = (cout + 15) / 16;
-  return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + 32;
-}
-
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF>
-int tm_conv_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part,
-                    tmm::XformArgs xa, tmm::BnBwdArgs ba, hipStream_t st) {
-  using G = tmm::Geo<CIN, TAPS, COUT>;
-  const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
-  const int grid = std::min(ntiles, std::min(cus * 4, kPairGrid));
-  const size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 4 * CIN : 0)) * sizeof(float);
-  static unsigned long long attr = 0;
-  allow_lds(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), lds, attr);
-  hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), dim3(grid), dim3(tmm::kThreads), lds, st, in,
-                     packet, out, frames, part, xa, ba);
-  return grid;
-}
-// One 1xk convolution on the MFMA kernels.  The shape decides the role: a layer's forward shape gets
-//   out = conv(in) + shift, optionally with the per-workgroup (sum, sum of squares) records in `part` (stats) and
-//   optionally with in = relu(bn(z)) rebuilt from the producer's z (xa);
-// a dgrad shape gets  out (=|+=) conv(in)  with in = dz, optionally rebuilt from (d_u, z) (ba).
-// Returns the grid size (= number of partial-sum records when stats), 0 if no kernel was built for the request.
-template <int CIN, int TAPS, int COUT, bool FWD>
-int tm_conv_launch(bool accum, bool stats, const float* in, const float* packet, float* out, int frames, int cus,
-                   double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
-  const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
-  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
-  if constexpr (FWD) {
-    if (accum || ba) return 0;
-    if (xa) {
-      if constexpr (CIN % 2 == 0) {
-        if (stats) return tm_conv_launch1<CIN, TAPS, COUT, false, true, tmm::kXfBnRelu>(in, packet, out, frames, cus, part, *xa, nb, st);
-        return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfBnRelu>(in, packet, out, frames, cus, nullptr, *xa, nb, st);
-      }
-      return 0;
-    }
-    if (stats) return tm_conv_launch1<CIN, TAPS, COUT, false, true, tmm::kXfNone>(in, packet, out, frames, cus, part, nx, nb, st);
-    return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
-  } else {
-    if (stats || xa) return 0;
-    if (ba) {
-      if constexpr (CIN % 2 == 0) {
-        if (accum) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfBnBwd>(in, packet, out, frames, cus, nullptr, nx, *ba, st);
-        return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfBnBwd>(in, packet, out, frames, cus, nullptr, nx, *ba, st);
-      }
-      return 0;
-    }
-    if (accum) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
-    return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
-  }
-}
-
-// forward shapes (cin, taps, cout) of CR-CED's 1xk layers, and the shapes of their dgrad convolutions
-// (CR-CED V3, then R-CED V1 whose channel counts are all even; V2 has odd ones and stays on the direct kernels)
+// ---- MFMA paths for the 1xk layers (kernels_train_mfma.h, launchers in train_mfma_dispatch.h) ----
+// forward shapes (cin, taps, cout) of the 1xk layers and the shapes of their dgrad convolutions (cout, taps, cin):
+// CR-CED V3, then R-CED V1.  R-CED V2 (even-padded internal layout) lives in train_mfma_v2.hip.
 #define RCED_TM_FWD(X)                        \
   X(8, 9, 18) X(18, 5, 30) X(30, 9, 8)        \
   X(12, 11, 16) X(16, 9, 20) X(20, 7, 24) X(24, 7, 32) X(32, 7, 24) X(24, 9, 20) X(20, 11, 16) X(16, 13, 12)
 #define RCED_TM_BWD(X)                                   \
   X(18, 9, 8) X(30, 5, 18) X(8, 9, 30) X(1, 129, 8)      \
   X(16, 11, 12) X(20, 9, 16) X(24, 7, 20) X(32, 7, 24) X(24, 7, 32) X(20, 9, 24) X(16, 11, 20) X(12, 13, 16)
+RCED_TM_DEFINE_DISPATCH(_main, RCED_TM_FWD, RCED_TM_BWD)
+}  // namespace
+// train_mfma_v2.hip
+int rced_tm_conv_v2(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet,
+                    float* out, int frames, int cus, double* part, const rced::tmm::XformArgs* xa,
+                    const rced::tmm::BnBwdArgs* ba, hipStream_t st);
+bool rced_tm_has_v2(bool fwd, int cin, int taps, int cout);
+int rced_tm_wgrad_v2(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
+                     const rced::tmm::XformArgs* xa, const rced::tmm::BnBwdArgs* ba, hipStream_t st);
+namespace {
+// Returns the grid size (= number of partial-sum records when stats), 0 if no kernel was built for the request.
 int tm_conv(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet, float* out,
             int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
-#define X(CI, TP, CO)                                                                                                   \
-  if (fwd && cin == CI && taps == TP && cout == CO)                                                                      \
-    return tm_conv_launch<CI, TP, CO, true>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
-  RCED_TM_FWD(X)
-#undef X
-#define X(CI, TP, CO)                                                                                                   \
-  if (!fwd && cin == CI && taps == TP && cout == CO)                                                                     \
-    return tm_conv_launch<CI, TP, CO, false>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
-  RCED_TM_BWD(X)
-#undef X
-  return 0;
+  if (tm_has_main(fwd, cin, taps, cout)) return tm_conv_main(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
+  return rced_tm_conv_v2(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
 }
-bool tm_has(bool fwd, int cin, int taps, int cout) {
-#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return true;
-  if (fwd) { RCED_TM_FWD(X) } else { RCED_TM_BWD(X) }
-#undef X
-  return false;
-}
-
-template <int CIN, int TAPS, int COUT, bool XF, bool DZF>
-int tm_wgrad_launch1(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, tmm::XformArgs xa,
-                     tmm::BnBwdArgs ba, hipStream_t st) {
-  using G = tmm::Geo<CIN, TAPS, COUT>;
-  const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
-  const int grid = std::min(ntiles, cus * 2);
-  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32 + 2 * CIN + 4 * COUT) * sizeof(float);
-  static unsigned long long attr = 0;
-  allow_lds(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>), lds, attr);
-  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW,
-                     dbias, frames, xa, ba);
-  return 1;
-}
-// xa: x is the producer's z (see tm_conv); ba: dz is d_u, rebuilt through BatchNorm backward from (d_u, z)
-template <int CIN, int TAPS, int COUT>
-int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, const tmm::XformArgs* xa,
-                    const tmm::BnBwdArgs* ba, hipStream_t st) {
-  const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
-  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
-  if (xa && ba) return tm_wgrad_launch1<CIN, TAPS, COUT, true, true>(x, dz, dW, dbias, frames, cus, *xa, *ba, st);
-  if (xa) return tm_wgrad_launch1<CIN, TAPS, COUT, true, false>(x, dz, dW, dbias, frames, cus, *xa, nb, st);
-  if (ba) return tm_wgrad_launch1<CIN, TAPS, COUT, false, true>(x, dz, dW, dbias, frames, cus, nx, *ba, st);
-  return tm_wgrad_launch1<CIN, TAPS, COUT, false, false>(x, dz, dW, dbias, frames, cus, nx, nb, st);
-}
+bool tm_has(bool fwd, int cin, int taps, int cout) { return tm_has_main(fwd, cin, taps, cout) || rced_tm_has_v2(fwd, cin, taps, cout); }
 int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
              const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
-#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return tm_wgrad_launch<CI, TP, CO>(x, dz, dW, dbias, frames, cus, xa, ba, st);
-  RCED_TM_FWD(X)      // the same list tm_has(true, ...) answers from: fuse_dz / virt rely on the two agreeing
-#undef X
-  return 0;
+  if (tm_has_main(true, cin, taps, cout)) return tm_wgrad_main(cin, taps, cout, x, dz, dW, dbias, frames, cus, xa, ba, st);
+  return rced_tm_wgrad_v2(cin, taps, cout, x, dz, dW, dbias, frames, cus, xa, ba, st);
 }
-
 
 // ---- first layer (8 x kw on the 1-channel input): MFMA wgrad (kernels_train_mfma.h) ----
 #define RCED_FIRST(X) X(9, 18) X(13, 12) X(11, 10)
@@ -393,17 +306,21 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
   rced_trainer* t = new rced_trainer();
   t->variant = variant;
   t->device = device;
-  t->net = net;
   t->batch_size = batch_size;
-  t->nvars = n_floats;
+  t->xvars = n_floats;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) t->num_cus = prop.multiProcessorCount;
     if (const char* e = getenv("RCED_TRAIN_MFMA")) t->use_mfma = atoi(e);
     if (const char* e = getenv("RCED_TRAIN_FUSE_DZ")) t->fuse_dz = atoi(e) != 0;
   }
-  const int L = net->n_layers;
-  std::vector<unsigned char> mask(n_floats, 0);
+  const NetSpec* xnet = net;     // the reference's layout (what crosses the ABI)
+  t->inet = *xnet;
+  const int L = xnet->n_layers;
+  if (t->use_mfma)
+    for (int l = 0; l < L; ++l)
+      if (xnet->layer[l].use_norm) t->inet.layer[l].cout = (xnet->layer[l].cout + 1) & ~1;
+  t->net = net = &t->inet;
   size_t o = 0;
   t->off.resize(L);
   for (int l = 0; l < L; ++l) {
@@ -416,17 +333,45 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     f.K = s.kh * s.kw * f.cin;
     f.kernel = o; o += (size_t)f.K * s.cout;
     f.bias = o; o += s.cout;
-    std::fill(mask.begin() + f.kernel, mask.begin() + o, 1);
     if (s.use_norm) {
       f.gamma = o; o += s.cout;
       f.beta = o; o += s.cout;
-      std::fill(mask.begin() + f.gamma, mask.begin() + o, 1);
       f.mmean = o; o += s.cout;
       f.mvar = o; o += s.cout;
     } else {
       f.gamma = f.beta = f.mmean = f.mvar = 0;
     }
   }
+  t->nvars = o;
+  // external -> internal index map (graph order: kernel [kh][kw][cin][cout], bias, gamma, beta, moving_mean, moving_variance),
+  // the trainable mask and the internal start values (phantom entries: 0, moving_variance 1)
+  std::vector<unsigned char> mask(t->nvars, 0);
+  std::vector<float> start(t->nvars, 0.f);
+  t->x2i.reserve(n_floats);
+  for (int l = 0; l < L; ++l) {
+    const LayerSpec& xs = xnet->layer[l];
+    const LayerOff& f = t->off[l];
+    const int xcin = layer_cin(*xnet, l), taps = xs.kh * xs.kw;
+    for (int r = 0; r < taps; ++r)
+      for (int ci = 0; ci < xcin; ++ci)
+        for (int co = 0; co < xs.cout; ++co) {
+          const size_t i = f.kernel + ((size_t)r * f.cin + ci) * f.cout + co;
+          t->x2i.push_back((int)i);
+          mask[i] = 1;
+        }
+    for (int co = 0; co < xs.cout; ++co) { t->x2i.push_back((int)(f.bias + co)); mask[f.bias + co] = 1; }
+    if (xs.use_norm) {
+      for (int co = 0; co < xs.cout; ++co) { t->x2i.push_back((int)(f.gamma + co)); mask[f.gamma + co] = 1; }
+      for (int co = 0; co < xs.cout; ++co) { t->x2i.push_back((int)(f.beta + co)); mask[f.beta + co] = 1; }
+      for (int co = 0; co < xs.cout; ++co) t->x2i.push_back((int)(f.mmean + co));
+      for (int co = 0; co < xs.cout; ++co) t->x2i.push_back((int)(f.mvar + co));
+      for (int co = 0; co < f.cout; ++co) start[f.mvar + co] = 1.f;
+    }
+  }
+  if (t->x2i.size() != n_floats) { delete t; return rced_fail(RCED_ERR_ARG, "blob layout: %zu floats mapped, %zu given", t->x2i.size(), n_floats); }
+  for (size_t e = 0; e < n_floats; ++e) start[t->x2i[e]] = blob[e];
+  n_floats = t->nvars;   // from here on: the internal blob
+  blob = start.data();
   auto fail_free = [&](int rc) { delete t; return rc; };
 #define TRY_OR_FREE(expr)                                                      \
   do {                                                                         \
@@ -495,36 +440,50 @@ void rced_train_destroy(rced_trainer* t) { delete t; }
 
 long long rced_train_global_step(rced_trainer* t) { return t ? t->global_step : -1; }
 
-int rced_train_get_variables(rced_trainer* t, float* blob_host, size_t n_floats) {
-  if (!t || !blob_host || n_floats != t->nvars) return rced_fail(RCED_ERR_ARG, "bad arguments");
-  DeviceGuard g(t->device);
-  HIP_TRY(hipMemcpy(blob_host, t->params, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+namespace {
+// internal (even-padded) device array -> the reference's layout on the host, and back (phantom entries become 0)
+int download_external(rced_trainer* t, const float* dev, float* host) {
+  std::vector<float> tmp(t->nvars);
+  HIP_TRY(hipMemcpy(tmp.data(), dev, t->nvars * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < t->xvars; ++e) host[e] = tmp[t->x2i[e]];
   return RCED_OK;
+}
+int upload_external(rced_trainer* t, const float* host, float* dev) {
+  std::vector<float> tmp(t->nvars, 0.f);
+  for (size_t e = 0; e < t->xvars; ++e) tmp[t->x2i[e]] = host[e];
+  HIP_TRY(hipMemcpy(dev, tmp.data(), t->nvars * sizeof(float), hipMemcpyHostToDevice));
+  return RCED_OK;
+}
+}  // namespace
+
+int rced_train_get_variables(rced_trainer* t, float* blob_host, size_t n_floats) {
+  if (!t || !blob_host || n_floats != t->xvars) return rced_fail(RCED_ERR_ARG, "bad arguments");
+  DeviceGuard g(t->device);
+  return download_external(t, t->params, blob_host);
 }
 
 int rced_train_get_gradients(rced_trainer* t, float* blob_host, size_t n_floats) {
-  if (!t || !blob_host || n_floats != t->nvars) return rced_fail(RCED_ERR_ARG, "bad arguments");
+  if (!t || !blob_host || n_floats != t->xvars) return rced_fail(RCED_ERR_ARG, "bad arguments");
   DeviceGuard g(t->device);
-  HIP_TRY(hipMemcpy(blob_host, t->grads, n_floats * sizeof(float), hipMemcpyDeviceToHost));
-  return RCED_OK;
+  return download_external(t, t->grads, blob_host);
 }
 
 int rced_train_get_state(rced_trainer* t, float* m_blob_host, float* v_blob_host, size_t n_floats, long long* global_step) {
-  if (!t || !m_blob_host || !v_blob_host || n_floats != t->nvars) return rced_fail(RCED_ERR_ARG, "bad arguments");
+  if (!t || !m_blob_host || !v_blob_host || n_floats != t->xvars) return rced_fail(RCED_ERR_ARG, "bad arguments");
   DeviceGuard g(t->device);
-  HIP_TRY(hipMemcpy(m_blob_host, t->m, n_floats * sizeof(float), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(v_blob_host, t->v, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  if (int rc = download_external(t, t->m, m_blob_host)) return rc;
+  if (int rc = download_external(t, t->v, v_blob_host)) return rc;
   if (global_step) *global_step = t->global_step;
   return RCED_OK;
 }
 
 int rced_train_set_state(rced_trainer* t, const float* m_blob_host, const float* v_blob_host, size_t n_floats,
                          long long global_step) {
-  if (!t || !m_blob_host || !v_blob_host || n_floats != t->nvars || global_step < 0)
+  if (!t || !m_blob_host || !v_blob_host || n_floats != t->xvars || global_step < 0)
     return rced_fail(RCED_ERR_ARG, "bad arguments");
   DeviceGuard g(t->device);
-  HIP_TRY(hipMemcpy(t->m, m_blob_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(t->v, v_blob_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  if (int rc = upload_external(t, m_blob_host, t->m)) return rc;
+  if (int rc = upload_external(t, v_blob_host, t->v)) return rc;
   t->global_step = global_step;
   return RCED_OK;
 }

@@ -1,0 +1,138 @@
+// Host-side launchers of the MFMA training kernels (kernels_train_mfma.h), shared by the translation units that
+// instantiate them: train_api.hip (CR-CED V3 and R-CED V1 shapes) and train_mfma_v2.hip (R-CED V2's even-padded
+// shapes) -- split so the two sets compile side by side.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "kernels_train_mfma.h"
+
+namespace rced {
+namespace tmd {
+
+constexpr int kPairGrid = 2048;     // workgroups of the channel-aligned elementwise kernels (and their partial sums)
+
+// Kernels that want more than the default dynamic LDS need the attribute once per (kernel, device): `done` is that
+// kernel's bit mask over device ordinals (a process may hold trainers on several devices).
+inline void allow_lds(const void* kernel, size_t lds, unsigned long long& done) {
+  if (lds <= 48 * 1024) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done & bit) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  done |= bit;
+}
+
+inline size_t tm_packet_floats(int cin, int taps, int cout) {
+  const int cinp = (cin + 1) & ~1, K = taps * cinp, MT = (cout + 15) / 16;
+  return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + 32;
+}
+
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF>
+int tm_conv_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part,
+                    tmm::XformArgs xa, tmm::BnBwdArgs ba, hipStream_t st) {
+  using G = tmm::Geo<CIN, TAPS, COUT>;
+  const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
+  const int grid = std::min(ntiles, std::min(cus * 4, kPairGrid));
+  const size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 4 * CIN : 0)) * sizeof(float);
+  static unsigned long long attr = 0;
+  allow_lds(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), lds, attr);
+  hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), dim3(grid), dim3(tmm::kThreads), lds, st, in,
+                     packet, out, frames, part, xa, ba);
+  return grid;
+}
+// One 1xk convolution on the MFMA kernels.  The shape decides the role: a layer's forward shape gets
+//   out = conv(in) + shift, optionally with the per-workgroup (sum, sum of squares) records in `part` (stats) and
+//   optionally with in = relu(bn(z)) rebuilt from the producer's z (xa);
+// a dgrad shape gets  out (=|+=) conv(in)  with in = dz, optionally rebuilt from (d_u, z) (ba).
+// Returns the grid size (= number of partial-sum records when stats), 0 if no kernel was built for the request.
+template <int CIN, int TAPS, int COUT, bool FWD>
+int tm_conv_launch(bool accum, bool stats, const float* in, const float* packet, float* out, int frames, int cus,
+                   double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
+  const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
+  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
+  if constexpr (FWD) {
+    if (accum || ba) return 0;
+    if (xa) {
+      if constexpr (CIN % 2 == 0) {
+        if (stats) return tm_conv_launch1<CIN, TAPS, COUT, false, true, tmm::kXfBnRelu>(in, packet, out, frames, cus, part, *xa, nb, st);
+        return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfBnRelu>(in, packet, out, frames, cus, nullptr, *xa, nb, st);
+      }
+      return 0;
+    }
+    if (stats) return tm_conv_launch1<CIN, TAPS, COUT, false, true, tmm::kXfNone>(in, packet, out, frames, cus, part, nx, nb, st);
+    return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
+  } else {
+    if (stats || xa) return 0;
+    if (ba) {
+      if constexpr (CIN % 2 == 0) {
+        if (accum) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfBnBwd>(in, packet, out, frames, cus, nullptr, nx, *ba, st);
+        return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfBnBwd>(in, packet, out, frames, cus, nullptr, nx, *ba, st);
+      }
+      return 0;
+    }
+    if (accum) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
+    return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
+  }
+}
+
+
+template <int CIN, int TAPS, int COUT, bool XF, bool DZF>
+int tm_wgrad_launch1(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, tmm::XformArgs xa,
+                     tmm::BnBwdArgs ba, hipStream_t st) {
+  using G = tmm::Geo<CIN, TAPS, COUT>;
+  const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
+  const int grid = std::min(ntiles, cus * 2);
+  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32 + 2 * CIN + 4 * COUT) * sizeof(float);
+  static unsigned long long attr = 0;
+  allow_lds(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>), lds, attr);
+  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW,
+                     dbias, frames, xa, ba);
+  return 1;
+}
+// xa: x is the producer's z (see tm_conv); ba: dz is d_u, rebuilt through BatchNorm backward from (d_u, z)
+template <int CIN, int TAPS, int COUT>
+int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, const tmm::XformArgs* xa,
+                    const tmm::BnBwdArgs* ba, hipStream_t st) {
+  const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
+  const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
+  if (xa && ba) return tm_wgrad_launch1<CIN, TAPS, COUT, true, true>(x, dz, dW, dbias, frames, cus, *xa, *ba, st);
+  if (xa) return tm_wgrad_launch1<CIN, TAPS, COUT, true, false>(x, dz, dW, dbias, frames, cus, *xa, nb, st);
+  if (ba) return tm_wgrad_launch1<CIN, TAPS, COUT, false, true>(x, dz, dW, dbias, frames, cus, nx, *ba, st);
+  return tm_wgrad_launch1<CIN, TAPS, COUT, false, false>(x, dz, dW, dbias, frames, cus, nx, nb, st);
+}
+
+// One list-driven dispatcher set per translation unit: TM_FWD / TM_BWD are X-macro lists of (cin, taps, cout).
+#define RCED_TM_DEFINE_DISPATCH(SUFFIX, TM_FWD, TM_BWD)                                                                   \
+  int tm_conv##SUFFIX(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet, \
+                      float* out, int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba,    \
+                      hipStream_t st) {                                                                                     \
+    TM_FWD(RCED_TM_CONV_FWD_CASE)                                                                                           \
+    TM_BWD(RCED_TM_CONV_BWD_CASE)                                                                                           \
+    return 0;                                                                                                               \
+  }                                                                                                                         \
+  bool tm_has##SUFFIX(bool fwd, int cin, int taps, int cout) {                                                              \
+    if (fwd) { TM_FWD(RCED_TM_HAS_CASE) } else { TM_BWD(RCED_TM_HAS_CASE) }                                                 \
+    return false;                                                                                                           \
+  }                                                                                                                         \
+  int tm_wgrad##SUFFIX(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames,   \
+                       int cus, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {                       \
+    TM_FWD(RCED_TM_WGRAD_CASE) /* the list tm_has(true, ...) answers from: fuse_dz / virt rely on the two agreeing */       \
+    return 0;                                                                                                               \
+  }
+#define RCED_TM_CONV_FWD_CASE(CI, TP, CO)                \
+  if (fwd && cin == CI && taps == TP && cout == CO)      \
+    return rced::tmd::tm_conv_launch<CI, TP, CO, true>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
+#define RCED_TM_CONV_BWD_CASE(CI, TP, CO)                \
+  if (!fwd && cin == CI && taps == TP && cout == CO)     \
+    return rced::tmd::tm_conv_launch<CI, TP, CO, false>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
+#define RCED_TM_HAS_CASE(CI, TP, CO) \
+  if (cin == CI && taps == TP && cout == CO) return true;
+#define RCED_TM_WGRAD_CASE(CI, TP, CO)              \
+  if (cin == CI && taps == TP && cout == CO)        \
+    return rced::tmd::tm_wgrad_launch<CI, TP, CO>(x, dz, dW, dbias, frames, cus, xa, ba, st);
+
+}  // namespace tmd
+}  // namespace rced
