@@ -57,6 +57,25 @@ def test_parity_vs_oracle_shapes(net_work, tag, variant, path, shape, built):
 
 
 @pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_parity_vs_oracle_random_shapes_weights_and_inputs(net_work, tag, variant, built):
+    """Fuzz: 8 seeded draws per net of batch, frames (1..40: below / across / far past the tile sizes 3 and 4),
+    weight seed, input scale and sparsity (zero frames, zero utterances), fused path vs the plain-C oracle in fp64."""
+    rng = np.random.default_rng(9000 + variant)
+    for _ in range(8):
+        n, t = int(rng.integers(1, 5)), int(rng.integers(1, 41))
+        w = rced_np.make_weights(net_work, seed=int(rng.integers(1, 1 << 30)))
+        x = rced_np.make_input(n, t, seed=int(rng.integers(1, 1 << 30))) * np.float32(rng.choice([1e-3, 1.0, 30.0]))
+        if rng.random() < 0.5:
+            x[:, rng.integers(0, t)] = 0.0           # a silent frame
+        if n > 1 and rng.random() < 0.3:
+            x[rng.integers(0, n)] = 0.0              # a silent utterance (zero padding of the loader, data_loader.py:198-209)
+        ref = rced_c.forward(net_work, w, x, np.float64)
+        y = make_model(variant, w, "auto")(x)
+        assert np.isfinite(y).all()
+        assert rel_err(y, ref) < RTOL, (n, t)
+
+
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
 def test_device_resident_path_equals_host_path(net_work, tag, variant, built):
     import torch
     w, g = load_golden(tag)
