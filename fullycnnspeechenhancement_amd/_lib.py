@@ -41,6 +41,7 @@ SYMBOLS = {
     "rced_train_destroy": (None, [_vp]),
     "rced_train_step": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.POINTER(ctypes.c_double), _vp]),
+    "rced_train_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "rced_train_global_step": (ctypes.c_longlong, [_vp]),
     "rced_train_get_variables": (ctypes.c_int, [_vp, _c_float_p, ctypes.c_size_t]),
     "rced_train_get_gradients": (ctypes.c_int, [_vp, _c_float_p, ctypes.c_size_t]),

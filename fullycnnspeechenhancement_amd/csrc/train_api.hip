@@ -488,10 +488,16 @@ int rced_train_set_state(rced_trainer* t, const float* m_blob_host, const float*
   return RCED_OK;
 }
 
-int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int N, int T, float lr, double* loss_out,
-                    void* stream) {
+}  // extern "C"
+
+namespace {
+// pred_dev != nullptr: forward only (rced_train_forward) -- batch-statistics BatchNorm, nothing is updated, the
+// prediction is copied to pred_dev.  Otherwise the full step.
+int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pred_dev, int N, int T, float lr,
+              double* loss_out, void* stream) {
   if (!t) return rced_fail(RCED_ERR_ARG, "trainer is NULL");
-  if (N <= 0 || T <= 0 || !x_dev || !y_dev) return rced_fail(RCED_ERR_ARG, "bad batch");
+  if (N <= 0 || T <= 0 || !x_dev || (!y_dev && !pred_dev)) return rced_fail(RCED_ERR_ARG, "bad batch");
+  const bool forward_only = pred_dev != nullptr;
   DeviceGuard g(t->device);
   if (!g.ok) return rced_fail(RCED_ERR_HIP, "hipSetDevice(%d) failed", t->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -585,7 +591,8 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
       else if (int rc = reduce_channels(t, t->z[l], t->z[l], nullptr, nullptr, P, s.cout, st))
         return rc;
       hipLaunchKernelGGL(train::bn_stats_finish, dim3(1), dim3(64), 0, st, (const double*)t->sums, (double)P, s.cout,
-                         kBnEps, kBnMomentum, t->mu[l], t->rstd[l], t->params + f.mmean, t->params + f.mvar);
+                         kBnEps, forward_only ? 1.f : kBnMomentum, t->mu[l], t->rstd[l], t->params + f.mmean,
+                         t->params + f.mvar);   // momentum 1: the moving statistics stay as they are
     }
     if (t->out[l + 1] != t->z[l] && !t->virt[l + 1]) {
       if (s.cout % 2 == 0)
@@ -602,6 +609,11 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
     }
   }
   HIP_TRY(hipGetLastError());
+  if (forward_only) {
+    HIP_TRY(hipMemcpyAsync(pred_dev, t->out[L], P * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RCED_OK;
+  }
   // ---- loss and its gradient (trainer.py:146-147,153)
   hipLaunchKernelGGL(train::loss_fwd_bwd, dim3(kReduceGrid), dim3(train::kThreads), 0, st, (const float*)t->out[L], y_dev,
                      P, 1.f / (float)t->batch_size, t->G[L], t->part);
@@ -723,6 +735,20 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
   for (double v : hp) loss += v;
   if (loss_out) *loss_out = loss / (double)t->batch_size;
   return RCED_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int N, int T, float lr, double* loss_out,
+                    void* stream) {
+  if (!y_dev) return rced_fail(RCED_ERR_ARG, "bad batch");
+  return train_run(t, x_dev, y_dev, nullptr, N, T, lr, loss_out, stream);
+}
+
+int rced_train_forward(rced_trainer* t, const float* x_dev, float* pred_dev, int N, int T, void* stream) {
+  if (!pred_dev) return rced_fail(RCED_ERR_ARG, "bad batch");
+  return train_run(t, x_dev, nullptr, pred_dev, N, T, 0.f, nullptr, stream);
 }
 
 }  // extern "C"

@@ -53,6 +53,24 @@ class FullyCNNTrainer(object):
                                                ctypes.c_float(self.lr), ctypes.byref(loss), st))
         return loss.value, None, self.global_step
 
+    def valid_step(self, input_x):
+        """trainer.py:245-250: `sess.run(self.pred)` on the training graph.  That graph was built with
+        is_training=True (trainer.py:165-172), so BatchNorm uses the statistics of the batch it is given; fetching
+        only `pred` runs no UPDATE_OPS and no optimizer step, so nothing changes.  ndarray in -> ndarray out, cuda
+        tensor in -> cuda tensor out.  (The inference graph of tester.py / infer.py, which normalises with the moving
+        statistics, is `build_model(net_work, False, weights=trainer.variables())`.)"""
+        import torch
+        dev = "cuda:%d" % self.device
+        is_tensor = hasattr(input_x, "is_cuda")
+        x = torch.as_tensor(input_x if is_tensor else np.asarray(input_x, dtype=np.float32), device=dev).float().contiguous()
+        if x.dim() != 4 or x.shape[2] != spec.FEATURE_DIM or x.shape[3] != 1:
+            raise ValueError("input must be [N, T, 129, 1]")
+        y = torch.empty_like(x)
+        if x.numel():
+            st = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(_lib.load().rced_train_forward(self._h, x.data_ptr(), y.data_ptr(), int(x.shape[0]), int(x.shape[1]), st))
+        return y if is_tensor else y.cpu().numpy()
+
     def fit_step(self, input_x, target_y):
         """One iteration of the loop body of trainer.py:212-215: step, then set lr for the next step."""
         out = self.train_step(input_x, target_y)

@@ -148,6 +148,12 @@ void rced_train_destroy(rced_trainer* t);
 int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int N, int T, float lr,
                     double* loss_out, void* stream);
 
+/* FullyCNNTrainer.valid_step (trainer.py:245-250): sess.run(self.pred) on the TRAINING graph, i.e. the model
+ * built with is_training=True -- BatchNorm normalises with the statistics of the batch it is given, and because
+ * only pred is fetched nothing is updated (no UPDATE_OPS, no optimizer step).  x_dev, pred_dev: DEVICE
+ * [N, T, 129, 1] float32.  Synchronises the stream. */
+int rced_train_forward(rced_trainer* t, const float* x_dev, float* pred_dev, int N, int T, void* stream);
+
 long long rced_train_global_step(rced_trainer* t);
 /* Current variables / last gradients, in blob order (gradients of moving statistics are 0). */
 int rced_train_get_variables(rced_trainer* t, float* blob_host, size_t n_floats);
