@@ -358,6 +358,11 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
                                                          (pxx - padl) * D.cinp + 2 * kq, w, lane, acc);
   }
   // ---- epilogue: (+skip) -> ReLU -> zero the gap pixels -> LDS (or the hand-off tensor)
+  // A layer that stores to global memory here (skip fragments, the hand-off tensor) waits NOW for the next packet's
+  // LDS-DMA -- issued a whole pass ago, so this costs nothing -- and ends on a bare barrier: its stores stay in flight
+  // across the barrier instead of exposing their latency in front of it (vmcnt counts loads and stores alike).  Nobody
+  // reads them before a later layer's vmcnt(0) has retired them.  The other layers wait at their end (layer_end_sync).
+  if constexpr (D.saves_skip || kLast) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int tile = t < NR ? wave + kWaves * t : xtile;
@@ -409,7 +414,8 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
       else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
     }
     wcur ^= 1;
-    layer_end_sync();
+    if constexpr (N::layer[L].saves_skip || L == N::kLayers - 1) __syncthreads();
+    else layer_end_sync();
     run_layers<N, L + 1>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0);
   }
 }

@@ -185,7 +185,10 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                        scratch, tid * 16, (G::skip_unit(D.skip_from) + t * MT + mt) * kThreads * 16, 0));
   }
-
+  // Layers that store to global memory in the epilogue (skip fragments, the hand-off tensor) wait HERE for the
+  // next packet's LDS-DMA (issued a whole pass ago) and end on a bare barrier, so the stores stay in flight across
+  // it; the other layers wait at their end (chain::layer_end_sync).  See chain::run_layer.
+  if constexpr (D.saves_skip || kLast) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -241,7 +244,8 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
     if (wave < G::kExtra) chain16::run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0);
     else chain16::run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
     wcur ^= 1;
-    chain::layer_end_sync();
+    if constexpr (N::layer[L].saves_skip || L == N::kLayers - 1) __syncthreads();
+    else chain::layer_end_sync();
     chain16::run_layers<N, L + 1>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0);
   }
 }
