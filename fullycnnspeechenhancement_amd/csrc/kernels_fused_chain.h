@@ -19,6 +19,10 @@
 
 #include "lds_dma.h"
 
+#ifndef RCED_CHAIN_DEPTH
+#define RCED_CHAIN_DEPTH 1   // operand prefetch depth (b64 steps) of the fp32 R-CED passes
+#endif
+
 namespace rced {
 namespace chain {
 
@@ -354,7 +358,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc);
   } else {
     constexpr int padl = (D.taps - 1) / 2;
-    gemm_pass<NR, NX, MT, G::K(L), 128 * D.cinp, 1, XMT>(in, (px0 - padl) * D.cinp + 2 * kq,
+    gemm_pass<NR, NX, MT, G::K(L), 128 * D.cinp, RCED_CHAIN_DEPTH, XMT>(in, (px0 - padl) * D.cinp + 2 * kq,
                                                          (pxx - padl) * D.cinp + 2 * kq, w, lane, acc);
   }
   // ---- epilogue: (+skip) -> ReLU -> zero the gap pixels -> LDS (or the hand-off tensor)
