@@ -31,13 +31,19 @@ struct Geo {
   static constexpr int kS = kF + kG;
   static constexpr int kNPX = kTF * kS;
   static constexpr int kTiles = (kNPX + 15) / 16;
-  static constexpr int kRegular = kTiles / kWaves, kExtra = kTiles - kRegular * kWaves;
-  static constexpr int kK = TAPS * kCinP;
+  static constexpr int kK = TAPS * kCinP;                // the layer's K
   static constexpr int kMT = (COUT + 15) / 16;
-  static constexpr int kNB64 = kK / 8, kNTail = (kK % 8 + 3) / 4;
+  // conv1xk_mfma with 8 output channels: an MFMA column is a PAIR of adjacent pixels and the 16 rows are
+  // (pixel parity, cout), so no row is wasted: K grows by one tap ((TAPS+1)*CinP, the parity-1 rows are the kernel
+  // shifted by one tap) and the number of column tiles halves.  kPH = parities per column.
+  static constexpr int kPH = COUT == 8 ? 2 : 1;
+  static constexpr int kCTiles = kPH == 2 ? (kNPX + 31) / 32 : kTiles;          // conv column tiles
+  static constexpr int kRegular = kCTiles / kWaves, kExtra = kCTiles - kRegular * kWaves;
+  static constexpr int kKP = (TAPS + kPH - 1) * kCinP;   // K of the conv packet
+  static constexpr int kNB64 = kKP / 8, kNTail = (kKP % 8 + 3) / 4;
   static constexpr int kData = kNB64 * kMT * 128 + kNTail * kMT * 64;
   static constexpr int kPacket = kData + 32;             // + shift[32]
-  static constexpr int kInRows = kG + 16 * kTiles + kG;
+  static constexpr int kInRows = kG + (kPH == 2 ? 32 * kCTiles + 1 : 16 * kTiles) + kG;
   static constexpr int kInFloats = ((kInRows * kCinP + 3) / 4) * 4;
   static constexpr int kLdsFloats = kInFloats + kPacket;
 };
@@ -47,15 +53,17 @@ struct Geo {
 // transpose = 1: dgrad    (rows = CIN_L outputs; the packet is for a conv whose input has COUT_L channels:
 //                          W_t[tap'][co_l][ci_l] = w[TAPS-1-tap'][ci_l][co_l]).
 // cin / cout below are those of the conv being PACKED (dgrad: cin = COUT_L, cout = CIN_L).
+// ph = 2 (cout = 8, Geo::kPH): rows are (parity p, co) = 8 p + co over K = (taps + 1) * cinp, row (p, co) holding the
+// kernel of output co shifted by p taps; shift[8 p + co] = shift[co].
 static __global__ void pack_packet(const float* __restrict__ w, const float* __restrict__ shift, int taps, int cin, int cout,
-                            int transpose, float* __restrict__ packet) {
-  const int cinp = (cin + 1) & ~1, K = taps * cinp, MT = (cout + 15) / 16;
+                            int transpose, int ph, float* __restrict__ packet) {
+  const int cinp = (cin + 1) & ~1, K = (taps + ph - 1) * cinp, MT = (cout + 15) / 16;
   const int NB = K / 8, NTL = (K % 8 + 3) / 4, data = NB * MT * 128 + NTL * MT * 64;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= data + 32) return;
   if (e >= data) {
     const int c = e - data;
-    packet[e] = (shift && c < cout) ? shift[c] : 0.f;
+    packet[e] = (shift && c < ph * cout) ? shift[ph == 2 ? (c & 7) : c] : 0.f;
     return;
   }
   int k, co;
@@ -69,8 +77,13 @@ static __global__ void pack_packet(const float* __restrict__ w, const float* __r
     co = 16 * mt + (lane & 15);
   }
   float v = 0.f;
-  const int tap = k / cinp, ci = k - tap * cinp;
-  if (k < K && co < cout && ci < cin)
+  int tap = k / cinp;
+  const int ci = k - tap * cinp;
+  if (ph == 2) {            // row = (parity, co): the parity-1 rows see the window one tap later
+    tap -= co >> 3;
+    co &= 7;
+  }
+  if (k < K && co < cout && ci < cin && tap >= 0 && tap < taps)
     v = transpose ? w[((taps - 1 - tap) * cout + co) * cin + ci]    // w[tap_l][ci_l = co][co_l = ci], layer dims (cout, cin)
                   : w[(tap * cin + ci) * cout + co];
   packet[e] = v;
@@ -237,11 +250,11 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
                                           int frames, int wave, int lane,
                                           double (&st1)[Geo<CIN, TAPS, COUT>::kMT][4], double (&st2)[Geo<CIN, TAPS, COUT>::kMT][4]) {
   using G = Geo<CIN, TAPS, COUT>;
-  constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMT;
+  constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMT, PH = G::kPH;
   const int n = lane & 15, kq = lane >> 4;
   const float* in = lds_in + G::kG * G::kCinP;
   const int xtile = NR * kWaves + wave;
-  const int px0 = 16 * wave + n, pxx = 16 * xtile + n;
+  const int px0 = 16 * wave + n, pxx = 16 * xtile + n;     // column index: a pixel, or a pixel pair when PH = 2
   f32x4 acc[NT][MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -249,8 +262,8 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t][mt] = sh;
   }
-  chain::gemm_pass<NR, NX, MT, G::kK, 64 * G::kCinP, 2>(in, (px0 - G::kG) * G::kCinP + 2 * kq,
-                                                        (pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc);
+  chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, 2>(in, (PH * px0 - G::kG) * G::kCinP + 2 * kq,
+                                                              (PH * pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc);
   float p1[MT][4], p2[MT][4];   // this tile's share of sum z, sum z^2 (<= NT values each, fp32)
   if constexpr (STATS) {
 #pragma unroll
@@ -260,7 +273,8 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int px = t < NR ? px0 + 64 * t : pxx;
+    const int col = t < NR ? px0 + 64 * t : pxx;
+    const int px = PH == 2 ? 2 * col + (kq >> 1) : col;   // PH = 2: lane rows 4kq.. = parity kq >> 1, couts 4 (kq & 1)..
     const int fr = px / G::kS, f = px - fr * G::kS;
     if (px >= G::kNPX || f >= kF || frame0 + fr >= frames) continue;
     if constexpr (STATS) {
@@ -276,7 +290,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
     float* op = out + ((size_t)(frame0 + fr) * kF + f) * COUT;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int co0 = 16 * mt + 4 * kq;
+      const int co0 = PH == 2 ? 4 * (kq & 1) : 16 * mt + 4 * kq;
       f32x4 v = acc[t][mt];
       if (co0 + 1 < COUT || (co0 < COUT && (COUT & 1))) {
         // 8-byte pieces where the row stride allows it (COUT even), else scalars
@@ -392,8 +406,12 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
           a += __shfl_xor(a, o, 64);
           b += __shfl_xor(b, o, 64);
         }
-        if ((lane & 15) == 0) {
-          const int c = 16 * mt + 4 * (lane >> 4) + j;
+        if constexpr (G::kPH == 2) {   // lanes kq and kq ^ 2 hold the two pixel parities of the same channels
+          a += __shfl_xor(a, 32, 64);
+          b += __shfl_xor(b, 32, 64);
+        }
+        if ((lane & 15) == 0 && (G::kPH == 1 || lane < 32)) {
+          const int c = G::kPH == 2 ? 4 * (lane >> 4) + j : 16 * mt + 4 * (lane >> 4) + j;
           red[(wave * 32 + c) * 2 + 0] = a;
           red[(wave * 32 + c) * 2 + 1] = b;
         }
@@ -417,17 +435,27 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
 // whole [K][COUT] partial in accumulators, and the workgroup adds it to dW with atomics at the end.
 // ---------------------------------------------------------------------------------------------
 // XF: x is the producer's z (rebuilt to relu(bn(z)));  DZF: dz is d_u (rebuilt to the BatchNorm-backward dz).
-template <int CIN, int TAPS, int COUT, bool XF, bool DZF>
+// PH = 2 (COUT = 8 only): 8 output channels would fill half of the 16 MFMA columns, so a column is (pixel parity, co)
+// and the pixel axis (MFMA K) walks pixel PAIRS q:  D[k'][(ph, co)] = sum_q x[2q + k'] * dz[2q + ph][co] with
+// k' = tap + ph in 0..TAPS, and dW[tap][ci][co] collects D[(tap + ph, ci)][(ph, co)] of both parities: one more tap
+// row (+1/TAPS MFMAs) for half the pixel steps.
+template <int CIN, int TAPS, int COUT, bool XF, bool DZF, int PH = 1>
 __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restrict__ x, const float* __restrict__ dz,
                                                            float* __restrict__ dW, float* __restrict__ dbias, int frames,
                                                            XformArgs xa, BnBwdArgs ba) {
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(CIN % 2 == 0 && COUT % 2 == 0, "wgrad1xk_mfma stages float4 / float2 pieces");
+  static_assert(PH == 1 || (PH == 2 && COUT == 8 && G::kNPX % 2 == 0), "two pixel parities x 8 channels = 16 columns");
   // one spare k row carries a constant 1, so its output row is sum_px dz = dbias
-  constexpr int KT = (G::kK + 1 + 15) / 16, NTo = G::kMT;
-  constexpr int kOneTile = G::kK / 16, kOneRow = G::kK % 16;
+  constexpr int kRowsK = (TAPS + PH - 1) * G::kCinP;   // window rows (PH = 1: the layer's K)
+  constexpr int KT = (kRowsK + 1 + 15) / 16, NTo = PH == 2 ? 1 : G::kMT;
+  constexpr int kOneTile = kRowsK / 16, kOneRow = kRowsK % 16;
   constexpr int kDzRows = 16 * G::kTiles + 4;
-  constexpr int kDzStride = 32;                        // floats per pixel row of the dz tile (>= 16*NTo, bank friendly)
+  constexpr int kDzStride = PH == 2 ? 8 : 32;          // floats per pixel row of the dz tile (>= 16*NTo, bank friendly)
+  constexpr int kGroups = PH == 2 ? (G::kNPX / 2 + 3) / 4 : G::kNPX / 4 + 1;   // 4 pixels (pixel pairs) per MFMA
+  // the last group's padded rows read past the staged window: into the 64-float slack, which stays zero
+  static_assert((4 * PH * (kGroups - 1) + PH * 3) * G::kCinP + 16 * (KT - 1) + 15 < G::kInFloats + 64, "A reads stay inside lin + slack");
+  static_assert(4 * PH * (kGroups - 1) + PH * 3 + (PH - 1) < kDzRows, "B reads stay inside the dz tile");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lin = lds;                                    // [kInRows + tail][CinP]
   float* ldz = lds + G::kInFloats + 64;                // [kDzRows][32]
@@ -452,8 +480,9 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
     if constexpr (DZF) tile_fetch<COUT>(ba.z, blockIdx.x * kTF, frames, tid, prez2);
   }
   __syncthreads();
-  const float* ain = lin + kq * G::kCinP + i;          // window start of pixel (px0 + kq) is row (px0 + kq) of lin
-  const float* bin = ldz + kq * kDzStride + i;
+  // window start of pixel p is row p of lin; lane kq owns pixel px0 + kq (PH = 1) or the pair starting at px0 + 2 kq
+  const float* ain = lin + PH * kq * G::kCinP + i;
+  const float* bin = PH == 2 ? ldz + (2 * kq + (i >> 3)) * kDzStride + (i & 7) : ldz + kq * kDzStride + i;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     auto where = [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; };
     if constexpr (XF) tile_commit_bnrelu<CIN>(lin, tid, prex, where, xt, tile * kTF, frames);
@@ -471,8 +500,8 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
       if constexpr (DZF) tile_fetch<COUT>(ba.z, (tile + gridDim.x) * kTF, frames, tid, prez2);
     }
     pin();
-    for (int g = wave; g < G::kNPX / 4 + 1; g += kWaves) {
-      const int px0 = 4 * g;
+    for (int g = wave; g < kGroups; g += kWaves) {
+      const int px0 = 4 * PH * g;
       float a[KT], b[NTo];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) a[kt] = ain[px0 * G::kCinP + 16 * kt];
@@ -486,19 +515,20 @@ __global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restric
     }
     __syncthreads();
   }
-  // D row = k = 16*kt + 4*kq + r, column = co = 16*nt + i
+  // D row = k = 16*kt + 4*kq + r, column = co = 16*nt + i   (PH = 2: column = (parity i >> 3, co = i & 7), tap = k' - parity)
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
     for (int nt = 0; nt < NTo; ++nt) {
-      const int co = 16 * nt + i;
+      const int co = PH == 2 ? (i & 7) : 16 * nt + i;
+      const int ph = PH == 2 ? (i >> 3) : 0;
       const float vv[4] = {acc[kt][nt].x, acc[kt][nt].y, acc[kt][nt].z, acc[kt][nt].w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = 16 * kt + 4 * kq + r;
-        const int tap = k / G::kCinP, ci = k - tap * G::kCinP;
-        if (k < G::kK && ci < CIN && co < COUT) atomicAdd(dW + (tap * CIN + ci) * COUT + co, vv[r]);
-        if (k == G::kK && co < COUT && dbias) atomicAdd(dbias + co, vv[r]);
+        const int tapk = k / G::kCinP, ci = k - tapk * G::kCinP, tap = tapk - ph;
+        if (k < kRowsK && ci < CIN && co < COUT && tap >= 0 && tap < TAPS) atomicAdd(dW + (tap * CIN + ci) * COUT + co, vv[r]);
+        if (k == kRowsK && co < COUT && dbias) atomicAdd(dbias + co, vv[r]);
       }
     }
 }

@@ -553,12 +553,13 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       if (t->pk_fwd[l]) {
         const int n = (int)tm_packet_floats(f.cin, s.kw, s.cout);
         hipLaunchKernelGGL(tmm::pack_packet, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
-                           (const float*)(t->params + f.bias), s.kw, f.cin, s.cout, 0, t->pk_fwd[l]);
+                           (const float*)(t->params + f.bias), s.kw, f.cin, s.cout, 0, rced::tmd::tm_packet_parities(s.cout),
+                           t->pk_fwd[l]);
       }
       if (t->pk_bwd[l]) {
         const int n = (int)tm_packet_floats(s.cout, s.kw, f.cin);
         hipLaunchKernelGGL(tmm::pack_packet, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
-                           (const float*)nullptr, s.kw, s.cout, f.cin, 1, t->pk_bwd[l]);
+                           (const float*)nullptr, s.kw, s.cout, f.cin, 1, rced::tmd::tm_packet_parities(f.cin), t->pk_bwd[l]);
       }
     }
   // ---- forward (is_training=True)

@@ -25,8 +25,9 @@ inline void allow_lds(const void* kernel, size_t lds, unsigned long long& done) 
   done |= bit;
 }
 
+inline int tm_packet_parities(int cout) { return cout == 8 ? 2 : 1; }   // Geo::kPH
 inline size_t tm_packet_floats(int cin, int taps, int cout) {
-  const int cinp = (cin + 1) & ~1, K = taps * cinp, MT = (cout + 15) / 16;
+  const int cinp = (cin + 1) & ~1, K = (taps + tm_packet_parities(cout) - 1) * cinp, MT = (cout + 15) / 16;
   return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + 32;
 }
 
@@ -85,10 +86,11 @@ int tm_wgrad_launch1(const float* x, const float* dz, float* dW, float* dbias, i
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const int grid = std::min(ntiles, cus * 2);
-  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * 32 + 2 * CIN + 4 * COUT) * sizeof(float);
+  constexpr int PH = COUT == 8 ? 2 : 1;   // 8 output channels: two pixel parities share the 16 MFMA columns
+  const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * (PH == 2 ? 8 : 32) + 2 * CIN + 4 * COUT) * sizeof(float);
   static unsigned long long attr = 0;
-  allow_lds(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>), lds, attr);
-  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW,
+  allow_lds(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF, PH>), lds, attr);
+  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF, PH>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW,
                      dbias, frames, xa, ba);
   return 1;
 }
