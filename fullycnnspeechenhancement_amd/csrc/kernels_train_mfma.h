@@ -22,6 +22,11 @@ using chain::pin;
 constexpr int kF = 129;
 constexpr int kTF = 2;                 // frames per tile
 constexpr int kWaves = 4, kThreads = 256;
+#ifndef RCED_TM_OCC
+#define RCED_TM_OCC 2   // workgroups per CU the register allocator must leave room for (conv / wgrad kernels): several
+                        // of them sat at 260-300 VGPRs+AGPRs = ONE workgroup per CU; 2 costs a few spilled dwords in the
+                        // largest, 3 spills hundreds of bytes and is slower (64.8 / 60.9 / 77.8 ms per CR-CED step)
+#endif
 
 template <int CIN, int TAPS, int COUT>
 struct Geo {
@@ -336,7 +341,7 @@ struct XformArgs {
 };
 constexpr int kXfNone = 0, kXfBnRelu = 1, kXfBnBwd = 2;
 template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF>
-__global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict__ in, const float* __restrict__ packet,
+__global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const float* __restrict__ in, const float* __restrict__ packet,
                                                           float* __restrict__ out, int frames, double* __restrict__ part,
                                                           XformArgs xa, BnBwdArgs ba) {
   using G = Geo<CIN, TAPS, COUT>;
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(kThreads) void conv1xk_mfma(const float* __restrict
 // k' = tap + ph in 0..TAPS, and dW[tap][ci][co] collects D[(tap + ph, ci)][(ph, co)] of both parities: one more tap
 // row (+1/TAPS MFMAs) for half the pixel steps.
 template <int CIN, int TAPS, int COUT, bool XF, bool DZF, int PH = 1>
-__global__ __launch_bounds__(kThreads) void wgrad1xk_mfma(const float* __restrict__ x, const float* __restrict__ dz,
+__global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const float* __restrict__ x, const float* __restrict__ dz,
                                                            float* __restrict__ dW, float* __restrict__ dbias, int frames,
                                                            XformArgs xa, BnBwdArgs ba) {
   using G = Geo<CIN, TAPS, COUT>;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels_train_mfma.h"
 
@@ -25,6 +26,19 @@ inline void allow_lds(const void* kernel, size_t lds, unsigned long long& done) 
   done |= bit;
 }
 
+// Persistent grids are sized from the occupancy the runtime reports for the kernel (registers + LDS): cus x resident
+// workgroups per CU, so every workgroup is resident from the start and walks the same number of tiles.
+// RCED_TM_GRID_MULT (experiments): oversubscribe by that factor.
+inline int resident_grid(const void* kernel, size_t lds, int cus, int& occ_cache) {
+  if (occ_cache <= 0) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, tmm::kThreads, lds) != hipSuccess || occ < 1) occ = 1;
+    static const int mult = [] { const char* e = getenv("RCED_TM_GRID_MULT"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    occ_cache = occ * mult;
+  }
+  return cus * occ_cache;
+}
+
 inline int tm_packet_parities(int cout) { return cout == 8 ? 2 : 1; }   // Geo::kPH
 inline size_t tm_packet_floats(int cin, int taps, int cout) {
   const int cinp = (cin + 1) & ~1, K = (taps + tm_packet_parities(cout) - 1) * cinp, MT = (cout + 15) / 16;
@@ -36,10 +50,12 @@ int tm_conv_launch1(const float* in, const float* packet, float* out, int frames
                     tmm::XformArgs xa, tmm::BnBwdArgs ba, hipStream_t st) {
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
-  const int grid = std::min(ntiles, std::min(cus * 4, kPairGrid));
   const size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 4 * CIN : 0)) * sizeof(float);
   static unsigned long long attr = 0;
-  allow_lds(reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), lds, attr);
+  static int occ = 0;
+  const void* kfn = reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>);
+  allow_lds(kfn, lds, attr);
+  const int grid = std::min(ntiles, std::min(resident_grid(kfn, lds, cus, occ), kPairGrid));
   hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), dim3(grid), dim3(tmm::kThreads), lds, st, in,
                      packet, out, frames, part, xa, ba);
   return grid;
@@ -85,11 +101,13 @@ int tm_wgrad_launch1(const float* x, const float* dz, float* dW, float* dbias, i
                      tmm::BnBwdArgs ba, hipStream_t st) {
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
-  const int grid = std::min(ntiles, cus * 2);
   constexpr int PH = COUT == 8 ? 2 : 1;   // 8 output channels: two pixel parities share the 16 MFMA columns
   const size_t lds = (G::kInFloats + 64 + (size_t)(16 * G::kTiles + 4) * (PH == 2 ? 8 : 32) + 2 * CIN + 4 * COUT) * sizeof(float);
   static unsigned long long attr = 0;
-  allow_lds(reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF, PH>), lds, attr);
+  static int occ = 0;
+  const void* kfn = reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF, PH>);
+  allow_lds(kfn, lds, attr);
+  const int grid = std::min(ntiles, resident_grid(kfn, lds, cus, occ));
   hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF, PH>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW,
                      dbias, frames, xa, ba);
   return 1;
