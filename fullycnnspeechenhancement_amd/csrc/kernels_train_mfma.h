@@ -250,11 +250,36 @@ __device__ __forceinline__ void tile_commit_bnbwd(float* lds, int tid, const f32
   }
 }
 
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX>
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15); the total is valid in lane 15 of the row.
+__device__ __forceinline__ float row_sum16(float v) {
+  // row_shr:1 / 2 / 4 / 8 (0x111, 0x112, 0x114, 0x118); bound_ctrl: lanes shifted in from outside the row read 0
+#define RCED_ROW_SHR(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+  v += RCED_ROW_SHR(v, 0x111);
+  v += RCED_ROW_SHR(v, 0x112);
+  v += RCED_ROW_SHR(v, 0x114);
+  v += RCED_ROW_SHR(v, 0x118);
+#undef RCED_ROW_SHR
+  return v;
+}
+
+// BatchNorm-backward sums of the PRODUCER of the tensor a dgrad writes its gradient for (SUMS kernels).  When that
+// tensor is the output of a plain conv+BN+ReLU layer, the gradient g this dgrad writes is only ever used masked:
+// d_u = g * [a*z + b > 0], and the layer's BatchNorm backward needs S1 = sum d_u and S2 = sum d_u * zhat over the
+// whole batch before anything else can run.  bwd_route2 got them from one more pass over g and z (HBM-bound, 8 ms of a
+// CR-CED step); here the dgrad forms them in its epilogue, where g is still in the accumulators: the tile of z arrives
+// by LDS-DMA (no VGPRs, in flight during the whole MFMA pass), and the kernel leaves per-workgroup records
+// (sum d_u, sum d_u * z) per channel in `part`; sums_fix turns the second into S2 = rstd * (sum d_u z - mu * S1).
+struct SumArgs {
+  const float* z;                          // pre-BatchNorm output of the producer, [frames][129][COUT]
+  const float *mu, *rstd, *gamma, *beta;   // its batch statistics and affine parameters
+};
+
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false>
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
                                           int frames, int wave, int lane,
-                                          double (&st1)[Geo<CIN, TAPS, COUT>::kMT][4], double (&st2)[Geo<CIN, TAPS, COUT>::kMT][4]) {
+                                          double* red_wave, const float* zt = nullptr, const float* stab = nullptr) {
   using G = Geo<CIN, TAPS, COUT>;
+  static_assert(!(SUMS && (STATS || ACCUM || G::kPH != 1 || (COUT & 1))), "SUMS: overwrite-mode dgrads with an even, unpaired cout");
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMT, PH = G::kPH;
   const int n = lane & 15, kq = lane >> 4;
   const float* in = lds_in + G::kG * G::kCinP;
@@ -269,8 +294,26 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
   }
   chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, 2>(in, (PH * px0 - G::kG) * G::kCinP + 2 * kq,
                                                               (PH * pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc);
-  float p1[MT][4], p2[MT][4];   // this tile's share of sum z, sum z^2 (<= NT values each, fp32)
-  if constexpr (STATS) {
+  float p1[MT][4], p2[MT][4];   // this tile's share of sum z, sum z^2 (<= NT values each, fp32); SUMS: sum d_u, sum d_u z
+  f32x4 sa4[MT], sb4[MT];       // SUMS: folded BatchNorm a, b of this lane's four channels per M-tile
+  if constexpr (SUMS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the z tile have landed in LDS ...
+    __syncthreads();                                    // ... and everybody else's
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co0 = 16 * mt + 4 * kq;
+      sa4[mt] = sb4[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (co0 + 1 < COUT) {
+        const f32x2 a = *reinterpret_cast<const f32x2*>(stab + co0), b = *reinterpret_cast<const f32x2*>(stab + COUT + co0);
+        sa4[mt].x = a.x; sa4[mt].y = a.y; sb4[mt].x = b.x; sb4[mt].y = b.y;
+      }
+      if (co0 + 3 < COUT) {
+        const f32x2 a = *reinterpret_cast<const f32x2*>(stab + co0 + 2), b = *reinterpret_cast<const f32x2*>(stab + COUT + co0 + 2);
+        sa4[mt].z = a.x; sa4[mt].w = a.y; sb4[mt].z = b.x; sb4[mt].w = b.y;
+      }
+    }
+  }
+  if constexpr (STATS || SUMS) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -291,6 +334,23 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
           p1[mt][j] += v;
           p2[mt][j] = fmaf(v, v, p2[mt][j]);
         }
+    }
+    if constexpr (SUMS) {
+      const float* zp = zt + (fr * kF + f) * COUT;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co0 = 16 * mt + 4 * kq;
+        f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+        if (co0 + 1 < COUT) { const f32x2 q = *reinterpret_cast<const f32x2*>(zp + co0); zv.x = q.x; zv.y = q.y; }
+        if (co0 + 3 < COUT) { const f32x2 q = *reinterpret_cast<const f32x2*>(zp + co0 + 2); zv.z = q.x; zv.w = q.y; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (co0 + (j | 1) >= COUT) continue;   // pairs: (0,1) need co0+1 < COUT, (2,3) need co0+3 < COUT
+          const float du = fmaf(sa4[mt][j], zv[j], sb4[mt][j]) > 0.f ? acc[t][mt][j] : 0.f;
+          p1[mt][j] += du;
+          p2[mt][j] = fmaf(du, zv[j], p2[mt][j]);
+        }
+      }
     }
     float* op = out + ((size_t)(frame0 + fr) * kF + f) * COUT;
 #pragma unroll
@@ -321,14 +381,59 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
       }
     }
   }
-  if constexpr (STATS) {
+  if constexpr (STATS || SUMS) {
+    // Running per-channel sums live in this wave's LDS record as doubles (in registers they cost 32 VGPRs for the whole
+    // kernel, which is what decided the occupancy): add the tile's fp32 shares over the 16 pixel lanes of a row with
+    // DPP shifts (lane 15 of the row ends up with the sum), then that lane adds them to red_wave[channel][2].
+    const bool writer = (lane & 15) == 15 && (PH == 1 || lane < 32);
+    float ra[MT][4], rb[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        st1[mt][j] += (double)p1[mt][j];
-        st2[mt][j] += (double)p2[mt][j];
+        float a = row_sum16(p1[mt][j]), b = row_sum16(p2[mt][j]);
+        if constexpr (PH == 2) {   // lanes kq and kq ^ 2 hold the two pixel parities of the same channels
+          a += __shfl_xor(a, 32, 64);
+          b += __shfl_xor(b, 32, 64);
+        }
+        ra[mt][j] = a;
+        rb[mt][j] = b;
       }
+    if (writer) {   // all reads, then all writes: one LDS round trip instead of one per value
+      typedef double f64x2 __attribute__((ext_vector_type(2)));
+      f64x2 cur[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          cur[mt][j] = *reinterpret_cast<const f64x2*>(red_wave + 2 * ((PH == 2 ? 0 : 16 * mt) + 4 * kq + j));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f64x2*>(red_wave + 2 * ((PH == 2 ? 0 : 16 * mt) + 4 * kq + j)) =
+              f64x2{cur[mt][j].x + (double)ra[mt][j], cur[mt][j].y + (double)rb[mt][j]};
+    }
+  }
+}
+
+// SUMS: the z tile of the frames a workgroup is about to write gradients for, global -> LDS by LDS-DMA (contiguous in
+// both; 16 bytes per lane, 1 KiB per wave instruction).  A tile cut short by the end of the batch is copied with
+// ordinary loads instead (a 16-byte piece could straddle the end of the tensor).
+template <int COUT>
+__device__ __forceinline__ void ztile_fetch(const float* __restrict__ z, float* zt, int frame0, int frames, int tid) {
+  using St = Stage<COUT>;
+  const float* src = z + (size_t)frame0 * St::kFrame;
+  if (frames - frame0 >= kTF) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // the LDS destination goes through M0
+    constexpr int chunks = (St::kVec + 63) / 64;
+    for (int c = wave; c < chunks; c += kWaves) {
+      const int idx = c * 64 + lane;
+      if (idx < St::kVec) lds_dma16(src + (size_t)idx * 4, zt + c * 256);
+    }
+  } else {
+    const int nvalid = (frames - frame0) * St::kFrame;
+    for (int e = tid; e < nvalid; e += kThreads) zt[e] = src[e];
   }
 }
 
@@ -340,11 +445,22 @@ struct XformArgs {
   const float *mu, *rstd, *gamma, *beta;
 };
 constexpr int kXfNone = 0, kXfBnRelu = 1, kXfBnBwd = 2;
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF>
+// LDS floats in front of the SUMS areas (z tile, then [a | b][COUT]): the staging buffers and the XF tables, 16-byte aligned
+template <int CIN, int TAPS, int COUT, int XF>
+constexpr int conv_sums_off() {
+  return (Geo<CIN, TAPS, COUT>::kLdsFloats + (XF == kXfBnRelu ? 2 * CIN : XF == kXfBnBwd ? 4 * CIN : 0) + 3) & ~3;
+}
+template <int CIN, int TAPS, int COUT, int XF, bool SUMS>
+constexpr int conv_red_off() {   // even float offset: the records are doubles
+  return conv_sums_off<CIN, TAPS, COUT, XF>() + (SUMS ? kTF * kF * COUT + ((2 * COUT + 3) & ~3) : 0);
+}
+constexpr int kConvRedFloats = kWaves * 64 * 2;
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF, bool SUMS = false>
 __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const float* __restrict__ in, const float* __restrict__ packet,
                                                           float* __restrict__ out, int frames, double* __restrict__ part,
-                                                          XformArgs xa, BnBwdArgs ba) {
+                                                          XformArgs xa, BnBwdArgs ba, SumArgs sa) {
   using G = Geo<CIN, TAPS, COUT>;
+  static_assert(!SUMS || CIN % 2 == 0, "SUMS lives in the wide-staging tile loop");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lin = lds;
   float* lw = lds + G::kInFloats;
@@ -354,12 +470,15 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
   float* xt = lds + G::kLdsFloats;                      // [2 or 3][CIN], only with XF
   if constexpr (XF == kXfBnRelu) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
   if constexpr (XF == kXfBnBwd) bnbwd_table_fill<CIN>(xt, ba, tid);
+  float* zt = lds + conv_sums_off<CIN, TAPS, COUT, XF>();   // [kTF][129][COUT], only with SUMS
+  float* stab = zt + (SUMS ? Stage<SUMS ? COUT : 2>::kElems : 0);
+  if constexpr (SUMS) xform_table_fill<COUT>(stab, sa.mu, sa.rstd, sa.gamma, sa.beta, tid);
+  // [wave][32 channels][2] running sums (STATS / SUMS), doubles, behind everything else
+  double* red = reinterpret_cast<double*>(lds + conv_red_off<CIN, TAPS, COUT, XF, SUMS>());
+  if constexpr (STATS || SUMS)
+    for (int e = tid; e < kWaves * 64; e += kThreads) red[e] = 0.0;
+  double* red_wave = red + wave * 64;
   __syncthreads();
-  double st1[G::kMT][4], st2[G::kMT][4];
-#pragma unroll
-  for (int mt = 0; mt < G::kMT; ++mt)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st1[mt][j] = st2[mt][j] = 0.0;
   const int ntiles = (frames + kTF - 1) / kTF;
   if constexpr (CIN % 2 == 0) {
     f32x4 pre[Stage<CIN>::kPer], pre2[XF == kXfBnBwd ? Stage<CIN>::kPer : 1];
@@ -374,13 +493,14 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
       else if constexpr (XF == kXfBnBwd) tile_commit_bnbwd<CIN>(lin, tid, pre, pre2, where, xt, frame0, frames, ba.beta != nullptr);
       else tile_commit<CIN>(lin, tid, pre, where);
       __syncthreads();
+      if constexpr (SUMS) ztile_fetch<COUT>(sa.z, zt, frame0, frames, tid);   // the previous tile's epilogue is behind a barrier
       if (tile + (int)gridDim.x < ntiles) {
         tile_fetch<CIN>(in, (tile + gridDim.x) * kTF, frames, tid, pre);
         if constexpr (XF == kXfBnBwd) tile_fetch<CIN>(ba.z, (tile + gridDim.x) * kTF, frames, tid, pre2);
       }
       pin();
-      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1>(lin, lw, out, frame0, frames, wave, lane, st1, st2);
-      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0>(lin, lw, out, frame0, frames, wave, lane, st1, st2);
+      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab);
+      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab);
       __syncthreads();
     }
   } else {
@@ -393,35 +513,13 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
         lin[(G::kG + fr * G::kS + f) * G::kCinP + ci] = (frame0 + fr < frames) ? src[e] : 0.f;
       }
       __syncthreads();
-      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1>(lin, lw, out, frame0, frames, wave, lane, st1, st2);
-      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0>(lin, lw, out, frame0, frames, wave, lane, st1, st2);
+      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1>(lin, lw, out, frame0, frames, wave, lane, red_wave);
+      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0>(lin, lw, out, frame0, frames, wave, lane, red_wave);
       __syncthreads();
     }
   }
-  if constexpr (STATS) {
-    // lane (n, kq) holds channels 16*mt + 4*kq + j of its pixels: add over the 16 pixel lanes, then over the waves
-    double* red = reinterpret_cast<double*>(lds);             // [wave][32 channels][2]; the tile loop is over
-#pragma unroll
-    for (int mt = 0; mt < G::kMT; ++mt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double a = st1[mt][j], b = st2[mt][j];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o, 64);
-          b += __shfl_xor(b, o, 64);
-        }
-        if constexpr (G::kPH == 2) {   // lanes kq and kq ^ 2 hold the two pixel parities of the same channels
-          a += __shfl_xor(a, 32, 64);
-          b += __shfl_xor(b, 32, 64);
-        }
-        if ((lane & 15) == 0 && (G::kPH == 1 || lane < 32)) {
-          const int c = G::kPH == 2 ? 4 * (lane >> 4) + j : 16 * mt + 4 * (lane >> 4) + j;
-          red[(wave * 32 + c) * 2 + 0] = a;
-          red[(wave * 32 + c) * 2 + 1] = b;
-        }
-      }
-    __syncthreads();
+  if constexpr (STATS || SUMS) {
+    __syncthreads();   // every wave's record is complete (conv_tile adds to it tile by tile)
     if (tid < 2 * COUT) {
       const int c = tid >> 1, k = tid & 1;
       double t = 0.0;

@@ -168,16 +168,17 @@ RCED_TM_DEFINE_DISPATCH(_main, RCED_TM_FWD, RCED_TM_BWD)
 // train_mfma_v2.hip
 int rced_tm_conv_v2(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet,
                     float* out, int frames, int cus, double* part, const rced::tmm::XformArgs* xa,
-                    const rced::tmm::BnBwdArgs* ba, hipStream_t st);
+                    const rced::tmm::BnBwdArgs* ba, hipStream_t st, const rced::tmm::SumArgs* sa);
 bool rced_tm_has_v2(bool fwd, int cin, int taps, int cout);
 int rced_tm_wgrad_v2(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
                      const rced::tmm::XformArgs* xa, const rced::tmm::BnBwdArgs* ba, hipStream_t st);
 namespace {
 // Returns the grid size (= number of partial-sum records when stats), 0 if no kernel was built for the request.
 int tm_conv(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet, float* out,
-            int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
-  if (tm_has_main(fwd, cin, taps, cout)) return tm_conv_main(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
-  return rced_tm_conv_v2(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
+            int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st,
+            const tmm::SumArgs* sa = nullptr) {
+  if (tm_has_main(fwd, cin, taps, cout)) return tm_conv_main(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa);
+  return rced_tm_conv_v2(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa);
 }
 bool tm_has(bool fwd, int cin, int taps, int cout) { return tm_has_main(fwd, cin, taps, cout) || rced_tm_has_v2(fwd, cin, taps, cout); }
 int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
@@ -279,6 +280,12 @@ int fin_wgrad(int ch, const float* x, const float* dz, float* dW, float* dbias, 
   RCED_FIN_CH(X)
 #undef X
   return 1;
+}
+
+// (sum d_u, sum d_u * z) from a SUMS dgrad -> (S1, S2 = sum d_u * zhat), zhat = (z - mu) * rstd
+__global__ void sums_fix(double* __restrict__ sums, const float* __restrict__ mu, const float* __restrict__ rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) sums[2 * c + 1] = (double)rstd[c] * (sums[2 * c + 1] - (double)mu[c] * sums[2 * c]);
 }
 
 __global__ void sums_to_float(const double* __restrict__ sums, int C, int which, float* __restrict__ dst) {
@@ -635,6 +642,21 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     for (int id = 1; id < L; ++id)
       if (!plain[id]) HIP_TRY(hipMemsetAsync(t->G[id], 0, P * net.layer[id - 1].cout * sizeof(float), st));
   }
+  // fused_sums[l] > 0: the dgrad that wrote G[l + 1] (layer l's only consumer) has left that many (sum d_u, sum d_u z)
+  // records of layer l's BatchNorm backward in t->part (tmm::SumArgs): no bwd_route2 pass for layer l.
+  std::vector<int> fused_sums(L, 0);
+  static const bool fuse_sums_on = [] { const char* e = getenv("RCED_TRAIN_FUSE_SUMS"); return !(e && atoi(e) == 0); }();
+  auto fuse_dz_of = [&](int l) {
+    const LayerSpec& s = net.layer[l];
+    const LayerOff& f = t->off[l];
+    return t->fuse_dz && t->use_mfma && s.use_norm && s.cout % 2 == 0 &&
+           ((t->use_mfma && first_has(s, f.cin)) || (s.kh == 1 && f.cin % 2 == 0 && tm_has(true, f.cin, s.kw, s.cout) &&
+                                                    (s.src == 0 || t->pk_bwd[l] != nullptr)));
+  };
+  auto lazy_mask_of = [&](int l) {
+    const LayerSpec& s = net.layer[l];
+    return fuse_dz_of(l) && s.use_act && s.skip_pre < 0 && s.skip_post < 0;
+  };
   for (int l = L - 1; l >= 0; --l) {
     const LayerSpec& s = net.layer[l];
     const LayerOff& f = t->off[l];
@@ -646,12 +668,14 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     // For a plain conv+BN+ReLU layer (no skip in or out) d_u is not materialised either: the consumers read the
     // incoming gradient g and apply the ReLU mask themselves; bwd_route2 then only produces the two sums.
     const bool first_mfma = t->use_mfma && first_has(s, f.cin);
-    const bool fuse_dz = t->fuse_dz && t->use_mfma && s.use_norm && pairs &&
-                         (first_mfma || (s.kh == 1 && f.cin % 2 == 0 && tm_has(true, f.cin, s.kw, s.cout) &&
-                                         (s.src == 0 || t->pk_bwd[l] != nullptr)));
-    const bool lazy_mask = fuse_dz && s.use_act && s.skip_pre < 0 && s.skip_post < 0;
+    const bool fuse_dz = fuse_dz_of(l);
+    const bool lazy_mask = lazy_mask_of(l);
     const float* dsrc = lazy_mask ? t->G[l + 1] : t->D;      // what wgrad / dgrad read as their "dz" input
-    if (pairs) {
+    if (lazy_mask && fused_sums[l] > 0) {
+      hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part,
+                         fused_sums[l], s.cout, t->sums);
+      hipLaunchKernelGGL(sums_fix, dim3(1), dim3(64), 0, st, t->sums, (const float*)mu, (const float*)t->rstd[l], s.cout);
+    } else if (pairs) {
       const dim3 grid = pair_grid(s.cout);
       hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
                          (const float2*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
@@ -711,6 +735,15 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     if (s.src > 0) {
       if (t->use_mfma && t->pk_fin_bwd && is_output_layer(s, f.cin) && consumers[s.src] == 1) {
         fin_dgrad(f.cin, t->D, t->params + f.kernel, t->pk_fin_bwd, t->G[s.src], frames, st);   // overwrites G[src]
+      } else if (const int pl = s.src - 1;   // the layer that produced this dgrad's output tensor
+                 fuse_sums_on && t->use_mfma && t->pk_bwd[l] && overwrite(l) && lazy_mask_of(pl) && [&] {
+                   const LayerOff& pf = t->off[pl];
+                   const tmm::SumArgs sa{t->z[pl], t->mu[pl], t->rstd[pl], t->params + pf.gamma, t->params + pf.beta};
+                   fused_sums[pl] = tm_conv(false, s.cout, s.kw, f.cin, false, false, dsrc, t->pk_bwd[l], t->G[s.src], frames,
+                                            t->num_cus, t->part, nullptr, ba, st, &sa);
+                   return fused_sums[pl] > 0;
+                 }()) {
+        // MFMA path; layer pl's BatchNorm-backward sums come out of the same kernel
       } else if (t->use_mfma && t->pk_bwd[l] &&
           tm_conv(false, s.cout, s.kw, f.cin, !overwrite(l), false, dsrc, t->pk_bwd[l], t->G[s.src], frames, t->num_cus,
                   nullptr, nullptr, ba, st)) {

@@ -45,19 +45,22 @@ inline size_t tm_packet_floats(int cin, int taps, int cout) {
   return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + 32;
 }
 
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF>
+constexpr tmm::SumArgs kNoSums{nullptr, nullptr, nullptr, nullptr, nullptr};
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF, bool SUMS = false>
 int tm_conv_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part,
-                    tmm::XformArgs xa, tmm::BnBwdArgs ba, hipStream_t st) {
+                    tmm::XformArgs xa, tmm::BnBwdArgs ba, hipStream_t st, tmm::SumArgs sa = kNoSums) {
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
-  const size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 4 * CIN : 0)) * sizeof(float);
+  size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 4 * CIN : 0)) * sizeof(float);
+  if constexpr (STATS || SUMS)   // (SUMS: + the z tile being written and the producer's folded BatchNorm) + the running sums
+    lds = (size_t)(tmm::conv_red_off<CIN, TAPS, COUT, XF, SUMS>() + tmm::kConvRedFloats) * sizeof(float);
   static unsigned long long attr = 0;
   static int occ = 0;
-  const void* kfn = reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>);
+  const void* kfn = reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF, SUMS>);
   allow_lds(kfn, lds, attr);
   const int grid = std::min(ntiles, std::min(resident_grid(kfn, lds, cus, occ), kPairGrid));
-  hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF>), dim3(grid), dim3(tmm::kThreads), lds, st, in,
-                     packet, out, frames, part, xa, ba);
+  hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF, SUMS>), dim3(grid), dim3(tmm::kThreads), lds, st, in,
+                     packet, out, frames, part, xa, ba, sa);
   return grid;
 }
 // One 1xk convolution on the MFMA kernels.  The shape decides the role: a layer's forward shape gets
@@ -65,11 +68,22 @@ int tm_conv_launch1(const float* in, const float* packet, float* out, int frames
 //   optionally with in = relu(bn(z)) rebuilt from the producer's z (xa);
 // a dgrad shape gets  out (=|+=) conv(in)  with in = dz, optionally rebuilt from (d_u, z) (ba).
 // Returns the grid size (= number of partial-sum records when stats), 0 if no kernel was built for the request.
+// sa (dgrad shapes, overwrite mode only): also leave the producer's BatchNorm-backward records in `part` (tmm::SumArgs);
+// 0 is returned when no such kernel exists for the shape and the caller launches again without sa.
 template <int CIN, int TAPS, int COUT, bool FWD>
 int tm_conv_launch(bool accum, bool stats, const float* in, const float* packet, float* out, int frames, int cus,
-                   double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st) {
+                   double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st,
+                   const tmm::SumArgs* sa = nullptr) {
   const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
   const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
+  if (sa) {
+    if constexpr (!FWD && CIN % 2 == 0 && COUT % 2 == 0 && COUT != 8) {
+      if (accum || stats || xa) return 0;
+      if (ba) return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfBnBwd, true>(in, packet, out, frames, cus, part, nx, *ba, st, *sa);
+      return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfNone, true>(in, packet, out, frames, cus, part, nx, nb, st, *sa);
+    }
+    return 0;
+  }
   if constexpr (FWD) {
     if (accum || ba) return 0;
     if (xa) {
@@ -128,7 +142,7 @@ int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, in
 #define RCED_TM_DEFINE_DISPATCH(SUFFIX, TM_FWD, TM_BWD)                                                                   \
   int tm_conv##SUFFIX(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet, \
                       float* out, int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba,    \
-                      hipStream_t st) {                                                                                     \
+                      hipStream_t st, const tmm::SumArgs* sa = nullptr) {                                                   \
     TM_FWD(RCED_TM_CONV_FWD_CASE)                                                                                           \
     TM_BWD(RCED_TM_CONV_BWD_CASE)                                                                                           \
     return 0;                                                                                                               \
@@ -144,10 +158,10 @@ int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, in
   }
 #define RCED_TM_CONV_FWD_CASE(CI, TP, CO)                \
   if (fwd && cin == CI && taps == TP && cout == CO)      \
-    return rced::tmd::tm_conv_launch<CI, TP, CO, true>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
+    return rced::tmd::tm_conv_launch<CI, TP, CO, true>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa);
 #define RCED_TM_CONV_BWD_CASE(CI, TP, CO)                \
   if (!fwd && cin == CI && taps == TP && cout == CO)     \
-    return rced::tmd::tm_conv_launch<CI, TP, CO, false>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st);
+    return rced::tmd::tm_conv_launch<CI, TP, CO, false>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa);
 #define RCED_TM_HAS_CASE(CI, TP, CO) \
   if (cin == CI && taps == TP && cout == CO) return true;
 #define RCED_TM_WGRAD_CASE(CI, TP, CO)              \
