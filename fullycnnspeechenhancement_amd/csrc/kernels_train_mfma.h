@@ -22,6 +22,11 @@ using chain::pin;
 constexpr int kF = 129;
 constexpr int kTF = 2;                 // frames per tile
 constexpr int kWaves = 4, kThreads = 256;
+#ifndef RCED_TM_EXP
+#define RCED_TM_EXP 0   // timing experiments only (results wrong): bit0 = conv kernels fetch no tile after their first,
+                        // bit1 = conv kernels store nothing, bit2 = conv kernels skip the MFMA pass, bit3 = they commit only their first tile,
+                        // bit4 = no masked sums in the SUMS epilogue
+#endif
 #ifndef RCED_TM_OCC
 #define RCED_TM_OCC 2   // workgroups per CU the register allocator must leave room for (conv / wgrad kernels): several
                         // of them sat at 260-300 VGPRs+AGPRs = ONE workgroup per CU; 2 costs a few spilled dwords in the
@@ -292,8 +297,9 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t][mt] = sh;
   }
-  chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, 2>(in, (PH * px0 - G::kG) * G::kCinP + 2 * kq,
-                                                              (PH * pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc);
+  if (!(RCED_TM_EXP & 4))
+    chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, 2>(in, (PH * px0 - G::kG) * G::kCinP + 2 * kq,
+                                                                (PH * pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc);
   float p1[MT][4], p2[MT][4];   // this tile's share of sum z, sum z^2 (<= NT values each, fp32); SUMS: sum d_u, sum d_u z
   f32x4 sa4[MT], sb4[MT];       // SUMS: folded BatchNorm a, b of this lane's four channels per M-tile
   if constexpr (SUMS) {
@@ -335,7 +341,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
           p2[mt][j] = fmaf(v, v, p2[mt][j]);
         }
     }
-    if constexpr (SUMS) {
+    if constexpr (SUMS && !(RCED_TM_EXP & 16)) {
       const float* zp = zt + (fr * kF + f) * COUT;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -353,6 +359,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
       }
     }
     float* op = out + ((size_t)(frame0 + fr) * kF + f) * COUT;
+    if ((RCED_TM_EXP & 2) && acc[t][0][0] != 12345.678f) continue;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int co0 = PH == 2 ? 4 * (kq & 1) : 16 * mt + 4 * kq;
@@ -489,12 +496,15 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int frame0 = tile * kTF;
       auto where = [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; };
+      if (!(RCED_TM_EXP & 8) || tile == (int)blockIdx.x) {
       if constexpr (XF == kXfBnRelu) tile_commit_bnrelu<CIN>(lin, tid, pre, where, xt, frame0, frames);
       else if constexpr (XF == kXfBnBwd) tile_commit_bnbwd<CIN>(lin, tid, pre, pre2, where, xt, frame0, frames, ba.beta != nullptr);
       else tile_commit<CIN>(lin, tid, pre, where);
+      }
       __syncthreads();
-      if constexpr (SUMS) ztile_fetch<COUT>(sa.z, zt, frame0, frames, tid);   // the previous tile's epilogue is behind a barrier
-      if (tile + (int)gridDim.x < ntiles) {
+      if constexpr (SUMS)
+        if (!(RCED_TM_EXP & 1) || tile == (int)blockIdx.x) ztile_fetch<COUT>(sa.z, zt, frame0, frames, tid);   // the previous tile's epilogue is behind a barrier
+      if (tile + (int)gridDim.x < ntiles && !(RCED_TM_EXP & 1)) {
         tile_fetch<CIN>(in, (tile + gridDim.x) * kTF, frames, tid, pre);
         if constexpr (XF == kXfBnBwd) tile_fetch<CIN>(ba.z, (tile + gridDim.x) * kTF, frames, tid, pre2);
       }

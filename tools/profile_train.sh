@@ -1,0 +1,46 @@
+#!/bin/bash
+# Run ON THE GPU BOX from the repo root: rocprofv3 kernel stats + PMC passes of the training step (tools/bench_train.py).
+# Usage: tools/profile_train.sh <tag>   -> gpurun_out/proft_<tag>/summary.txt   (counters in separate passes, kernel-trace only)
+set -u
+TAG=${1:-run}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/proft_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ROOT/tools/bench_train.py > "$OUT/trace.log" 2>&1
+pmc() { local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 $ROOT/tools/bench_train.py > "$OUT/pmc_$name.log" 2>&1; }
+pmc fetch FETCH_SIZE
+pmc write WRITE_SIZE
+pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
+pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA
+cd "$ROOT"
+python3 - "$OUT" > "$OUT/summary.txt" <<'PY'
+import csv, glob, os, sys
+from collections import defaultdict
+out = sys.argv[1]
+def find(d, pat): return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+def short(n): return n.split('(')[0].replace('void ', '').replace('rced::', '')[:62]
+print("# rocprofv3, tools/bench_train.py (CR-CED V3 train step, batch 256 x 512, 4 steps)")
+for f in find(os.path.join(out, "trace"), "*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    print("## kernel-trace --stats, per step (4 steps)")
+    for r in rows[:26]:
+        print('%-62s calls/step %5.1f  ms/step %7.2f  avg %7.3f' % (short(r['Name']), int(r['Calls']) / 4, float(r['TotalDurationNs']) / 4e6, float(r['AverageNs']) / 1e6))
+    print('total ms/step %.2f' % (tot / 4e6))
+print("## PMC, average per dispatch")
+acc = defaultdict(lambda: [0.0, 0])
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d): continue
+    for f in find(d, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            k = (short(r.get("Kernel_Name", "")), r.get("Counter_Name"))
+            acc[k][0] += float(r.get("Counter_Value", 0) or 0); acc[k][1] += 1
+kern = sorted({k for k, _ in acc})
+for k in kern:
+    if not any(s in k for s in ("mfma", "bwd_route2", "first_", "final_", "bn_act")): continue
+    print(k)
+    print("   " + "  ".join("%s=%.4g" % (c, acc[(kk, c)][0] / max(acc[(kk, c)][1], 1)) for (kk, c) in sorted(acc) if kk == k))
+PY
+cat "$OUT/summary.txt"
