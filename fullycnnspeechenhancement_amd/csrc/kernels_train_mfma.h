@@ -9,6 +9,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "kernels_fused_chain.h"
 
 namespace rced {
@@ -22,6 +24,22 @@ using chain::pin;
 constexpr int kF = 129;
 constexpr int kTF = 2;                 // frames per tile
 constexpr int kWaves = 4, kThreads = 256;
+#ifndef RCED_TM_STAMPS
+#define RCED_TM_STAMPS 0   // diagnostic build: s_memtime phase sums of workgroup 0 of the 30->18 SUMS dgrad, printed at its end
+#endif
+#if RCED_TM_STAMPS
+__device__ __forceinline__ unsigned long long tm_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+__device__ unsigned long long g_tm[4][4];   // [wave][gemm, barrier 2, epilogue, vmcnt wait] of conv_tile
+#define TM_ST(i) do { if (stamps_on) { const unsigned long long n_ = tm_stamp(); ts[i] += n_ - tlast; tlast = n_; } } while (0)
+#else
+#define TM_ST(i)
+#endif
 #ifndef RCED_TM_EXP
 #define RCED_TM_EXP 0   // timing experiments only (results wrong): bit0 = conv kernels fetch no tile after their first,
                         // bit1 = conv kernels store nothing, bit2 = conv kernels skip the MFMA pass, bit3 = they commit only their first tile,
@@ -279,32 +297,61 @@ struct SumArgs {
   const float *mu, *rstd, *gamma, *beta;   // its batch statistics and affine parameters
 };
 
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false>
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false, bool OPQ = false>
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
                                           int frames, int wave, int lane,
                                           double* red_wave, const float* zt = nullptr, const float* stab = nullptr) {
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(!(SUMS && (STATS || ACCUM || G::kPH != 1 || (COUT & 1))), "SUMS: overwrite-mode dgrads with an even, unpaired cout");
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMT, PH = G::kPH;
-  const int n = lane & 15, kq = lane >> 4;
   const float* in = lds_in + G::kG * G::kCinP;
   const int xtile = NR * kWaves + wave;
-  const int px0 = 16 * wave + n, pxx = 16 * xtile + n;     // column index: a pixel, or a pixel pair when PH = 2
   f32x4 acc[NT][MT];
+#if RCED_TM_STAMPS
+  const bool st_on = SUMS && CIN == 30 && blockIdx.x == 0;
+  unsigned long long c0 = 0;
+#endif
+  {
+    const int n = lane & 15, kq = lane >> 4;
+    const int px0 = 16 * wave + n, pxx = 16 * xtile + n;     // column index: a pixel, or a pixel pair when PH = 2
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(lds_w + G::kData + 16 * mt + 4 * kq);
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(lds_w + G::kData + 16 * mt + 4 * kq);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t][mt] = sh;
+      for (int t = 0; t < NT; ++t) acc[t][mt] = sh;
+    }
+#if RCED_TM_STAMPS
+    c0 = st_on ? tm_stamp() : 0;
+#endif
+    if (!(RCED_TM_EXP & 4))
+      chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, 2>(in, (PH * px0 - G::kG) * G::kCinP + 2 * kq,
+                                                                  (PH * pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc);
   }
-  if (!(RCED_TM_EXP & 4))
-    chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, 2>(in, (PH * px0 - G::kG) * G::kCinP + 2 * kq,
-                                                                (PH * pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc);
+  // The epilogue's lane coordinates are re-derived behind an opaque barrier: left visible, hipcc hoists every per-lane
+  // address of the epilogue (pixel -> frame / bin splits, LDS offsets of the z tile, 64-bit row offsets) out of the tile
+  // loop, keeps them live across the MFMA pass and spills them; each reload in the epilogue is a scratch load +
+  // s_waitcnt vmcnt(0), which also waits for the global stores issued just before it -- a full HBM write round trip per
+  // reload, 15.8 k cycles of epilogue per tile against 10.5 k of MFMA pass (s_memtime stamps, RCED_TM_STAMPS).
+  // Only where the prefetched next tile is large enough for that to happen (OPQ): the kernels that have the registers
+  // lose 5-10 % to the recomputation.
+  int le = lane;
+  if constexpr (OPQ) asm volatile("" : "+v"(le));
+  const int n = le & 15, kq = le >> 4;
+  const int px0 = 16 * wave + n, pxx = 16 * xtile + n;
   float p1[MT][4], p2[MT][4];   // this tile's share of sum z, sum z^2 (<= NT values each, fp32); SUMS: sum d_u, sum d_u z
   f32x4 sa4[MT], sb4[MT];       // SUMS: folded BatchNorm a, b of this lane's four channels per M-tile
+#if RCED_TM_STAMPS
+  if (st_on) { const unsigned long long n = tm_stamp(); if (lane == 0) g_tm[wave][0] += n - c0; c0 = n; }
+#endif
   if constexpr (SUMS) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the z tile have landed in LDS ...
+#if RCED_TM_STAMPS
+    if (st_on) { const unsigned long long n = tm_stamp(); if (lane == 0) g_tm[wave][3] += n - c0; c0 = n; }
+#endif
     __syncthreads();                                    // ... and everybody else's
+#if RCED_TM_STAMPS
+    if (st_on) { const unsigned long long n = tm_stamp(); if (lane == 0) g_tm[wave][1] += n - c0; c0 = n; }
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int co0 = 16 * mt + 4 * kq;
@@ -406,6 +453,9 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
         ra[mt][j] = a;
         rb[mt][j] = b;
       }
+#if RCED_TM_STAMPS
+    if (st_on) { const unsigned long long n = tm_stamp(); if (lane == 0) g_tm[wave][2] += n - c0; c0 = n; }
+#endif
     if (writer) {   // all reads, then all writes: one LDS round trip instead of one per value
       typedef double f64x2 __attribute__((ext_vector_type(2)));
       f64x2 cur[MT][4];
@@ -493,15 +543,26 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
       tile_fetch<CIN>(in, blockIdx.x * kTF, frames, tid, pre);
       if constexpr (XF == kXfBnBwd) tile_fetch<CIN>(ba.z, blockIdx.x * kTF, frames, tid, pre2);
     }
+#if RCED_TM_STAMPS
+    const bool stamps_on = SUMS && CIN == 30 && blockIdx.x == 0;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamps_on ? tm_stamp() : 0;
+    if (stamps_on && lane == 0) for (int i = 0; i < 4; ++i) g_tm[wave][i] = 0;
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int frame0 = tile * kTF;
       auto where = [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; };
+#if RCED_TM_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TM_ST(0);   // wait for the prefetched tile
+#endif
       if (!(RCED_TM_EXP & 8) || tile == (int)blockIdx.x) {
       if constexpr (XF == kXfBnRelu) tile_commit_bnrelu<CIN>(lin, tid, pre, where, xt, frame0, frames);
       else if constexpr (XF == kXfBnBwd) tile_commit_bnbwd<CIN>(lin, tid, pre, pre2, where, xt, frame0, frames, ba.beta != nullptr);
       else tile_commit<CIN>(lin, tid, pre, where);
       }
+      TM_ST(1);   // commit
       __syncthreads();
+      TM_ST(2);   // barrier 1
       if constexpr (SUMS)
         if (!(RCED_TM_EXP & 1) || tile == (int)blockIdx.x) ztile_fetch<COUT>(sa.z, zt, frame0, frames, tid);   // the previous tile's epilogue is behind a barrier
       if (tile + (int)gridDim.x < ntiles && !(RCED_TM_EXP & 1)) {
@@ -509,10 +570,19 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
         if constexpr (XF == kXfBnBwd) tile_fetch<CIN>(ba.z, (tile + gridDim.x) * kTF, frames, tid, pre2);
       }
       pin();
-      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab);
-      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab);
+      TM_ST(3);   // fetch issue
+      constexpr bool kOpq = (XF == kXfBnBwd ? 2 : 1) * Stage<CIN>::kPer * 4 >= 64;   // VGPRs holding the next tile
+      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab);
+      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab);
+      TM_ST(4);   // conv_tile
       __syncthreads();
+      TM_ST(5);   // barrier 3
     }
+#if RCED_TM_STAMPS
+    if (stamps_on && lane == 0)
+      printf("TMST wave %d: loadwait %llu commit %llu bar1 %llu fetch %llu tile %llu bar3 %llu | gemm %llu vmwait %llu bar2 %llu epi %llu\n", wave, ts[0], ts[1],
+             ts[2], ts[3], ts[4], ts[5], g_tm[wave][0], g_tm[wave][3], g_tm[wave][1], g_tm[wave][2]);
+#endif
   } else {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int frame0 = tile * kTF;

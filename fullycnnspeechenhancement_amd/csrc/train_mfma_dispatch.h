@@ -34,7 +34,8 @@ inline int resident_grid(const void* kernel, size_t lds, int cus, int& occ_cache
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, tmm::kThreads, lds) != hipSuccess || occ < 1) occ = 1;
     static const int mult = [] { const char* e = getenv("RCED_TM_GRID_MULT"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
-    occ_cache = occ * mult;
+    static const int cap = [] { const char* e = getenv("RCED_TM_MAXOCC"); return e && atoi(e) > 0 ? atoi(e) : 64; }();
+    occ_cache = std::min(occ, cap) * mult;
   }
   return cus * occ_cache;
 }
