@@ -35,6 +35,7 @@ __device__ __forceinline__ unsigned long long tm_stamp() {
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
+__device__ unsigned long long g_tm2[4][4];  // [wave][coords, z reads + masked sums, stores, reduce] inside the epilogue
 __device__ unsigned long long g_tm[4][4];   // [wave][gemm, barrier 2, epilogue, vmcnt wait] of conv_tile
 #define TM_ST(i) do { if (stamps_on) { const unsigned long long n_ = tm_stamp(); ts[i] += n_ - tlast; tlast = n_; } } while (0)
 #else
@@ -134,6 +135,15 @@ __device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int f
   using St = Stage<C>;
   const float* src = base + (size_t)frame0 * St::kFrame;
   const int left = frames - frame0;
+  if (left >= kTF) {   // whole tile (wave-uniform): straight-line 16-byte loads, no per-piece bounds logic
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + tid;
+#pragma unroll
+    for (int i = 0; i < St::kPer; ++i) {
+      if ((i + 1) * kThreads <= St::kVec) pre[i] = s4[i * kThreads];
+      else pre[i] = tid + i * kThreads < St::kVec ? s4[i * kThreads] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
   const int nvalid = (left < kTF ? left : kTF) * St::kFrame;
 #pragma unroll
   for (int i = 0; i < St::kPer; ++i) {
@@ -372,11 +382,18 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #pragma unroll
       for (int j = 0; j < 4; ++j) p1[mt][j] = p2[mt][j] = 0.f;
   }
+#if RCED_TM_STAMPS
+  unsigned long long e0 = st_on ? tm_stamp() : 0, ea[4] = {0, 0, 0, 0};
+#define TM_E(i) do { if (st_on) { const unsigned long long n_ = tm_stamp(); ea[i] += n_ - e0; e0 = n_; } } while (0)
+#else
+#define TM_E(i)
+#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = t < NR ? px0 + 64 * t : pxx;
     const int px = PH == 2 ? 2 * col + (kq >> 1) : col;   // PH = 2: lane rows 4kq.. = parity kq >> 1, couts 4 (kq & 1)..
     const int fr = px / G::kS, f = px - fr * G::kS;
+    TM_E(0);
     if (px >= G::kNPX || f >= kF || frame0 + fr >= frames) continue;
     if constexpr (STATS) {
 #pragma unroll
@@ -405,6 +422,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
         }
       }
     }
+    TM_E(1);
     float* op = out + ((size_t)(frame0 + fr) * kF + f) * COUT;
     if ((RCED_TM_EXP & 2) && acc[t][0][0] != 12345.678f) continue;
 #pragma unroll
@@ -434,7 +452,11 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
         }
       }
     }
+    TM_E(2);
   }
+#if RCED_TM_STAMPS
+  if (st_on && lane == 0) for (int i = 0; i < 3; ++i) g_tm2[wave][i] += ea[i];
+#endif
   if constexpr (STATS || SUMS) {
     // Running per-channel sums live in this wave's LDS record as doubles (in registers they cost 32 VGPRs for the whole
     // kernel, which is what decided the occupancy): add the tile's fp32 shares over the 16 pixel lanes of a row with
@@ -546,7 +568,7 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
 #if RCED_TM_STAMPS
     const bool stamps_on = SUMS && CIN == 30 && blockIdx.x == 0;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamps_on ? tm_stamp() : 0;
-    if (stamps_on && lane == 0) for (int i = 0; i < 4; ++i) g_tm[wave][i] = 0;
+    if (stamps_on && lane == 0) for (int i = 0; i < 4; ++i) g_tm[wave][i] = g_tm2[wave][i] = 0;
 #endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int frame0 = tile * kTF;
@@ -579,6 +601,8 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
       TM_ST(5);   // barrier 3
     }
 #if RCED_TM_STAMPS
+    if (stamps_on && lane == 0)
+      printf("TMSE wave %d: coords %llu zsum %llu stores %llu\n", wave, g_tm2[wave][0], g_tm2[wave][1], g_tm2[wave][2]);
     if (stamps_on && lane == 0)
       printf("TMST wave %d: loadwait %llu commit %llu bar1 %llu fetch %llu tile %llu bar3 %llu | gemm %llu vmwait %llu bar2 %llu epi %llu\n", wave, ts[0], ts[1],
              ts[2], ts[3], ts[4], ts[5], g_tm[wave][0], g_tm[wave][3], g_tm[wave][1], g_tm[wave][2]);
