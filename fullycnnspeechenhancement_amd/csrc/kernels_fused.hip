@@ -30,6 +30,7 @@ struct rced_fused {
   int wide = 0;               // option "v3_wide": 1 = sixteen-wave kernel (kernels_fused_v3w.h)
   int bf16 = 0;               // option "bf16" (V1/V2): bf16 activations + weights (kernels_fused_chain16.h)
   float* wpack16 = nullptr;   // its packet stream (built when the option is first set)
+  unsigned short* fin_apack16 = nullptr;   // the output layer's Toeplitz A fragments in bf16 (chain16::final_gemm16_kernel)
   float* scratch16 = nullptr; // skip fragments for 2 workgroups per CU
   int bf16_wgs_per_cu = 1;
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
@@ -305,6 +306,22 @@ int chain16_enable(rced_model* m, rced_fused* f) {
   std::vector<float> wpack;
   pack_chain16<N>(m, &wpack);
   if (int rc = upload(&f->wpack16, wpack)) return rc;
+  {  // output layer: the fp32 pack's values A[f, k] (pack_chain), rounded to bf16, in K-16 fragment order
+    constexpr int CH = N::kFinalCh;
+    using F16 = chain16::Final16<CH>;
+    const rced_layer_dev& lf = m->layers[N::kLayers];
+    std::vector<unsigned short> fin16(F16::kPack16, 0);
+    for (int S = 0; S < F16::kSteps; ++S)
+      for (int mt = 0; mt < F16::kMT; ++mt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 4; ++j) {
+            const int k = 16 * S + 4 * (lane >> 4) + j, fo = 16 * mt + (lane & 15), fp = k / CH, ci = k % CH, tap = fp - fo + 64;
+            const float v = (k < F16::kK && fo < 129 && tap >= 0 && tap < 129) ? wq(lf, tap, ci, 0, CH) : 0.f;
+            fin16[((size_t)(S * F16::kMT + mt) * 64 + lane) * 4 + j] = bf16_rne(v);
+          }
+    HIP_TRY(hipMalloc(&f->fin_apack16, fin16.size() * sizeof(unsigned short)));
+    HIP_TRY(hipMemcpy(f->fin_apack16, fin16.data(), fin16.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMalloc(&f->scratch16, (size_t)2 * m->num_cus * G::kScratchFloatsPerWg * sizeof(float)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain16::fused_chain16_kernel<N>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
@@ -335,7 +352,13 @@ int chain16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int 
   HIP_TRY(hipGetLastError());
   const int frames = Nb * T;
   m->prof_begin(RCED_K_FINAL, st);
-  chain_final_layer<N::kFinalCh>(f, y, frames, st);
+  static const bool final16 = [] { const char* e = getenv("RCED_C16_FINAL16"); return !(e && atoi(e) == 0); }();
+  if (final16 && f->fin_apack16)
+    hipLaunchKernelGGL(chain16::final_gemm16_kernel<N::kFinalCh>, dim3((frames + chain::kFinFrames - 1) / chain::kFinFrames),
+                       dim3(chain::kFinThreads), 0, st, (const float*)f->h, (const unsigned short*)f->fin_apack16, f->fin_bias, y,
+                       frames);
+  else
+    chain_final_layer<N::kFinalCh>(f, y, frames, st);
   m->prof_end(RCED_K_FINAL, st);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
@@ -391,6 +414,7 @@ void fused_destroy(rced_model* m) {
   if (!f) return;
   if (f->wpack) (void)hipFree(f->wpack);
   if (f->wpack16) (void)hipFree(f->wpack16);
+  if (f->fin_apack16) (void)hipFree(f->fin_apack16);
   if (f->scratch16) (void)hipFree(f->scratch16);
   if (f->fin_apack) (void)hipFree(f->fin_apack);
   if (f->h) (void)hipFree(f->h);

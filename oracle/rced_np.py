@@ -93,13 +93,14 @@ def bf16_round(a):
     return r.view(np.float32).reshape(np.shape(a))
 
 
-def forward_bf16(net_work, weights, x):
+def forward_bf16(net_work, weights, x, final_bf16=True):
     """Emulation of the bf16 variant of the R-CED kernels (csrc/kernels_fused_chain16.h; BASELINE config 2).
 
     Not a statement about the reference (which is fp32): it restates what the bf16 KERNEL computes, so that the
     kernel can be tested.  Inner layers: BatchNorm-folded kernels rounded to bf16, bf16 activations in, fp32 (here
     fp64) accumulation, fp32 shift, (+ skip), ReLU, result rounded to bf16.  First layer: fp32 input and folded fp32
-    kernel, output rounded to bf16.  Last layer (1x129): fp32 kernel on the bf16 activations, fp32 output.
+    kernel, output rounded to bf16.  Last layer (1x129): kernel rounded to bf16 (chain16::final_gemm16_kernel; with
+    RCED_C16_FINAL16=0 the library keeps it fp32 -- final_bf16=False) on the bf16 activations, fp32 output.
     """
     layers = L.layers_for(net_work)
     tensors = [np.asarray(x, dtype=np.float64)]
@@ -114,7 +115,7 @@ def forward_bf16(net_work, weights, x):
             shift = (shift - m) * s + b
         k = k.astype(np.float32)                 # the folded kernel as the library holds it
         first, last = i == 0, i == len(layers) - 1
-        if not (first or last):
+        if not (first or (last and not final_bf16)):
             k = bf16_round(k)
         y = conv2d_same(tensors[l.src], k, shift.astype(np.float32), np.float64)
         if l.skip_pre >= 0:

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""bf16 R-CED kernels vs their emulation (oracle.rced_np.forward_bf16) on a multi-workgroup ragged batch, both forms of
+the output layer; then config-2 timing.  tools/bf16_final_check.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from fullycnnspeechenhancement_amd import build_model
+from oracle import rced_np
+
+for net in ("FullyCNN", "FullyCNNV2"):
+    w = rced_np.make_weights(net, seed=42)
+    x = rced_np.make_input(3, 47, seed=5)      # 141 frames: three 64-frame workgroups of the output layer, the last ragged
+    m = build_model(net, False, weights=w, dtype="bfloat16")
+    y = m(x)
+    for fb in (True, False):
+        ref = rced_np.forward_bf16(net, w, x, final_bf16=fb)
+        print(net, "final_bf16=%s" % fb, "rel err vs emulation %.3e" % (np.abs(y - ref).max() / np.abs(ref).max()))
+    print(net, "vs fp32 oracle %.3e" % (np.abs(y - rced_np.forward(net, w, x)).max() / np.abs(y).max()))
