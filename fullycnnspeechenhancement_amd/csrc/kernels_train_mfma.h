@@ -46,6 +46,9 @@ __device__ unsigned long long g_tm[4][4];   // [wave][gemm, barrier 2, epilogue,
                         // bit1 = conv kernels store nothing, bit2 = conv kernels skip the MFMA pass, bit3 = they commit only their first tile,
                         // bit4 = no masked sums in the SUMS epilogue
 #endif
+#ifndef RCED_TM_FIXCH
+#define RCED_TM_FIXCH 1   // staging stride chosen so that a thread's pieces share their channels (Stage<C>::kStride)
+#endif
 #ifndef RCED_TM_OCC
 #define RCED_TM_OCC 2   // workgroups per CU the register allocator must leave room for (conv / wgrad kernels): several
                         // of them sat at 260-300 VGPRs+AGPRs = ONE workgroup per CU; 2 costs a few spilled dwords in the
@@ -123,11 +126,19 @@ static __global__ void pack_packet(const float* __restrict__ w, const float* __r
 // a whole number of float4).  A thread keeps PER float4 in flight (fetch), and writes them to LDS later (commit) as
 // float2 pieces, which never straddle a frame or a pixel because C is even.  The fetch of the NEXT tile is issued
 // before the MFMA work of the current one so HBM latency hides behind it.
+// A thread's i-th float4 is piece tid + i * kStride, with kStride the largest thread count <= 256 for which
+// 4 * kStride is a multiple of C: every piece of a thread then starts at the SAME channel, so whatever per-channel
+// values the commit transforms need (BatchNorm folds) are loop-invariant for the thread -- read once per commit instead
+// of once per piece (each read was an LDS round trip the compiler could not overlap: 4.4 k cycles of commit per tile).
+// The few threads past kStride idle during staging.
 template <int C>
 struct Stage {
   static constexpr int kFrame = kF * C, kElems = kTF * kFrame, kVec = kElems / 4;
-  static constexpr int kPer = (kVec + kThreads - 1) / kThreads;
+  static constexpr int kMod = C % 4 == 0 ? C / 4 : C / 2;              // pieces per channel period
+  static constexpr int kStride = RCED_TM_FIXCH ? kThreads - kThreads % kMod : kThreads;
+  static constexpr int kPer = (kVec + kStride - 1) / kStride;
   static_assert(C % 2 == 0 && kElems % 4 == 0, "wide staging needs an even channel count");
+  static_assert(!RCED_TM_FIXCH || (4 * kStride) % C == 0, "a thread's pieces all start at the same channel");
 };
 template <int C>
 __device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int frame0, int frames, int tid,
@@ -137,19 +148,20 @@ __device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int f
   const int left = frames - frame0;
   if (left >= kTF) {   // whole tile (wave-uniform): straight-line 16-byte loads, no per-piece bounds logic
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + tid;
+    const bool active = St::kStride == kThreads || tid < St::kStride;
 #pragma unroll
     for (int i = 0; i < St::kPer; ++i) {
-      if ((i + 1) * kThreads <= St::kVec) pre[i] = s4[i * kThreads];
-      else pre[i] = tid + i * kThreads < St::kVec ? s4[i * kThreads] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((i + 1) * St::kStride <= St::kVec) pre[i] = active ? s4[i * St::kStride] : f32x4{0.f, 0.f, 0.f, 0.f};
+      else pre[i] = (active && tid + i * St::kStride < St::kVec) ? s4[i * St::kStride] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     return;
   }
   const int nvalid = (left < kTF ? left : kTF) * St::kFrame;
 #pragma unroll
   for (int i = 0; i < St::kPer; ++i) {
-    const int q = tid + i * kThreads;
+    const int q = tid + i * St::kStride;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (q < St::kVec) {
+    if (q < St::kVec && tid < St::kStride) {
       if (4 * q + 4 <= nvalid) {
         v = *reinterpret_cast<const f32x4*>(src + 4 * q);
       } else {
@@ -182,8 +194,8 @@ __device__ __forceinline__ void tile_commit(float* lds, int tid, const f32x4 (&p
   using St = Stage<C>;
 #pragma unroll
   for (int i = 0; i < St::kPer; ++i) {
-    const int q = tid + i * kThreads;
-    if (q < St::kVec) {
+    const int q = tid + i * St::kStride;
+    if (q < St::kVec && tid < St::kStride) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int e = 4 * q + 2 * h;
@@ -193,26 +205,36 @@ __device__ __forceinline__ void tile_commit(float* lds, int tid, const f32x4 (&p
     }
   }
 }
-// The same with the BatchNorm + ReLU transform.  The channel of a thread's i-th float4 advances by a constant
-// (4 * kThreads mod C), so it is tracked incrementally instead of by a modulo per element.
+// The same with the BatchNorm + ReLU transform.  All of a thread's float4 start at channel c = 4 tid mod C
+// (Stage<C>::kStride), so the two channel pairs' (a, b) are read from the table once, in front of the pieces.
 template <int C, class MAP>
 __device__ __forceinline__ void tile_commit_bnrelu(float* lds, int tid, const f32x4 (&pre)[Stage<C>::kPer], MAP map,
                                                    const float* table, int frame0, int frames) {
   using St = Stage<C>;
   static_assert(St::kFrame % C == 0 && C % 2 == 0, "frames start at channel 0; float2 pieces stay inside a pixel");
-  constexpr int kStep = (4 * kThreads) % C;
+  constexpr int kStep = (4 * St::kStride) % C;   // 0 with RCED_TM_FIXCH
   int c = (4 * tid) % C;
+  f32x2 ta[2], tb[2];
+  auto load_tables = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ch = c + 2 * h;
+      if (ch >= C) ch -= C;
+      ta[h] = *reinterpret_cast<const f32x2*>(table + ch);
+      tb[h] = *reinterpret_cast<const f32x2*>(table + C + ch);
+    }
+  };
+  if (kStep == 0) load_tables();
 #pragma unroll
   for (int i = 0; i < St::kPer; ++i) {
-    const int q = tid + i * kThreads;
-    if (q < St::kVec) {
+    const int q = tid + i * St::kStride;
+    if (kStep != 0) load_tables();
+    if (q < St::kVec && tid < St::kStride) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int e = 4 * q + 2 * h;
         const int fr = e / St::kFrame, r = e - fr * St::kFrame;
-        int ch = c + 2 * h;
-        if (ch >= C) ch -= C;
-        const f32x2 a = *reinterpret_cast<const f32x2*>(table + ch), b = *reinterpret_cast<const f32x2*>(table + C + ch);
+        const f32x2 a = ta[h], b = tb[h];
         f32x2 v = {fmaxf(fmaf(a.x, pre[i][2 * h], b.x), 0.f), fmaxf(fmaf(a.y, pre[i][2 * h + 1], b.y), 0.f)};
         if (frame0 + fr >= frames) v = f32x2{0.f, 0.f};      // frames past the batch stay zero
         *reinterpret_cast<f32x2*>(lds + map(fr, r)) = v;
@@ -253,23 +275,34 @@ __device__ __forceinline__ void tile_commit_bnbwd(float* lds, int tid, const f32
                                                   int frame0, int frames, bool mask) {
   using St = Stage<C>;
   static_assert(St::kFrame % C == 0 && C % 2 == 0, "frames start at channel 0; float2 pieces stay inside a pixel");
-  constexpr int kStep = (4 * kThreads) % C;
+  constexpr int kStep = (4 * St::kStride) % C;   // 0 with RCED_TM_FIXCH: the tables are read once per commit
   int c = (4 * tid) % C;
+  f32x2 tA[2], tB[2], tK[2], tF[2];
+  auto load_tables = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ch = c + 2 * h;
+      if (ch >= C) ch -= C;
+      tA[h] = *reinterpret_cast<const f32x2*>(table + ch);
+      tB[h] = *reinterpret_cast<const f32x2*>(table + C + ch);
+      tK[h] = *reinterpret_cast<const f32x2*>(table + 2 * C + ch);
+      tF[h] = *reinterpret_cast<const f32x2*>(table + 3 * C + ch);
+    }
+  };
+  if (kStep == 0) load_tables();
 #pragma unroll
   for (int i = 0; i < St::kPer; ++i) {
-    const int q = tid + i * kThreads;
-    if (q < St::kVec) {
+    const int q = tid + i * St::kStride;
+    if (kStep != 0) load_tables();
+    if (q < St::kVec && tid < St::kStride) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int e = 4 * q + 2 * h;
         const int fr = e / St::kFrame, r = e - fr * St::kFrame;
-        int ch = c + 2 * h;
-        if (ch >= C) ch -= C;
-        const f32x2 A = *reinterpret_cast<const f32x2*>(table + ch), B = *reinterpret_cast<const f32x2*>(table + C + ch);
-        const f32x2 K = *reinterpret_cast<const f32x2*>(table + 2 * C + ch);
+        const f32x2 A = tA[h], B = tB[h], K = tK[h];
         f32x2 d = {pd[i][2 * h], pd[i][2 * h + 1]};
         if (mask) {   // wave-uniform: the input is g, not d_u
-          const f32x2 fb = *reinterpret_cast<const f32x2*>(table + 3 * C + ch);
+          const f32x2 fb = tF[h];
           d.x = fmaf(A.x, pz[i][2 * h], fb.x) > 0.f ? d.x : 0.f;
           d.y = fmaf(A.y, pz[i][2 * h + 1], fb.y) > 0.f ? d.y : 0.f;
         }
