@@ -46,6 +46,11 @@ __device__ unsigned long long g_tm[4][4];   // [wave][gemm, barrier 2, epilogue,
                         // bit1 = conv kernels store nothing, bit2 = conv kernels skip the MFMA pass, bit3 = they commit only their first tile,
                         // bit4 = no masked sums in the SUMS epilogue
 #endif
+#ifndef RCED_TM_OPQ_MIN
+#define RCED_TM_OPQ_MIN 1000   // prefetch size (VGPRs) from which the conv kernels' epilogue re-derives its lane coordinates
+                               // (64 paid while the largest dgrad spilled; with the loop-invariant staging channels nothing
+                               // spills and the recomputation only costs: 56.0 vs 56.9 ms per CR-CED step)
+#endif
 #ifndef RCED_TM_FIXCH
 #define RCED_TM_FIXCH 1   // staging stride chosen so that a thread's pieces share their channels (Stage<C>::kStride)
 #endif
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
       }
       pin();
       TM_ST(3);   // fetch issue
-      constexpr bool kOpq = (XF == kXfBnBwd ? 2 : 1) * Stage<CIN>::kPer * 4 >= 64;   // VGPRs holding the next tile
+      constexpr bool kOpq = (XF == kXfBnBwd ? 2 : 1) * Stage<CIN>::kPer * 4 >= RCED_TM_OPQ_MIN;   // VGPRs holding the next tile
       if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab);
       else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab);
       TM_ST(4);   // conv_tile
