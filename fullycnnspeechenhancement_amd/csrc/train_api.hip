@@ -69,6 +69,7 @@ struct rced_trainer {
   std::vector<float*> pk_fwd, pk_bwd;            // per layer: MFMA A-fragment packets (1xk layers with an MFMA kernel)
   int use_mfma = 1;
   bool fuse_dz = true;         // RCED_TRAIN_FUSE_DZ=0: always materialise dz with bn_bwd_apply
+  bool fuse_sums = true;       // RCED_TRAIN_FUSE_SUMS=0: BatchNorm-backward sums of plain layers from bwd_route2, not from the dgrad
   std::vector<char> virt;      // virt[id]: tensor id (= relu(bn(z[id-1]))) is never materialised; its consumer rebuilds it
   float* pk_first = nullptr;   // A fragments of the 8xk first layer (rebuilt every step)
   float* pk_fin = nullptr, *pk_fin_bwd = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
@@ -320,6 +321,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) t->num_cus = prop.multiProcessorCount;
     if (const char* e = getenv("RCED_TRAIN_MFMA")) t->use_mfma = atoi(e);
     if (const char* e = getenv("RCED_TRAIN_FUSE_DZ")) t->fuse_dz = atoi(e) != 0;
+    if (const char* e = getenv("RCED_TRAIN_FUSE_SUMS")) t->fuse_sums = atoi(e) != 0;
   }
   const NetSpec* xnet = net;     // the reference's layout (what crosses the ABI)
   t->inet = *xnet;
@@ -645,7 +647,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
   // fused_sums[l] > 0: the dgrad that wrote G[l + 1] (layer l's only consumer) has left that many (sum d_u, sum d_u z)
   // records of layer l's BatchNorm backward in t->part (tmm::SumArgs): no bwd_route2 pass for layer l.
   std::vector<int> fused_sums(L, 0);
-  static const bool fuse_sums_on = [] { const char* e = getenv("RCED_TRAIN_FUSE_SUMS"); return !(e && atoi(e) == 0); }();
+  const bool fuse_sums_on = t->fuse_sums;
   auto fuse_dz_of = [&](int l) {
     const LayerSpec& s = net.layer[l];
     const LayerOff& f = t->off[l];

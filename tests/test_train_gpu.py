@@ -202,6 +202,30 @@ def test_mfma_kernels_agree_with_generic_on_a_multi_tile_ragged_batch(net_work, 
         assert cosine(g1, g0) > COS, name
 
 
+def test_sums_from_the_dgrad_agree_with_the_separate_pass(built, monkeypatch):
+    """CR-CED's plain layers (18 and 30 channels) get their BatchNorm-backward sums S1, S2 from the epilogue of the dgrad
+    that writes their gradient (tmm::SumArgs: z tile by LDS-DMA, masked sums, sums_fix); RCED_TRAIN_FUSE_SUMS=0 is the
+    bwd_route2 pass over g and z they replace.  Same ragged multi-tile batch as above: the partial last tile takes the
+    ordinary-load path of ztile_fetch.  The two differ only in summation order (fp32 per-tile partials vs fp64 per element)."""
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer
+    w = rced_np.make_weights("FullyCNNV3", seed=27)
+    x = rced_np.make_input(37, 131, seed=41)
+    y = rced_np.make_input(37, 131, seed=42)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RCED_TRAIN_FUSE_SUMS", mode)
+        tr = FullyCNNTrainer("FullyCNNV3", batch_size=37, lr=1e-3, weights=w)
+        loss, _, _ = tr.train_step(x, y)
+        out[mode] = (loss, tr.gradients())
+        tr.close()
+    assert out["0"][0] == out["1"][0]                       # the forward is the same code
+    for name, g0 in out["0"][1].items():
+        if "moving_" in name or (name.endswith("/bias") and not name.startswith("decode_final")):
+            continue                                        # a bias in front of BatchNorm has gradient 0: rounding noise only
+        assert rel(out["1"][1][name], g0) < 1e-4, name
+        assert cosine(out["1"][1][name], g0) > 1 - 1e-8, name
+
+
 def test_padded_layout_round_trips_variables_and_adam_state(built):
     """R-CED V2 trains in an even-padded internal layout; what crosses the ABI (variables, gradients, Adam slots) is the
     reference's unpadded layout: get -> set -> get is the identity and a resumed trainer continues like the original."""
