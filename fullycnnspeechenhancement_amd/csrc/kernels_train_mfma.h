@@ -22,7 +22,7 @@ using chain::mfma;
 using chain::pin;
 
 constexpr int kF = 129;
-constexpr int kTF = 2;                 // frames per tile
+constexpr int kTF = 2;                 // frames per tile (frame-of-element splits are written as one compare: keep it 2)
 constexpr int kWaves = 4, kThreads = 256;
 #ifndef RCED_TM_STAMPS
 #define RCED_TM_STAMPS 0   // diagnostic build: s_memtime phase sums of workgroup 0 of the 30->18 SUMS dgrad, printed at its end
@@ -136,24 +136,24 @@ static __global__ void pack_packet(const float* __restrict__ w, const float* __r
 // values the commit transforms need (BatchNorm folds) are loop-invariant for the thread -- read once per commit instead
 // of once per piece (each read was an LDS round trip the compiler could not overlap: 4.4 k cycles of commit per tile).
 // The few threads past kStride idle during staging.
-template <int C>
+template <int C, int NTHR = kThreads>
 struct Stage {
   static constexpr int kFrame = kF * C, kElems = kTF * kFrame, kVec = kElems / 4;
   static constexpr int kMod = C % 4 == 0 ? C / 4 : C / 2;              // pieces per channel period
-  static constexpr int kStride = RCED_TM_FIXCH ? kThreads - kThreads % kMod : kThreads;
+  static constexpr int kStride = RCED_TM_FIXCH ? NTHR - NTHR % kMod : NTHR;
   static constexpr int kPer = (kVec + kStride - 1) / kStride;
   static_assert(C % 2 == 0 && kElems % 4 == 0, "wide staging needs an even channel count");
   static_assert(!RCED_TM_FIXCH || (4 * kStride) % C == 0, "a thread's pieces all start at the same channel");
 };
-template <int C>
+template <int C, int NTHR = kThreads>
 __device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int frame0, int frames, int tid,
-                                           f32x4 (&pre)[Stage<C>::kPer]) {
-  using St = Stage<C>;
+                                           f32x4 (&pre)[Stage<C, NTHR>::kPer]) {
+  using St = Stage<C, NTHR>;
   const float* src = base + (size_t)frame0 * St::kFrame;
   const int left = frames - frame0;
   if (left >= kTF) {   // whole tile (wave-uniform): straight-line 16-byte loads, no per-piece bounds logic
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + tid;
-    const bool active = St::kStride == kThreads || tid < St::kStride;
+    const bool active = St::kStride == NTHR || tid < St::kStride;
 #pragma unroll
     for (int i = 0; i < St::kPer; ++i) {
       if ((i + 1) * St::kStride <= St::kVec) pre[i] = active ? s4[i * St::kStride] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -194,9 +194,9 @@ __device__ __forceinline__ void xform_table_fill(float* table, const float* mu, 
   }
 }
 
-template <int C, class MAP>
-__device__ __forceinline__ void tile_commit(float* lds, int tid, const f32x4 (&pre)[Stage<C>::kPer], MAP map) {
-  using St = Stage<C>;
+template <int C, int NTHR = kThreads, class MAP>
+__device__ __forceinline__ void tile_commit(float* lds, int tid, const f32x4 (&pre)[Stage<C, NTHR>::kPer], MAP map) {
+  using St = Stage<C, NTHR>;
 #pragma unroll
   for (int i = 0; i < St::kPer; ++i) {
     const int q = tid + i * St::kStride;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void tile_commit(float* lds, int tid, const f32x4 (&p
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int e = 4 * q + 2 * h;
-        const int fr = e / St::kFrame, r = e - fr * St::kFrame;
+        const int fr = e >= St::kFrame ? 1 : 0, r = e - (fr ? St::kFrame : 0);   // kTF = 2: a compare, not a division
         *reinterpret_cast<f32x2*>(lds + map(fr, r)) = f32x2{pre[i][2 * h], pre[i][2 * h + 1]};
       }
     }
@@ -212,10 +212,10 @@ __device__ __forceinline__ void tile_commit(float* lds, int tid, const f32x4 (&p
 }
 // The same with the BatchNorm + ReLU transform.  All of a thread's float4 start at channel c = 4 tid mod C
 // (Stage<C>::kStride), so the two channel pairs' (a, b) are read from the table once, in front of the pieces.
-template <int C, class MAP>
-__device__ __forceinline__ void tile_commit_bnrelu(float* lds, int tid, const f32x4 (&pre)[Stage<C>::kPer], MAP map,
+template <int C, int NTHR = kThreads, class MAP>
+__device__ __forceinline__ void tile_commit_bnrelu(float* lds, int tid, const f32x4 (&pre)[Stage<C, NTHR>::kPer], MAP map,
                                                    const float* table, int frame0, int frames) {
-  using St = Stage<C>;
+  using St = Stage<C, NTHR>;
   static_assert(St::kFrame % C == 0 && C % 2 == 0, "frames start at channel 0; float2 pieces stay inside a pixel");
   constexpr int kStep = (4 * St::kStride) % C;   // 0 with RCED_TM_FIXCH
   int c = (4 * tid) % C;
@@ -238,7 +238,7 @@ __device__ __forceinline__ void tile_commit_bnrelu(float* lds, int tid, const f3
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int e = 4 * q + 2 * h;
-        const int fr = e / St::kFrame, r = e - fr * St::kFrame;
+        const int fr = e >= St::kFrame ? 1 : 0, r = e - (fr ? St::kFrame : 0);   // kTF = 2: a compare, not a division
         const f32x2 a = ta[h], b = tb[h];
         f32x2 v = {fmaxf(fmaf(a.x, pre[i][2 * h], b.x), 0.f), fmaxf(fmaf(a.y, pre[i][2 * h + 1], b.y), 0.f)};
         if (frame0 + fr >= frames) v = f32x2{0.f, 0.f};      // frames past the batch stay zero
@@ -274,11 +274,11 @@ __device__ __forceinline__ void bnbwd_table_fill(float* table, const BnBwdArgs& 
     table[3 * C + tid] = a.beta ? a.beta[tid] - gr * a.mu[tid] : 0.f;   // b of the folded forward a*z + b (a = gr)
   }
 }
-template <int C, class MAP>
-__device__ __forceinline__ void tile_commit_bnbwd(float* lds, int tid, const f32x4 (&pd)[Stage<C>::kPer],
-                                                  const f32x4 (&pz)[Stage<C>::kPer], MAP map, const float* table,
+template <int C, int NTHR = kThreads, class MAP>
+__device__ __forceinline__ void tile_commit_bnbwd(float* lds, int tid, const f32x4 (&pd)[Stage<C, NTHR>::kPer],
+                                                  const f32x4 (&pz)[Stage<C, NTHR>::kPer], MAP map, const float* table,
                                                   int frame0, int frames, bool mask) {
-  using St = Stage<C>;
+  using St = Stage<C, NTHR>;
   static_assert(St::kFrame % C == 0 && C % 2 == 0, "frames start at channel 0; float2 pieces stay inside a pixel");
   constexpr int kStep = (4 * St::kStride) % C;   // 0 with RCED_TM_FIXCH: the tables are read once per commit
   int c = (4 * tid) % C;
@@ -303,7 +303,7 @@ __device__ __forceinline__ void tile_commit_bnbwd(float* lds, int tid, const f32
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int e = 4 * q + 2 * h;
-        const int fr = e / St::kFrame, r = e - fr * St::kFrame;
+        const int fr = e >= St::kFrame ? 1 : 0, r = e - (fr ? St::kFrame : 0);   // kTF = 2: a compare, not a division
         const f32x2 A = tA[h], B = tB[h], K = tK[h];
         f32x2 d = {pd[i][2 * h], pd[i][2 * h + 1]};
         if (mask) {   // wave-uniform: the input is g, not d_u
@@ -345,7 +345,10 @@ struct SumArgs {
   const float *mu, *rstd, *gamma, *beta;   // its batch statistics and affine parameters
 };
 
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false, bool OPQ = false>
+// SUMX (with SUMS, the fused backward kernel): the masked sums are formed from the TRANSFORMED tile x = relu(a z + b) the
+// same workgroup has staged for its wgrad half (zt = that tile, pixel p at row kG + p): x > 0 is the mask and the second
+// sum is sum d_u * x (sums_fix_x turns it into S2); no z tile, no extra barrier.
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false, bool OPQ = false, bool SUMX = false>
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
                                           int frames, int wave, int lane,
                                           double* red_wave, const float* zt = nullptr, const float* stab = nullptr) {
@@ -391,7 +394,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #if RCED_TM_STAMPS
   if (st_on) { const unsigned long long n = tm_stamp(); if (lane == 0) g_tm[wave][0] += n - c0; c0 = n; }
 #endif
-  if constexpr (SUMS) {
+  if constexpr (SUMS && !SUMX) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the z tile have landed in LDS ...
 #if RCED_TM_STAMPS
     if (st_on) { const unsigned long long n = tm_stamp(); if (lane == 0) g_tm[wave][3] += n - c0; c0 = n; }
@@ -430,7 +433,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
   for (int t = 0; t < NT; ++t) {
     const int col = t < NR ? px0 + 64 * t : pxx;
     const int px = PH == 2 ? 2 * col + (kq >> 1) : col;   // PH = 2: lane rows 4kq.. = parity kq >> 1, couts 4 (kq & 1)..
-    const int fr = px / G::kS, f = px - fr * G::kS;
+    const int fr = px >= G::kS ? 1 : 0, f = px - (fr ? G::kS : 0);   // kTF = 2 (px < 2 kS + 16 is checked below)
     TM_E(0);
     if (px >= G::kNPX || f >= kF || frame0 + fr >= frames) continue;
     if constexpr (STATS) {
@@ -443,7 +446,24 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
           p2[mt][j] = fmaf(v, v, p2[mt][j]);
         }
     }
-    if constexpr (SUMS && !(RCED_TM_EXP & 16)) {
+    if constexpr (SUMS && SUMX) {
+      const float* zp = zt + (G::kG + fr * G::kS + f) * COUT;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co0 = 16 * mt + 4 * kq;
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+        if (co0 + 1 < COUT) { const f32x2 q = *reinterpret_cast<const f32x2*>(zp + co0); xv.x = q.x; xv.y = q.y; }
+        if (co0 + 3 < COUT) { const f32x2 q = *reinterpret_cast<const f32x2*>(zp + co0 + 2); xv.z = q.x; xv.w = q.y; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (co0 + (j | 1) >= COUT) continue;
+          const float du = xv[j] > 0.f ? acc[t][mt][j] : 0.f;
+          p1[mt][j] += du;
+          p2[mt][j] = fmaf(du, xv[j], p2[mt][j]);
+        }
+      }
+    }
+    if constexpr (SUMS && !SUMX && !(RCED_TM_EXP & 16)) {
       const float* zp = zt + (fr * kF + f) * COUT;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -696,7 +716,9 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const flo
   constexpr int KT = (kRowsK + 1 + 15) / 16, NTo = PH == 2 ? 1 : G::kMT;
   constexpr int kOneTile = kRowsK / 16, kOneRow = kRowsK % 16;
   constexpr int kDzRows = 16 * G::kTiles + 4;
-  constexpr int kDzStride = PH == 2 ? 8 : 32;          // floats per pixel row of the dz tile (>= 16*NTo, bank friendly)
+  constexpr int kDzStride = COUT;                      // floats per pixel row of the dz tile = the tensor's own row: staging needs no
+                                                       // per-piece division (columns co >= COUT of the second N-tile read the next
+                                                       // pixel's first channels and are never written out); the launcher allocates 32
   constexpr int kGroups = PH == 2 ? (G::kNPX / 2 + 3) / 4 : G::kNPX / 4 + 1;   // 4 pixels (pixel pairs) per MFMA
   // the last group's padded rows read past the staged window: into the 64-float slack, which stays zero
   static_assert((4 * PH * (kGroups - 1) + PH * 3) * G::kCinP + 16 * (KT - 1) + 15 < G::kInFloats + 64, "A reads stay inside lin + slack");
@@ -732,10 +754,7 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const flo
     auto where = [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; };
     if constexpr (XF) tile_commit_bnrelu<CIN>(lin, tid, prex, where, xt, tile * kTF, frames);
     else tile_commit<CIN>(lin, tid, prex, where);
-    auto where_dz = [](int fr, int r) {
-      const int f = r / COUT, co = r - f * COUT;
-      return (fr * G::kS + f) * kDzStride + co;
-    };
+    auto where_dz = [](int fr, int r) { return fr * G::kS * kDzStride + r; };
     if constexpr (DZF) tile_commit_bnbwd<COUT>(ldz, tid, prez, prez2, where_dz, dt, tile * kTF, frames, ba.beta != nullptr);
     else tile_commit<COUT>(ldz, tid, prez, where_dz);
     __syncthreads();
@@ -778,6 +797,148 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const flo
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward of one 1xk layer in ONE kernel: wgrad and dgrad share the staged tiles.
+// Both read the same (d_u or g, z) pair of the layer to rebuild dz (tile_commit_bnbwd), and once each of them ran at the
+// 3.5-3.9 TB/s the memory system gives these kernels, reading that pair twice was the largest avoidable traffic of the step
+// (4 GB per 30-channel layer).  One workgroup of EIGHT waves per CU: all 512 threads prefetch and commit the next tile
+// (x with its halo, dz with its halo); then waves 0..3 run the dgrad pass over the dz tile (conv_tile, as conv1xk_mfma) while
+// waves 4..7 run the wgrad MFMAs over (x, dz) (as wgrad1xk_mfma; its B operand comes straight out of the dgrad's dz tile,
+// pixel stride COUT) -- the two halves of every SIMD's wave pair do different work, so one's epilogue / operand waits sit
+// beside the other's MFMAs.  Two barriers per tile instead of five.  SUMS: the dgrad half also forms the producer's
+// BatchNorm-backward sums, from the transformed x tile that is in LDS anyway (conv_tile SUMX): no z tile is fetched.
+// CIN / COUT are the LAYER's (x has CIN channels, dz COUT); the packet is the dgrad packet (pack_packet transpose = 1).
+// ---------------------------------------------------------------------------------------------
+constexpr int kBwdThreads = 512;
+template <int CIN, int TAPS, int COUT>
+struct BwdGeo {
+  using GD = Geo<COUT, TAPS, CIN>;     // the dgrad convolution: dz (COUT channels) -> dx (CIN channels)
+  using GW = Geo<CIN, TAPS, COUT>;     // the wgrad's view: x tile with CIN channels
+  static constexpr int r4(int v) { return (v + 3) & ~3; }
+  static constexpr int kDzOff = 0;                                   // [GD::kInRows][COUT] (+ slack for the last group's reads)
+  static constexpr int kPkOff = r4(GD::kInFloats + 64);
+  static constexpr int kXOff = r4(kPkOff + GD::kPacket);             // [GW::kInRows][CIN] (+ slack)
+  static constexpr int kTabOff = r4(kXOff + GW::kInFloats + 64);     // [2][CIN] BatchNorm + ReLU of x, then [4][COUT] BatchNorm backward
+  static constexpr int kRedOff = r4(kTabOff + 2 * CIN + 4 * COUT);   // [4 waves][32][2] doubles
+  static constexpr int kLdsFloats = kRedOff + kConvRedFloats;
+  static_assert(GD::kG == GW::kG && GD::kS == GW::kS, "one pixel space");
+};
+
+// Measured alternatives: tile i+1 committed into a second pair of LDS buffers by the wgrad half alone while
+// tile i is computed (one barrier per tile), with the staging behind or in front of that half's MFMAs, with s_setprio on
+// the staging half: 3.17 ms against 3.09 ms for this form -- the two waves of a SIMD do not overlap one's VALU / staging
+// work with the other's MFMA chain to any useful degree; what counts is the instruction total per SIMD.
+template <int CIN, int TAPS, int COUT, bool XF, bool SUMS>
+__global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __restrict__ x, const float* __restrict__ du,
+                                                               const float* __restrict__ packet, float* __restrict__ dx,
+                                                               float* __restrict__ dW, float* __restrict__ dbias, int frames,
+                                                               double* __restrict__ part, XformArgs xa, BnBwdArgs ba) {
+  using B = BwdGeo<CIN, TAPS, COUT>;
+  using GD = typename B::GD;
+  using GW = typename B::GW;
+  static_assert(CIN % 2 == 0 && COUT % 2 == 0, "wide staging");
+  constexpr int NTH = kBwdThreads;
+  constexpr int PH = COUT == 8 ? 2 : 1;                       // wgrad column packing (see wgrad1xk_mfma)
+  constexpr int kRowsK = (TAPS + PH - 1) * GW::kCinP;
+  constexpr int KT = (kRowsK + 1 + 15) / 16, NTo = PH == 2 ? 1 : GW::kMT;
+  constexpr int kOneTile = kRowsK / 16, kOneRow = kRowsK % 16;
+  constexpr int kGroups = PH == 2 ? (GW::kNPX / 2 + 3) / 4 : GW::kNPX / 4 + 1;
+  static_assert((4 * PH * (kGroups - 1) + PH * 3) * GW::kCinP + 16 * (KT - 1) + 15 < GW::kInFloats + 64, "A reads stay inside the x tile + slack");
+  static_assert((GD::kG + 4 * PH * (kGroups - 1) + PH * 3 + (PH - 1)) * COUT + 31 < GD::kInFloats + 64, "B reads stay inside the dz tile + slack");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldz = lds + B::kDzOff;
+  float* lw = lds + B::kPkOff;
+  float* lx = lds + B::kXOff;
+  float* xt = lds + B::kTabOff;
+  float* dt = xt + 2 * CIN;
+  double* red = reinterpret_cast<double*>(lds + B::kRedOff);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave8 >> 2, wave = wave8 & 3;              // role 0: dgrad, 1: wgrad
+  const int i = lane & 15, kq = lane >> 4;
+  for (int e = tid; e < B::kLdsFloats; e += NTH)
+    lds[e] = (e >= B::kPkOff && e < B::kPkOff + GD::kPacket) ? packet[e - B::kPkOff] : 0.f;
+  __syncthreads();
+  if constexpr (XF) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
+  bnbwd_table_fill<COUT>(dt, ba, tid);
+  f32x4 acc[KT][NTo];
+#pragma unroll
+  for (int a = 0; a < KT; ++a)
+#pragma unroll
+    for (int b = 0; b < NTo; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (frames + kTF - 1) / kTF;
+  f32x4 prex[Stage<CIN, NTH>::kPer], pred[Stage<COUT, NTH>::kPer], prez[Stage<COUT, NTH>::kPer];
+  if ((int)blockIdx.x < ntiles) {
+    tile_fetch<CIN, NTH>(x, blockIdx.x * kTF, frames, tid, prex);
+    tile_fetch<COUT, NTH>(du, blockIdx.x * kTF, frames, tid, pred);
+    tile_fetch<COUT, NTH>(ba.z, blockIdx.x * kTF, frames, tid, prez);
+  }
+  __syncthreads();
+  const float* ain = lx + PH * kq * GW::kCinP + i;
+  const float* ldzp = ldz + GD::kG * COUT;
+  const float* bin = PH == 2 ? ldzp + (2 * kq + (i >> 3)) * COUT + (i & 7) : ldzp + kq * COUT + i;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int frame0 = tile * kTF;
+    auto where_x = [](int fr, int r) { return (GW::kG + fr * GW::kS) * CIN + r; };
+    auto where_dz = [](int fr, int r) { return (GD::kG + fr * GD::kS) * COUT + r; };
+    if constexpr (XF) tile_commit_bnrelu<CIN, NTH>(lx, tid, prex, where_x, xt, frame0, frames);
+    else tile_commit<CIN, NTH>(lx, tid, prex, where_x);
+    tile_commit_bnbwd<COUT, NTH>(ldz, tid, pred, prez, where_dz, dt, frame0, frames, ba.beta != nullptr);
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) {
+      tile_fetch<CIN, NTH>(x, (tile + gridDim.x) * kTF, frames, tid, prex);
+      tile_fetch<COUT, NTH>(du, (tile + gridDim.x) * kTF, frames, tid, pred);
+      tile_fetch<COUT, NTH>(ba.z, (tile + gridDim.x) * kTF, frames, tid, prez);
+    }
+    pin();
+    if (role == 0) {
+      if (wave < GD::kExtra) conv_tile<COUT, TAPS, CIN, false, false, 1, SUMS, false, true>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx);
+      else conv_tile<COUT, TAPS, CIN, false, false, 0, SUMS, false, true>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx);
+    } else {
+      for (int g = wave; g < kGroups; g += kWaves) {
+        const int px0 = 4 * PH * g;
+        float a[KT], b[NTo];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) a[kt] = ain[px0 * GW::kCinP + 16 * kt];
+        if (i == kOneRow) a[kOneTile] = 1.f;
+#pragma unroll
+        for (int nt = 0; nt < NTo; ++nt) b[nt] = bin[px0 * COUT + 16 * nt];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int nt = 0; nt < NTo; ++nt) acc[kt][nt] = mfma(a[kt], b[nt], acc[kt][nt]);
+      }
+    }
+    __syncthreads();
+  }
+  if (role == 1) {
+    // D row = k = 16*kt + 4*kq + r, column = co = 16*nt + i   (PH = 2: column = (parity i >> 3, co = i & 7), tap = k' - parity)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NTo; ++nt) {
+        const int co = PH == 2 ? (i & 7) : 16 * nt + i;
+        const int ph = PH == 2 ? (i >> 3) : 0;
+        const float vv[4] = {acc[kt][nt].x, acc[kt][nt].y, acc[kt][nt].z, acc[kt][nt].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * kt + 4 * kq + r;
+          const int tapk = k / GW::kCinP, ci = k - tapk * GW::kCinP, tap = tapk - ph;
+          if (k < kRowsK && ci < CIN && co < COUT && tap >= 0 && tap < TAPS) atomicAdd(dW + (tap * CIN + ci) * COUT + co, vv[r]);
+          if (k == kRowsK && co < COUT && dbias) atomicAdd(dbias + co, vv[r]);
+        }
+      }
+  }
+  if constexpr (SUMS) {
+    if (tid < 2 * CIN) {   // the dgrad half's records (complete: the tile loop ends on a barrier); channels of dx = CIN
+      const int c = tid >> 1, k = tid & 1;
+      double t = 0.0;
+      for (int w = 0; w < kWaves; ++w) t += red[(w * 32 + c) * 2 + k];
+      part[((size_t)blockIdx.x * CIN + c) * 2 + k] = t;
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // The 1x129, CH -> 1 output layer (decode_5 / decode_8 / decode_final; model.py:24,56,89).

@@ -69,6 +69,7 @@ struct rced_trainer {
   std::vector<float*> pk_fwd, pk_bwd;            // per layer: MFMA A-fragment packets (1xk layers with an MFMA kernel)
   int use_mfma = 1;
   bool fuse_dz = true;         // RCED_TRAIN_FUSE_DZ=0: always materialise dz with bn_bwd_apply
+  bool fuse_bwd = true;        // RCED_TRAIN_FUSE_BWD=0: separate wgrad and dgrad kernels everywhere
   bool fuse_sums = true;       // RCED_TRAIN_FUSE_SUMS=0: BatchNorm-backward sums of plain layers from bwd_route2, not from the dgrad
   std::vector<char> virt;      // virt[id]: tensor id (= relu(bn(z[id-1]))) is never materialised; its consumer rebuilds it
   float* pk_first = nullptr;   // A fragments of the 8xk first layer (rebuilt every step)
@@ -188,6 +189,23 @@ int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float
   return rced_tm_wgrad_v2(cin, taps, cout, x, dz, dW, dbias, frames, cus, xa, ba, st);
 }
 
+// ---- wgrad + dgrad of a layer in one kernel (tmm::bwd_fused_mfma): the CR-CED shapes whose input tensor has one consumer ----
+#define RCED_TM_FUSED(X) X(18, 5, 30) X(30, 9, 8)
+// (x virtual, sums) must be (1, 1) or (0, 0).  Returns the grid size, 0 if no kernel was built for the request.
+int tm_bwd_fused(int cin, int taps, int cout, bool xf_sums, const float* x, const float* du, const float* packet, float* dx,
+                 float* dW, float* dbias, int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba,
+                 hipStream_t st) {
+  const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
+  if (!ba || (xf_sums && !xa)) return 0;
+#define X(CI, TP, CO)                                                                                                          \
+  if (cin == CI && taps == TP && cout == CO)                                                                                   \
+    return xf_sums ? rced::tmd::tm_bwd_fused_launch<CI, TP, CO, true, true>(x, du, packet, dx, dW, dbias, frames, cus, part, *xa, *ba, st) \
+                   : rced::tmd::tm_bwd_fused_launch<CI, TP, CO, false, false>(x, du, packet, dx, dW, dbias, frames, cus, part, nx, *ba, st);
+  RCED_TM_FUSED(X)
+#undef X
+  return 0;
+}
+
 // ---- first layer (8 x kw on the 1-channel input): MFMA wgrad (kernels_train_mfma.h) ----
 #define RCED_FIRST(X) X(9, 18) X(13, 12) X(11, 10)
 bool first_has(const LayerSpec& s, int cin) {
@@ -289,6 +307,17 @@ __global__ void sums_fix(double* __restrict__ sums, const float* __restrict__ mu
   if (c < C) sums[2 * c + 1] = (double)rstd[c] * (sums[2 * c + 1] - (double)mu[c] * sums[2 * c]);
 }
 
+// (sum d_u, sum d_u * x), x = relu(a z + b), from the fused backward kernel -> (S1, S2): where d_u != 0, z = (x - b) / a
+__global__ void sums_fix_x(double* __restrict__ sums, const float* __restrict__ mu, const float* __restrict__ rstd,
+                           const float* __restrict__ gamma, const float* __restrict__ beta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float a = gamma[c] * rstd[c];                 // the folded forward, exactly as xform_table_fill forms it
+  const float b = beta[c] - a * mu[c];
+  const double s1 = sums[2 * c], sx = sums[2 * c + 1];
+  sums[2 * c + 1] = a != 0.f ? (double)rstd[c] * ((sx - (double)b * s1) / (double)a - (double)mu[c] * s1) : 0.0;   // a = 0: dz = 0 anyway
+}
+
 __global__ void sums_to_float(const double* __restrict__ sums, int C, int which, float* __restrict__ dst) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) dst[c] = (float)sums[2 * c + which];
@@ -322,6 +351,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     if (const char* e = getenv("RCED_TRAIN_MFMA")) t->use_mfma = atoi(e);
     if (const char* e = getenv("RCED_TRAIN_FUSE_DZ")) t->fuse_dz = atoi(e) != 0;
     if (const char* e = getenv("RCED_TRAIN_FUSE_SUMS")) t->fuse_sums = atoi(e) != 0;
+    if (const char* e = getenv("RCED_TRAIN_FUSE_BWD")) t->fuse_bwd = atoi(e) != 0;
   }
   const NetSpec* xnet = net;     // the reference's layout (what crosses the ABI)
   t->inet = *xnet;
@@ -647,6 +677,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
   // fused_sums[l] > 0: the dgrad that wrote G[l + 1] (layer l's only consumer) has left that many (sum d_u, sum d_u z)
   // records of layer l's BatchNorm backward in t->part (tmm::SumArgs): no bwd_route2 pass for layer l.
   std::vector<int> fused_sums(L, 0);
+  std::vector<char> sums_from_x(L, 0);   // those records hold (sum d_u, sum d_u * x) (fused backward kernel) rather than (.., sum d_u * z)
   const bool fuse_sums_on = t->fuse_sums;
   auto fuse_dz_of = [&](int l) {
     const LayerSpec& s = net.layer[l];
@@ -676,7 +707,11 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     if (lazy_mask && fused_sums[l] > 0) {
       hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part,
                          fused_sums[l], s.cout, t->sums);
-      hipLaunchKernelGGL(sums_fix, dim3(1), dim3(64), 0, st, t->sums, (const float*)mu, (const float*)t->rstd[l], s.cout);
+      if (sums_from_x[l])
+        hipLaunchKernelGGL(sums_fix_x, dim3(1), dim3(64), 0, st, t->sums, (const float*)mu, (const float*)t->rstd[l],
+                           (const float*)(t->params + f.gamma), (const float*)(t->params + f.beta), s.cout);
+      else
+        hipLaunchKernelGGL(sums_fix, dim3(1), dim3(64), 0, st, t->sums, (const float*)mu, (const float*)t->rstd[l], s.cout);
     } else if (pairs) {
       const dim3 grid = pair_grid(s.cout);
       hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
@@ -713,8 +748,24 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
                            (const float*)t->rstd[l], (const float*)(t->params + f.gamma), (const double*)t->sums, (double)P, n,
                            s.cout);
     }
+    // wgrad and dgrad in one kernel where the layer's input tensor has this layer as its only consumer
+    bool fused_done = false;
+    if (t->fuse_bwd && t->use_mfma && s.kh == 1 && s.src > 0 && fuse_dz && t->pk_bwd[l] && overwrite(l)) {
+      const int pl = s.src - 1;
+      const bool xvirt = t->virt[s.src] != 0, want_sums = fuse_sums_on && lazy_mask_of(pl);
+      if (xvirt == want_sums) {
+        const int g = tm_bwd_fused(f.cin, s.kw, s.cout, xvirt, conv_in(s.src), dsrc, t->pk_bwd[l], t->G[s.src], t->grads + f.kernel,
+                                   t->grads + f.bias, frames, t->num_cus, t->part, xform_of(s.src, &xa_tmp), ba, st);
+        if (g > 0) {
+          fused_done = true;
+          if (want_sums) { fused_sums[pl] = g; sums_from_x[pl] = 1; }
+        }
+      }
+    }
     // dW and dbias = sum dz (the MFMA wgrad kernel produces both)
-    if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, conv_in(s.src), dsrc, t->grads + f.kernel,
+    if (fused_done) {
+      // both gradients are out
+    } else if (t->use_mfma && s.kh == 1 && tm_wgrad(f.cin, s.kw, s.cout, conv_in(s.src), dsrc, t->grads + f.kernel,
                                              t->grads + f.bias, frames, t->num_cus, xform_of(s.src, &xa_tmp), ba, st)) {
       // MFMA path
     } else if (first_mfma && first_wgrad(s, x_dev, dsrc, t->grads + f.kernel, t->grads + f.bias, frames, T, t->num_cus, ba, st)) {
@@ -734,7 +785,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
                          (const float*)t->D, T, F, f.cin, s.cout, s.kh, s.kw, frames, fpw, t->grads + f.kernel);
     }
     // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
-    if (s.src > 0) {
+    if (s.src > 0 && !fused_done) {
       if (t->use_mfma && t->pk_fin_bwd && is_output_layer(s, f.cin) && consumers[s.src] == 1) {
         fin_dgrad(f.cin, t->D, t->params + f.kernel, t->pk_fin_bwd, t->G[s.src], frames, st);   // overwrites G[src]
       } else if (const int pl = s.src - 1;   // the layer that produced this dgrad's output tensor

@@ -29,10 +29,10 @@ inline void allow_lds(const void* kernel, size_t lds, unsigned long long& done) 
 // Persistent grids are sized from the occupancy the runtime reports for the kernel (registers + LDS): cus x resident
 // workgroups per CU, so every workgroup is resident from the start and walks the same number of tiles.
 // RCED_TM_GRID_MULT (experiments): oversubscribe by that factor.
-inline int resident_grid(const void* kernel, size_t lds, int cus, int& occ_cache) {
+inline int resident_grid(const void* kernel, size_t lds, int cus, int& occ_cache, int threads = tmm::kThreads) {
   if (occ_cache <= 0) {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, tmm::kThreads, lds) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds) != hipSuccess || occ < 1) occ = 1;
     static const int mult = [] { const char* e = getenv("RCED_TM_GRID_MULT"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
     static const int cap = [] { const char* e = getenv("RCED_TM_MAXOCC"); return e && atoi(e) > 0 ? atoi(e) : 64; }();
     occ_cache = std::min(occ, cap) * mult;
@@ -137,6 +137,23 @@ int tm_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, in
   if (xa) return tm_wgrad_launch1<CIN, TAPS, COUT, true, false>(x, dz, dW, dbias, frames, cus, *xa, nb, st);
   if (ba) return tm_wgrad_launch1<CIN, TAPS, COUT, false, true>(x, dz, dW, dbias, frames, cus, nx, *ba, st);
   return tm_wgrad_launch1<CIN, TAPS, COUT, false, false>(x, dz, dW, dbias, frames, cus, nx, nb, st);
+}
+
+// wgrad + dgrad of one layer in one kernel (tmm::bwd_fused_mfma).  Returns the grid size (= partial-sum records when sums).
+template <int CIN, int TAPS, int COUT, bool XF, bool SUMS>
+int tm_bwd_fused_launch(const float* x, const float* du, const float* packet, float* dx, float* dW, float* dbias, int frames,
+                        int cus, double* part, tmm::XformArgs xa, tmm::BnBwdArgs ba, hipStream_t st) {
+  using B = tmm::BwdGeo<CIN, TAPS, COUT>;
+  const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
+  const size_t lds = (size_t)B::kLdsFloats * sizeof(float);
+  static unsigned long long attr = 0;
+  static int occ = 0;
+  const void* kfn = reinterpret_cast<const void*>(tmm::bwd_fused_mfma<CIN, TAPS, COUT, XF, SUMS>);
+  allow_lds(kfn, lds, attr);
+  const int grid = std::min(ntiles, std::min(resident_grid(kfn, lds, cus, occ, tmm::kBwdThreads), kPairGrid));
+  hipLaunchKernelGGL((tmm::bwd_fused_mfma<CIN, TAPS, COUT, XF, SUMS>), dim3(grid), dim3(tmm::kBwdThreads), lds, st, x, du, packet,
+                     dx, dW, dbias, frames, part, xa, ba);
+  return grid;
 }
 
 // One list-driven dispatcher set per translation unit: TM_FWD / TM_BWD are X-macro lists of (cin, taps, cout).
