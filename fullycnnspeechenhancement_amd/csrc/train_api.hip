@@ -220,11 +220,14 @@ int first_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias,
   constexpr int RS = 129 + KW - 1;
   const size_t lds = (((size_t)(tmm::kTF * 8 * RS + 32 + 3) / 4) * 4 + (size_t)(tmm::kTF * 132 + 4) * 32 + 4 * COUT) * sizeof(float);
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
-  const dim3 grid(std::min(ntiles, cus * 3));
   const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
   static unsigned long long attr_t = 0, attr_f = 0;
+  static int occ_t = 0, occ_f = 0;
   allow_lds(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, true>), lds, attr_t);
   allow_lds(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, false>), lds, attr_f);
+  // persistent grid = what is resident (it was cus * 3 with two workgroups per CU resident: half of the second round idle)
+  const dim3 grid(std::min(ntiles, ba ? rced::tmd::resident_grid(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, true>), lds, cus, occ_t)
+                                      : rced::tmd::resident_grid(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, false>), lds, cus, occ_f)));
   if (ba) hipLaunchKernelGGL((tmm::first_wgrad<KW, COUT, true>), grid, dim3(tmm::kThreads), lds, st, x, dz, dW, dbias, frames, T, *ba);
   else hipLaunchKernelGGL((tmm::first_wgrad<KW, COUT, false>), grid, dim3(tmm::kThreads), lds, st, x, dz, dW, dbias, frames, T, nb);
   return 1;
@@ -244,7 +247,10 @@ int first_fwd_launch(const float* x, const float* w, const float* bias, float* p
   hipLaunchKernelGGL(tmm::pack_first, dim3((data + 32 + 255) / 256), dim3(256), 0, st, w, bias, KW, COUT, packet);
   const size_t lds = (((size_t)(tmm::kTF * 8 * RS + 32 + 3) / 4) * 4 + data + 32) * sizeof(float);
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
-  const int grid = std::min(ntiles, std::min(cus * 4, kPairGrid));
+  static int occ_s = 0, occ_n = 0;
+  const int res = stats ? rced::tmd::resident_grid(reinterpret_cast<const void*>(tmm::first_fwd<KW, COUT, true>), lds, cus, occ_s)
+                        : rced::tmd::resident_grid(reinterpret_cast<const void*>(tmm::first_fwd<KW, COUT, false>), lds, cus, occ_n);
+  const int grid = std::min(ntiles, std::min(res, kPairGrid));
   if (stats) hipLaunchKernelGGL((tmm::first_fwd<KW, COUT, true>), dim3(grid), dim3(tmm::kThreads), lds, st, x, (const float*)packet, z, frames, T, part);
   else hipLaunchKernelGGL((tmm::first_fwd<KW, COUT, false>), dim3(grid), dim3(tmm::kThreads), lds, st, x, (const float*)packet, z, frames, T, part);
   return grid;
