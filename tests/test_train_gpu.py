@@ -202,8 +202,11 @@ def test_mfma_kernels_agree_with_generic_on_a_multi_tile_ragged_batch(net_work, 
         assert cosine(g1, g0) > COS, name
 
 
-def test_sums_from_the_dgrad_agree_with_the_separate_pass(built, monkeypatch):
-    """CR-CED's plain layers (18 and 30 channels) get their BatchNorm-backward sums S1, S2 from the epilogue of the dgrad
+@pytest.mark.parametrize("switch", ["RCED_TRAIN_FUSE_SUMS", "RCED_TRAIN_FUSE_BWD"])
+def test_sums_from_the_dgrad_agree_with_the_separate_pass(switch, built, monkeypatch):
+    """RCED_TRAIN_FUSE_BWD: wgrad + dgrad of the 18->30 and 30->8 layers in one kernel (tmm::bwd_fused_mfma, sums from the
+    transformed x tile) against the separate wgrad / dgrad kernels (sums from the dgrad's z tile).  RCED_TRAIN_FUSE_SUMS:
+    CR-CED's plain layers (18 and 30 channels) get their BatchNorm-backward sums S1, S2 from the epilogue of the dgrad
     that writes their gradient (tmm::SumArgs: z tile by LDS-DMA, masked sums, sums_fix); RCED_TRAIN_FUSE_SUMS=0 is the
     bwd_route2 pass over g and z they replace.  Same ragged multi-tile batch as above: the partial last tile takes the
     ordinary-load path of ztile_fetch.  The two differ only in summation order (fp32 per-tile partials vs fp64 per element)."""
@@ -213,7 +216,7 @@ def test_sums_from_the_dgrad_agree_with_the_separate_pass(built, monkeypatch):
     y = rced_np.make_input(37, 131, seed=42)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("RCED_TRAIN_FUSE_SUMS", mode)
+        monkeypatch.setenv(switch, mode)
         tr = FullyCNNTrainer("FullyCNNV3", batch_size=37, lr=1e-3, weights=w)
         loss, _, _ = tr.train_step(x, y)
         out[mode] = (loss, tr.gradients())
