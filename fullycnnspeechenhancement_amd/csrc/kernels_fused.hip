@@ -547,6 +547,10 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
     *value = m->fused->grid_limit;
     return RCED_OK;
   }
+  if (!strcmp(key, "fused_final")) {   // 1: the 1x129 output layer runs inside the fused kernel (no hand-off tensor in HBM)
+    *value = 0;
+    return RCED_OK;
+  }
   if (!strcmp(key, "v3_wide")) {
     *value = m->fused->wide;
     return RCED_OK;

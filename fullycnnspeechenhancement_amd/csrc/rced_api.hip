@@ -123,6 +123,7 @@ rced_model::~rced_model() {
   }
   if (workspace) (void)hipFree(workspace);
   for (auto st : host_streams) if (st) (void)hipStreamDestroy(st);
+  for (auto ev : host_events) if (ev) (void)hipEventDestroy(ev);
   if (stage_x) (void)hipFree(stage_x);
   if (stage_y) (void)hipFree(stage_y);
   if (fused) fused_destroy(this);
@@ -415,7 +416,11 @@ int rced_forward_host(rced_model* m, const float* x_host, float* y_host, int N, 
     m->stage_x = m->stage_y = nullptr;
     m->stage_bytes = 0;
     HIP_TRY(hipMalloc(&m->stage_x, bytes));
-    HIP_TRY(hipMalloc(&m->stage_y, bytes));
+    if (hipError_t e = hipMalloc(&m->stage_y, bytes); e != hipSuccess) {
+      (void)hipFree(m->stage_x);
+      m->stage_x = nullptr;
+      return fail(RCED_ERR_ALLOC, "hipMalloc(stage_y, %zu): %s", bytes, hipGetErrorString(e));
+    }
     m->stage_bytes = bytes;
   }
   // Small batches: copy in, run, copy out.  Large ones: split the utterances into chunks and overlap the three
@@ -434,11 +439,22 @@ int rced_forward_host(rced_model* m, const float* x_host, float* y_host, int N, 
     for (auto& st : m->host_streams) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   }
   hipStream_t s_in = m->host_streams[0], s_run = m->host_streams[1], s_out = m->host_streams[2];
-  std::vector<hipEvent_t> ev_in(chunks), ev_done(chunks);
-  for (int i = 0; i < chunks; ++i) {
-    HIP_TRY(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
+  // workspace for the LARGEST chunk up front: chunks differ by one utterance, and growing it mid-pipeline would
+  // synchronise the device and reallocate under the overlap this path exists for
+  if (int rc = rced_reserve(m, (N + chunks - 1) / chunks, T)) return rc;
+  if ((int)m->host_events.size() < 2 * chunks) {   // events live in the model and are reused by later calls
+    const size_t have = m->host_events.size();
+    m->host_events.resize(2 * chunks, nullptr);
+    for (size_t i = have; i < m->host_events.size(); ++i) {
+      const hipError_t e = hipEventCreateWithFlags(&m->host_events[i], hipEventDisableTiming);
+      if (e != hipSuccess) {
+        m->host_events.resize(i);   // keep what exists (freed with the model)
+        return fail(RCED_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+      }
+    }
   }
+  hipEvent_t* ev_in = m->host_events.data();
+  hipEvent_t* ev_done = m->host_events.data() + chunks;
   auto first = [&](int i) { return (int)((long long)N * i / chunks); };
   std::atomic<int> launched{0};
   std::atomic<bool> abort_flag{false};
@@ -473,7 +489,6 @@ int rced_forward_host(rced_model* m, const float* x_host, float* y_host, int N, 
   if (rc != RCED_OK || in_err != hipSuccess) abort_flag.store(true);
   downloader.join();
   (void)hipStreamSynchronize(s_run);
-  for (int i = 0; i < chunks; ++i) { (void)hipEventDestroy(ev_in[i]); (void)hipEventDestroy(ev_done[i]); }
   if (rc != RCED_OK) return rc;
   if (in_err != hipSuccess) return fail(RCED_ERR_HIP, "host path upload: %s", hipGetErrorString(in_err));
   if (out_err != hipSuccess) return fail(RCED_ERR_HIP, "host path download: %s", hipGetErrorString(out_err));

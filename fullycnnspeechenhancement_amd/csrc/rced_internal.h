@@ -37,6 +37,7 @@ struct rced_model {
   void *stage_x = nullptr, *stage_y = nullptr;
   size_t stage_bytes = 0;
   hipStream_t host_streams[3] = {nullptr, nullptr, nullptr};   // rced_forward_host: upload, compute, download
+  std::vector<hipEvent_t> host_events;                         // its per-chunk events (upload done / compute done), reused
   int host_chunks = 0;                                         // option "host_chunks" (0 = default 8)
   // options
   int path = 0;

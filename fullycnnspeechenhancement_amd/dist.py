@@ -2,14 +2,26 @@
 
 The reference has no parallelism of any kind (single tf.Session on one device: SURVEY F9); what
 shards naturally here is the utterance (batch) axis of `sess.run(pred, {input_x: x})`
-(model_utils/tester.py:85-90): inference BatchNorm uses moving statistics, so utterances are
-independent and NO collective is needed on the data path when each rank already owns its shard
-(`forward_resident`, what bench.py times).  When one rank (the reference's single host process)
-holds the whole batch, `forward_from_root` scatters contiguous batch slices and gathers the masks
-back with grouped point-to-point transfers (ncclSend/ncclRecv under torch.distributed's "nccl"
-backend = RCCL; one peer per xGMI link, so the root's 7 links work in parallel), optionally in
-chunks so that transfers overlap compute.  The same code runs on the "gloo" backend with CPU
-tensors, which is how tests/ cover the world_size > 1 logic without GPUs.
+(model_utils/tester.py:85-90; layout data_utils/data_loader.py:198-209): inference BatchNorm uses
+moving statistics, so utterances are independent and NO collective is needed on the data path when
+each rank already owns its shard (`forward_resident`, what bench.py's `value` times).  When one rank
+(the reference's single host process) holds the whole batch, `forward_from_root` scatters contiguous
+batch slices and gathers the masks back with point-to-point transfers (ncclSend/ncclRecv under
+torch.distributed's "nccl" backend = RCCL; one peer per xGMI link, so the root's 7 links work in
+parallel).
+
+Overlap on RCCL.  Every peer's slice is cut into `chunks` pieces and the pipeline is
+    scatter chunk c+1   ||   compute chunk c   ||   gather chunk c-1.
+Two things make that real on RCCL and not only on gloo:
+  * ONE `batch_isend_irecv` PER CHUNK.  Under NCCL/RCCL a batch is one coalesced group with one
+    work handle that completes when its LAST transfer does, so a single batch holding every chunk
+    (round 1) could not release chunk 0 before chunk k had arrived.
+  * The two directions run on TWO process groups (= two communicators, each with its own stream):
+    operations of one communicator execute in issue order, so with a single one the send of chunk
+    c+1 would queue behind the receive of result c, which waits for the peer's compute -- a
+    serial scatter -> compute -> gather per chunk.
+The same code runs on the "gloo" backend with CPU tensors, which is how tests/ cover the
+world_size > 1 logic without GPUs.
 """
 
 import torch
@@ -38,16 +50,31 @@ def chunk_bounds(lo, hi, chunks):
 
 class BatchShardedForward(object):
     """forward: callable mapping a [n, T, 129, 1] tensor on this rank's device to the same shape
-    (a fullycnnspeechenhancement_amd model on GPU; any stand-in under gloo in tests)."""
+    (a fullycnnspeechenhancement_amd model on GPU; any stand-in under gloo in tests).
 
-    def __init__(self, forward, group=None, device=None):
+    Construction is collective (every rank of `group` must construct it): it creates the two
+    direction groups.  `trace`, if given, is a list that receives ("recv"|"fwd"|"send"|"result", chunk)
+    events in the order this rank passed them (tests use it to check the pipeline order)."""
+
+    def __init__(self, forward, group=None, device=None, trace=None, forward_into=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (one process per GPU)")
         self.forward = forward
+        self.forward_into = forward_into     # optional (x, out) -> None: writes the result in place (no copy on the root)
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.trace = trace
+        ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
+        self._ranks = ranks
+        # scatter (root -> peers) and gather (peers -> root) each get a communicator of their own
+        self.scatter_group = dist.new_group(ranks=ranks) if self.world > 1 else group
+        self.gather_group = dist.new_group(ranks=ranks) if self.world > 1 else group
+
+    def _note(self, what, c):
+        if self.trace is not None:
+            self.trace.append((what, c))
 
     # -- every rank already holds its own utterances: no data-path collective -----------------
     def forward_resident(self, x_local):
@@ -56,36 +83,45 @@ class BatchShardedForward(object):
     # -- one rank holds the whole batch (the reference's calling convention) -------------------
     def forward_from_root(self, x_root, root=0, chunks=1):
         """x_root: [N, T, 129, 1] on `root` (ignored elsewhere).  Returns [N, T, 129, 1] on root, None
-        on the other ranks.  `chunks` > 1 pipelines each peer's slice: receive chunk c+1 while
-        computing chunk c, send results back as they finish."""
+        on the other ranks.  `root` is a rank of `group`.  chunks > 1 pipelines each peer's slice."""
         meta = [None]
         if self.rank == root:
             if x_root.dim() != 4 or x_root.shape[2] != 129 or x_root.shape[3] != 1:
                 raise ValueError("input must be [N, T, 129, 1], got %s" % (tuple(x_root.shape),))
             meta = [(tuple(x_root.shape), str(x_root.dtype))]
-        dist.broadcast_object_list(meta, src=root, group=self.group)
+        if self.world > 1:
+            dist.broadcast_object_list(meta, src=self._ranks[root], group=self.group)
         shape, dtype_name = meta[0]
         dtype = getattr(torch, dtype_name.split(".")[-1])
         n, t = shape[0], shape[1]
         bounds = shard_bounds(n, self.world)
+        groot = self._ranks[root]            # P2POp peers are global ranks
 
         if self.rank == root:
             x_root = x_root.contiguous()
             y = torch.empty_like(x_root)
-            sends, recvs = [], []
-            for r in range(self.world):
-                if r == root:
-                    continue
-                for lo, hi in chunk_bounds(*bounds[r], chunks):
-                    sends.append(dist.P2POp(dist.isend, x_root[lo:hi], r, self.group))
-                    recvs.append(dist.P2POp(dist.irecv, y[lo:hi], r, self.group))
-            works = dist.batch_isend_irecv(sends + recvs) if sends else []
+            pieces = {r: chunk_bounds(*bounds[r], chunks) for r in range(self.world) if r != root}
+            depth = max([len(p) for p in pieces.values()] + [0])
+            send_works, recv_works = [], []
+            for c in range(depth):       # chunk c of every peer: one grouped batch per direction
+                sends = [dist.P2POp(dist.isend, x_root[p[c][0]:p[c][1]], self._ranks[r], self.scatter_group)
+                         for r, p in pieces.items() if c < len(p)]
+                recvs = [dist.P2POp(dist.irecv, y[p[c][0]:p[c][1]], self._ranks[r], self.gather_group)
+                         for r, p in pieces.items() if c < len(p)]
+                send_works.append(dist.batch_isend_irecv(sends))
+                recv_works.append(dist.batch_isend_irecv(recvs))
             lo, hi = bounds[root]
             if hi > lo:   # the root's own slice computes while its links carry the others'
-                for a, b in chunk_bounds(lo, hi, chunks):
-                    y[a:b] = self.forward(x_root[a:b])
-            for w in works:
-                w.wait()
+                for i, (a, b) in enumerate(chunk_bounds(lo, hi, chunks)):
+                    if self.forward_into is not None:
+                        self.forward_into(x_root[a:b], y[a:b])
+                    else:
+                        y[a:b] = self.forward(x_root[a:b])
+                    self._note("fwd", i)
+            for c in range(depth):       # results stream back chunk by chunk
+                for w in send_works[c] + recv_works[c]:
+                    w.wait()
+                self._note("result", c)
             return y
 
         lo, hi = bounds[self.rank]
@@ -93,14 +129,18 @@ class BatchShardedForward(object):
         if not pieces:
             return None
         bufs = [torch.empty((b - a, t) + tuple(shape[2:]), dtype=dtype, device=self.device) for a, b in pieces]
-        recv_works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, root, self.group) for buf in bufs])
+        # every receive is posted up front, each as a batch of its own: chunk c+1 lands while chunk c computes
+        recv_works = [dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, groot, self.scatter_group)]) for buf in bufs]
         send_works, outs = [], []
-        for i, buf in enumerate(bufs):
-            # batch_isend_irecv may return one work for the whole group (nccl) or one per op (gloo)
-            recv_works[min(i, len(recv_works) - 1)].wait()
+        for c, buf in enumerate(bufs):
+            for w in recv_works[c]:
+                w.wait()                 # nccl: the current stream waits for THIS chunk only
+            self._note("recv", c)
             out = self.forward(buf).contiguous()
-            outs.append(out)   # keep alive until sent
-            send_works += dist.batch_isend_irecv([dist.P2POp(dist.isend, out, root, self.group)])
+            self._note("fwd", c)
+            outs.append(out)             # keep alive until sent
+            send_works += dist.batch_isend_irecv([dist.P2POp(dist.isend, out, groot, self.gather_group)])
+            self._note("send", c)
         for w in send_works:
             w.wait()
         return None

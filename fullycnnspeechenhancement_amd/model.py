@@ -8,6 +8,7 @@ x is [N, T, 129, 1] float32 NHWC and the result has the same shape.  In the refe
 adds nodes to a TF graph and `sess.run` executes them (tester.py:85-90); here `model(x)` executes:
   * numpy in  -> numpy out   (host buffers, H2D/D2H inside; the reference's own calling convention)
   * torch.cuda tensor in -> torch.cuda tensor out (device-resident, zero copy, current stream)
+Model(is_training=True)(x) is the graph trainer.py:165-172 builds: BatchNorm with batch statistics.
 Weights are the TF variables by name (weights.py); `restore()` plays Saver.restore.
 There is no CPU path: a missing HIP extension or GPU raises.
 """
@@ -26,35 +27,46 @@ def _is_torch(x):
 class _RcedNet(object):
     variant = None
     _handle = None
+    _train = None
 
-    def __init__(self, is_training, weights=None, device=0, seed=None):
-        if is_training:
-            # trainer.py:156-179 builds the same graph with is_training=True (batch-stat BN + Adam);
-            # that is SURVEY 8(f) N3, not part of the forward hot path.
-            raise NotImplementedError("Model(is_training=True) only exists inside the training step: use "
-                                      "fullycnnspeechenhancement_amd.FullyCNNTrainer (rced_train_step)")
-        self.is_training = False
+    def __init__(self, is_training, weights=None, device=0, seed=None, batch_size=1):
+        """is_training=False: the inference graph of tester.py:69-83 / infer.py:36-52 (BatchNorm with the moving
+        statistics; the fused forward kernels).  is_training=True: the graph trainer.py:165-172 builds --
+        `model(x)` normalises every layer with the statistics of the batch it is given and updates nothing (only
+        `pred` is fetched; the UPDATE_OPS and the optimizer belong to train_op).  It runs on the training-step
+        library object (rced_train_forward); FullyCNNTrainer shares that handle for train_step.  batch_size is
+        the configured size the trainer's loss divides by (trainer.py:146-147), unused by `model(x)` itself."""
+        self.is_training = bool(is_training)
         self.device = int(device)
+        self.batch_size = int(batch_size)
         self._handle = None
+        self._train = None
         self._weights = None
-        self._path = _lib.PATH_AUTO
+        self._options = {}       # everything set through set_option / set_path: replayed by restore()
         self.restore(weights if weights is not None else _weights.initial_weights(self.variant, seed))
 
     # -- weights ---------------------------------------------------------------------------
     def restore(self, weights):
-        """Saver.restore analogue (tester.py:36-39): dict keyed by TF variable names, or a .npz path."""
+        """Saver.restore analogue (tester.py:36-39): dict keyed by TF variable names, or a .npz path.
+        Options set earlier (path, bf16, host_chunks, fused_grid, ...) carry over to the new handle."""
         if isinstance(weights, str):
             weights = _weights.load_npz(weights)
         blob = _weights.pack_blob(self.variant, weights)
         lib = _lib.load()
         h = ctypes.c_void_p()
-        _lib.check(lib.rced_create(self.variant, blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), blob.size,
-                                   self.device, ctypes.byref(h)))
-        self._release()
-        self._handle = h
+        fp = blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        if self.is_training:
+            _lib.check(lib.rced_train_create(self.variant, fp, blob.size, self.batch_size, self.device, ctypes.byref(h)))
+            self._release()
+            self._train = h
+        else:
+            _lib.check(lib.rced_create(self.variant, fp, blob.size, self.device, ctypes.byref(h)))
+            self._release()
+            self._handle = h
+            for key, value in self._options.items():
+                if key != "profile":
+                    _lib.check(lib.rced_set_option(self._handle, key.encode(), int(value)))
         self._weights = {k: np.array(v, dtype=np.float32) for k, v in weights.items()}
-        if self._path != _lib.PATH_AUTO:
-            self.set_path(self._path)
         return self
 
     @property
@@ -69,27 +81,32 @@ class _RcedNet(object):
     def set_path(self, path):
         """'auto' | 'layerwise' | 'fused' (rced.h RCED_PATH_*)."""
         code = {"auto": _lib.PATH_AUTO, "layerwise": _lib.PATH_LAYERWISE, "fused": _lib.PATH_FUSED}.get(path, path)
-        _lib.check(_lib.load().rced_set_option(self._handle, b"path", int(code)))
-        self._path = int(code)
+        self.set_option("path", int(code))
         return self
 
+    def _infer_handle(self):
+        if self._handle is None:
+            raise RuntimeError("this option / query belongs to the inference graph (Model(is_training=False))")
+        return self._handle
+
     def set_option(self, key, value):
-        _lib.check(_lib.load().rced_set_option(self._handle, key.encode(), int(value)))
+        _lib.check(_lib.load().rced_set_option(self._infer_handle(), key.encode(), int(value)))
+        self._options[key] = int(value)
 
     def get_option(self, key):
         v = ctypes.c_int()
-        _lib.check(_lib.load().rced_get_option(self._handle, key.encode(), ctypes.byref(v)))
+        _lib.check(_lib.load().rced_get_option(self._infer_handle(), key.encode(), ctypes.byref(v)))
         return v.value
 
     def reserve(self, n, t):
-        _lib.check(_lib.load().rced_reserve(self._handle, int(n), int(t)))
+        _lib.check(_lib.load().rced_reserve(self._infer_handle(), int(n), int(t)))
 
     def profile(self, on=True):
         self.set_option("profile", 1 if on else 0)
 
     def profile_query(self, kind):
         ms, cnt = ctypes.c_float(), ctypes.c_int()
-        _lib.check(_lib.load().rced_profile_query(self._handle, int(kind), ctypes.byref(ms), ctypes.byref(cnt)))
+        _lib.check(_lib.load().rced_profile_query(self._infer_handle(), int(kind), ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
 
     # -- forward ---------------------------------------------------------------------------
@@ -98,7 +115,9 @@ class _RcedNet(object):
         if len(shape) != 4 or shape[2] != spec.FEATURE_DIM or shape[3] != 1:
             raise ValueError("input must be [N, T, %d, 1] (NHWC), got %s" % (spec.FEATURE_DIM, tuple(shape)))
 
-    def __call__(self, x):
+    def __call__(self, x, out=None):
+        """y = model(x).  numpy in -> numpy out; torch.cuda in -> torch.cuda out (`out`: an optional preallocated
+        contiguous float32 cuda tensor of x's shape to write into)."""
         lib = _lib.load()
         if _is_torch(x):
             import torch
@@ -110,17 +129,31 @@ class _RcedNet(object):
             if x.dtype != torch.float32:
                 x = x.float()
             x = x.contiguous()
-            y = torch.empty_like(x)
+            if out is None:
+                y = torch.empty_like(x)
+            else:
+                if (not _is_torch(out) or out.shape != x.shape or out.dtype != torch.float32 or out.device != x.device
+                        or not out.is_contiguous()):
+                    raise ValueError("out must be a contiguous float32 tensor of the input's shape on its device")
+                y = out
             n, t = int(x.shape[0]), int(x.shape[1])
             if n and t:
                 st = torch.cuda.current_stream(x.device).cuda_stream
-                _lib.check(lib.rced_forward(self._handle, x.data_ptr(), y.data_ptr(), n, t, st))
+                if self.is_training:
+                    _lib.check(lib.rced_train_forward(self._train, x.data_ptr(), y.data_ptr(), n, t, st))
+                else:
+                    _lib.check(lib.rced_forward(self._handle, x.data_ptr(), y.data_ptr(), n, t, st))
             return y
         x = np.asarray(x)
         self._check_shape(x.shape)
         x = np.ascontiguousarray(x, dtype=np.float32)
-        y = np.empty_like(x)
         n, t = x.shape[0], x.shape[1]
+        if self.is_training:        # the training graph lives on device tensors: stage through torch
+            import torch
+            if not (n and t):
+                return np.empty_like(x)
+            return self(torch.from_numpy(x).to("cuda:%d" % self.device)).cpu().numpy()
+        y = np.empty_like(x)
         if n and t:
             _lib.check(lib.rced_forward_host(self._handle, x.ctypes.data, y.ctypes.data, n, t))
         return y
@@ -133,6 +166,12 @@ class _RcedNet(object):
             except Exception:
                 pass
             self._handle = None
+        if self._train is not None:
+            try:
+                _lib.load().rced_train_destroy(self._train)
+            except Exception:
+                pass
+            self._train = None
 
     def close(self):
         self._release()

@@ -533,5 +533,29 @@ def load_training_state(path, variant):
     for slot in ADAM_SLOTS:
         keys = ["%s/%s" % (n, slot) for n in names if not n.endswith(("moving_mean", "moving_variance"))]
         slots.append({k.rsplit("/", 1)[0]: np.asarray(allv[k], np.float32) for k in keys} if all(k in allv for k in keys) else None)
-    step = int(allv["global_step"]) if "global_step" in allv else 0
+    step = int(allv["global_step"]) if "global_step" in allv else None
+    # tf.train.AdamOptimizer keeps beta1^(t+1) after t applied updates in `beta1_power`; the library derives Adam's t
+    # from the step counter, so the two must agree (they do for every checkpoint the reference trainer writes:
+    # train_op bumps global_step once per update, trainer.py:178).  A checkpoint without global_step resumes at
+    # the t that beta1_power implies.
+    t_adam = None
+    if "beta1_power" in allv:
+        b1p = float(np.asarray(allv["beta1_power"]).reshape(-1)[0])
+        if 0.0 < b1p < 1.0:
+            t_adam = int(round(np.log(b1p) / np.log(0.9))) - 1
+    if step is None:
+        step = max(t_adam, 0) if t_adam is not None else 0
+    elif t_adam is not None and t_adam != step:
+        import warnings
+        warnings.warn("%s: beta1_power implies %d Adam updates but global_step is %d; resuming at global_step"
+                      % (path, t_adam, step))
     return weights, slots[0], slots[1], step
+
+
+def write_checkpoint_state(prefix):
+    """The `checkpoint` state file tf.train.latest_checkpoint reads (CheckpointState text proto), next to the
+    bundle: the reference's `continue_train` finds its checkpoint through it (trainer.py:52-58)."""
+    d = os.path.dirname(os.path.abspath(prefix))
+    name = os.path.basename(prefix)
+    with open(os.path.join(d, "checkpoint"), "w") as fh:
+        fh.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (name, name))

@@ -11,7 +11,7 @@ import ctypes
 
 import numpy as np
 
-from . import _lib, spec, weights as _weights
+from . import _lib, model as _model, spec, weights as _weights
 
 
 class FullyCNNTrainer(object):
@@ -26,10 +26,10 @@ class FullyCNNTrainer(object):
         self.device = int(device)
         w = weights if weights is not None else _weights.initial_weights(self.variant, seed)
         self._blob_n = spec.num_weights(self.variant)
-        blob = _weights.pack_blob(self.variant, w)
-        self._h = ctypes.c_void_p()
-        _lib.check(_lib.load().rced_train_create(self.variant, blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
-                                                 blob.size, self.batch_size, self.device, ctypes.byref(self._h)))
+        # creat_graph (trainer.py:165-172): self.model = Model(is_training=True); self.pred = self.model(self.input_x).
+        # The model object owns the library's training handle; train_step runs on the same one.
+        self.model = _model.build_model(net_work, True, weights=w, device=self.device, batch_size=self.batch_size)
+        self._h = self.model._train
 
     def noam_scheme(self, global_step, warmup_steps=None):
         """trainer.py:68-76."""
@@ -59,17 +59,7 @@ class FullyCNNTrainer(object):
         only `pred` runs no UPDATE_OPS and no optimizer step, so nothing changes.  ndarray in -> ndarray out, cuda
         tensor in -> cuda tensor out.  (The inference graph of tester.py / infer.py, which normalises with the moving
         statistics, is `build_model(net_work, False, weights=trainer.variables())`.)"""
-        import torch
-        dev = "cuda:%d" % self.device
-        is_tensor = hasattr(input_x, "is_cuda")
-        x = torch.as_tensor(input_x if is_tensor else np.asarray(input_x, dtype=np.float32), device=dev).float().contiguous()
-        if x.dim() != 4 or x.shape[2] != spec.FEATURE_DIM or x.shape[3] != 1:
-            raise ValueError("input must be [N, T, 129, 1]")
-        y = torch.empty_like(x)
-        if x.numel():
-            st = torch.cuda.current_stream(x.device).cuda_stream
-            _lib.check(_lib.load().rced_train_forward(self._h, x.data_ptr(), y.data_ptr(), int(x.shape[0]), int(x.shape[1]), st))
-        return y if is_tensor else y.cpu().numpy()
+        return self.model(input_x)
 
     def fit_step(self, input_x, target_y):
         """One iteration of the loop body of trainer.py:212-215: step, then set lr for the next step."""
@@ -138,7 +128,11 @@ class FullyCNNTrainer(object):
         training graph (trainer.py:50-51): the model variables, `global_step`, and -- with_optimizer -- the Adam
         slots `<var>/Adam`, `<var>/Adam_1` and the `beta1_power` / `beta2_power` accumulators (beta^(t+1) after t
         steps, as tf.train.AdamOptimizer keeps them).  The reference's test / infer / freeze graphs restore the model
-        variables from it (tester.py:36-39); `FullyCNNTrainer.from_checkpoint` resumes from it."""
+        variables from it (tester.py:36-39); `FullyCNNTrainer.from_checkpoint` resumes from it.  Also written: the
+        `checkpoint` state file `tf.train.latest_checkpoint` needs.  NOT written: `<prefix>.meta` (a serialized
+        MetaGraphDef of the TF graph, which only TensorFlow can produce) -- the reference's own `continue_train`
+        restores only when `continue_from + '.meta'` exists (trainer.py:59-65), so resuming THERE additionally needs
+        a .meta from any checkpoint of the same graph (or `touch`, since only its existence is tested)."""
         from . import tf_checkpoint
         tensors = dict(self.variables())
         m, v, step = self.optimizer_state()
@@ -150,6 +144,7 @@ class FullyCNNTrainer(object):
             tensors["beta1_power"] = np.asarray(0.9 ** (step + 1), np.float32)
             tensors["beta2_power"] = np.asarray(0.999 ** (step + 1), np.float32)
         tf_checkpoint.write_checkpoint(prefix, tensors)
+        tf_checkpoint.write_checkpoint_state(prefix)
         return prefix
 
     @classmethod
@@ -164,7 +159,7 @@ class FullyCNNTrainer(object):
 
     def close(self):
         if self._h is not None:
-            _lib.load().rced_train_destroy(self._h)
+            self.model.close()     # the model owns the handle
             self._h = None
 
     def __del__(self):

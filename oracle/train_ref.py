@@ -33,20 +33,73 @@ def trainable_names(net_work):
 
 
 class TrainRef:
-    def __init__(self, net_work, weights, batch_size, dtype=torch.float64):
+    def __init__(self, net_work, weights, batch_size, dtype=torch.float64, device="cpu", conv="conv2d"):
+        """device / conv: the default is F.conv2d on the CPU.  conv="taps" computes every convolution as a sum over
+        kernel taps of [pixels, cin] x [cin, cout] matmuls on NHWC tensors -- plain torch matmuls, which also run in
+        float64 on a GPU (tests use it to restate BASELINE config 5 at full size, where batch statistics need the
+        whole 256 x 512 batch)."""
         self.layers = L.layers_for(net_work)
         self.net_work = net_work
         self.batch_size = batch_size
         self.dtype = dtype
-        self.vars = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in weights.items()}
+        self.device = torch.device(device)
+        self.conv = conv
+        self.vars = {k: torch.tensor(np.asarray(v), dtype=dtype, device=self.device) for k, v in weights.items()}
         for k in trainable_names(net_work):
             self.vars[k].requires_grad_(True)
         self.m = {k: torch.zeros_like(self.vars[k]) for k in trainable_names(net_work)}
         self.v = {k: torch.zeros_like(self.vars[k]) for k in trainable_names(net_work)}
         self.global_step = 0
 
+    def _forward_train_taps(self, x, keep_preact=False):
+        """The same graph on NHWC tensors with tap-wise matmuls (module.py:27 `SAME`: (k-1)//2 before, the rest after)."""
+        tens = [torch.as_tensor(x).to(device=self.device, dtype=self.dtype)]
+        stats, pre = [], []
+        for l in self.layers:
+            k = self.vars[l.scope + "/kernel"]                                    # HWIO
+            pt, pb = (l.kh - 1) // 2, (l.kh - 1) - (l.kh - 1) // 2
+            pl, pr = (l.kw - 1) // 2, (l.kw - 1) - (l.kw - 1) // 2
+            src = tens[l.src]
+            n, t, f, _ = src.shape
+            xp = Fn.pad(src, (0, 0, pl, pr, pt, pb))
+            y = None
+            for i in range(l.kh):
+                for j in range(l.kw):
+                    term = xp[:, i:i + t, j:j + f, :] @ k[i, j]
+                    y = term if y is None else y.add_(term)
+            del xp
+            y = y + self.vars[l.scope + "/bias"]
+            if l.use_norm:
+                p = l.scope + "/batch_norm/"
+                mean = y.mean(dim=(0, 1, 2))
+                var = ((y - mean) ** 2).mean(dim=(0, 1, 2))
+                y = (y - mean) / torch.sqrt(var + L.BN_EPS) * self.vars[p + "gamma"] + self.vars[p + "beta"]
+                stats.append((l.scope, mean.detach(), var.detach(), y.numel() // y.shape[-1]))
+            if l.skip_pre >= 0:
+                y = y + tens[l.skip_pre]
+            if l.use_act:
+                if keep_preact:
+                    pre.append(float(y.detach().abs().min()))
+                y = torch.relu(y)
+            if l.skip_post >= 0:
+                y = y + tens[l.skip_post]
+            tens.append(y)
+        self.last_hidden = tens[-2]
+        return (tens[-1], stats, pre) if keep_preact else (tens[-1], stats)
+
+    def min_abs_preactivation(self, x):
+        """Smallest |value entering a ReLU| over the whole net for this input: a ReLU whose input is within fp32
+        rounding of zero may take the other branch in an fp32 implementation, which changes gradients by whole
+        terms.  Tests screen their inputs with it (reject-and-redraw) so that tight gradient bounds are meaningful."""
+        with torch.no_grad():
+            ref = TrainRef(self.net_work, {k: v.detach().cpu().numpy() for k, v in self.vars.items()}, self.batch_size,
+                           self.dtype, self.device, "taps")
+            return min(ref._forward_train_taps(x, keep_preact=True)[2])
+
     def forward_train(self, x):
         """model(x) with is_training=True; returns (pred, list of (scope, batch_mean, batch_var_biased, count))."""
+        if self.conv == "taps":
+            return self._forward_train_taps(x)
         tens = [torch.as_tensor(x).to(self.dtype).permute(0, 3, 1, 2)]
         stats = []
         for l in self.layers:
@@ -74,7 +127,7 @@ class TrainRef:
         for k in self.m:
             self.vars[k].grad = None
         pred, stats = self.forward_train(x)
-        loss = ((torch.as_tensor(target).to(self.dtype) - pred) ** 2).sum() / self.batch_size
+        loss = ((torch.as_tensor(target).to(device=pred.device, dtype=self.dtype) - pred) ** 2).sum() / self.batch_size
         loss.backward()
         return loss.item(), {k: self.vars[k].grad.clone() for k in self.m}, stats
 

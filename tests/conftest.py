@@ -37,3 +37,20 @@ def rel_err(y, ref):
     import numpy as np
     ref = np.asarray(ref, dtype=np.float64)
     return float(np.abs(np.asarray(y, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def check_parity(y, ref, rtol=RTOL, what=""):
+    """The fp32 bar, two ways: max|y - ref| <= rtol * max|ref| (the north star's "1e-4 rel" read against the mask's
+    scale) AND element-wise |y - ref| <= rtol * |ref| + 0.1 * rtol * max|ref| (numpy.allclose with an absolute floor of
+    1e-5 of the scale, so that entries near zero are not asked for more digits than fp32 summation has).
+    Returns the measured max error relative to the scale."""
+    import numpy as np
+    y = np.asarray(y, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    err = float(np.abs(y - ref).max() / scale)
+    assert err < rtol, "%s max error %.3e of the scale (bar %.1e)" % (what, err, rtol)
+    bad = np.abs(y - ref) > rtol * np.abs(ref) + 0.1 * rtol * scale
+    assert not bad.any(), "%s %d entries outside rtol %.1e / atol %.1e*scale" % (what, int(bad.sum()), rtol, 0.1 * rtol)
+    return err

@@ -2,6 +2,8 @@
 
 import configparser
 
+import os
+
 import numpy as np
 import pytest
 
@@ -56,10 +58,31 @@ def test_npz_round_trip(tmp_path, built):
     assert np.array_equal(weights.pack_blob(2, w), weights.pack_blob(2, w2))
 
 
-def test_training_mode_is_refused(built):
-    from fullycnnspeechenhancement_amd import FullyCNNSEModelV3
-    with pytest.raises(NotImplementedError):
-        FullyCNNSEModelV3(True)
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks(built):
+    """`python bench.py --gpus 2` with RANK unset must start 2 ranks as a child (torch.distributed.run) and hand back
+    the child's exit code.  Here there is no GPU, so each rank stops at bench.py's own "needs a GPU" check: what is
+    checked is that two ranks with WORLD_SIZE=2 ran, and that the parent relayed their failure."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # also on a GPU box: this test is about the launcher only
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    assert r.stdout.strip() == ""            # no JSON line was produced, none was invented
+
+
+def test_bench_rejects_a_world_size_that_is_not_gpus(built):
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and ("needs a GPU" in r.stderr or "WORLD_SIZE" in r.stderr)
 
 
 def test_shape_check_messages(built):

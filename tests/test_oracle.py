@@ -156,3 +156,23 @@ def test_bf16_emulation_rounding_and_scale():
         y32, y16 = rced_np.forward(net_work, w, x), rced_np.forward_bf16(net_work, w, x)
         err = np.abs(y16 - y32).max() / np.abs(y32).max()
         assert 1e-4 < err < 3e-2, err          # really bf16 (not fp32), and no worse than 15 layers of 8-bit mantissas
+
+
+def test_same_padding_agrees_with_a_third_partys_same_rule():
+    """An independent check of the `SAME` convention the restatement hard-codes (module.py:27 passes padding='SAME';
+    TF splits k-1 as (k-1)//2 before, the rest after: 3 / 4 for the 8-tall first kernels).  torch.nn.functional.conv2d's
+    padding='same' implements the same rule for even kernels (the extra element goes AFTER) and, like TF, computes a
+    cross-correlation: every kernel shape the three nets use must agree."""
+    import torch
+    import torch.nn.functional as Fn
+    rng = np.random.default_rng(3)
+    for kh, kw, cin, cout in ((8, 13, 1, 12), (8, 11, 1, 10), (8, 9, 1, 18), (1, 5, 18, 30), (1, 9, 30, 8), (1, 7, 23, 25),
+                              (1, 129, 8, 1), (4, 6, 2, 3)):
+        x = rng.standard_normal((2, 11, 129, cin))
+        k = rng.standard_normal((kh, kw, cin, cout))
+        b = rng.standard_normal(cout)
+        ours = rced_np.conv2d_same(x, k, b, np.float64)
+        theirs = Fn.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(k).permute(3, 2, 0, 1).contiguous(),
+                           torch.from_numpy(b), padding="same").permute(0, 2, 3, 1).numpy()
+        assert np.abs(ours - theirs).max() < 1e-10 * np.abs(theirs).max(), (kh, kw)
+        assert tuple(rced_np.same_pad(kh)) == ((kh - 1) // 2, kh - 1 - (kh - 1) // 2)

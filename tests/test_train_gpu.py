@@ -279,3 +279,127 @@ def test_valid_step_is_the_training_graph_forward_and_changes_nothing(net_work, 
     on_dev = tr.valid_step(torch.from_numpy(x).cuda())
     assert on_dev.is_cuda and np.array_equal(on_dev.cpu().numpy(), pred)
     tr.close()
+
+
+def screened_input(ref, n, t, seed0, margin=1e-5):
+    """Reject-and-redraw: the first seeded input for which NO value entering a ReLU is within `margin` of zero in the
+    fp64 restatement (the GPU's fp32 pre-activations differ from it by ~1e-6), so that no ReLU mask can flip and
+    gradients can be compared tightly.  ~1e5 pre-activations of unit scale: about one draw in five passes."""
+    for s in range(400):
+        x = rced_np.make_input(n, t, seed=seed0 + s)
+        if ref.min_abs_preactivation(x) > margin:
+            return x, seed0 + s
+    raise AssertionError("no screened input in 400 draws")
+
+
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_all_gradients_tight_on_inputs_without_relu_ties(net_work, tag, variant, built, capsys):
+    """Every gradient of every layer, element-wise, within 1e-4 of the tensor's largest entry against the fp64 autograd
+    restatement (trainer.py:146-147 loss, module.py:27-33 layers), on an input screened so that no ReLU argument lies
+    within 1e-5 of zero -- the loose bounds of test_loss_and_gradients_all_nets exist only because of such ties."""
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer
+    w = rced_np.make_weights(net_work, seed=11)
+    ref = train_ref.TrainRef(net_work, w, batch_size=4)
+    x, seed = screened_input(ref, 2, 3, 5000 + 100 * variant)
+    y = rced_np.make_input(2, 3, seed=77 + variant)
+    loss_ref, grads_ref, _ = ref.loss_and_grads(x, y)
+    tr = FullyCNNTrainer(net_work, batch_size=4, lr=1e-4, weights=w)
+    loss, _, _ = tr.train_step(x, y)
+    assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref)
+    g = tr.gradients()
+    worst = {}
+    for name, gr in grads_ref.items():
+        gr = gr.numpy()
+        if name.endswith("/bias") and (name[:-5] + "/batch_norm/gamma") in grads_ref:
+            # a bias in front of BatchNorm: the true gradient is exactly 0 (the batch mean removes it)
+            assert np.abs(g[name]).max() <= 1e-4 * max(np.abs(g[name[:-5] + "/kernel"]).max(), 1e-30), name
+            continue
+        scale = np.abs(gr).max()
+        err = np.abs(g[name].astype(np.float64) - gr).max() / scale
+        worst[name] = err
+        assert err < TIGHT, (name, err)
+    with capsys.disabled():
+        k = max(worst, key=worst.get)
+        print("\n[train parity] %s seed %d: loss rel err %.2e, worst gradient %s %.2e of its max (%d tensors)" % (
+            net_work, seed, abs(loss - loss_ref) / abs(loss_ref), k, worst[k], len(worst)))
+    tr.close()
+
+
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_model_is_training_true_is_the_training_graph(net_work, tag, variant, built):
+    """trainer.py:165-172 builds `Model(is_training=True)`; model(x) then normalises with the statistics of the batch
+    (module.py:29 with training=True) and changes no variable.  Checked against the fp64 restatement; the trainer runs
+    its steps on the same library handle (`trainer.model`)."""
+    import torch
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer, build_model
+    w = rced_np.make_weights(net_work, seed=60 + variant)
+    x = rced_np.make_input(3, 11, seed=61)
+    ref = train_ref.TrainRef(net_work, w, 3).forward_train(torch.from_numpy(x).double())[0].detach().numpy()
+    m = build_model(net_work, True, weights=w)
+    assert m.is_training
+    pred = m(x)
+    assert isinstance(pred, np.ndarray) and pred.dtype == np.float32 and rel(pred, ref) < 1e-4
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty_like(xd)
+    assert m(xd, out=out) is out and np.array_equal(out.cpu().numpy(), pred)
+    with pytest.raises(RuntimeError):
+        m.set_option("bf16", 1)                      # inference-kernel options do not exist on the training graph
+    m.close()
+    tr = FullyCNNTrainer(net_work, batch_size=3, lr=1e-3, weights=w)
+    assert tr.model.is_training and np.array_equal(tr.model(x), pred)        # same graph, same handle as train_step
+    tr.train_step(x, x)
+    assert rel(tr.model(x), pred) > 1e-6                                     # the step moved the shared variables
+    tr.close()
+
+
+def test_full_size_config5_against_fp64_restatement_on_the_gpu(built, capsys):
+    """BASELINE configs[4] at its full size (CR-CED V3, batch 256 x 512 frames; trainer.py:181-192).  Batch statistics
+    couple all 16.9 M pixels, so nothing can be sampled: the whole forward is restated in float64 with plain torch
+    matmuls on the same GPU (oracle/train_ref.py, conv="taps").  Checked: the loss (1e-5), every layer's batch mean and
+    variance as they reach the moving statistics (momentum 0.99, unbiased variance), and the output layer's gradients
+    (autograd through the fp64 restatement's last layer)."""
+    import torch
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer
+    B, T = 256, 512
+    w = rced_np.make_weights("FullyCNNV3", seed=42)
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.randn((B, T, 129, 1), generator=g, device="cuda").abs_()
+    y = 0.5 * torch.randn((B, T, 129, 1), generator=g, device="cuda").abs_()
+    tr = FullyCNNTrainer("FullyCNNV3", batch_size=B, lr=1e-3, weights=w)
+    loss, _, step = tr.train_step(x, y)
+    assert step == 1 and np.isfinite(loss)
+    grads, after = tr.gradients(), tr.variables()
+    tr.close()
+    torch.cuda.empty_cache()
+    ref = train_ref.TrainRef("FullyCNNV3", w, B, device="cuda", conv="taps")
+    with torch.no_grad():
+        pred, stats = ref.forward_train(x)
+        hidden = ref.last_hidden
+    loss_ref = float(((y.double() - pred) ** 2).sum() / B)
+    assert abs(loss - loss_ref) <= 1e-5 * loss_ref, (loss, loss_ref)
+    worst = 0.0
+    for scope, mean, var, n in stats:
+        p = scope + "/batch_norm/"
+        mm = 0.99 * np.asarray(w[p + "moving_mean"], np.float64) + 0.01 * mean.cpu().numpy()
+        mv = 0.99 * np.asarray(w[p + "moving_variance"], np.float64) + 0.01 * var.cpu().numpy() * n / (n - 1)
+        e1 = np.abs(after[p + "moving_mean"] - mm).max() / max(np.abs(mm).max(), 1e-30)
+        e2 = np.abs(after[p + "moving_variance"] - mv).max() / np.abs(mv).max()
+        worst = max(worst, e1, e2)
+        assert e1 < 1e-5 and e2 < 1e-5, (scope, e1, e2)
+    # output layer: d loss / d (kernel, bias) by autograd through the restatement's last layer only
+    kf = ref.vars["decode_final/kernel"].detach().clone().requires_grad_(True)
+    bf = ref.vars["decode_final/bias"].detach().clone().requires_grad_(True)
+    hp = torch.nn.functional.pad(hidden, (0, 0, 64, 64))
+    out = sum(hp[:, :, j:j + 129, :] @ kf[0, j] for j in range(129)) + bf
+    (((y.double() - out) ** 2).sum() / B).backward()
+    eg = {}
+    for name, gr in (("decode_final/kernel", kf.grad), ("decode_final/bias", bf.grad)):
+        gr = gr.cpu().numpy()
+        eg[name] = np.abs(grads[name] - gr).max() / np.abs(gr).max()
+        assert eg[name] < TIGHT, (name, eg[name])
+    del ref, pred, hidden, hp, out
+    torch.cuda.empty_cache()
+    with capsys.disabled():
+        print("\n[config 5 full size] loss %.6f vs fp64 %.6f (rel %.1e); BN statistics worst rel err %.1e; "
+              "decode_final grads %.1e / %.1e" % (loss, loss_ref, abs(loss - loss_ref) / loss_ref, worst,
+                                                 eg["decode_final/kernel"], eg["decode_final/bias"]))

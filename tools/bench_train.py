@@ -5,13 +5,12 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from fullycnnspeechenhancement_amd import FullyCNNTrainer
-from oracle import rced_np
+from fullycnnspeechenhancement_amd import FullyCNNTrainer, spec, weights as _weights
 
 NET = os.environ.get("NET", "FullyCNNV3")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-w = rced_np.make_weights(NET, seed=42)
+w = _weights.synthetic_weights(spec.variant_of(NET), seed=42)
 tr = FullyCNNTrainer(NET, batch_size=B, lr=1e-3, warmup_steps=4000.0, weights=w)
 g = torch.Generator(device="cuda").manual_seed(1234)
 x = torch.randn((B, T, 129, 1), generator=g, device="cuda").abs_()

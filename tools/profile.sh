@@ -8,7 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-profile $*"
+python3 $ROOT/__graft_entry__.py > /dev/null 2>&1   # build first, in a process of its own (never under the profiler)
+BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-profile --no-secondary $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps 10 --warmup 3 > "$OUT/trace.log" 2>&1
 pmc() { # name counters...
   local name=$1; shift
@@ -19,5 +20,5 @@ pmc write WRITE_SIZE
 pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
 pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA
 cd "$ROOT"
-python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 tools/summarize_prof.py "$OUT" "$OUT/pmc_traffic.json" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

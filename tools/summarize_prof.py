@@ -19,6 +19,36 @@ def short(name):
     return name[:60]
 
 
+def traffic_json(out, path):
+    """profiles/rNN_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE per launch (KiB) of the forward kernels, tagged with the
+    hash of the kernel sources they were measured on (bench.py attaches roofline.traffic only on a match).
+    FETCH_SIZE is doubled for kernels whose dominant read stream is 16 B/lane (MI355X_MICROARCH.md, HBM section):
+    the final GEMM's h rows.  The fused kernel's input rows are 4 B/lane loads: uncalibrated width, left as counted."""
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as ge
+    vals = defaultdict(lambda: [0.0, 0])
+    for d in glob.glob(os.path.join(out, "pmc_*")):
+        for f in find(d, "*counter_collection.csv"):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    if r.get("Counter_Name") in ("FETCH_SIZE", "WRITE_SIZE"):
+                        k = (short(r.get("Kernel_Name", "")), r.get("Counter_Name"))
+                        vals[k][0] += float(r.get("Counter_Value", 0) or 0)
+                        vals[k][1] += 1
+    rec = {"_comment": "HBM traffic per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB); "
+                       "tools/profile.sh -> bench.py --steps 2 --warmup 1 at the default workload",
+           "kernel_hash": ge.forward_kernel_hash(), "workload": {"variant": 3, "batch": 256, "frames": 512}}
+    for kern in ("fused_v3_kernel", "final_gemm_kernel"):
+        f, w = vals.get((kern, "FETCH_SIZE")), vals.get((kern, "WRITE_SIZE"))
+        if f and w and f[1] and w[1]:
+            raw = f[0] / f[1]
+            rec[kern] = {"fetch_kib": 2 * raw if kern == "final_gemm_kernel" else raw, "fetch_kib_raw": raw,
+                         "write_kib": w[0] / w[1]}
+    with open(path, "w") as fh:
+        json.dump(rec, fh, indent=1)
+
+
 def main(out):
     print("# rocprofv3 summary:", os.path.basename(out))
     for f in find(os.path.join(out, "trace"), "*kernel_stats.csv"):
@@ -61,3 +91,5 @@ def main(out):
 
 if __name__ == "__main__":
     main(sys.argv[1])
+    if len(sys.argv) > 2:
+        traffic_json(sys.argv[1], sys.argv[2])
