@@ -11,8 +11,6 @@
 #include "kernels_fused_chain.h"
 #include "kernels_fused_v3.h"
 #include "kernels_fused_chain16.h"
-#include "kernels_fused_v3t.h"
-#include "kernels_fused_v3w.h"
 #include "rced_internal.h"
 
 using namespace rced;
@@ -26,14 +24,14 @@ struct rced_fused {
   float* h = nullptr;         // [frames, 129, 8] hand-off to the final layer
   size_t h_bytes = 0;
   unsigned long long* stamps = nullptr;  // diagnostic builds (RCED_STAMPS) only
-  int teams = 0;              // option "v3_teams": 1 = two-team kernel (kernels_fused_v3t.h)
-  int wide = 0;               // option "v3_wide": 1 = sixteen-wave kernel (kernels_fused_v3w.h)
   int bf16 = 0;               // option "bf16" (V1/V2): bf16 activations + weights (kernels_fused_chain16.h)
   float* wpack16 = nullptr;   // its packet stream (built when the option is first set)
   unsigned short* fin_apack16 = nullptr;   // the output layer's Toeplitz A fragments in bf16 (chain16::final_gemm16_kernel)
   float* scratch16 = nullptr; // skip fragments for 2 workgroups per CU
   int bf16_wgs_per_cu = 1;
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
+  unsigned* err_host = nullptr;   // sticky error word of the CR-CED kernel's wave-to-wave hand-offs: pinned host memory the
+  unsigned* err_dev = nullptr;    // kernel reaches through its device alias, so the host reads it without a device sync
 };
 
 #define HIP_TRY(expr)                                                                          \
@@ -375,8 +373,6 @@ int upload(float** dev, const std::vector<float>& host) {
 int fused_create(rced_model* m) {
   m->fused = nullptr;
   rced_fused* f = new rced_fused();
-  if (const char* e = getenv("RCED_V3_TEAMS")) f->teams = atoi(e) != 0;   // experiment switch
-  if (const char* e = getenv("RCED_V3_WIDE")) f->wide = atoi(e) != 0;
   if (m->variant != RCED_V3) {
     m->fused = f;
     const int rc = m->variant == RCED_V1 ? chain_create<chain::NetV1>(m, f) : chain_create<chain::NetV2>(m, f);
@@ -391,12 +387,14 @@ int fused_create(rced_model* m) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3::fused_v3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLdsBytes);
     if (e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(LDS %d): %s", v3::kLdsBytes, hipGetErrorString(e));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3w::fused_v3w_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, v3w::kLdsBytes);
-    if (!rc && e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(v3w): %s", hipGetErrorString(e));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3t::fused_v3t_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, v3t::kLdsBytes);
-    if (!rc && e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(v3t): %s", hipGetErrorString(e));
+  }
+  if (!rc) {
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&f->err_host), 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+      *f->err_host = 0u;
+      e = hipHostGetDevicePointer(reinterpret_cast<void**>(&f->err_dev), f->err_host, 0);
+    }
+    if (e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "error word (pinned host memory): %s", hipGetErrorString(e));
   }
 #if RCED_STAMPS
   if (!rc && hipMalloc(&f->stamps, (64 + 24) * sizeof(unsigned long long)) != hipSuccess) f->stamps = nullptr;
@@ -419,6 +417,7 @@ void fused_destroy(rced_model* m) {
   if (f->fin_apack) (void)hipFree(f->fin_apack);
   if (f->h) (void)hipFree(f->h);
   if (f->scratch) (void)hipFree(f->scratch);
+  if (f->err_host) (void)hipHostFree(f->err_host);
   delete f;
   m->fused = nullptr;
 }
@@ -439,6 +438,18 @@ int fused_reserve(rced_model* m, int N, int T) {
   return RCED_OK;
 }
 
+// The CR-CED kernel's split-tile hand-offs wait on LDS flag words with a bounded spin; a flag that never arrives is
+// recorded in a sticky word instead of hanging the GPU (kernels_fused_v3.h flag_wait).  The results of that launch are
+// wrong, so the model refuses further work: checked before every launch and after every synchronising entry point.
+int fused_check(rced_model* m) {
+  rced_fused* f = m->fused;
+  if (!f || !f->err_host) return RCED_OK;
+  const unsigned e = *reinterpret_cast<volatile unsigned*>(f->err_host);
+  if (e == 0u) return RCED_OK;
+  return rced_fail(RCED_ERR_STATE, "fused CR-CED kernel: a wave-to-wave hand-off timed out (code %u); results of that "
+                                   "launch are invalid -- destroy and recreate the model", e);
+}
+
 int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStream_t st) {
   rced_fused* f = m->fused;
   if (int rc = fused_reserve(m, N, T)) return rc;
@@ -448,32 +459,9 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   if (m->variant == RCED_V2)
     return f->bf16 ? chain16_forward<chain16::WithTF<chain::NetV2, RCED_C16_TF>>(m, f, x, y, N, T, st)
                    : chain_forward<chain::NetV2>(m, f, x, y, N, T, st);
-  if (f->teams) {
-    v3t::Params Q;
-    Q.x = x;
-    Q.h = f->h;
-    Q.wpack = f->wpack;
-    Q.N = N;
-    Q.T = T;
-    Q.tiles_per_utt = (T + v3t::kTF - 1) / v3t::kTF;
-    Q.total_tiles = N * Q.tiles_per_utt;
-    Q.stamps = f->stamps;
-    const int cus2 = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
-    const int grid2 = std::min((Q.total_tiles + v3t::kTeams - 1) / v3t::kTeams, cus2);
-    m->prof_begin(RCED_K_FUSED, st);
-    hipLaunchKernelGGL(v3t::fused_v3t_kernel, dim3(grid2), dim3(v3t::kThreads), v3t::kLdsBytes, st, Q);
-    m->prof_end(RCED_K_FUSED, st);
-    HIP_TRY(hipGetLastError());
-    const int frames2 = N * T;
-    m->prof_begin(RCED_K_FINAL, st);
-    hipLaunchKernelGGL(v3::final_gemm_kernel, dim3((frames2 + v3::kFinFrames - 1) / v3::kFinFrames),
-                       dim3(v3::kFinThreads), 0, st, (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y,
-                       frames2);
-    m->prof_end(RCED_K_FINAL, st);
-    HIP_TRY(hipGetLastError());
-    return RCED_OK;
-  }
+  if (int rc = fused_check(m)) return rc;   // a hand-off flag that never came in an EARLIER launch: refuse to go on
   v3::Params P;
+  P.err = f->err_dev;
   P.x = x;
   P.h = f->h;
   P.wpack = f->wpack;
@@ -485,8 +473,7 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   const int cus = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
   const int grid = std::min(P.total_tiles, cus);
   m->prof_begin(RCED_K_FUSED, st);
-  if (f->wide) hipLaunchKernelGGL(v3w::fused_v3w_kernel, dim3(grid), dim3(v3w::kThreads), v3w::kLdsBytes, st, P);
-  else hipLaunchKernelGGL(v3::fused_v3_kernel, dim3(grid), dim3(v3::kThreads), v3::kLdsBytes, st, P);
+  hipLaunchKernelGGL(v3::fused_v3_kernel, dim3(grid), dim3(v3::kThreads), v3::kLdsBytes, st, P);
   m->prof_end(RCED_K_FUSED, st);
   HIP_TRY(hipGetLastError());
   const int frames = N * T;
@@ -511,10 +498,6 @@ int fused_set_option(rced_model* m, const char* key, int value) {
     m->fused->grid_limit = value;
     return RCED_OK;
   }
-  if (!strcmp(key, "v3_wide") && m->variant == RCED_V3) {
-    m->fused->wide = value != 0;
-    return RCED_OK;
-  }
   if (!strcmp(key, "bf16")) {
     if (m->variant == RCED_V3) return value ? rced_fail(RCED_ERR_ARG, "bf16 is built for R-CED V1 / V2 only") : RCED_OK;
     if (value) {
@@ -522,10 +505,6 @@ int fused_set_option(rced_model* m, const char* key, int value) {
         return rc;
     }
     m->fused->bf16 = value != 0;
-    return RCED_OK;
-  }
-  if (!strcmp(key, "v3_teams") && m->variant == RCED_V3) {
-    m->fused->teams = value != 0;
     return RCED_OK;
   }
   return RCED_ERR_ARG;
@@ -551,16 +530,8 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
     *value = 0;
     return RCED_OK;
   }
-  if (!strcmp(key, "v3_wide")) {
-    *value = m->fused->wide;
-    return RCED_OK;
-  }
   if (!strcmp(key, "bf16")) {
     *value = m->fused->bf16;
-    return RCED_OK;
-  }
-  if (!strcmp(key, "v3_teams")) {
-    *value = m->fused->teams;
     return RCED_OK;
   }
   return RCED_ERR_ARG;

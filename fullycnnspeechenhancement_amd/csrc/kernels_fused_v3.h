@@ -16,37 +16,28 @@
 //     16,17 for 8 adjacent pixels at once (rows = 8 phases x 2 channels, K = 16 taps);
 //   * the two CR-CED block skips (model.py:75-76, added after ReLU) never touch LDS: they stay in
 //     the accumulator registers of the wave that produced them;
-//   * operands are software-pipelined by hand (read step s+1 or s+2, then the MFMAs of step s):
-//     left alone, hipcc issues each LDS read right before its use and the MFMA pipe starves.
+//   * operands are software-pipelined by hand (read slot i+2, then the MFMAs of slot i): left alone, hipcc issues
+//     each LDS read right before its use and the MFMA pipe starves;
+//   * a wave walks its tiles one after the other and stores tile j's results between the MFMAs of tile j+1
+//     ("slot streams", below): the epilogues' LDS stores no longer sit on every layer's tail.
 //
 // Pixel space of a tile: kTF frames, frame i at flat pixels [i*kS, i*kS+129); the kS-129 = 4 gap
 // pixels between frames are always zero and serve as the SAME-padding halo of both neighbours.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "lds_dma.h"
 
-#ifndef RCED_EXP_NOBAR
-#define RCED_EXP_NOBAR 0  // timing experiment only (results wrong): 1 = no per-layer barrier, no hand-off waits (waves drift
-                          // freely inside a tile); >= 2 = no barrier at all and waves 4..7 start ~4 k cycles * value late
-#endif
-#ifndef RCED_EXP_NOEPI
-#define RCED_EXP_NOEPI 0  // timing experiments only: bit0/1/2 drop the epilogue (ReLU + LDS stores) of L1/L2/L3 (results wrong)
-#endif
-#ifndef RCED_EXP_SKIP
-#define RCED_EXP_SKIP 0   // timing experiments only: bit0 skip L1 math, bit1 L2, bit2 L3 (results wrong)
-#endif
 #ifndef RCED_D1
-#define RCED_D1 2   // operand prefetch depth (steps) of the layer-1 / layer-2 / layer-3 passes
+#define RCED_D1 2   // operand prefetch depth (slots) of the layer-1 / layer-2 / layer-3 streams
 #endif
 #ifndef RCED_D2
-#define RCED_D2 1
+#define RCED_D2 2
 #endif
 #ifndef RCED_D3
 #define RCED_D3 2
-#endif
-#ifndef RCED_EXP_WGLOBAL
-#define RCED_EXP_WGLOBAL 0   // experiment: A fragments straight from global/L2 instead of the LDS packet
 #endif
 #ifndef RCED_STAMPS
 #define RCED_STAMPS 0     // diagnostic build: s_memtime stamps around every layer's math and barrier
@@ -153,6 +144,7 @@ struct Params {
   int tiles_per_utt;    // ceil(T / kTF)
   int total_tiles;      // N * tiles_per_utt
   unsigned long long* stamps;  // diagnostic builds only (RCED_STAMPS): [wave][8] cycle sums of workgroup 0
+  unsigned* err;        // sticky error word (host-visible): bit 1 / 2 = a layer-2 / layer-3 hand-off flag never came
 };
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
@@ -169,20 +161,13 @@ __device__ __forceinline__ void lds_poke(void* p, unsigned v) {
   *(volatile __attribute__((address_space(3))) unsigned*)p = v;
 }
 
-// Experiment switch: re-derive lane coordinates behind an opaque barrier in every layer, so that hipcc
-// does not hoist every layer's address arithmetic out of the loops (VGPRs 238 -> 136, but the
-// recomputation costs 3 % here; the chain kernel needs it to avoid spills).
-// Always-on variant for the few values only the split-tile code needs: recomputed where used (3-4 VALU)
-// instead of being hoisted out of the tile loop by LICM and kept live in VGPRs across all fifteen layers.
+// hipcc hoists loop-invariant per-lane address arithmetic out of the tile loop -- every layer's, for every wave role --
+// and then keeps (or spills) dozens of VGPRs across all fifteen layers.  Each layer function therefore re-derives its
+// lane coordinates from a copy of the lane id the optimiser cannot see through: a handful of VALU per layer.
 __device__ __forceinline__ int opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
-#ifdef RCED_V3_OPAQUE
-#define OPAQUE_LANE(l) asm volatile("" : "+v"(l))
-#else
-#define OPAQUE_LANE(l)
-#endif
 
 // Stream one weight packet global -> LDS with LDS-DMA (no VGPR staging, no ds_write): wave w copies
 // the 1-KiB chunks w, w+8, w+16; lane l of a chunk moves 16 bytes.  Completion: vmcnt(0) + barrier
@@ -203,126 +188,9 @@ __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float*
 }
 __device__ __forceinline__ void layer_end_sync() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
-  if (!RCED_EXP_NOBAR) __syncthreads();
+  __syncthreads();
 }
 
-// ---------------------------------------------------------------------------------------------
-// Implicit-GEMM pass: NB64 b64 steps (k = 8s + 2kq + e) plus one b32 tail step (k = 8*NB64 + kq),
-// hand-pipelined DEPTH steps ahead.
-//   NR regular slots at float offsets off0 + t*STRIDE run every step and every M-tile.
-//   NX (0/1) extra slot at offx runs b64 steps [XS0, XS1), the tail iff XTAIL, and only M-tile XMT
-//   (XMT < 0: all) -- this is how an odd tile is shared between two waves (by M-tile or along K).
-//   w: LDS packet [NB64][MT][lane][2] then tail [MT][lane].  tailoff: per-lane float delta of the
-//   tail read relative to off + 8*NB64 (kq_eff - 2*kq: lanes past K re-read in-window data, their
-//   weights are zero).
-// ---------------------------------------------------------------------------------------------
-template <int NR, int NX, int MT, int XMT, int NB64, int XS0, int XS1, bool XTAIL, int STRIDE, int DEPTH>
-__device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, int tailoff, const float* w, int lane,
-                                          f32x4 (&acc)[NR + NX][MT]) {
-  constexpr int NT = NR + NX;
-  constexpr int RING = DEPTH + 1;
-  const f32x2* wp = reinterpret_cast<const f32x2*>(w) + lane;
-  const float* wt = w + NB64 * MT * 128 + lane;
-  f32x2 a[RING][MT], b[RING][NT];
-  float at[MT], bt[NT];
-  auto xlive = [](int s) { return NX > 0 && s >= XS0 && s < XS1; };
-  auto xmt = [](int mt) { return XMT < 0 || mt == XMT; };
-  auto load = [&](int s, f32x2(&as)[MT], f32x2(&bs)[NT]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) as[mt] = wp[(s * MT + mt) * 64];
-#pragma unroll
-    for (int t = 0; t < NR; ++t) bs[t] = *reinterpret_cast<const f32x2*>(act + off0 + t * STRIDE + 8 * s);
-    if constexpr (NX > 0)
-      if (xlive(s)) bs[NR] = *reinterpret_cast<const f32x2*>(act + offx + 8 * s);
-  };
-  // tail operands first: they are needed last and cost MT + NT registers
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) at[mt] = wt[mt * 64];
-#pragma unroll
-  for (int t = 0; t < NR; ++t) bt[t] = act[off0 + t * STRIDE + 8 * NB64 + tailoff];
-  if constexpr (NX > 0 && XTAIL) bt[NR] = act[offx + 8 * NB64 + tailoff];
-#pragma unroll
-  for (int s = 0; s < DEPTH && s < NB64; ++s) load(s, a[s % RING], b[s % RING]);
-#pragma unroll
-  for (int s = 0; s < NB64; ++s) {
-    if (s + DEPTH < NB64) load(s + DEPTH, a[(s + DEPTH) % RING], b[(s + DEPTH) % RING]);
-    pin();
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-#pragma unroll
-      for (int t = 0; t < NR; ++t)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(a[s % RING][mt][e], b[s % RING][t][e], acc[t][mt]);
-      if constexpr (NX > 0)
-        if (xlive(s)) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            if (xmt(mt)) acc[NR][mt] = mfma(a[s % RING][mt][e], b[s % RING][NR][e], acc[NR][mt]);
-        }
-    }
-    pin();
-  }
-#pragma unroll
-  for (int t = 0; t < NR; ++t)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(at[mt], bt[t], acc[t][mt]);
-  if constexpr (NX > 0 && XTAIL) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      if (xmt(mt)) acc[NR][mt] = mfma(at[mt], bt[NR], acc[NR][mt]);
-  }
-}
-
-// Layer 1 of blocks 1..4: main pass (NM = NMR regular + NMX extra tiles, 9 b64-steps) and remainder
-// pass (NR tiles of 8-pixel columns, 16 b64-steps) issued as ONE pipelined stream of 16 slots; the
-// remainder accumulates even / odd steps in two independent chains.
-template <int NMR, int NMX, int NR>
-__device__ __forceinline__ void l1_pass(const float* b8, int offm0, int offmx, const int (&offr)[NR == 0 ? 1 : NR],
-                                        const float* w, int lane, f32x4 (&accm)[NMR + NMX][1],
-                                        f32x4 (&accr)[NR == 0 ? 1 : NR][2]) {
-  constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR, DEPTH = RCED_D1, RING = DEPTH + 1;
-  constexpr int SLOTS = NR > 0 ? 16 : 9;
-  const f32x2* wm = reinterpret_cast<const f32x2*>(w) + lane;
-  const f32x2* wr = reinterpret_cast<const f32x2*>(w + kW1Main) + lane;
-  f32x2 am[RING], bm[RING][NM], ar[RING], br[RING][NRA];
-  // main step issued in slot i (or -1): 9 main steps spread over the 16 remainder steps
-  auto main_step = [](int i) { return NR > 0 ? ((i * 9) / 16 != ((i + 1) * 9) / 16 ? (i * 9) / 16 : -1) : i; };
-  auto load = [&](int i, int buf) {
-    if constexpr (NR > 0) {
-      ar[buf] = wr[i * 64];
-#pragma unroll
-      for (int t = 0; t < NR; ++t) br[buf][t] = *reinterpret_cast<const f32x2*>(b8 + offr[t] + kB8S * i);
-    }
-    const int m = main_step(i);
-    if (m >= 0) {
-      am[buf] = wm[m * 64];
-#pragma unroll
-      for (int t = 0; t < NMR; ++t)
-        bm[buf][t] = *reinterpret_cast<const f32x2*>(b8 + offm0 + t * 128 * kB8S + kB8S * m);
-      if constexpr (NMX > 0) bm[buf][NMR] = *reinterpret_cast<const f32x2*>(b8 + offmx + kB8S * m);
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < DEPTH; ++i) load(i, i % RING);
-#pragma unroll
-  for (int i = 0; i < SLOTS; ++i) {
-    if (i + DEPTH < SLOTS) load(i + DEPTH, (i + DEPTH) % RING);
-    pin();
-    const int buf = i % RING;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      if constexpr (NR > 0) {
-#pragma unroll
-        for (int t = 0; t < NR; ++t) accr[t][i & 1] = mfma(ar[buf][e], br[buf][t][e], accr[t][i & 1]);
-      }
-      if (main_step(i) >= 0) {
-#pragma unroll
-        for (int t = 0; t < NM; ++t) accm[t][0] = mfma(am[buf][e], bm[buf][t][e], accm[t][0]);
-      }
-    }
-    pin();
-  }
-}
 
 // The same for block 0 (8x9 kernel on the 1-channel input, b32 steps): main 18 k-steps (ih, j<9),
 // remainder 32 k-steps (ih, u<16); lane kq <-> time tap 4*ih + kq.
@@ -462,14 +330,527 @@ __device__ __forceinline__ void xstage_store(const XStage& st, float* x0, int ti
 }
 static_assert(kX0Floats <= 3 * kThreads, "XStage holds 3 floats per thread");
 
-// ---- the three layer kinds, templated on the calling wave's tile signature -------------------
-template <int NMR, int NMX, int NR>
-__device__ __forceinline__ void layer1(float* lds, const float* w, bool first, int wave, int lane, int xm, int xr0,
-                                       int xr1) {
-  constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR;
-  OPAQUE_LANE(lane);
+// ---------------------------------------------------------------------------------------------
+// Layer passes as SLOT STREAMS.
+//
+// What the passes are built around (measured, tools/micro/mfma_lds_rate.hip and the s_memtime stamps):
+//   * v_mfma_f32_16x16x4_f32 shares the SIMD's vector ALU with ordinary VALU work: VALU instructions issued by either
+//     wave of a SIMD are NOT hidden behind the other wave's MFMAs (4 extra VALU per 4-MFMA slot: 95 % -> 70 % of the
+//     MFMA rate).  So the passes spend as few VALU instructions as they can: every LDS address is a per-lane base that
+//     is computed once per kernel (struct Lane) plus a compile-time immediate; gap pixels are handled by exec masks from
+//     precomputed validity bits behind wave-uniform branches (3 of 33 tiles), not by per-element selects; block-dependent
+//     work (skip adds, skip saves, the last block's global stores) sits behind wave-uniform branches.
+//   * LDS reads are cheap beside MFMAs (0.4 -> 1 read per MFMA costs ~2 %), LDS STORES are not (~85 B/clk per CU: a
+//     layer's 64 KB of outputs is ~750 cycles): a wave therefore walks its tiles in small jobs ("slots" = one b64 K-step
+//     of one job) in ONE software-pipelined stream -- operands of slot i+D are read while the MFMAs of slot i issue,
+//     across job boundaries -- and job j's stores are issued between the MFMAs of job j+1.
+//   * Split tiles (the odd tile of layers 2 and 3, shared by waves 0..3 so that every SIMD carries the same MFMA count)
+//     are each wave's FIRST job: a helper publishes its partial sums through LDS scratch + a tagged flag word a few slots
+//     into its next job and the reducer picks them up after its last job, when they have long been there.  LDS
+//     operations of one wave execute in order, so "data store, then flag store" / "flag poll, then data load" need no
+//     fence -- only the compiler must keep the order (volatile flag accesses + cbar()).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }
+
+// Compile-time slot loop: the streams are 40-90 slots long and every slot differs (job, step, which epilogue piece rides
+// along), so they are instantiated slot by slot instead of being left to the loop unroller -- a `#pragma unroll` loop
+// of this size exceeds hipcc's pragma-unroll threshold, stays a loop, and then indexes its operand ring and
+// accumulators dynamically (s_set_gpr_idx: 2.6x slower).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+template <int V>
+using IC = std::integral_constant<int, V>;
+
+// ---- LDS by byte address: base VGPR + immediate ------------------------------------------------------
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <class T>
+__device__ __forceinline__ T lds_ld(unsigned base, int imm) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) T*>(reinterpret_cast<const lds_char*>(base) + imm);
+}
+template <class T>
+__device__ __forceinline__ void lds_st(unsigned base, int imm, T v) {
+  *reinterpret_cast<__attribute__((address_space(3))) T*>(reinterpret_cast<lds_char*>(base) + imm) = v;
+}
+__device__ __forceinline__ unsigned lds_peek_a(unsigned addr) {
+  return *reinterpret_cast<volatile const __attribute__((address_space(3))) unsigned*>(reinterpret_cast<const lds_char*>(addr));
+}
+__device__ __forceinline__ void lds_poke_a(unsigned addr, unsigned v) {
+  *reinterpret_cast<volatile __attribute__((address_space(3))) unsigned*>(reinterpret_cast<lds_char*>(addr)) = v;
+}
+
+// Per-lane LDS byte addresses and masks, computed ONCE per kernel (they depend on the lane and the wave only).
+// Everything a layer touches is one of these plus a compile-time immediate (plus, for the odd tiles, a wave-uniform
+// delta: one v_add per layer).
+struct Lane {
+  unsigned a8, a4, kq16;   // lane*8, lane*4, (lane>>4)*16: offsets inside a weight packet (A fragments, tail, shifts)
+  unsigned rd1, rd1b, wr1; // layer 1 main tile `wave` (/ the tile 8 further: a base of its own, see make_lane): B8 window start, B18 output
+  unsigned rd1r, wr1r;     // layer 1 remainder tile xr0 (waves 4..7)
+  unsigned rd2, rd2b, rd2t, wr2; // layer 2 tile `wave` (/ + 8): B18 window start (b64 steps / tail), B30 output
+  unsigned rd3, rd3b, rd3t, wr3; // layer 3 pair tile `wave` (/ + 8): B30 window start (b64 steps / tail), B8 output
+  unsigned scr;            // lane*16: offset inside a hand-off scratch area
+  unsigned vbits;          // validity bits, see kV*
+};
+// vbits: bit t (0..3) main tile wave+8t pixel is a real bin; 4,5 / 6,7: remainder tile 0 / 1, this lane's two pixels;
+// 8,9: layer-3 pair tiles 0,1; 10: pair tile 16 (the split one); 11: lane < 48 (kq != 3: channels 28,29 vs padding 30,31)
+constexpr int kVMain = 0, kVRem = 4, kVL3 = 8, kVL3X = 10, kVLt48 = 11;
+constexpr int kT1R = 128 * kB8S * 4, kT1W = 128 * 18 * 4;     // byte strides between a wave's regular tiles (8 tiles apart)
+constexpr int kT2R = 128 * 18 * 4, kT2W = 128 * 30 * 4;
+constexpr int kT3R = 128 * 60 * 4, kT3W = 256 * kB8S * 4;
+
+__device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr0) {
   const int n = lane & 15, kq = lane >> 4;
-  float* b8 = lds + kB8Off + kB8Pad * kB8S;
+  const unsigned B8 = lds_addr(lds + kB8Off + kB8Pad * kB8S), B18 = lds_addr(lds + kB18Off + kB18Pad * 18),
+                 B30 = lds_addr(lds + kB30Off + kB30Pad * 30);
+  const int px0 = 16 * wave + n;
+  Lane L;
+  L.a8 = lane * 8;
+  L.a4 = lane * 4;
+  L.kq16 = kq * 16;
+  L.scr = lane * 16;
+  L.rd1 = B8 + 4 * ((px0 - 4) * kB8S + 2 * kq);
+  L.wr1 = B18 + 4 * (px0 * 18 + 4 * kq);
+  const int rpx = 8 * (16 * xr0 + n);                       // first pixel of this lane's octet in remainder tile xr0
+  L.rd1r = B8 + 4 * ((rpx - 4) * kB8S + 2 * kq);
+  L.wr1r = B18 + 4 * ((rpx + 2 * kq) * 18 + 16);            // channels 16,17 of pixels rpx+2kq, +1
+  L.rd2 = B18 + 4 * ((px0 - 2) * 18 + 2 * kq);
+  L.rd2t = L.rd2 + 4 * (8 * kL2Steps + (kq < 1 ? kq : 1) - 2 * kq);   // K = 90: tail k = 88 + kq is real for kq < 2
+  L.wr2 = B30 + 4 * (px0 * 30 + 4 * kq);
+  L.rd3 = B30 + 4 * ((2 * px0 - 4) * 30 + 2 * kq);          // px0 doubles as the pixel-PAIR index of layer 3
+  L.rd3t = L.rd3 + 4 * (8 * kL3Steps - kq);                 // K = 300: tail k = 296 + kq, all four real
+  L.wr3 = B8 + 4 * ((2 * px0 + (kq >> 1)) * kB8S + 4 * (kq & 1));
+  unsigned v = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v |= (unsigned)px_valid(px0 + 128 * t) << (kVMain + t);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {   // remainder tiles xr0 and (wave 7 only) 4
+    const int p = 8 * (16 * (r == 0 ? xr0 : 4) + n) + 2 * kq;
+    v |= (unsigned)(p >= 0 && px_valid(p)) << (kVRem + 2 * r);
+    v |= (unsigned)(p >= 0 && px_valid(p + 1)) << (kVRem + 2 * r + 1);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) v |= (unsigned)px_valid(2 * (px0 + 128 * t) + (kq >> 1)) << (kVL3 + t);
+  v |= (unsigned)px_valid(2 * (256 + n) + (kq >> 1)) << kVL3X;
+  v |= (unsigned)(lane < 48) << kVLt48;
+  L.vbits = v;
+  // The second tile of a pair job gets a base register of its own, hidden from the optimiser: with one base and two
+  // immediates hipcc fuses the two reads of a slot into one ds_read2[st64]_b64, which needs a per-slot v_add for its
+  // re-based address (VALU beside MFMAs is not free) and takes twice the LDS cycles of two ds_read_b64.
+  L.rd1b = L.rd1 + kT1R;
+  L.rd2b = L.rd2 + kT2R;
+  L.rd3b = L.rd3 + kT3R;
+  asm volatile("" : "+v"(L.rd1b), "+v"(L.rd2b), "+v"(L.rd3b));
+  return L;
+}
+__device__ __forceinline__ bool vbit(const Lane& L, int b) { return (L.vbits >> b) & 1u; }
+
+// Bounded wait for a tagged LDS flag word.  All waves of the workgroup are resident, so the flag always comes; if it
+// does not within ~4 M polls the wave records it in the sticky error word the host checks (RCED_ERR_STATE) and goes on
+// rather than hang the GPU.
+__device__ __forceinline__ void flag_wait(unsigned flag_addr, unsigned tag, unsigned* err, unsigned code) {
+  bool ok = false;
+  for (int spin = 0; spin < (1 << 22); ++spin) {
+    if (__builtin_amdgcn_readfirstlane(lds_peek_a(flag_addr)) == tag) {
+      ok = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (!ok && err && (threadIdx.x & 63) == 0) atomicOr(err, code);
+  cbar();
+}
+
+// wave-uniform: does 16-pixel tile T (pixels 16T..16T+15) contain a gap pixel?  (tiles 8, 16, 24)
+__device__ __forceinline__ bool tile_has_gap(int T) { return span_has_gap(16 * T, 16); }
+
+// ---- layer 1 of blocks 1..4: 1x9, 8 -> 18 ----------------------------------------------------------
+// Jobs, in this order: NR remainder tiles (channels 16,17 of 128 pixels as 8 phases x 2 channels: 16 slots x 2 MFMAs),
+// the odd main tile if the wave has an odd number of them (9 slots x 2 MFMAs), then pairs of main tiles (channels 0..15
+// of 16 pixels each; 9 slots x 4 MFMAs, one A fragment for both).  XM: this wave owns the extra main tile xm.
+template <int NMR, int NMX, int NR>
+__device__ __forceinline__ void l1_stream(const Lane& L, unsigned wbase, int wave, int xm, int xr1) {
+  constexpr int D = RCED_D1, RING = D + 1;
+  constexpr int NM = NMR + NMX;
+  constexpr int NSING = NM & 1, NPAIR = NM / 2;
+  constexpr int NJ = NR + NSING + NPAIR;
+  constexpr int S_REM = 16 * NR, S_SING = 9 * NSING;
+  constexpr int NS = S_REM + S_SING + 9 * NPAIR;
+  // main tile numbering: m = 0..NM-1; m < NMX: the extra tile xm; else regular tile (m - NMX).  The single job takes
+  // m = 0, pair p takes m = NSING + 2p, +1.
+  const unsigned wa = wbase + L.a8;                      // A fragments: main [s][lane] x 8 B, remainder from kW1Main
+  const f32x4 sh = lds_ld<f32x4>(wbase + L.kq16, kW1Data * 4);
+  const f32x2 s2 = lds_ld<f32x2>(wbase, (kW1Data + 16) * 4);
+  unsigned rdx = 0, wrx = 0;
+  if constexpr (NMX > 0) {
+    rdx = L.rd1 + (xm - wave) * (16 * kB8S * 4);
+    wrx = L.wr1 + (xm - wave) * (16 * 18 * 4);
+  }
+  const unsigned rdr1 = L.rd1r + (xr1 - (wave == 7 ? 3 : 0)) * (8 * 16 * kB8S * 4);   // second remainder tile (wave 7: 4 vs 3)
+  const unsigned wrr1 = L.wr1r + (xr1 - (wave == 7 ? 3 : 0)) * (8 * 16 * 18 * 4);
+  auto m_rd = [&](int m) { return m < NMX ? rdx : ((m - NMX) & 1) ? L.rd1b : L.rd1; };
+  auto m_wr = [&](int m) { return m < NMX ? wrx : L.wr1; };
+  auto m_ro = [](int m) { return m < NMX ? 0 : ((m - NMX) & ~1) * kT1R; };
+  auto m_wo = [](int m) { return m < NMX ? 0 : (m - NMX) * kT1W; };
+  f32x2 a[RING], b[RING][2];
+  f32x4 acc[2][2];   // [job parity][tile of the job]
+  auto load = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int r = i % RING;
+    if constexpr (i < S_REM) {
+      constexpr int j = i / 16, st = i % 16;
+      a[r] = lds_ld<f32x2>(wa, (kW1Main + st * 128) * 4);
+      b[r][0] = lds_ld<f32x2>(j == 0 ? L.rd1r : rdr1, kB8S * 4 * st);
+    } else if constexpr (i < S_REM + S_SING) {
+      constexpr int st = i - S_REM;
+      a[r] = lds_ld<f32x2>(wa, st * 128 * 4);
+      b[r][0] = lds_ld<f32x2>(m_rd(0), m_ro(0) + kB8S * 4 * st);
+    } else {
+      constexpr int p = (i - S_REM - S_SING) / 9, st = (i - S_REM - S_SING) % 9, m = NSING + 2 * p;
+      a[r] = lds_ld<f32x2>(wa, st * 128 * 4);
+      b[r][0] = lds_ld<f32x2>(m_rd(m), m_ro(m) + kB8S * 4 * st);
+      b[r][1] = lds_ld<f32x2>(m_rd(m + 1), m_ro(m + 1) + kB8S * 4 * st);
+    }
+  };
+  auto store_main = [&](f32x4 acc4, auto mc) {   // channels 4kq..4kq+3 of this lane's pixel of main tile m
+    constexpr int m = decltype(mc)::value;
+    const f32x4 v = relu4(acc4);
+    const int T = m < NMX ? xm : wave + 8 * (m - NMX);
+    if (m >= NMX && m - NMX > 0 && tile_has_gap(T)) {   // wave-uniform; only tiles 8, 16, 24 (wave 0)
+      if (vbit(L, kVMain + (m - NMX))) {
+        lds_st<f32x2>(m_wr(m), m_wo(m), f32x2{v.x, v.y});
+        lds_st<f32x2>(m_wr(m), m_wo(m) + 8, f32x2{v.z, v.w});
+      }
+    } else {
+      lds_st<f32x2>(m_wr(m), m_wo(m), f32x2{v.x, v.y});
+      lds_st<f32x2>(m_wr(m), m_wo(m) + 8, f32x2{v.z, v.w});
+    }
+  };
+  auto epilogue = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < NR) {   // remainder tile: rows 4kq+jj = (phase 2kq + (jj>>1), channel 16 + (jj&1))
+      const f32x4 v = relu4(acc[j & 1][0]);
+      const unsigned wr = j == 0 ? L.wr1r : wrr1;
+      const int xr = j == 0 ? (wave == 7 ? 3 : wave - 4) : xr1;
+      if (xr > 0) {   // wave-uniform: every remainder tile but tile 0 contains gap pixels (tile 4 also runs past the tile)
+        if (vbit(L, kVRem + 2 * j)) lds_st<f32x2>(wr, 0, f32x2{v.x, v.y});
+        if (vbit(L, kVRem + 2 * j + 1)) lds_st<f32x2>(wr, 18 * 4, f32x2{v.z, v.w});
+      } else {
+        lds_st<f32x2>(wr, 0, f32x2{v.x, v.y});
+        lds_st<f32x2>(wr, 18 * 4, f32x2{v.z, v.w});
+      }
+    } else if constexpr (j < NR + NSING) {
+      store_main(acc[j & 1][0], IC<0>{});
+    } else {
+      constexpr int m = NSING + 2 * (j - NR - NSING);
+      store_main(acc[j & 1][0], IC<m>{});
+      store_main(acc[j & 1][1], IC<m + 1>{});
+    }
+  };
+  static_for<0, (D < NS ? D : NS)>(load);
+  static_for<0, NS>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int r = i % RING;
+    if constexpr (i + D < NS) load(IC<i + D>{});
+    pin();
+    if constexpr (i < S_REM) {
+      constexpr int j = i / 16, st = i % 16;
+      if constexpr (st == 0) acc[j & 1][0] = f32x4{s2.x, s2.y, s2.x, s2.y};
+      acc[j & 1][0] = mfma(a[r].x, b[r][0].x, acc[j & 1][0]);
+      acc[j & 1][0] = mfma(a[r].y, b[r][0].y, acc[j & 1][0]);
+      if constexpr (st == 2 && j > 0) epilogue(IC<(j > 0 ? j - 1 : 0)>{});
+    } else if constexpr (i < S_REM + S_SING) {
+      constexpr int j = NR, st = i - S_REM;
+      if constexpr (st == 0) acc[j & 1][0] = sh;
+      acc[j & 1][0] = mfma(a[r].x, b[r][0].x, acc[j & 1][0]);
+      acc[j & 1][0] = mfma(a[r].y, b[r][0].y, acc[j & 1][0]);
+      if constexpr (st == 2 && j > 0) epilogue(IC<(j > 0 ? j - 1 : 0)>{});
+    } else {
+      constexpr int p = (i - S_REM - S_SING) / 9, st = (i - S_REM - S_SING) % 9, j = NR + NSING + p;
+      if constexpr (st == 0) acc[j & 1][0] = acc[j & 1][1] = sh;
+      acc[j & 1][0] = mfma(a[r].x, b[r][0].x, acc[j & 1][0]);
+      acc[j & 1][1] = mfma(a[r].x, b[r][1].x, acc[j & 1][1]);
+      acc[j & 1][0] = mfma(a[r].y, b[r][0].y, acc[j & 1][0]);
+      acc[j & 1][1] = mfma(a[r].y, b[r][1].y, acc[j & 1][1]);
+      if constexpr (st == 2 && j > 0) epilogue(IC<(j > 0 ? j - 1 : 0)>{});
+    }
+    pin();
+  });
+  epilogue(IC<NJ - 1>{});
+}
+
+// ---- layer 2: 1x5, 18 -> 30 (two M-tiles) ------------------------------------------------------------
+// Every wave has four regular tiles, walked as two pair jobs (11 b64 slots + the b32 tail; both tiles, both M-tiles:
+// 8 / 4 MFMAs per slot on four accumulation chains, two A fragments for both tiles).  Tile 32 (pixels 512..527) is cut
+// in four equal pieces, one per SIMD, so that the layer's MFMA count is the same on every SIMD: M-tile XMT x K-half.
+// Waves 0 / 1 are the helpers (slots [0, kL2Cut) of M-tile 0 / 1), waves 2 / 3 the reducers (slots [kL2Cut, 11) + tail
+// of M-tile 0 / 1; they add the helper's partial sums and own the epilogue).  The share is the wave's first job.
+// Scratch: in the B8 buffer, which is dead during layer 2 (layer 3 rewrites every real pixel of it).
+constexpr int kL2Cut = 6;
+constexpr int kScratch2Off = kB8Off + kB8Pad * kB8S + 8 * kB8S;   // B8 rows 8.. of frame 0 (2 x 256 floats + 2 flags)
+constexpr int kFlag2Off = kScratch2Off + 2 * 256;
+static_assert((kScratch2Off * 4) % 16 == 0, "scratch is read/written with b128");
+static_assert(8 + (2 * 256 + 2 + kB8S - 1) / kB8S <= kF, "layer-2 scratch stays inside frame 0's real pixels");
+constexpr int kL2Plain = 0, kL2Reducer = 1, kL2Helper = 2;
+
+template <int ROLE, int XMTP>   // XMTP: the M-tile of tile 32 this wave works on (plain: unused)
+__device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wbase, int wave, unsigned tag, unsigned* err) {
+  constexpr int D = RCED_D2, RING = D + 1;
+  constexpr bool HASX = ROLE != kL2Plain;
+  constexpr int XS0 = ROLE == kL2Reducer ? kL2Cut : 0;
+  constexpr int XS1 = ROLE == kL2Helper ? kL2Cut : kL2Steps + 1;   // slot kL2Steps is the tail
+  constexpr int NX = HASX ? XS1 - XS0 : 0;
+  constexpr int NJS = kL2Steps + 1;
+  constexpr int NS = NX + 2 * NJS;
+  constexpr int XM = HASX ? XMTP : 0;
+  const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
+  f32x4 sh[2];
+  sh[0] = lds_ld<f32x4>(wbase + L.kq16, kW2Data * 4);
+  sh[1] = lds_ld<f32x4>(wbase + L.kq16, (kW2Data + 16) * 4);
+  unsigned rdx = 0, rdxt = 0, wrx = 0;
+  if constexpr (HASX) {   // tile 32: wave-uniform deltas
+    rdx = L.rd2 + (32 - wave) * (16 * 18 * 4);
+    rdxt = L.rd2t + (32 - wave) * (16 * 18 * 4);
+    wrx = L.wr2 + (32 - wave) * (16 * 30 * 4);
+  }
+  f32x2 a[RING][2], b[RING][2];
+  f32x4 acc[2][2][2];   // [job parity][tile of the pair][M-tile]
+  f32x4 accx = ROLE == kL2Reducer ? sh[XM] : f32x4{0.f, 0.f, 0.f, 0.f};   // the helper's share starts from zero
+  auto load = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int r = i % RING;
+    if constexpr (i < NX) {
+      constexpr int st = XS0 + i;
+      if constexpr (st < kL2Steps) {
+        a[r][XM] = lds_ld<f32x2>(wa, (st * 2 + XM) * 128 * 4);
+        b[r][0] = lds_ld<f32x2>(rdx, 32 * st);
+      } else {
+        a[r][XM].x = lds_ld<float>(wt, (kL2Steps * 2 * 128 + XM * 64) * 4);
+        b[r][0].x = lds_ld<float>(rdxt, 0);
+      }
+    } else {
+      constexpr int j = (i - NX) / NJS, st = (i - NX) % NJS;
+      if constexpr (st < kL2Steps) {
+        a[r][0] = lds_ld<f32x2>(wa, (st * 2 + 0) * 128 * 4);
+        a[r][1] = lds_ld<f32x2>(wa, (st * 2 + 1) * 128 * 4);
+        b[r][0] = lds_ld<f32x2>(L.rd2, (2 * j) * kT2R + 32 * st);
+        b[r][1] = lds_ld<f32x2>(L.rd2b, (2 * j) * kT2R + 32 * st);
+      } else {
+        a[r][0].x = lds_ld<float>(wt, (kL2Steps * 2 * 128) * 4);
+        a[r][1].x = lds_ld<float>(wt, (kL2Steps * 2 * 128 + 64) * 4);
+        b[r][0].x = lds_ld<float>(L.rd2t, (2 * j) * kT2R);
+        b[r][1].x = lds_ld<float>(L.rd2t, (2 * j + 1) * kT2R);
+      }
+    }
+  };
+  auto store_mt = [&](f32x4 acc4, unsigned wr, int off, auto mc, bool masked, int vb) {
+    constexpr int mt = decltype(mc)::value;
+    const f32x4 v = relu4(acc4);
+    if (masked) {
+      if (vbit(L, vb)) {
+        lds_st<f32x2>(wr, off + 64 * mt, f32x2{v.x, v.y});
+        if (mt == 0 || vbit(L, kVLt48)) lds_st<f32x2>(wr, off + 64 * mt + 8, f32x2{v.z, v.w});
+      }
+    } else {
+      lds_st<f32x2>(wr, off + 64 * mt, f32x2{v.x, v.y});
+      if (mt == 0 || vbit(L, kVLt48)) lds_st<f32x2>(wr, off + 64 * mt + 8, f32x2{v.z, v.w});
+    }
+  };
+  auto epilogue = [&](auto jc, auto tc, auto mc) {   // one M-tile of tile t of pair j: ReLU, [pixel][30] stores
+    constexpr int j = decltype(jc)::value, t = decltype(tc)::value, mt = decltype(mc)::value, tt = 2 * j + t;
+    store_mt(acc[j & 1][t][mt], L.wr2, tt * kT2W, IC<mt>{}, tt > 0 && tile_has_gap(wave + 8 * tt), kVMain + tt);
+  };
+  static_for<0, D>(load);
+  static_for<0, NS>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int r = i % RING;
+    if constexpr (i + D < NS) load(IC<i + D>{});
+    pin();
+    if constexpr (i < NX) {
+      accx = mfma(a[r][XM].x, b[r][0].x, accx);
+      if constexpr (XS0 + i < kL2Steps) accx = mfma(a[r][XM].y, b[r][0].y, accx);
+    } else {
+      constexpr int j = (i - NX) / NJS, st = (i - NX) % NJS, jp = j & 1;
+      if constexpr (st == 0) {
+        acc[jp][0][0] = acc[jp][1][0] = sh[0];
+        acc[jp][0][1] = acc[jp][1][1] = sh[1];
+      }
+      acc[jp][0][0] = mfma(a[r][0].x, b[r][0].x, acc[jp][0][0]);
+      acc[jp][0][1] = mfma(a[r][1].x, b[r][0].x, acc[jp][0][1]);
+      acc[jp][1][0] = mfma(a[r][0].x, b[r][1].x, acc[jp][1][0]);
+      acc[jp][1][1] = mfma(a[r][1].x, b[r][1].x, acc[jp][1][1]);
+      if constexpr (st < kL2Steps) {
+        acc[jp][0][0] = mfma(a[r][0].y, b[r][0].y, acc[jp][0][0]);
+        acc[jp][0][1] = mfma(a[r][1].y, b[r][0].y, acc[jp][0][1]);
+        acc[jp][1][0] = mfma(a[r][0].y, b[r][1].y, acc[jp][1][0]);
+        acc[jp][1][1] = mfma(a[r][1].y, b[r][1].y, acc[jp][1][1]);
+      }
+      if constexpr (ROLE == kL2Helper && j == 0 && st == 1) {   // publish the share of tile 32 (MFMAs issued 2 slots ago)
+        lds_st<f32x4>(lds0 + L.scr, (kScratch2Off + XM * 256) * 4, accx);
+        cbar();
+        if (L.a4 == 0) lds_poke_a(lds0 + (kFlag2Off + XM) * 4, tag);
+      }
+      if constexpr (j == 1 && st == 2) epilogue(IC<0>{}, IC<0>{}, IC<0>{});   // pair 0's stores, spread over pair 1's slots
+      if constexpr (j == 1 && st == 4) epilogue(IC<0>{}, IC<0>{}, IC<1>{});
+      if constexpr (j == 1 && st == 6) epilogue(IC<0>{}, IC<1>{}, IC<0>{});
+      if constexpr (j == 1 && st == 8) epilogue(IC<0>{}, IC<1>{}, IC<1>{});
+    }
+    pin();
+  });
+  epilogue(IC<1>{}, IC<0>{}, IC<0>{});
+  epilogue(IC<1>{}, IC<0>{}, IC<1>{});
+  epilogue(IC<1>{}, IC<1>{}, IC<0>{});
+  epilogue(IC<1>{}, IC<1>{}, IC<1>{});
+  if constexpr (ROLE == kL2Reducer) {
+    flag_wait(lds0 + (kFlag2Off + XM) * 4, tag, err, 2u);
+    const f32x4 v = accx + lds_ld<f32x4>(lds0 + L.scr, (kScratch2Off + XM * 256) * 4);
+    store_mt(v, wrx, 0, IC<XM>{}, false, 0);   // tile 32 (pixels 512..527): no gap inside
+  }
+}
+
+// ---- layer 3: 1x9, 30 -> 8 on pixel pairs ------------------------------------------------------------
+// Rows = 2 pixel phases x 8 channels, K = 10 taps x 30 = 300 (37 b64 slots + the b32 tail).  Every wave has two regular
+// pair tiles, run in lockstep (one A fragment per slot for both: the layer's epilogue is small, 8 channels).  Pair tile
+// 16 is split ALONG K in four, one part per SIMD (waves 0..3): the reducer (wave 0: slots [0,10), owns the epilogue and
+// the skip registers) and three helpers (waves 1..3: [10,19), [19,28), [28,37) + tail).  The share is each wave's first
+// job; partial sums go through 1-KiB scratch areas in the (dead during layer 3) B18 buffer + tagged flag words.
+constexpr int kRolePlain = 0, kRoleReducer = 1, kRoleHelper = 2;
+constexpr int kL3Cut1 = 10, kL3Cut2 = 19, kL3Cut3 = 28;
+constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;   // pixels 8..51 of frame 0: always rewritten by layer 1
+constexpr int kFlagOff = kScratchOff + 3 * 256;
+static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
+static_assert(8 + (3 * 256 + 3 + 17) / 18 <= kF, "scratch + flags stay inside frame 0's real pixels");
+
+template <int ROLE, int HID>   // HID: helper number 1..3 (0 otherwise)
+__device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned lds0, unsigned wbase, int blk, int wave,
+                                       int lane, unsigned tag, int utt, int t0, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
+  constexpr int D = RCED_D3, RING = D + 1;
+  constexpr bool HASX = ROLE != kRolePlain;
+  constexpr int XS0 = ROLE != kRoleHelper ? 0 : HID == 1 ? kL3Cut1 : HID == 2 ? kL3Cut2 : kL3Cut3;
+  constexpr int XS1 = ROLE == kRoleReducer ? kL3Cut1 : HID == 1 ? kL3Cut2 : HID == 2 ? kL3Cut3 : kL3Steps + 1;
+  constexpr int NX = HASX ? XS1 - XS0 : 0;
+  constexpr int NM = kL3Steps + 1;   // 37 b64 slots + the tail
+  constexpr int NS = NX + NM;
+  constexpr int NEPI = ROLE == kRoleReducer ? 3 : 2;   // tiles this wave finishes
+  const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
+  const f32x4 sh = lds_ld<f32x4>(wbase + (L.kq16 & 16), kW3Data * 4);   // shift[4*(kq&1) ..]
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned rdx = 0, rdxt = 0, wrx = 0;
+  if constexpr (HASX) {   // pair tile 16: wave-uniform deltas
+    rdx = L.rd3 + (16 - wave) * (16 * 60 * 4);
+    rdxt = L.rd3t + (16 - wave) * (16 * 60 * 4);
+    wrx = L.wr3 + (16 - wave) * (32 * kB8S * 4);
+  }
+  f32x2 a[RING], b[RING][2];
+  f32x4 acc[3] = {sh, sh, ROLE == kRoleReducer ? sh : zero4};   // [2]: the share of pair tile 16
+  auto load = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int r = i % RING;
+    if constexpr (i < NX) {
+      constexpr int st = XS0 + i;
+      if constexpr (st < kL3Steps) {
+        a[r] = lds_ld<f32x2>(wa, st * 128 * 4);
+        b[r][0] = lds_ld<f32x2>(rdx, 32 * st);
+      } else {
+        a[r].x = lds_ld<float>(wt, kL3Steps * 128 * 4);
+        b[r][0].x = lds_ld<float>(rdxt, 0);
+      }
+    } else {
+      constexpr int st = i - NX;
+      if constexpr (st < kL3Steps) {
+        a[r] = lds_ld<f32x2>(wa, st * 128 * 4);
+        b[r][0] = lds_ld<f32x2>(L.rd3, 32 * st);
+        b[r][1] = lds_ld<f32x2>(L.rd3b, 32 * st);
+      } else {
+        a[r].x = lds_ld<float>(wt, kL3Steps * 128 * 4);
+        b[r][0].x = lds_ld<float>(L.rd3t, 0);
+        b[r][1].x = lds_ld<float>(L.rd3t, kT3R);
+      }
+    }
+  };
+  static_for<0, D>(load);
+  static_for<0, NS>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int r = i % RING;
+    if constexpr (i + D < NS) load(IC<i + D>{});
+    pin();
+    if constexpr (i < NX) {
+      acc[2] = mfma(a[r].x, b[r][0].x, acc[2]);
+      if constexpr (XS0 + i < kL3Steps) acc[2] = mfma(a[r].y, b[r][0].y, acc[2]);
+    } else {
+      constexpr int st = i - NX;
+      acc[0] = mfma(a[r].x, b[r][0].x, acc[0]);
+      acc[1] = mfma(a[r].x, b[r][1].x, acc[1]);
+      if constexpr (st < kL3Steps) {
+        acc[0] = mfma(a[r].y, b[r][0].y, acc[0]);
+        acc[1] = mfma(a[r].y, b[r][1].y, acc[1]);
+      }
+      if constexpr (ROLE == kRoleHelper && st == 1) {   // publish the partial sums of pair tile 16
+        lds_st<f32x4>(lds0 + L.scr, (kScratchOff + (HID - 1) * 256) * 4, acc[2]);
+        cbar();
+        if (L.a4 == 0) lds_poke_a(lds0 + (kFlagOff + (HID - 1)) * 4, tag);
+      }
+    }
+    pin();
+  });
+  if constexpr (ROLE == kRoleReducer) {   // collect the helpers' shares: published at the start of their passes
+#pragma unroll
+    for (int h = 0; h < 3; ++h) flag_wait(lds0 + (kFlagOff + h) * 4, tag, P.err, 4u);
+#pragma unroll
+    for (int h = 0; h < 3; ++h) acc[2] += lds_ld<f32x4>(lds0 + L.scr, (kScratchOff + h * 256) * 4);
+  }
+  // Block-dependent work (model.py:84-88: CE1 / CE2 outputs are kept, and added to CD2 / CD1 AFTER the ReLU) sits behind
+  // wave-uniform branches on blk; every tile is handled with compile-time indices so that the skip registers stay
+  // individual registers (as runtime-indexed arrays hipcc copied them wholesale at every branch merge).
+  static_for<0, NEPI>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    f32x4 v = relu4(acc[t]);
+    if (blk == 3) {
+      v += skip_ce2[t];
+    } else if (blk == 4) {
+      v += skip_ce1[t];
+    }
+    constexpr int vb = t < 2 ? kVL3 + t : kVL3X;
+    const bool gap = span_has_gap(32 * (t < 2 ? wave + 8 * t : 16), 32);   // wave-uniform: pair tiles 4, 8, 12, 16
+    if (blk < 4) {
+      const unsigned wr = t < 2 ? L.wr3 : wrx;
+      constexpr int off = t < 2 ? t * kT3W : 0;
+      if (gap) {   // gap / past-the-tile pixels are never written: they stay zero
+        if (vbit(L, vb)) {
+          lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
+          lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
+        }
+      } else {
+        lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
+        lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
+      }
+    } else {
+      const int n = lane & 15, kq = lane >> 4;
+      const int px = 2 * ((t < 2 ? 16 * wave + 128 * t : 256) + n) + (kq >> 1);
+      const int fr = px / kS, f = px - fr * kS;
+      if (vbit(L, vb) && t0 + fr < P.T) {
+        float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * kHCh + 4 * (kq & 1);
+        *reinterpret_cast<f32x4*>(hp) = v;
+      }
+    }
+    // keep CE1 / CE2 (values of gap lanes are whatever was computed: they only ever meet gap pixels again)
+    skip_ce1[t] = blk == 0 ? v : skip_ce1[t];
+    skip_ce2[t] = blk == 1 ? v : skip_ce2[t];
+  });
+}
+
+// ---- layer 1 dispatch: block 0 (8x9 on the 1-channel input rows, lockstep pass) / blocks 1..4 (stream) --------
+template <int NMR, int NMX, int NR>
+__device__ __forceinline__ void layer1_first(float* lds, const float* w, int wave, int lane, int xm, int xr0, int xr1) {
+  constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR;
+  lane = opaque(lane);
+  const int n = lane & 15, kq = lane >> 4;
   float* b18 = lds + kB18Off + kB18Pad * 18;
   const float* x0 = lds + kX0Off;
   const int px0 = 16 * wave + n, pxx = 16 * xm + n;
@@ -486,189 +867,26 @@ __device__ __forceinline__ void layer1(float* lds, const float* w, bool first, i
     accr[t][0] = f32x4{s2.x, s2.y, s2.x, s2.y};
     accr[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  if (!(RCED_EXP_SKIP & 1)) {
-    if (first) {
 #pragma unroll
-      for (int t = 0; t < NRA; ++t) offr[t] = pxr[t] + kq * kS;
-      l1_first_pass<NMR, NMX, NR>(x0, px0 + kq * kS, pxx + kq * kS, offr, w, lane, accm, accr);
-    } else {
+  for (int t = 0; t < NRA; ++t) offr[t] = pxr[t] + kq * kS;
+  l1_first_pass<NMR, NMX, NR>(x0, px0 + kq * kS, pxx + kq * kS, offr, w, lane, accm, accr);
 #pragma unroll
-      for (int t = 0; t < NRA; ++t) offr[t] = (pxr[t] - 4) * kB8S + 2 * kq;
-      l1_pass<NMR, NMX, NR>(b8, (px0 - 4) * kB8S + 2 * kq, (pxx - 4) * kB8S + 2 * kq, offr, w, lane, accm, accr);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NMR; ++t)
-    if (!(RCED_EXP_NOEPI & 1) || accm[t][0].x == 12345.678f)
-      store_p1<1, 18>(b18, accm[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
-  if constexpr (NMX > 0)
-    if (!(RCED_EXP_NOEPI & 1) || accm[NMR][0].x == 12345.678f) store_p1<1, 18>(b18, accm[NMR], pxx, kq, span_has_gap(16 * xm, 16));
+  for (int t = 0; t < NMR; ++t) store_p1<1, 18>(b18, accm[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
+  if constexpr (NMX > 0) store_p1<1, 18>(b18, accm[NMR], pxx, kq, span_has_gap(16 * xm, 16));
   if constexpr (NR > 0) {
 #pragma unroll
     for (int t = 0; t < NR; ++t)
-      if (!(RCED_EXP_NOEPI & 1) || accr[t][0].x + accr[t][1].x == 12345.678f)
-        store_rem(b18, accr[t][0] + accr[t][1], pxr[t], kq, span_has_gap(128 * (t == 0 ? xr0 : xr1), 128));
+      store_rem(b18, accr[t][0] + accr[t][1], pxr[t], kq, span_has_gap(128 * (t == 0 ? xr0 : xr1), 128));
   }
 }
 
-#if RCED_STAMPS
-__device__ unsigned long long g_fine[8][4];   // [wave][prologue, gemm, epilogue, -] of layer 2, workgroup 0
-#endif
-
-// Layer 2.  Every wave has four regular tiles.  Tile 32 (pixels 512..527) is cut in four equal pieces, one per
-// SIMD, so that the layer's MFMA count is the same on every SIMD: M-tile XMT x K-half.  Waves 0 / 1 are the
-// helpers (steps [0, kL2Cut) of M-tile 0 / 1), waves 2 / 3 the reducers (steps [kL2Cut, 11) + tail of M-tile
-// 0 / 1; they add the helper's partial sums and own the epilogue).  Hand-off as in layer 3, through scratch
-// in the B8 buffer, which is dead during layer 2 (layer 3 rewrites every real pixel of it).
-constexpr int kL2Cut = 6;
-constexpr int kScratch2Off = kB8Off + kB8Pad * kB8S + 8 * kB8S;   // B8 rows 8.. of frame 0 (2 x 256 floats + 2 flags)
-constexpr int kFlag2Off = kScratch2Off + 2 * 256;
-static_assert((kScratch2Off * 4) % 16 == 0, "scratch is read/written with b128");
-static_assert(8 + (2 * 256 + 2 + kB8S - 1) / kB8S <= kF, "layer-2 scratch stays inside frame 0's real pixels");
-constexpr int kL2Plain = 0, kL2Reducer = 1, kL2Helper = 2;
-
-template <int ROLE, int XMTP>   // XMTP: the M-tile of tile 32 this wave works on (plain: unused)
-__device__ __forceinline__ void layer2(float* lds, const float* w, int wave, int lane, unsigned tag) {
-  constexpr int NX = ROLE == kL2Plain ? 0 : 1, NT = 4 + NX;
-  constexpr int XMT = ROLE == kL2Plain ? -1 : XMTP;
-  OPAQUE_LANE(lane);
-  const int n = lane & 15, kq = lane >> 4;
-  const float* b18 = lds + kB18Off + kB18Pad * 18;
-  float* b30 = lds + kB30Off + kB30Pad * 30;
-#if RCED_STAMPS
-  const unsigned long long f0 = stamp();
-#endif
-  const int lx = NX > 0 ? opaque(lane) : lane;   // lane copy for the split tile's addresses (see opaque())
-  const int px0 = 16 * wave + n, pxx = 16 * 32 + (lx & 15), kqx = lx >> 4;
-  f32x4 acc[NT][2];
-  f32x4 sh[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) sh[mt] = *reinterpret_cast<const f32x4*>(w + kW2Data + 16 * mt + 4 * kq);
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const bool partial = t == 4 && ROLE == kL2Helper;   // the helper's share starts from zero, the reducer's from the shift
-    acc[t][0] = partial ? f32x4{0.f, 0.f, 0.f, 0.f} : sh[0];
-    acc[t][1] = partial ? f32x4{0.f, 0.f, 0.f, 0.f} : sh[1];
-  }
-  const int tailoff = (kq < 1 ? kq : 1) - 2 * kq;   // K = 90: tail k = 88 + kq is real for kq < 2
-#if RCED_STAMPS
-  const unsigned long long f1 = stamp();
-#endif
-  if (!(RCED_EXP_SKIP & 2)) {
-    constexpr int XS0 = ROLE == kL2Reducer ? kL2Cut : 0;
-    constexpr int XS1 = ROLE == kL2Helper ? kL2Cut : kL2Steps;
-    gemm_pass<4, NX, 2, XMT, kL2Steps, XS0, XS1, ROLE == kL2Reducer, 128 * 18, RCED_D2>(
-        b18, (px0 - 2) * 18 + 2 * kq, (pxx - 2) * 18 + 2 * kqx, tailoff, w, lane, acc);
-  }
-#if RCED_STAMPS
-  const unsigned long long f2 = stamp();
-#endif
-  if constexpr (ROLE == kL2Helper) {
-    *reinterpret_cast<f32x4*>(lds + kScratch2Off + XMTP * 256 + 4 * lx) = acc[4][XMTP];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lx == 0) lds_poke(lds + kFlag2Off + XMTP, tag);
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-    if (!(RCED_EXP_NOEPI & 2) || acc[t][0].x + acc[t][1].x == 12345.678f)
-      store_p1<2, 30>(b30, acc[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
-  if constexpr (ROLE == kL2Reducer) {   // after the own tiles' epilogue: the helper has had time to finish
-    for (int spin = 0; spin < (RCED_EXP_NOBAR ? 0 : (1 << 22)); ++spin) {
-      if (__builtin_amdgcn_readfirstlane(lds_peek(lds + kFlag2Off + XMTP)) == tag) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const f32x4 v = acc[4][XMTP] + *reinterpret_cast<const f32x4*>(lds + kScratch2Off + XMTP * 256 + 4 * lx);
-    store_p1_mt<30>(b30, v, pxx, kqx, XMTP);
-  }
-#if RCED_STAMPS
-  const unsigned long long f3 = stamp();
-  if (blockIdx.x == 0 && lane == 0) {
-    g_fine[wave][0] += f1 - f0;
-    g_fine[wave][1] += f2 - f1;
-    g_fine[wave][2] += f3 - f2;
-  }
-#endif
-}
-
-// Layer 3 roles: every wave has two regular pair tiles; pair tile 16 is split ALONG K in four, one part per
-// SIMD (waves 0..3), so that every SIMD carries the same MFMA count in this layer (the barrier that ends the
-// layer waits for the most loaded SIMD): the reducer (wave 0: steps [0,10), owns the epilogue and the skip
-// registers) and three helpers (waves 1..3: steps [10,19), [19,28), [28,37) + tail), which hand their partial
-// sums over through 1-KiB scratch areas in the (dead during layer 3) B18 buffer and tagged flag words --
-// pairwise hand-offs, no extra barrier.
-constexpr int kRolePlain = 0, kRoleReducer = 1, kRoleHelper = 2;
-constexpr int kL3Cut1 = 10, kL3Cut2 = 19, kL3Cut3 = 28;
-constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;   // pixels 8..51 of frame 0: always rewritten by layer 1
-constexpr int kFlagOff = kScratchOff + 3 * 256;
-static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
-static_assert(8 + (3 * 256 + 3 + 17) / 18 <= kF, "scratch + flags stay inside frame 0's real pixels");
-
-template <int ROLE, int HID>   // HID: helper number 1..3 (0 otherwise)
-__device__ __forceinline__ void layer3(const Params& P, float* lds, const float* w, int blk, int wave, int lane,
-                                       unsigned tag, int utt, int t0, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
-  constexpr int NX = ROLE == kRolePlain ? 0 : 1, NT = 2 + NX;
-  constexpr int NEPI = ROLE == kRoleHelper ? 2 : NT;   // tiles this wave finishes
-  OPAQUE_LANE(lane);
-  const int n = lane & 15, kq = lane >> 4;
-  const float* b30 = lds + kB30Off + kB30Pad * 30;
-  float* b8 = lds + kB8Off + kB8Pad * kB8S;
-  const int lx = NX > 0 ? opaque(lane) : lane;   // lane copy for the split tile's addresses (see opaque())
-  const int q0 = 16 * wave + n, qx = 16 * 16 + (lx & 15), kqx = lx >> 4;   // pixel pair indices
-  f32x4 acc[NT][1];
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(w + kW3Data + 4 * (kq & 1));
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t][0] = (t == 2 && ROLE == kRoleHelper) ? f32x4{0.f, 0.f, 0.f, 0.f} : sh;
-  const int tailoff = -kq;   // K = 300: tail k = 296 + kq, all four real
-  if (!(RCED_EXP_SKIP & 4)) {
-    constexpr int XS0 = ROLE != kRoleHelper ? 0 : HID == 1 ? kL3Cut1 : HID == 2 ? kL3Cut2 : kL3Cut3;
-    constexpr int XS1 = ROLE == kRoleReducer ? kL3Cut1 : ROLE != kRoleHelper ? kL3Steps
-                        : HID == 1 ? kL3Cut2 : HID == 2 ? kL3Cut3 : kL3Steps;
-    constexpr bool XT = ROLE == kRoleHelper && HID == 3;
-    gemm_pass<2, NX, 1, -1, kL3Steps, XS0, XS1, XT, 128 * 60, RCED_D3>(
-        b30, (2 * q0 - 4) * 30 + 2 * kq, (2 * qx - 4) * 30 + 2 * kqx, tailoff, w, lane, acc);
-  }
-  if constexpr (ROLE == kRoleHelper) {   // publish the partial sums of pair tile 16
-    *reinterpret_cast<f32x4*>(lds + kScratchOff + (HID - 1) * 256 + 4 * lx) = acc[2][0];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lx == 0) lds_poke(lds + kFlagOff + (HID - 1), tag);
-  }
-  if constexpr (ROLE == kRoleReducer) {  // collect them (bounded spins: all waves are resident)
-#pragma unroll
-    for (int h = 0; h < 3; ++h) {
-      for (int spin = 0; spin < (RCED_EXP_NOBAR ? 0 : (1 << 22)); ++spin) {
-        if (__builtin_amdgcn_readfirstlane(lds_peek(lds + kFlagOff + h)) == tag) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-    for (int h = 0; h < 3; ++h) acc[2][0] += *reinterpret_cast<const f32x4*>(lds + kScratchOff + h * 256 + 4 * lx);
-  }
-#pragma unroll
-  for (int t = 0; t < NEPI; ++t) {
-    if ((RCED_EXP_NOEPI & 4) && acc[t][0].x != 12345.678f) continue;
-    const int q = (t < 2) ? q0 + 128 * t : qx;
-    const int px = 2 * q + (kq >> 1);   // this lane's output pixel (phase = kq >> 1)
-    f32x4 v = relu4(acc[t][0]);
-    if (blk == 3) v += skip_ce2[t];   // CD1 + CE2 (model.py:87, 75-76: after the ReLU)
-    if (blk == 4) v += skip_ce1[t];   // CD2 + CE1 (model.py:88)
-    const bool gap = span_has_gap(32 * (t < 2 ? wave + 8 * t : 16), 32);   // wave-uniform
-    const int fr = px / kS, f = px - fr * kS;
-    const bool ok = gap ? (px < kNPX && f < kF) : true;
-    if (gap && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    skip_ce1[t] = (blk == 0) ? v : skip_ce1[t];
-    skip_ce2[t] = (blk == 1) ? v : skip_ce2[t];
-    if (blk < 4) {
-      if (gap && px >= kNPX) continue;   // rows past the tile are not allocated
-      float* bp = b8 + px * kB8S + 4 * (kq & 1);   // 8-byte aligned (stride 10): two b64 stores
-      *reinterpret_cast<f32x2*>(bp) = f32x2{v.x, v.y};
-      *reinterpret_cast<f32x2*>(bp + 2) = f32x2{v.z, v.w};
-    } else if (ok && t0 + fr < P.T) {
-      float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * kHCh + 4 * (kq & 1);
-      *reinterpret_cast<f32x4*>(hp) = v;
-    }
-  }
+template <int NMR, int NMX, int NR>
+__device__ __forceinline__ void layer1(const Lane& L, float* lds, const float* w, bool first, int wave, int lane, int xm,
+                                       int xr0, int xr1) {
+  if (first)
+    layer1_first<NMR, NMX, NR>(lds, w, wave, lane, xm, xr0, xr1);
+  else
+    l1_stream<NMR, NMX, NR>(L, lds_addr(w), wave, xm, xr1);
 }
 
 __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
@@ -685,7 +903,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   // packet of the very first layer into region 0; input rows of the first tile into registers
   packet_dma<kW1>(P.wpack, WREG(0), wave, lane);
   int wcur = 0;
-  unsigned epoch = 0;   // layer-3 instances so far (tags the K-split hand-off)
+  unsigned epoch = 0;   // layer-3 instances so far (tags the split-tile hand-offs)
   XStage xst = xstage_load(P, blockIdx.x, tid);
 #if RCED_STAMPS
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -695,16 +913,16 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   // extra tiles of this wave (see the assignment comment above)
   const int xm = wave == 0 ? 32 : 31;                           // layer 1 main, waves 0 and 1
   const int xr0 = wave == 7 ? 3 : wave - 4, xr1 = 4;            // layer 1 remainder, waves 4..7
+  const Lane L = make_lane(lds, wave, lane, xr0 < 0 ? 0 : xr0);
+  const unsigned lds0 = lds_addr(lds);
 
-  if (RCED_EXP_NOBAR >= 2 && wave >= 4)   // experiment: put the second wave of every SIMD half a layer behind the first
-    for (int i = 0; i < RCED_EXP_NOBAR; ++i) __builtin_amdgcn_s_sleep(64);   // ~4 k cycles each
   for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
     const int utt = tile / P.tiles_per_utt;
     const int t0 = (tile - utt * P.tiles_per_utt) * kTF;   // first frame of the tile
     // input rows prefetched during the previous tile -> X0 (B30 is dead: its last reader finished
     // before the barrier that ended the previous tile)
     xstage_store(xst, lds + kX0Off, tid);
-    if (RCED_EXP_NOBAR < 2) __syncthreads();
+    __syncthreads();
 
     f32x4 skip_ce1[3], skip_ce2[3];
 #pragma unroll
@@ -715,12 +933,12 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
     for (int blk = 0; blk < 5; ++blk) {
       {  // ---- layer 1: (8x9, 1->18) for block 0, (1x9, 8->18) otherwise
         STAMP_BEGIN();
-        if (!RCED_EXP_WGLOBAL) packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
-        const float* w = RCED_EXP_WGLOBAL ? wsrc : WREG(wcur);
-        if (wave < 2) layer1<4, 1, 0>(lds, w, blk == 0, wave, lane, xm, 0, 0);
-        else if (wave < 4) layer1<4, 0, 0>(lds, w, blk == 0, wave, lane, 0, 0, 0);
-        else if (wave < 7) layer1<4, 0, 1>(lds, w, blk == 0, wave, lane, 0, xr0, 0);
-        else layer1<3, 0, 2>(lds, w, blk == 0, wave, lane, 0, xr0, xr1);
+        packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
+        const float* w = WREG(wcur);
+        if (wave < 2) layer1<4, 1, 0>(L, lds, w, blk == 0, wave, lane, xm, 0, 0);
+        else if (wave < 4) layer1<4, 0, 0>(L, lds, w, blk == 0, wave, lane, 0, 0, 0);
+        else if (wave < 7) layer1<4, 0, 1>(L, lds, w, blk == 0, wave, lane, 0, xr0, 0);
+        else layer1<3, 0, 2>(L, lds, w, blk == 0, wave, lane, 0, xr0, xr1);
         wcur ^= 1;
 #if RCED_STAMPS
         const unsigned long long st_b_ = stamp();
@@ -733,14 +951,15 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
       }
       {  // ---- layer 2: (1x5, 18->30)
         STAMP_BEGIN();
-        if (!RCED_EXP_WGLOBAL) packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane);
-        const float* w = RCED_EXP_WGLOBAL ? wsrc + kW1 : WREG(wcur);
+        packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane);
+        const float* w = WREG(wcur);
         const unsigned tag2 = 0xC0000000u | (epoch + 1u);   // distinct from layer 3's tags (0x8.......)
-        if (wave == 0) layer2<kL2Helper, 0>(lds, w, wave, lane, tag2);
-        else if (wave == 1) layer2<kL2Helper, 1>(lds, w, wave, lane, tag2);
-        else if (wave == 2) layer2<kL2Reducer, 0>(lds, w, wave, lane, tag2);
-        else if (wave == 3) layer2<kL2Reducer, 1>(lds, w, wave, lane, tag2);
-        else layer2<kL2Plain, 0>(lds, w, wave, lane, tag2);
+        const unsigned wb = lds_addr(w);
+        if (wave == 0) layer2<kL2Helper, 0>(L, lds0, wb, wave, tag2, P.err);
+        else if (wave == 1) layer2<kL2Helper, 1>(L, lds0, wb, wave, tag2, P.err);
+        else if (wave == 2) layer2<kL2Reducer, 0>(L, lds0, wb, wave, tag2, P.err);
+        else if (wave == 3) layer2<kL2Reducer, 1>(L, lds0, wb, wave, tag2, P.err);
+        else layer2<kL2Plain, 0>(L, lds0, wb, wave, tag2, P.err);
         wcur ^= 1;
         STAMP_MATH(1);
         layer_end_sync();
@@ -749,16 +968,17 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
       {  // ---- layer 3: (1x9, 30->8) on pixel pairs; block skips; hand-off
         STAMP_BEGIN();
         // next packet: layer 1 of the next block, or of block 0 of the next tile (the stream wraps)
-        if (!RCED_EXP_WGLOBAL) packet_dma<kW1>(blk == 4 ? P.wpack : wsrc + kWBlock, WREG(wcur ^ 1), wave, lane);
+        packet_dma<kW1>(blk == 4 ? P.wpack : wsrc + kWBlock, WREG(wcur ^ 1), wave, lane);
         if (blk == 4) xst = xstage_load(P, tile + gridDim.x, tid);   // next tile's input rows
-        const float* w = RCED_EXP_WGLOBAL ? wsrc + kW1 + kW2 : WREG(wcur);
+        const float* w = WREG(wcur);
         ++epoch;
         const unsigned tag = 0x80000000u | epoch;   // sign bit set: never the bits of a ReLU output
-        if (wave == 0) layer3<kRoleReducer, 0>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
-        else if (wave == 1) layer3<kRoleHelper, 1>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
-        else if (wave == 2) layer3<kRoleHelper, 2>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
-        else if (wave == 3) layer3<kRoleHelper, 3>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
-        else layer3<kRolePlain, 0>(P, lds, w, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        const unsigned wb = lds_addr(w);
+        if (wave == 0) layer3<kRoleReducer, 0>(P, L, lds0, wb, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        else if (wave == 1) layer3<kRoleHelper, 1>(P, L, lds0, wb, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        else if (wave == 2) layer3<kRoleHelper, 2>(P, L, lds0, wb, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        else if (wave == 3) layer3<kRoleHelper, 3>(P, L, lds0, wb, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        else layer3<kRolePlain, 0>(P, L, lds0, wb, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
         wcur ^= 1;
         STAMP_MATH(2);
         layer_end_sync();
@@ -771,10 +991,9 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
 #if RCED_STAMPS
   if (P.stamps && blockIdx.x == 0 && lane == 0)
     for (int i = 0; i < 8; ++i) P.stamps[wave * 8 + i] = tsum[i];
-  if (P.stamps && blockIdx.x == 0 && lane == 0)
-    for (int i = 0; i < 3; ++i) P.stamps[64 + wave * 3 + i] = g_fine[wave][i];
 #endif
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // decode_final (1x129, 8->1, no BN, no ReLU; model.py:89-90) as a dense Toeplitz GEMM:

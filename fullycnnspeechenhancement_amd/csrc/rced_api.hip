@@ -433,7 +433,7 @@ int rced_forward_host(rced_model* m, const float* x_host, float* y_host, int N, 
     HIP_TRY(hipMemcpy(m->stage_x, x_host, bytes, hipMemcpyHostToDevice));
     if (int rc = rced_forward(m, (const float*)m->stage_x, (float*)m->stage_y, N, T, nullptr)) return rc;
     HIP_TRY(hipMemcpy(y_host, m->stage_y, bytes, hipMemcpyDeviceToHost));  // synchronises
-    return RCED_OK;
+    return fused_check(m);
   }
   if (!m->host_streams[0]) {
     for (auto& st : m->host_streams) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -492,7 +492,7 @@ int rced_forward_host(rced_model* m, const float* x_host, float* y_host, int N, 
   if (rc != RCED_OK) return rc;
   if (in_err != hipSuccess) return fail(RCED_ERR_HIP, "host path upload: %s", hipGetErrorString(in_err));
   if (out_err != hipSuccess) return fail(RCED_ERR_HIP, "host path download: %s", hipGetErrorString(out_err));
-  return RCED_OK;
+  return fused_check(m);
 }
 
 int rced_conv_bn_relu(const float* x, float* y, const float* kernel, const float* bias, const float* bn,
@@ -548,6 +548,7 @@ float rced_last_kernel_ms(rced_model* m) {
 int rced_profile_query(rced_model* m, int kind, float* total_ms, int* launches) {
   if (!m || !total_ms || !launches) return fail(RCED_ERR_ARG, "null argument");
   DeviceGuard g(m->device);
+  if (int rc = fused_check(m)) return rc;
   float tot = 0.f;
   int n = 0;
   for (auto& e : m->prof_events) {

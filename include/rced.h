@@ -89,11 +89,8 @@ int rced_reserve(rced_model* m, int N, int T);
  *   "fused_grid"  workgroups of the persistent fused kernel (0 = one per CU)
  *   "bf16"        R-CED V1 / V2 only: 1 = bf16 activations + inner-layer weights, fp32 accumulation (BASELINE config 2;
  *                 ~6e-3 of the largest output away from the fp32 result -- opt-in)
- *   "v3_teams"    1: experimental two-team CR-CED kernel (slower)
- *   "v3_wide"     1: experimental sixteen-wave CR-CED kernel (slower)
- *   "has_fused", "num_cus"  get only
- * Environment (read at create): RCED_V3_TEAMS / RCED_V3_WIDE as "v3_teams" / "v3_wide"; RCED_FINAL_LDS=0 (CR-CED's last layer on the
- * kernel without LDS staging; read at the first forward); for rced_train_create RCED_TRAIN_MFMA=0 (direct-conv
+ *   "has_fused", "num_cus", "fused_final"  get only ("fused_final": the 1x129 output layer runs inside the fused kernel)
+ * Environment: RCED_FINAL_LDS=0 (the last layer's GEMM without LDS staging; read at the first forward); for rced_train_create RCED_TRAIN_MFMA=0 (direct-conv
  * kernels only), RCED_TRAIN_FUSE_ACT=0, RCED_TRAIN_FUSE_DZ=0 (materialise activations / dz). */
 int rced_set_option(rced_model* m, const char* key, int value);
 int rced_get_option(rced_model* m, const char* key, int* value);

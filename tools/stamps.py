@@ -3,7 +3,7 @@
 each wave of workgroup 0, kilo-cycles spent in each layer kind's math and barrier wait."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("RCED_LIB", os.path.join(ROOT, "exp", "librced_stamps.so"))
+os.environ.setdefault("RCED_LIB", os.path.join(ROOT, "exp", "stamps.so"))
 sys.path.insert(0, ROOT)
 import torch
 from fullycnnspeechenhancement_amd import build_model
