@@ -192,52 +192,6 @@ __device__ __forceinline__ void layer_end_sync() {
 }
 
 
-// The same for block 0 (8x9 kernel on the 1-channel input, b32 steps): main 18 k-steps (ih, j<9),
-// remainder 32 k-steps (ih, u<16); lane kq <-> time tap 4*ih + kq.
-template <int NMR, int NMX, int NR>
-__device__ __forceinline__ void l1_first_pass(const float* x0, int offm0, int offmx,
-                                              const int (&offr)[NR == 0 ? 1 : NR], const float* w, int lane,
-                                              f32x4 (&accm)[NMR + NMX][1], f32x4 (&accr)[NR == 0 ? 1 : NR][2]) {
-  constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR, DEPTH = 3, RING = DEPTH + 1;
-  constexpr int SLOTS = NR > 0 ? 32 : 18;
-  const float* wm = w + lane;
-  const float* wr = w + kW1Main + lane;
-  float am[RING], bm[RING][NM], ar[RING], br[RING][NRA];
-  auto main_step = [](int i) { return NR > 0 ? ((i * 18) / 32 != ((i + 1) * 18) / 32 ? (i * 18) / 32 : -1) : i; };
-  auto load = [&](int i, int buf) {
-    if constexpr (NR > 0) {
-      ar[buf] = wr[i * 64];
-#pragma unroll
-      for (int t = 0; t < NR; ++t) br[buf][t] = x0[offr[t] + (i / 16) * 4 * kS + (i % 16)];
-    }
-    const int m = main_step(i);
-    if (m >= 0) {
-      am[buf] = wm[m * 64];
-      const int d = (m / 9) * 4 * kS + (m % 9);
-#pragma unroll
-      for (int t = 0; t < NMR; ++t) bm[buf][t] = x0[offm0 + t * 128 + d];
-      if constexpr (NMX > 0) bm[buf][NMR] = x0[offmx + d];
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < DEPTH; ++i) load(i, i % RING);
-#pragma unroll
-  for (int i = 0; i < SLOTS; ++i) {
-    if (i + DEPTH < SLOTS) load(i + DEPTH, (i + DEPTH) % RING);
-    pin();
-    const int buf = i % RING;
-    if constexpr (NR > 0) {
-#pragma unroll
-      for (int t = 0; t < NR; ++t) accr[t][i & 1] = mfma(ar[buf], br[buf][t], accr[t][i & 1]);
-    }
-    if (main_step(i) >= 0) {
-#pragma unroll
-      for (int t = 0; t < NM; ++t) accm[t][0] = mfma(am[buf], bm[buf][t], accm[t][0]);
-    }
-    pin();
-  }
-}
-
 // ReLU as ONE integer max per element: for IEEE floats max(bits, 0) == bits of relu(x) (negative
 // floats are negative ints).  fmaxf() on an MFMA result makes hipcc add a canonicalising
 // v_max_f32 v,v,v in front (2 VALU per element); an inline-asm v_max_f32 is NOT an option: hipcc pads
@@ -391,6 +345,7 @@ __device__ __forceinline__ void lds_poke_a(unsigned addr, unsigned v) {
 // delta: one v_add per layer).
 struct Lane {
   unsigned a8, a4, kq16;   // lane*8, lane*4, (lane>>4)*16: offsets inside a weight packet (A fragments, tail, shifts)
+  unsigned rd0, rd0b, rd0r;// block 0's layer 1: input-row window start of main tile `wave` (/ + 8) and of remainder tile xr0
   unsigned rd1, rd1b, wr1; // layer 1 main tile `wave` (/ the tile 8 further: a base of its own, see make_lane): B8 window start, B18 output
   unsigned rd1r, wr1r;     // layer 1 remainder tile xr0 (waves 4..7)
   unsigned rd2, rd2b, rd2t, wr2; // layer 2 tile `wave` (/ + 8): B18 window start (b64 steps / tail), B30 output
@@ -415,6 +370,9 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   L.a4 = lane * 4;
   L.kq16 = kq * 16;
   L.scr = lane * 16;
+  const unsigned X0 = lds_addr(lds + kX0Off);
+  L.rd0 = X0 + 4 * (px0 + kq * kS);                         // lane kq <-> time taps 4*ih + kq
+  L.rd0r = X0 + 4 * (8 * (16 * xr0 + n) + kq * kS);
   L.rd1 = B8 + 4 * ((px0 - 4) * kB8S + 2 * kq);
   L.wr1 = B18 + 4 * (px0 * 18 + 4 * kq);
   const int rpx = 8 * (16 * xr0 + n);                       // first pixel of this lane's octet in remainder tile xr0
@@ -443,10 +401,11 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   // The second tile of a pair job gets a base register of its own, hidden from the optimiser: with one base and two
   // immediates hipcc fuses the two reads of a slot into one ds_read2[st64]_b64, which needs a per-slot v_add for its
   // re-based address (VALU beside MFMAs is not free) and takes twice the LDS cycles of two ds_read_b64.
+  L.rd0b = L.rd0 + 128 * 4;
   L.rd1b = L.rd1 + kT1R;
   L.rd2b = L.rd2 + kT2R;
   L.rd3b = L.rd3 + kT3R;
-  asm volatile("" : "+v"(L.rd1b), "+v"(L.rd2b), "+v"(L.rd3b));
+  asm volatile("" : "+v"(L.rd0b), "+v"(L.rd1b), "+v"(L.rd2b), "+v"(L.rd3b));
   return L;
 }
 __device__ __forceinline__ bool vbit(const Lane& L, int b) { return (L.vbits >> b) & 1u; }
@@ -470,52 +429,69 @@ __device__ __forceinline__ void flag_wait(unsigned flag_addr, unsigned tag, unsi
 // wave-uniform: does 16-pixel tile T (pixels 16T..16T+15) contain a gap pixel?  (tiles 8, 16, 24)
 __device__ __forceinline__ bool tile_has_gap(int T) { return span_has_gap(16 * T, 16); }
 
-// ---- layer 1 of blocks 1..4: 1x9, 8 -> 18 ----------------------------------------------------------
-// Jobs, in this order: NR remainder tiles (channels 16,17 of 128 pixels as 8 phases x 2 channels: 16 slots x 2 MFMAs),
-// the odd main tile if the wave has an odd number of them (9 slots x 2 MFMAs), then pairs of main tiles (channels 0..15
-// of 16 pixels each; 9 slots x 4 MFMAs, one A fragment for both).  XM: this wave owns the extra main tile xm.
-template <int NMR, int NMX, int NR>
+// ---- layer 1: 8x9, 1 -> 18 on the input rows (block 0, FIRST) / 1x9, 8 -> 18 on B8 (blocks 1..4) -----------
+// Jobs, in this order: NR remainder tiles (channels 16,17 of 128 pixels as 8 phases x 2 channels), the odd main tile if
+// the wave has an odd number of them, then pairs of main tiles (channels 0..15 of 16 pixels each, one A fragment for
+// both).  Blocks 1..4: a slot is a b64 K-step (two k-quads: 16 / 9 slots per remainder / main job, k = tap*8 + ci).
+// Block 0: a slot is a b32 K-step (one k-quad = time taps 4*ih + kq at one frequency tap: 32 / 18 slots, B operand
+// straight out of the staged input rows X0).
+template <int NMR, int NMX, int NR, bool FIRST>
 __device__ __forceinline__ void l1_stream(const Lane& L, unsigned wbase, int wave, int xm, int xr1) {
-  constexpr int D = RCED_D1, RING = D + 1;
+  constexpr int D = FIRST ? 2 * RCED_D1 : RCED_D1, RING = D + 1;
   constexpr int NM = NMR + NMX;
   constexpr int NSING = NM & 1, NPAIR = NM / 2;
   constexpr int NJ = NR + NSING + NPAIR;
-  constexpr int S_REM = 16 * NR, S_SING = 9 * NSING;
-  constexpr int NS = S_REM + S_SING + 9 * NPAIR;
+  constexpr int SR = FIRST ? 32 : 16, SM = FIRST ? 18 : 9;   // slots of a remainder / main job
+  constexpr int S_REM = SR * NR, S_SING = SM * NSING;
+  constexpr int NS = S_REM + S_SING + SM * NPAIR;
   // main tile numbering: m = 0..NM-1; m < NMX: the extra tile xm; else regular tile (m - NMX).  The single job takes
   // m = 0, pair p takes m = NSING + 2p, +1.
-  const unsigned wa = wbase + L.a8;                      // A fragments: main [s][lane] x 8 B, remainder from kW1Main
+  const unsigned wa = wbase + (FIRST ? L.a4 : L.a8);     // A fragments: main [s][lane], remainder from kW1Main
   const f32x4 sh = lds_ld<f32x4>(wbase + L.kq16, kW1Data * 4);
   const f32x2 s2 = lds_ld<f32x2>(wbase, (kW1Data + 16) * 4);
+  const unsigned rd = FIRST ? L.rd0 : L.rd1, rdb = FIRST ? L.rd0b : L.rd1b, rdr = FIRST ? L.rd0r : L.rd1r;
+  constexpr int kTR = FIRST ? 128 * 4 : kT1R;            // byte stride between a wave's regular tiles, read side
+  constexpr int kTileR = FIRST ? 16 * 4 : 16 * kB8S * 4; // ... between adjacent 16-pixel tiles
   unsigned rdx = 0, wrx = 0;
   if constexpr (NMX > 0) {
-    rdx = L.rd1 + (xm - wave) * (16 * kB8S * 4);
+    rdx = rd + (xm - wave) * kTileR;
     wrx = L.wr1 + (xm - wave) * (16 * 18 * 4);
   }
-  const unsigned rdr1 = L.rd1r + (xr1 - (wave == 7 ? 3 : 0)) * (8 * 16 * kB8S * 4);   // second remainder tile (wave 7: 4 vs 3)
+  const unsigned rdr1 = rdr + (xr1 - (wave == 7 ? 3 : 0)) * (8 * kTileR);   // second remainder tile (wave 7: 4 vs 3)
   const unsigned wrr1 = L.wr1r + (xr1 - (wave == 7 ? 3 : 0)) * (8 * 16 * 18 * 4);
-  auto m_rd = [&](int m) { return m < NMX ? rdx : ((m - NMX) & 1) ? L.rd1b : L.rd1; };
+  auto m_rd = [&](int m) { return m < NMX ? rdx : ((m - NMX) & 1) ? rdb : rd; };
   auto m_wr = [&](int m) { return m < NMX ? wrx : L.wr1; };
-  auto m_ro = [](int m) { return m < NMX ? 0 : ((m - NMX) & ~1) * kT1R; };
+  auto m_ro = [](int m) { return m < NMX ? 0 : ((m - NMX) & ~1) * kTR; };
   auto m_wo = [](int m) { return m < NMX ? 0 : (m - NMX) * kT1W; };
+  // byte offset of K-step st inside a lane's window: blocks 1..4: one pixel per b64 step; block 0: (ih, j)
+  auto koff = [](int st, int per) { return FIRST ? ((st / per) * 4 * kS + st % per) * 4 : kB8S * 4 * st; };
   f32x2 a[RING], b[RING][2];
   f32x4 acc[2][2];   // [job parity][tile of the job]
+  auto ld_a = [&](f32x2& dst, int off_floats) {
+    if constexpr (FIRST) dst.x = lds_ld<float>(wa, off_floats * 4);
+    else dst = lds_ld<f32x2>(wa, off_floats * 4);
+  };
+  auto ld_b = [&](f32x2& dst, unsigned base, int off) {
+    if constexpr (FIRST) dst.x = lds_ld<float>(base, off);
+    else dst = lds_ld<f32x2>(base, off);
+  };
+  constexpr int kAStep = FIRST ? 64 : 128;   // floats per K-step of A fragments
   auto load = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
     constexpr int r = i % RING;
     if constexpr (i < S_REM) {
-      constexpr int j = i / 16, st = i % 16;
-      a[r] = lds_ld<f32x2>(wa, (kW1Main + st * 128) * 4);
-      b[r][0] = lds_ld<f32x2>(j == 0 ? L.rd1r : rdr1, kB8S * 4 * st);
+      constexpr int j = i / SR, st = i % SR;
+      ld_a(a[r], kW1Main + st * kAStep);
+      ld_b(b[r][0], j == 0 ? rdr : rdr1, koff(st, 16));
     } else if constexpr (i < S_REM + S_SING) {
       constexpr int st = i - S_REM;
-      a[r] = lds_ld<f32x2>(wa, st * 128 * 4);
-      b[r][0] = lds_ld<f32x2>(m_rd(0), m_ro(0) + kB8S * 4 * st);
+      ld_a(a[r], st * kAStep);
+      ld_b(b[r][0], m_rd(0), m_ro(0) + koff(st, 9));
     } else {
-      constexpr int p = (i - S_REM - S_SING) / 9, st = (i - S_REM - S_SING) % 9, m = NSING + 2 * p;
-      a[r] = lds_ld<f32x2>(wa, st * 128 * 4);
-      b[r][0] = lds_ld<f32x2>(m_rd(m), m_ro(m) + kB8S * 4 * st);
-      b[r][1] = lds_ld<f32x2>(m_rd(m + 1), m_ro(m + 1) + kB8S * 4 * st);
+      constexpr int p = (i - S_REM - S_SING) / SM, st = (i - S_REM - S_SING) % SM, m = NSING + 2 * p;
+      ld_a(a[r], st * kAStep);
+      ld_b(b[r][0], m_rd(m), m_ro(m) + koff(st, 9));
+      ld_b(b[r][1], m_rd(m + 1), m_ro(m + 1) + koff(st, 9));
     }
   };
   auto store_main = [&](f32x4 acc4, auto mc) {   // channels 4kq..4kq+3 of this lane's pixel of main tile m
@@ -553,6 +529,10 @@ __device__ __forceinline__ void l1_stream(const Lane& L, unsigned wbase, int wav
       store_main(acc[j & 1][1], IC<m + 1>{});
     }
   };
+  auto mm = [&](f32x4& c, const f32x2& av, const f32x2& bv) {
+    c = mfma(av.x, bv.x, c);
+    if constexpr (!FIRST) c = mfma(av.y, bv.y, c);
+  };
   static_for<0, (D < NS ? D : NS)>(load);
   static_for<0, NS>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -560,24 +540,27 @@ __device__ __forceinline__ void l1_stream(const Lane& L, unsigned wbase, int wav
     if constexpr (i + D < NS) load(IC<i + D>{});
     pin();
     if constexpr (i < S_REM) {
-      constexpr int j = i / 16, st = i % 16;
+      constexpr int j = i / SR, st = i % SR;
       if constexpr (st == 0) acc[j & 1][0] = f32x4{s2.x, s2.y, s2.x, s2.y};
-      acc[j & 1][0] = mfma(a[r].x, b[r][0].x, acc[j & 1][0]);
-      acc[j & 1][0] = mfma(a[r].y, b[r][0].y, acc[j & 1][0]);
+      mm(acc[j & 1][0], a[r], b[r][0]);
       if constexpr (st == 2 && j > 0) epilogue(IC<(j > 0 ? j - 1 : 0)>{});
     } else if constexpr (i < S_REM + S_SING) {
       constexpr int j = NR, st = i - S_REM;
       if constexpr (st == 0) acc[j & 1][0] = sh;
-      acc[j & 1][0] = mfma(a[r].x, b[r][0].x, acc[j & 1][0]);
-      acc[j & 1][0] = mfma(a[r].y, b[r][0].y, acc[j & 1][0]);
+      mm(acc[j & 1][0], a[r], b[r][0]);
       if constexpr (st == 2 && j > 0) epilogue(IC<(j > 0 ? j - 1 : 0)>{});
     } else {
-      constexpr int p = (i - S_REM - S_SING) / 9, st = (i - S_REM - S_SING) % 9, j = NR + NSING + p;
+      constexpr int p = (i - S_REM - S_SING) / SM, st = (i - S_REM - S_SING) % SM, j = NR + NSING + p;
       if constexpr (st == 0) acc[j & 1][0] = acc[j & 1][1] = sh;
-      acc[j & 1][0] = mfma(a[r].x, b[r][0].x, acc[j & 1][0]);
-      acc[j & 1][1] = mfma(a[r].x, b[r][1].x, acc[j & 1][1]);
-      acc[j & 1][0] = mfma(a[r].y, b[r][0].y, acc[j & 1][0]);
-      acc[j & 1][1] = mfma(a[r].y, b[r][1].y, acc[j & 1][1]);
+      if constexpr (FIRST) {
+        acc[j & 1][0] = mfma(a[r].x, b[r][0].x, acc[j & 1][0]);
+        acc[j & 1][1] = mfma(a[r].x, b[r][1].x, acc[j & 1][1]);
+      } else {
+        acc[j & 1][0] = mfma(a[r].x, b[r][0].x, acc[j & 1][0]);
+        acc[j & 1][1] = mfma(a[r].x, b[r][1].x, acc[j & 1][1]);
+        acc[j & 1][0] = mfma(a[r].y, b[r][0].y, acc[j & 1][0]);
+        acc[j & 1][1] = mfma(a[r].y, b[r][1].y, acc[j & 1][1]);
+      }
       if constexpr (st == 2 && j > 0) epilogue(IC<(j > 0 ? j - 1 : 0)>{});
     }
     pin();
@@ -749,6 +732,7 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
   }
   f32x2 a[RING], b[RING][2];
   f32x4 acc[3] = {sh, sh, ROLE == kRoleReducer ? sh : zero4};   // [2]: the share of pair tile 16
+  f32x4 accb[2] = {zero4, zero4};   // second chain of the regular tiles (the slot's second k-quad): 4 chains, not 2 (+2.4 %)
   auto load = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
     constexpr int r = i % RING;
@@ -788,8 +772,8 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
       acc[0] = mfma(a[r].x, b[r][0].x, acc[0]);
       acc[1] = mfma(a[r].x, b[r][1].x, acc[1]);
       if constexpr (st < kL3Steps) {
-        acc[0] = mfma(a[r].y, b[r][0].y, acc[0]);
-        acc[1] = mfma(a[r].y, b[r][1].y, acc[1]);
+        accb[0] = mfma(a[r].y, b[r][0].y, accb[0]);
+        accb[1] = mfma(a[r].y, b[r][1].y, accb[1]);
       }
       if constexpr (ROLE == kRoleHelper && st == 1) {   // publish the partial sums of pair tile 16
         lds_st<f32x4>(lds0 + L.scr, (kScratchOff + (HID - 1) * 256) * 4, acc[2]);
@@ -808,6 +792,8 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
   // Block-dependent work (model.py:84-88: CE1 / CE2 outputs are kept, and added to CD2 / CD1 AFTER the ReLU) sits behind
   // wave-uniform branches on blk; every tile is handled with compile-time indices so that the skip registers stay
   // individual registers (as runtime-indexed arrays hipcc copied them wholesale at every branch merge).
+  acc[0] += accb[0];
+  acc[1] += accb[1];
   static_for<0, NEPI>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     f32x4 v = relu4(acc[t]);
@@ -845,48 +831,12 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
   });
 }
 
-// ---- layer 1 dispatch: block 0 (8x9 on the 1-channel input rows, lockstep pass) / blocks 1..4 (stream) --------
 template <int NMR, int NMX, int NR>
-__device__ __forceinline__ void layer1_first(float* lds, const float* w, int wave, int lane, int xm, int xr0, int xr1) {
-  constexpr int NM = NMR + NMX, NRA = NR == 0 ? 1 : NR;
-  lane = opaque(lane);
-  const int n = lane & 15, kq = lane >> 4;
-  float* b18 = lds + kB18Off + kB18Pad * 18;
-  const float* x0 = lds + kX0Off;
-  const int px0 = 16 * wave + n, pxx = 16 * xm + n;
-  int pxr[NRA] = {8 * (16 * xr0 + n)};
-  if constexpr (NR > 1) pxr[1] = 8 * (16 * xr1 + n);
-  int offr[NRA];
-  f32x4 accm[NM][1], accr[NRA][2];
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(w + kW1Data + 4 * kq);
-  const f32x2 s2 = *reinterpret_cast<const f32x2*>(w + kW1Data + 16);
-#pragma unroll
-  for (int t = 0; t < NM; ++t) accm[t][0] = sh;
-#pragma unroll
-  for (int t = 0; t < NRA; ++t) {
-    accr[t][0] = f32x4{s2.x, s2.y, s2.x, s2.y};
-    accr[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int t = 0; t < NRA; ++t) offr[t] = pxr[t] + kq * kS;
-  l1_first_pass<NMR, NMX, NR>(x0, px0 + kq * kS, pxx + kq * kS, offr, w, lane, accm, accr);
-#pragma unroll
-  for (int t = 0; t < NMR; ++t) store_p1<1, 18>(b18, accm[t], px0 + 128 * t, kq, span_has_gap(16 * (wave + 8 * t), 16));
-  if constexpr (NMX > 0) store_p1<1, 18>(b18, accm[NMR], pxx, kq, span_has_gap(16 * xm, 16));
-  if constexpr (NR > 0) {
-#pragma unroll
-    for (int t = 0; t < NR; ++t)
-      store_rem(b18, accr[t][0] + accr[t][1], pxr[t], kq, span_has_gap(128 * (t == 0 ? xr0 : xr1), 128));
-  }
-}
-
-template <int NMR, int NMX, int NR>
-__device__ __forceinline__ void layer1(const Lane& L, float* lds, const float* w, bool first, int wave, int lane, int xm,
-                                       int xr0, int xr1) {
+__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, bool first, int wave, int xm, int xr1) {
   if (first)
-    layer1_first<NMR, NMX, NR>(lds, w, wave, lane, xm, xr0, xr1);
+    l1_stream<NMR, NMX, NR, true>(L, wbase, wave, xm, xr1);
   else
-    l1_stream<NMR, NMX, NR>(L, lds_addr(w), wave, xm, xr1);
+    l1_stream<NMR, NMX, NR, false>(L, wbase, wave, xm, xr1);
 }
 
 __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
@@ -935,10 +885,11 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         STAMP_BEGIN();
         packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
         const float* w = WREG(wcur);
-        if (wave < 2) layer1<4, 1, 0>(L, lds, w, blk == 0, wave, lane, xm, 0, 0);
-        else if (wave < 4) layer1<4, 0, 0>(L, lds, w, blk == 0, wave, lane, 0, 0, 0);
-        else if (wave < 7) layer1<4, 0, 1>(L, lds, w, blk == 0, wave, lane, 0, xr0, 0);
-        else layer1<3, 0, 2>(L, lds, w, blk == 0, wave, lane, 0, xr0, xr1);
+        const unsigned wb = lds_addr(w);
+        if (wave < 2) layer1<4, 1, 0>(L, wb, blk == 0, wave, xm, 0);
+        else if (wave < 4) layer1<4, 0, 0>(L, wb, blk == 0, wave, 0, 0);
+        else if (wave < 7) layer1<4, 0, 1>(L, wb, blk == 0, wave, 0, 0);
+        else layer1<3, 0, 2>(L, wb, blk == 0, wave, 0, xr1);
         wcur ^= 1;
 #if RCED_STAMPS
         const unsigned long long st_b_ = stamp();
