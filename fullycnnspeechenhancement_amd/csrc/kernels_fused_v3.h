@@ -348,8 +348,8 @@ struct Lane {
   unsigned rd0, rd0b, rd0r;// block 0's layer 1: input-row window start of main tile `wave` (/ + 8) and of remainder tile xr0
   unsigned rd1, rd1b, wr1; // layer 1 main tile `wave` (/ the tile 8 further: a base of its own, see make_lane): B8 window start, B18 output
   unsigned rd1r, wr1r;     // layer 1 remainder tile xr0 (waves 4..7)
-  unsigned rd2, rd2b, rd2t, wr2; // layer 2 tile `wave` (/ + 8): B18 window start (b64 steps / tail), B30 output
-  unsigned rd3, rd3b, rd3t, wr3; // layer 3 pair tile `wave` (/ + 8): B30 window start (b64 steps / tail), B8 output
+  unsigned rd2, rd2b, rd2t, rd2tb, wr2; // layer 2 tile `wave` (/ + 8): B18 window start (b64 steps / tail), B30 output
+  unsigned rd3, rd3b, rd3t, rd3tb, wr3; // layer 3 pair tile `wave` (/ + 8): B30 window start (b64 steps / tail), B8 output
   unsigned scr;            // lane*16: offset inside a hand-off scratch area
   unsigned vbits;          // validity bits, see kV*
 };
@@ -405,7 +405,9 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   L.rd1b = L.rd1 + kT1R;
   L.rd2b = L.rd2 + kT2R;
   L.rd3b = L.rd3 + kT3R;
-  asm volatile("" : "+v"(L.rd0b), "+v"(L.rd1b), "+v"(L.rd2b), "+v"(L.rd3b));
+  L.rd2tb = L.rd2t + kT2R;
+  L.rd3tb = L.rd3t + kT3R;
+  asm volatile("" : "+v"(L.rd0b), "+v"(L.rd1b), "+v"(L.rd2b), "+v"(L.rd3b), "+v"(L.rd2tb), "+v"(L.rd3tb));
   return L;
 }
 __device__ __forceinline__ bool vbit(const Lane& L, int b) { return (L.vbits >> b) & 1u; }
@@ -429,373 +431,370 @@ __device__ __forceinline__ void flag_wait(unsigned flag_addr, unsigned tag, unsi
 // wave-uniform: does 16-pixel tile T (pixels 16T..16T+15) contain a gap pixel?  (tiles 8, 16, 24)
 __device__ __forceinline__ bool tile_has_gap(int T) { return span_has_gap(16 * T, 16); }
 
+// ---- jobs -----------------------------------------------------------------------------------------------
+// A job = one mini-stream: D slots of operands are read ahead, then every slot reads the operands of slot i+D and issues
+// its MFMAs.  Jobs are self-contained (a wave's pipeline drains between two jobs: its SIMD partner's MFMAs fill the
+// gap) so that ONE copy of each job's code serves every wave and every tile: what differs -- which tiles, the odd
+// tiles, the shares of the split tiles -- is base registers and wave-uniform branches around the shared code.  With
+// one unrolled stream per wave role (an earlier version) the kernel was 60 KB of code and ran 40 % slower than at
+// 52 KB: the instruction cache (64 KB for two CUs) no longer held what 16 waves were executing.
+template <int NSLOT, int D, class LoadF, class MathF>
+__device__ __forceinline__ void run_job(LoadF&& load, MathF&& math) {
+  static_for<0, (D < NSLOT ? D : NSLOT)>(load);
+  static_for<0, NSLOT>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i + D < NSLOT) load(IC<i + D>{});
+    pin();
+    math(ic);
+    pin();
+  });
+}
+
 // ---- layer 1: 8x9, 1 -> 18 on the input rows (block 0, FIRST) / 1x9, 8 -> 18 on B8 (blocks 1..4) -----------
-// Jobs, in this order: NR remainder tiles (channels 16,17 of 128 pixels as 8 phases x 2 channels), the odd main tile if
-// the wave has an odd number of them, then pairs of main tiles (channels 0..15 of 16 pixels each, one A fragment for
-// both).  Blocks 1..4: a slot is a b64 K-step (two k-quads: 16 / 9 slots per remainder / main job, k = tap*8 + ci).
-// Block 0: a slot is a b32 K-step (one k-quad = time taps 4*ih + kq at one frequency tap: 32 / 18 slots, B operand
-// straight out of the staged input rows X0).
-template <int NMR, int NMX, int NR, bool FIRST>
-__device__ __forceinline__ void l1_stream(const Lane& L, unsigned wbase, int wave, int xm, int xr1) {
-  constexpr int D = FIRST ? 2 * RCED_D1 : RCED_D1, RING = D + 1;
-  constexpr int NM = NMR + NMX;
-  constexpr int NSING = NM & 1, NPAIR = NM / 2;
-  constexpr int NJ = NR + NSING + NPAIR;
-  constexpr int SR = FIRST ? 32 : 16, SM = FIRST ? 18 : 9;   // slots of a remainder / main job
-  constexpr int S_REM = SR * NR, S_SING = SM * NSING;
-  constexpr int NS = S_REM + S_SING + SM * NPAIR;
-  // main tile numbering: m = 0..NM-1; m < NMX: the extra tile xm; else regular tile (m - NMX).  The single job takes
-  // m = 0, pair p takes m = NSING + 2p, +1.
+// Blocks 1..4: a slot is a b64 K-step (two k-quads; k = tap*8 + ci): 9 slots per main tile (channels 0..15 of 16
+// pixels), 16 per remainder tile (channels 16,17 of 128 pixels as 8 phases x 2 channels, K = 16 taps).  Block 0: a slot
+// is a b32 K-step (one k-quad = time taps 4*ih + kq at one frequency tap; B operand straight out of the staged input
+// rows X0): 18 / 32 slots.  Main tiles run in pairs (one A fragment for both); waves 0, 1 (tile 32 / 31) and wave 7
+// (three regular tiles) have one single tile.
+template <bool FIRST>
+struct L1Geo {
+  static constexpr int SR = FIRST ? 32 : 16, SM = FIRST ? 18 : 9;      // slots of a remainder / main job
+  static constexpr int kAStep = FIRST ? 64 : 128;                       // floats per K-step of A fragments
+  static constexpr int kTR = FIRST ? 128 * 4 : kT1R;                    // read-side byte stride between a wave's regular tiles
+  static constexpr int kTileR = FIRST ? 16 * 4 : 16 * kB8S * 4;         // ... between adjacent 16-pixel tiles
+  static constexpr int D = FIRST ? 2 * RCED_D1 : RCED_D1;
+  // byte offset of K-step st inside a lane's window: blocks 1..4: one pixel per b64 step; block 0: (ih, j)
+  static constexpr int koff(int st, int per) { return FIRST ? ((st / per) * 4 * kS + st % per) * 4 : kB8S * 4 * st; }
+};
+
+template <bool FIRST, int NT, bool REM>   // NT tiles in lockstep (1 or 2); REM: remainder tile (NT = 1)
+__device__ __forceinline__ void l1_job(unsigned wa, unsigned rdA, unsigned rdB, f32x4 init, f32x4 (&acc)[2]) {
+  using G = L1Geo<FIRST>;
+  constexpr int NS = REM ? G::SR : G::SM, D = G::D, RING = D + 1, PER = REM ? 16 : 9;
+  f32x2 a[RING], b[RING][NT];
+  acc[0] = init;
+  if constexpr (NT > 1) acc[1] = init;
+  run_job<NS, D>(
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value, r = i % RING, aoff = ((REM ? kW1Main : 0) + i * G::kAStep) * 4;
+        if constexpr (FIRST) {
+          a[r].x = lds_ld<float>(wa, aoff);
+          b[r][0].x = lds_ld<float>(rdA, G::koff(i, PER));
+          if constexpr (NT > 1) b[r][1].x = lds_ld<float>(rdB, G::koff(i, PER));
+        } else {
+          a[r] = lds_ld<f32x2>(wa, aoff);
+          b[r][0] = lds_ld<f32x2>(rdA, G::koff(i, PER));
+          if constexpr (NT > 1) b[r][1] = lds_ld<f32x2>(rdB, G::koff(i, PER));
+        }
+      },
+      [&](auto ic) {
+        constexpr int r = decltype(ic)::value % RING;
+        acc[0] = mfma(a[r].x, b[r][0].x, acc[0]);
+        if constexpr (NT > 1) acc[1] = mfma(a[r].x, b[r][1].x, acc[1]);
+        if constexpr (!FIRST) {
+          acc[0] = mfma(a[r].y, b[r][0].y, acc[0]);
+          if constexpr (NT > 1) acc[1] = mfma(a[r].y, b[r][1].y, acc[1]);
+        }
+      });
+}
+
+// [pixel][18] store of a main tile's channels 4kq..4kq+3 (masked: the tile has gap pixels; wave-uniform)
+__device__ __forceinline__ void l1_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
+  const f32x4 v = relu4(acc4);
+  if (masked) {
+    if (vbit(L, vb)) {
+      lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
+      lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
+    }
+  } else {
+    lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
+    lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
+  }
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave) {
+  using G = L1Geo<FIRST>;
   const unsigned wa = wbase + (FIRST ? L.a4 : L.a8);     // A fragments: main [s][lane], remainder from kW1Main
   const f32x4 sh = lds_ld<f32x4>(wbase + L.kq16, kW1Data * 4);
   const f32x2 s2 = lds_ld<f32x2>(wbase, (kW1Data + 16) * 4);
-  const unsigned rd = FIRST ? L.rd0 : L.rd1, rdb = FIRST ? L.rd0b : L.rd1b, rdr = FIRST ? L.rd0r : L.rd1r;
-  constexpr int kTR = FIRST ? 128 * 4 : kT1R;            // byte stride between a wave's regular tiles, read side
-  constexpr int kTileR = FIRST ? 16 * 4 : 16 * kB8S * 4; // ... between adjacent 16-pixel tiles
-  unsigned rdx = 0, wrx = 0;
-  if constexpr (NMX > 0) {
-    rdx = rd + (xm - wave) * kTileR;
-    wrx = L.wr1 + (xm - wave) * (16 * 18 * 4);
+  f32x4 acc[2];
+  // ---- remainder tiles: waves 4, 5, 6 -> tiles 0, 1, 2; wave 7 -> tiles 3 and 4
+  const int nrem = wave < 4 ? 0 : wave == 7 ? 2 : 1;
+  unsigned rdr = FIRST ? L.rd0r : L.rd1r, wrr = L.wr1r;
+  int xr = wave == 7 ? 3 : wave - 4, vb = kVRem;
+#pragma unroll 1
+  for (int r = 0; r < nrem; ++r) {
+    l1_job<FIRST, 1, true>(wa, rdr, 0u, f32x4{s2.x, s2.y, s2.x, s2.y}, acc);
+    const f32x4 v = relu4(acc[0]);   // rows 4kq+jj = (phase 2kq + (jj>>1), channel 16 + (jj&1)): two pixels x channels 16,17
+    if (xr > 0) {   // every remainder tile but tile 0 contains gap pixels (tile 4 also runs past the tile): never written
+      if (vbit(L, vb)) lds_st<f32x2>(wrr, 0, f32x2{v.x, v.y});
+      if (vbit(L, vb + 1)) lds_st<f32x2>(wrr, 18 * 4, f32x2{v.z, v.w});
+    } else {
+      lds_st<f32x2>(wrr, 0, f32x2{v.x, v.y});
+      lds_st<f32x2>(wrr, 18 * 4, f32x2{v.z, v.w});
+    }
+    rdr += 8 * G::kTileR;            // wave 7's second tile: 4 = 3 + 1
+    wrr += 8 * 16 * 18 * 4;
+    xr += 1;
+    vb += 2;
   }
-  const unsigned rdr1 = rdr + (xr1 - (wave == 7 ? 3 : 0)) * (8 * kTileR);   // second remainder tile (wave 7: 4 vs 3)
-  const unsigned wrr1 = L.wr1r + (xr1 - (wave == 7 ? 3 : 0)) * (8 * 16 * 18 * 4);
-  auto m_rd = [&](int m) { return m < NMX ? rdx : ((m - NMX) & 1) ? rdb : rd; };
-  auto m_wr = [&](int m) { return m < NMX ? wrx : L.wr1; };
-  auto m_ro = [](int m) { return m < NMX ? 0 : ((m - NMX) & ~1) * kTR; };
-  auto m_wo = [](int m) { return m < NMX ? 0 : (m - NMX) * kT1W; };
-  // byte offset of K-step st inside a lane's window: blocks 1..4: one pixel per b64 step; block 0: (ih, j)
-  auto koff = [](int st, int per) { return FIRST ? ((st / per) * 4 * kS + st % per) * 4 : kB8S * 4 * st; };
-  f32x2 a[RING], b[RING][2];
-  f32x4 acc[2][2];   // [job parity][tile of the job]
-  auto ld_a = [&](f32x2& dst, int off_floats) {
-    if constexpr (FIRST) dst.x = lds_ld<float>(wa, off_floats * 4);
-    else dst = lds_ld<f32x2>(wa, off_floats * 4);
-  };
-  auto ld_b = [&](f32x2& dst, unsigned base, int off) {
-    if constexpr (FIRST) dst.x = lds_ld<float>(base, off);
-    else dst = lds_ld<f32x2>(base, off);
-  };
-  constexpr int kAStep = FIRST ? 64 : 128;   // floats per K-step of A fragments
-  auto load = [&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    constexpr int r = i % RING;
-    if constexpr (i < S_REM) {
-      constexpr int j = i / SR, st = i % SR;
-      ld_a(a[r], kW1Main + st * kAStep);
-      ld_b(b[r][0], j == 0 ? rdr : rdr1, koff(st, 16));
-    } else if constexpr (i < S_REM + S_SING) {
-      constexpr int st = i - S_REM;
-      ld_a(a[r], st * kAStep);
-      ld_b(b[r][0], m_rd(0), m_ro(0) + koff(st, 9));
-    } else {
-      constexpr int p = (i - S_REM - S_SING) / SM, st = (i - S_REM - S_SING) % SM, m = NSING + 2 * p;
-      ld_a(a[r], st * kAStep);
-      ld_b(b[r][0], m_rd(m), m_ro(m) + koff(st, 9));
-      ld_b(b[r][1], m_rd(m + 1), m_ro(m + 1) + koff(st, 9));
-    }
-  };
-  auto store_main = [&](f32x4 acc4, auto mc) {   // channels 4kq..4kq+3 of this lane's pixel of main tile m
-    constexpr int m = decltype(mc)::value;
-    const f32x4 v = relu4(acc4);
-    const int T = m < NMX ? xm : wave + 8 * (m - NMX);
-    if (m >= NMX && m - NMX > 0 && tile_has_gap(T)) {   // wave-uniform; only tiles 8, 16, 24 (wave 0)
-      if (vbit(L, kVMain + (m - NMX))) {
-        lds_st<f32x2>(m_wr(m), m_wo(m), f32x2{v.x, v.y});
-        lds_st<f32x2>(m_wr(m), m_wo(m) + 8, f32x2{v.z, v.w});
-      }
-    } else {
-      lds_st<f32x2>(m_wr(m), m_wo(m), f32x2{v.x, v.y});
-      lds_st<f32x2>(m_wr(m), m_wo(m) + 8, f32x2{v.z, v.w});
-    }
-  };
-  auto epilogue = [&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    if constexpr (j < NR) {   // remainder tile: rows 4kq+jj = (phase 2kq + (jj>>1), channel 16 + (jj&1))
-      const f32x4 v = relu4(acc[j & 1][0]);
-      const unsigned wr = j == 0 ? L.wr1r : wrr1;
-      const int xr = j == 0 ? (wave == 7 ? 3 : wave - 4) : xr1;
-      if (xr > 0) {   // wave-uniform: every remainder tile but tile 0 contains gap pixels (tile 4 also runs past the tile)
-        if (vbit(L, kVRem + 2 * j)) lds_st<f32x2>(wr, 0, f32x2{v.x, v.y});
-        if (vbit(L, kVRem + 2 * j + 1)) lds_st<f32x2>(wr, 18 * 4, f32x2{v.z, v.w});
-      } else {
-        lds_st<f32x2>(wr, 0, f32x2{v.x, v.y});
-        lds_st<f32x2>(wr, 18 * 4, f32x2{v.z, v.w});
-      }
-    } else if constexpr (j < NR + NSING) {
-      store_main(acc[j & 1][0], IC<0>{});
-    } else {
-      constexpr int m = NSING + 2 * (j - NR - NSING);
-      store_main(acc[j & 1][0], IC<m>{});
-      store_main(acc[j & 1][1], IC<m + 1>{});
-    }
-  };
-  auto mm = [&](f32x4& c, const f32x2& av, const f32x2& bv) {
-    c = mfma(av.x, bv.x, c);
-    if constexpr (!FIRST) c = mfma(av.y, bv.y, c);
-  };
-  static_for<0, (D < NS ? D : NS)>(load);
-  static_for<0, NS>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    constexpr int r = i % RING;
-    if constexpr (i + D < NS) load(IC<i + D>{});
-    pin();
-    if constexpr (i < S_REM) {
-      constexpr int j = i / SR, st = i % SR;
-      if constexpr (st == 0) acc[j & 1][0] = f32x4{s2.x, s2.y, s2.x, s2.y};
-      mm(acc[j & 1][0], a[r], b[r][0]);
-      if constexpr (st == 2 && j > 0) epilogue(IC<(j > 0 ? j - 1 : 0)>{});
-    } else if constexpr (i < S_REM + S_SING) {
-      constexpr int j = NR, st = i - S_REM;
-      if constexpr (st == 0) acc[j & 1][0] = sh;
-      mm(acc[j & 1][0], a[r], b[r][0]);
-      if constexpr (st == 2 && j > 0) epilogue(IC<(j > 0 ? j - 1 : 0)>{});
-    } else {
-      constexpr int p = (i - S_REM - S_SING) / SM, st = (i - S_REM - S_SING) % SM, j = NR + NSING + p;
-      if constexpr (st == 0) acc[j & 1][0] = acc[j & 1][1] = sh;
-      if constexpr (FIRST) {
-        acc[j & 1][0] = mfma(a[r].x, b[r][0].x, acc[j & 1][0]);
-        acc[j & 1][1] = mfma(a[r].x, b[r][1].x, acc[j & 1][1]);
-      } else {
-        acc[j & 1][0] = mfma(a[r].x, b[r][0].x, acc[j & 1][0]);
-        acc[j & 1][1] = mfma(a[r].x, b[r][1].x, acc[j & 1][1]);
-        acc[j & 1][0] = mfma(a[r].y, b[r][0].y, acc[j & 1][0]);
-        acc[j & 1][1] = mfma(a[r].y, b[r][1].y, acc[j & 1][1]);
-      }
-      if constexpr (st == 2 && j > 0) epilogue(IC<(j > 0 ? j - 1 : 0)>{});
-    }
-    pin();
-  });
-  epilogue(IC<NJ - 1>{});
+  // ---- the single main tile: waves 0 / 1 -> tile 32 / 31 (no gap pixels); wave 7 -> its third regular tile (23)
+  const unsigned rd = FIRST ? L.rd0 : L.rd1, rdb = FIRST ? L.rd0b : L.rd1b;
+  if (wave < 2 || wave == 7) {
+    const int dt = wave == 0 ? 32 : wave == 1 ? 30 : 16;   // tiles away from regular tile `wave`
+    l1_job<FIRST, 1, false>(wa, rd + dt * G::kTileR, 0u, sh, acc);
+    l1_store(L, acc[0], L.wr1 + dt * (16 * 18 * 4), 0, false, 0);
+  }
+  // ---- pairs of regular tiles: (wave, wave+8), (wave+16, wave+24); wave 7 only the first
+  const int npair = wave == 7 ? 1 : 2;
+  unsigned rdA = rd, rdB = rdb, wr = L.wr1;
+  int T = wave;
+  vb = kVMain;
+#pragma unroll 1
+  for (int p = 0; p < npair; ++p) {
+    l1_job<FIRST, 2, false>(wa, rdA, rdB, sh, acc);
+    l1_store(L, acc[0], wr, 0, T > 0 && tile_has_gap(T), vb);           // tiles 8, 16, 24 (wave 0) have gap pixels
+    l1_store(L, acc[1], wr, kT1W, tile_has_gap(T + 8), vb + 1);
+    rdA += 2 * G::kTR;
+    rdB += 2 * G::kTR;
+    wr += 2 * kT1W;
+    T += 16;
+    vb += 2;
+  }
 }
 
 // ---- layer 2: 1x5, 18 -> 30 (two M-tiles) ------------------------------------------------------------
 // Every wave has four regular tiles, walked as two pair jobs (11 b64 slots + the b32 tail; both tiles, both M-tiles:
 // 8 / 4 MFMAs per slot on four accumulation chains, two A fragments for both tiles).  Tile 32 (pixels 512..527) is cut
-// in four equal pieces, one per SIMD, so that the layer's MFMA count is the same on every SIMD: M-tile XMT x K-half.
+// in four equal pieces, one per SIMD, so that the layer's MFMA count is the same on every SIMD: M-tile XM x K-half.
 // Waves 0 / 1 are the helpers (slots [0, kL2Cut) of M-tile 0 / 1), waves 2 / 3 the reducers (slots [kL2Cut, 11) + tail
-// of M-tile 0 / 1; they add the helper's partial sums and own the epilogue).  The share is the wave's first job.
-// Scratch: in the B8 buffer, which is dead during layer 2 (layer 3 rewrites every real pixel of it).
+// of M-tile 0 / 1; they add the helper's partial sums and own the epilogue).  The share is the wave's FIRST job: a helper
+// publishes it through LDS scratch + a tagged flag word before its regular tiles, and the reducer picks it up after
+// its last job, when it has long been there.  Scratch: in the B8 buffer, which is dead during layer 2 (layer 3
+// rewrites every real pixel of it).
 constexpr int kL2Cut = 6;
 constexpr int kScratch2Off = kB8Off + kB8Pad * kB8S + 8 * kB8S;   // B8 rows 8.. of frame 0 (2 x 256 floats + 2 flags)
 constexpr int kFlag2Off = kScratch2Off + 2 * 256;
 static_assert((kScratch2Off * 4) % 16 == 0, "scratch is read/written with b128");
 static_assert(8 + (2 * 256 + 2 + kB8S - 1) / kB8S <= kF, "layer-2 scratch stays inside frame 0's real pixels");
-constexpr int kL2Plain = 0, kL2Reducer = 1, kL2Helper = 2;
 
-template <int ROLE, int XMTP>   // XMTP: the M-tile of tile 32 this wave works on (plain: unused)
+template <int XM, bool HELPER>   // the share of tile 32: M-tile XM, slots [0, kL2Cut) (helper) or [kL2Cut, 11) + tail
+__device__ __forceinline__ f32x4 l2_share(unsigned wa, unsigned wt, unsigned rdx, unsigned rdxt, f32x4 init) {
+  constexpr int S0 = HELPER ? 0 : kL2Cut, NS = HELPER ? kL2Cut : kL2Steps + 1 - kL2Cut, D = RCED_D2, RING = D + 1;
+  f32x2 a[RING], b[RING];
+  f32x4 acc = init;
+  run_job<NS, D>(
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value, r = i % RING, st = S0 + i;
+        if constexpr (st < kL2Steps) {
+          a[r] = lds_ld<f32x2>(wa, (st * 2 + XM) * 128 * 4);
+          b[r] = lds_ld<f32x2>(rdx, 32 * st);
+        } else {
+          a[r].x = lds_ld<float>(wt, (kL2Steps * 2 * 128 + XM * 64) * 4);
+          b[r].x = lds_ld<float>(rdxt, 0);
+        }
+      },
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value, r = i % RING;
+        acc = mfma(a[r].x, b[r].x, acc);
+        if constexpr (S0 + i < kL2Steps) acc = mfma(a[r].y, b[r].y, acc);
+      });
+  return acc;
+}
+
+// one M-tile of one tile: ReLU, [pixel][30] stores; lanes kq = 3 of M-tile 1 hold channels 28,29 and the padding 30,31
+template <int MT>
+__device__ __forceinline__ void l2_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
+  const f32x4 v = relu4(acc4);
+  if (masked) {
+    if (vbit(L, vb)) {
+      lds_st<f32x2>(wr, off + 64 * MT, f32x2{v.x, v.y});
+      if (MT == 0 || vbit(L, kVLt48)) lds_st<f32x2>(wr, off + 64 * MT + 8, f32x2{v.z, v.w});
+    }
+  } else {
+    lds_st<f32x2>(wr, off + 64 * MT, f32x2{v.x, v.y});
+    if (MT == 0 || vbit(L, kVLt48)) lds_st<f32x2>(wr, off + 64 * MT + 8, f32x2{v.z, v.w});
+  }
+}
+
 __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wbase, int wave, unsigned tag, unsigned* err) {
-  constexpr int D = RCED_D2, RING = D + 1;
-  constexpr bool HASX = ROLE != kL2Plain;
-  constexpr int XS0 = ROLE == kL2Reducer ? kL2Cut : 0;
-  constexpr int XS1 = ROLE == kL2Helper ? kL2Cut : kL2Steps + 1;   // slot kL2Steps is the tail
-  constexpr int NX = HASX ? XS1 - XS0 : 0;
-  constexpr int NJS = kL2Steps + 1;
-  constexpr int NS = NX + 2 * NJS;
-  constexpr int XM = HASX ? XMTP : 0;
+  constexpr int D = RCED_D2, RING = D + 1, NS = kL2Steps + 1;
   const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
   f32x4 sh[2];
   sh[0] = lds_ld<f32x4>(wbase + L.kq16, kW2Data * 4);
   sh[1] = lds_ld<f32x4>(wbase + L.kq16, (kW2Data + 16) * 4);
-  unsigned rdx = 0, rdxt = 0, wrx = 0;
-  if constexpr (HASX) {   // tile 32: wave-uniform deltas
-    rdx = L.rd2 + (32 - wave) * (16 * 18 * 4);
-    rdxt = L.rd2t + (32 - wave) * (16 * 18 * 4);
-    wrx = L.wr2 + (32 - wave) * (16 * 30 * 4);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // ---- the share of tile 32 (waves 0..3), first
+  f32x4 accx = zero4;
+  if (wave < 4) {
+    const unsigned rdx = L.rd2 + (32 - wave) * (16 * 18 * 4), rdxt = L.rd2t + (32 - wave) * (16 * 18 * 4);
+    if (wave == 0) accx = l2_share<0, true>(wa, wt, rdx, rdxt, zero4);        // a helper's share starts from zero,
+    else if (wave == 1) accx = l2_share<1, true>(wa, wt, rdx, rdxt, zero4);
+    else if (wave == 2) accx = l2_share<0, false>(wa, wt, rdx, rdxt, sh[0]);  // the reducer's from the shift
+    else accx = l2_share<1, false>(wa, wt, rdx, rdxt, sh[1]);
+    if (wave < 2) {   // publish (LDS operations of a wave execute in order: data, then flag)
+      lds_st<f32x4>(lds0 + L.scr + wave * 1024, kScratch2Off * 4, accx);
+      cbar();
+      if (L.a4 == 0) lds_poke_a(lds0 + (kFlag2Off + wave) * 4, tag);
+    }
   }
-  f32x2 a[RING][2], b[RING][2];
-  f32x4 acc[2][2][2];   // [job parity][tile of the pair][M-tile]
-  f32x4 accx = ROLE == kL2Reducer ? sh[XM] : f32x4{0.f, 0.f, 0.f, 0.f};   // the helper's share starts from zero
-  auto load = [&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    constexpr int r = i % RING;
-    if constexpr (i < NX) {
-      constexpr int st = XS0 + i;
-      if constexpr (st < kL2Steps) {
-        a[r][XM] = lds_ld<f32x2>(wa, (st * 2 + XM) * 128 * 4);
-        b[r][0] = lds_ld<f32x2>(rdx, 32 * st);
-      } else {
-        a[r][XM].x = lds_ld<float>(wt, (kL2Steps * 2 * 128 + XM * 64) * 4);
-        b[r][0].x = lds_ld<float>(rdxt, 0);
-      }
-    } else {
-      constexpr int j = (i - NX) / NJS, st = (i - NX) % NJS;
-      if constexpr (st < kL2Steps) {
-        a[r][0] = lds_ld<f32x2>(wa, (st * 2 + 0) * 128 * 4);
-        a[r][1] = lds_ld<f32x2>(wa, (st * 2 + 1) * 128 * 4);
-        b[r][0] = lds_ld<f32x2>(L.rd2, (2 * j) * kT2R + 32 * st);
-        b[r][1] = lds_ld<f32x2>(L.rd2b, (2 * j) * kT2R + 32 * st);
-      } else {
-        a[r][0].x = lds_ld<float>(wt, (kL2Steps * 2 * 128) * 4);
-        a[r][1].x = lds_ld<float>(wt, (kL2Steps * 2 * 128 + 64) * 4);
-        b[r][0].x = lds_ld<float>(L.rd2t, (2 * j) * kT2R);
-        b[r][1].x = lds_ld<float>(L.rd2t, (2 * j + 1) * kT2R);
-      }
-    }
-  };
-  auto store_mt = [&](f32x4 acc4, unsigned wr, int off, auto mc, bool masked, int vb) {
-    constexpr int mt = decltype(mc)::value;
-    const f32x4 v = relu4(acc4);
-    if (masked) {
-      if (vbit(L, vb)) {
-        lds_st<f32x2>(wr, off + 64 * mt, f32x2{v.x, v.y});
-        if (mt == 0 || vbit(L, kVLt48)) lds_st<f32x2>(wr, off + 64 * mt + 8, f32x2{v.z, v.w});
-      }
-    } else {
-      lds_st<f32x2>(wr, off + 64 * mt, f32x2{v.x, v.y});
-      if (mt == 0 || vbit(L, kVLt48)) lds_st<f32x2>(wr, off + 64 * mt + 8, f32x2{v.z, v.w});
-    }
-  };
-  auto epilogue = [&](auto jc, auto tc, auto mc) {   // one M-tile of tile t of pair j: ReLU, [pixel][30] stores
-    constexpr int j = decltype(jc)::value, t = decltype(tc)::value, mt = decltype(mc)::value, tt = 2 * j + t;
-    store_mt(acc[j & 1][t][mt], L.wr2, tt * kT2W, IC<mt>{}, tt > 0 && tile_has_gap(wave + 8 * tt), kVMain + tt);
-  };
-  static_for<0, D>(load);
-  static_for<0, NS>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    constexpr int r = i % RING;
-    if constexpr (i + D < NS) load(IC<i + D>{});
-    pin();
-    if constexpr (i < NX) {
-      accx = mfma(a[r][XM].x, b[r][0].x, accx);
-      if constexpr (XS0 + i < kL2Steps) accx = mfma(a[r][XM].y, b[r][0].y, accx);
-    } else {
-      constexpr int j = (i - NX) / NJS, st = (i - NX) % NJS, jp = j & 1;
-      if constexpr (st == 0) {
-        acc[jp][0][0] = acc[jp][1][0] = sh[0];
-        acc[jp][0][1] = acc[jp][1][1] = sh[1];
-      }
-      acc[jp][0][0] = mfma(a[r][0].x, b[r][0].x, acc[jp][0][0]);
-      acc[jp][0][1] = mfma(a[r][1].x, b[r][0].x, acc[jp][0][1]);
-      acc[jp][1][0] = mfma(a[r][0].x, b[r][1].x, acc[jp][1][0]);
-      acc[jp][1][1] = mfma(a[r][1].x, b[r][1].x, acc[jp][1][1]);
-      if constexpr (st < kL2Steps) {
-        acc[jp][0][0] = mfma(a[r][0].y, b[r][0].y, acc[jp][0][0]);
-        acc[jp][0][1] = mfma(a[r][1].y, b[r][0].y, acc[jp][0][1]);
-        acc[jp][1][0] = mfma(a[r][0].y, b[r][1].y, acc[jp][1][0]);
-        acc[jp][1][1] = mfma(a[r][1].y, b[r][1].y, acc[jp][1][1]);
-      }
-      if constexpr (ROLE == kL2Helper && j == 0 && st == 1) {   // publish the share of tile 32 (MFMAs issued 2 slots ago)
-        lds_st<f32x4>(lds0 + L.scr, (kScratch2Off + XM * 256) * 4, accx);
-        cbar();
-        if (L.a4 == 0) lds_poke_a(lds0 + (kFlag2Off + XM) * 4, tag);
-      }
-      if constexpr (j == 1 && st == 2) epilogue(IC<0>{}, IC<0>{}, IC<0>{});   // pair 0's stores, spread over pair 1's slots
-      if constexpr (j == 1 && st == 4) epilogue(IC<0>{}, IC<0>{}, IC<1>{});
-      if constexpr (j == 1 && st == 6) epilogue(IC<0>{}, IC<1>{}, IC<0>{});
-      if constexpr (j == 1 && st == 8) epilogue(IC<0>{}, IC<1>{}, IC<1>{});
-    }
-    pin();
-  });
-  epilogue(IC<1>{}, IC<0>{}, IC<0>{});
-  epilogue(IC<1>{}, IC<0>{}, IC<1>{});
-  epilogue(IC<1>{}, IC<1>{}, IC<0>{});
-  epilogue(IC<1>{}, IC<1>{}, IC<1>{});
-  if constexpr (ROLE == kL2Reducer) {
-    flag_wait(lds0 + (kFlag2Off + XM) * 4, tag, err, 2u);
-    const f32x4 v = accx + lds_ld<f32x4>(lds0 + L.scr, (kScratch2Off + XM * 256) * 4);
-    store_mt(v, wrx, 0, IC<XM>{}, false, 0);   // tile 32 (pixels 512..527): no gap inside
+  // ---- two pair jobs: tiles (wave, wave+8), (wave+16, wave+24)
+  unsigned rdA = L.rd2, rdB = L.rd2b, rdAt = L.rd2t, rdBt = L.rd2tb, wr = L.wr2;
+  int T = wave, vb = kVMain;
+#pragma unroll 1
+  for (int p = 0; p < 2; ++p) {
+    f32x2 a[RING][2], b[RING][2];
+    f32x4 acc[2][2] = {{sh[0], sh[1]}, {sh[0], sh[1]}};   // [tile][M-tile]
+    run_job<NS, D>(
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, r = i % RING;
+          if constexpr (i < kL2Steps) {
+            a[r][0] = lds_ld<f32x2>(wa, (i * 2 + 0) * 128 * 4);
+            a[r][1] = lds_ld<f32x2>(wa, (i * 2 + 1) * 128 * 4);
+            b[r][0] = lds_ld<f32x2>(rdA, 32 * i);
+            b[r][1] = lds_ld<f32x2>(rdB, 32 * i);
+          } else {
+            a[r][0].x = lds_ld<float>(wt, (kL2Steps * 2 * 128) * 4);
+            a[r][1].x = lds_ld<float>(wt, (kL2Steps * 2 * 128 + 64) * 4);
+            b[r][0].x = lds_ld<float>(rdAt, 0);
+            b[r][1].x = lds_ld<float>(rdBt, 0);
+          }
+        },
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, r = i % RING;
+          acc[0][0] = mfma(a[r][0].x, b[r][0].x, acc[0][0]);
+          acc[0][1] = mfma(a[r][1].x, b[r][0].x, acc[0][1]);
+          acc[1][0] = mfma(a[r][0].x, b[r][1].x, acc[1][0]);
+          acc[1][1] = mfma(a[r][1].x, b[r][1].x, acc[1][1]);
+          if constexpr (i < kL2Steps) {
+            acc[0][0] = mfma(a[r][0].y, b[r][0].y, acc[0][0]);
+            acc[0][1] = mfma(a[r][1].y, b[r][0].y, acc[0][1]);
+            acc[1][0] = mfma(a[r][0].y, b[r][1].y, acc[1][0]);
+            acc[1][1] = mfma(a[r][1].y, b[r][1].y, acc[1][1]);
+          }
+        });
+    const bool g0 = T > 0 && tile_has_gap(T), g1 = tile_has_gap(T + 8);   // tiles 8, 16, 24 (wave 0)
+    l2_store<0>(L, acc[0][0], wr, 0, g0, vb);
+    l2_store<1>(L, acc[0][1], wr, 0, g0, vb);
+    l2_store<0>(L, acc[1][0], wr, kT2W, g1, vb + 1);
+    l2_store<1>(L, acc[1][1], wr, kT2W, g1, vb + 1);
+    rdA += 2 * kT2R;
+    rdB += 2 * kT2R;
+    rdAt += 2 * kT2R;
+    rdBt += 2 * kT2R;
+    wr += 2 * kT2W;
+    T += 16;
+    vb += 2;
+  }
+  // ---- reducers: add the helper's share, store tile 32 (pixels 512..527: no gap inside)
+  if (wave == 2 || wave == 3) {
+    const int xm = wave - 2;
+    flag_wait(lds0 + (kFlag2Off + xm) * 4, tag, err, 2u);
+    const f32x4 v = accx + lds_ld<f32x4>(lds0 + L.scr + xm * 1024, kScratch2Off * 4);
+    const unsigned wrx = L.wr2 + (32 - wave) * (16 * 30 * 4);
+    if (xm == 0) l2_store<0>(L, v, wrx, 0, false, 0);
+    else l2_store<1>(L, v, wrx, 0, false, 0);
   }
 }
 
 // ---- layer 3: 1x9, 30 -> 8 on pixel pairs ------------------------------------------------------------
 // Rows = 2 pixel phases x 8 channels, K = 10 taps x 30 = 300 (37 b64 slots + the b32 tail).  Every wave has two regular
-// pair tiles, run in lockstep (one A fragment per slot for both: the layer's epilogue is small, 8 channels).  Pair tile
-// 16 is split ALONG K in four, one part per SIMD (waves 0..3): the reducer (wave 0: slots [0,10), owns the epilogue and
-// the skip registers) and three helpers (waves 1..3: [10,19), [19,28), [28,37) + tail).  The share is each wave's first
-// job; partial sums go through 1-KiB scratch areas in the (dead during layer 3) B18 buffer + tagged flag words.
-constexpr int kRolePlain = 0, kRoleReducer = 1, kRoleHelper = 2;
+// pair tiles, run in lockstep (one A fragment per slot for both, four accumulation chains: tile x k-quad of the slot).
+// Pair tile 16 is split ALONG K in four, one part per SIMD (waves 0..3): the reducer (wave 0: slots [0,10), owns the
+// epilogue and the skip registers) and three helpers (waves 1..3: [10,19), [19,28), [28,37) + tail).  The share is each
+// wave's first job; partial sums go through 1-KiB scratch areas in the (dead during layer 3) B18 buffer + flag words.
 constexpr int kL3Cut1 = 10, kL3Cut2 = 19, kL3Cut3 = 28;
 constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;   // pixels 8..51 of frame 0: always rewritten by layer 1
 constexpr int kFlagOff = kScratchOff + 3 * 256;
 static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
 static_assert(8 + (3 * 256 + 3 + 17) / 18 <= kF, "scratch + flags stay inside frame 0's real pixels");
 
-template <int ROLE, int HID>   // HID: helper number 1..3 (0 otherwise)
+template <int S0, int S1>   // the share of pair tile 16: slots [S0, S1) (slot kL3Steps = the tail)
+__device__ __forceinline__ f32x4 l3_share(unsigned wa, unsigned wt, unsigned rdx, unsigned rdxt, f32x4 init) {
+  constexpr int NS = S1 - S0, D = RCED_D3, RING = D + 1;
+  f32x2 a[RING], b[RING];
+  f32x4 acc = init;
+  run_job<NS, D>(
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value, r = i % RING, st = S0 + i;
+        if constexpr (st < kL3Steps) {
+          a[r] = lds_ld<f32x2>(wa, st * 128 * 4);
+          b[r] = lds_ld<f32x2>(rdx, 32 * st);
+        } else {
+          a[r].x = lds_ld<float>(wt, kL3Steps * 128 * 4);
+          b[r].x = lds_ld<float>(rdxt, 0);
+        }
+      },
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value, r = i % RING;
+        acc = mfma(a[r].x, b[r].x, acc);
+        if constexpr (S0 + i < kL3Steps) acc = mfma(a[r].y, b[r].y, acc);
+      });
+  return acc;
+}
+
 __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned lds0, unsigned wbase, int blk, int wave,
                                        int lane, unsigned tag, int utt, int t0, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
-  constexpr int D = RCED_D3, RING = D + 1;
-  constexpr bool HASX = ROLE != kRolePlain;
-  constexpr int XS0 = ROLE != kRoleHelper ? 0 : HID == 1 ? kL3Cut1 : HID == 2 ? kL3Cut2 : kL3Cut3;
-  constexpr int XS1 = ROLE == kRoleReducer ? kL3Cut1 : HID == 1 ? kL3Cut2 : HID == 2 ? kL3Cut3 : kL3Steps + 1;
-  constexpr int NX = HASX ? XS1 - XS0 : 0;
-  constexpr int NM = kL3Steps + 1;   // 37 b64 slots + the tail
-  constexpr int NS = NX + NM;
-  constexpr int NEPI = ROLE == kRoleReducer ? 3 : 2;   // tiles this wave finishes
+  constexpr int D = RCED_D3, RING = D + 1, NS = kL3Steps + 1;
   const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
   const f32x4 sh = lds_ld<f32x4>(wbase + (L.kq16 & 16), kW3Data * 4);   // shift[4*(kq&1) ..]
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  unsigned rdx = 0, rdxt = 0, wrx = 0;
-  if constexpr (HASX) {   // pair tile 16: wave-uniform deltas
-    rdx = L.rd3 + (16 - wave) * (16 * 60 * 4);
-    rdxt = L.rd3t + (16 - wave) * (16 * 60 * 4);
-    wrx = L.wr3 + (16 - wave) * (32 * kB8S * 4);
+  f32x4 acc[3] = {sh, sh, zero4};   // [2]: pair tile 16 (wave 0)
+  // ---- the share of pair tile 16 (waves 0..3), first
+  if (wave < 4) {
+    const unsigned rdx = L.rd3 + (16 - wave) * (16 * 60 * 4), rdxt = L.rd3t + (16 - wave) * (16 * 60 * 4);
+    if (wave == 0) acc[2] = l3_share<0, kL3Cut1>(wa, wt, rdx, rdxt, sh);
+    else if (wave == 1) acc[2] = l3_share<kL3Cut1, kL3Cut2>(wa, wt, rdx, rdxt, zero4);
+    else if (wave == 2) acc[2] = l3_share<kL3Cut2, kL3Cut3>(wa, wt, rdx, rdxt, zero4);
+    else acc[2] = l3_share<kL3Cut3, kL3Steps + 1>(wa, wt, rdx, rdxt, zero4);
+    if (wave > 0) {   // publish the partial sums
+      lds_st<f32x4>(lds0 + L.scr + (wave - 1) * 1024, kScratchOff * 4, acc[2]);
+      cbar();
+      if (L.a4 == 0) lds_poke_a(lds0 + (kFlagOff + wave - 1) * 4, tag);
+    }
   }
-  f32x2 a[RING], b[RING][2];
-  f32x4 acc[3] = {sh, sh, ROLE == kRoleReducer ? sh : zero4};   // [2]: the share of pair tile 16
-  f32x4 accb[2] = {zero4, zero4};   // second chain of the regular tiles (the slot's second k-quad): 4 chains, not 2 (+2.4 %)
-  auto load = [&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    constexpr int r = i % RING;
-    if constexpr (i < NX) {
-      constexpr int st = XS0 + i;
-      if constexpr (st < kL3Steps) {
-        a[r] = lds_ld<f32x2>(wa, st * 128 * 4);
-        b[r][0] = lds_ld<f32x2>(rdx, 32 * st);
-      } else {
-        a[r].x = lds_ld<float>(wt, kL3Steps * 128 * 4);
-        b[r][0].x = lds_ld<float>(rdxt, 0);
-      }
-    } else {
-      constexpr int st = i - NX;
-      if constexpr (st < kL3Steps) {
-        a[r] = lds_ld<f32x2>(wa, st * 128 * 4);
-        b[r][0] = lds_ld<f32x2>(L.rd3, 32 * st);
-        b[r][1] = lds_ld<f32x2>(L.rd3b, 32 * st);
-      } else {
-        a[r].x = lds_ld<float>(wt, kL3Steps * 128 * 4);
-        b[r][0].x = lds_ld<float>(L.rd3t, 0);
-        b[r][1].x = lds_ld<float>(L.rd3t, kT3R);
-      }
-    }
-  };
-  static_for<0, D>(load);
-  static_for<0, NS>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    constexpr int r = i % RING;
-    if constexpr (i + D < NS) load(IC<i + D>{});
-    pin();
-    if constexpr (i < NX) {
-      acc[2] = mfma(a[r].x, b[r][0].x, acc[2]);
-      if constexpr (XS0 + i < kL3Steps) acc[2] = mfma(a[r].y, b[r][0].y, acc[2]);
-    } else {
-      constexpr int st = i - NX;
-      acc[0] = mfma(a[r].x, b[r][0].x, acc[0]);
-      acc[1] = mfma(a[r].x, b[r][1].x, acc[1]);
-      if constexpr (st < kL3Steps) {
-        accb[0] = mfma(a[r].y, b[r][0].y, accb[0]);
-        accb[1] = mfma(a[r].y, b[r][1].y, accb[1]);
-      }
-      if constexpr (ROLE == kRoleHelper && st == 1) {   // publish the partial sums of pair tile 16
-        lds_st<f32x4>(lds0 + L.scr, (kScratchOff + (HID - 1) * 256) * 4, acc[2]);
-        cbar();
-        if (L.a4 == 0) lds_poke_a(lds0 + (kFlagOff + (HID - 1)) * 4, tag);
-      }
-    }
-    pin();
-  });
-  if constexpr (ROLE == kRoleReducer) {   // collect the helpers' shares: published at the start of their passes
+  // ---- the two regular pair tiles
+  {
+    f32x2 a[RING], b[RING][2];
+    f32x4 accb[2] = {zero4, zero4};   // second chain of each tile (the slot's second k-quad)
+    run_job<NS, D>(
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, r = i % RING;
+          if constexpr (i < kL3Steps) {
+            a[r] = lds_ld<f32x2>(wa, i * 128 * 4);
+            b[r][0] = lds_ld<f32x2>(L.rd3, 32 * i);
+            b[r][1] = lds_ld<f32x2>(L.rd3b, 32 * i);
+          } else {
+            a[r].x = lds_ld<float>(wt, kL3Steps * 128 * 4);
+            b[r][0].x = lds_ld<float>(L.rd3t, 0);
+            b[r][1].x = lds_ld<float>(L.rd3tb, 0);
+          }
+        },
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, r = i % RING;
+          acc[0] = mfma(a[r].x, b[r][0].x, acc[0]);
+          acc[1] = mfma(a[r].x, b[r][1].x, acc[1]);
+          if constexpr (i < kL3Steps) {
+            accb[0] = mfma(a[r].y, b[r][0].y, accb[0]);
+            accb[1] = mfma(a[r].y, b[r][1].y, accb[1]);
+          }
+        });
+    acc[0] += accb[0];
+    acc[1] += accb[1];
+  }
+  if (wave == 0) {   // collect the helpers' shares: published at the start of their passes
 #pragma unroll
     for (int h = 0; h < 3; ++h) flag_wait(lds0 + (kFlagOff + h) * 4, tag, P.err, 4u);
 #pragma unroll
-    for (int h = 0; h < 3; ++h) acc[2] += lds_ld<f32x4>(lds0 + L.scr, (kScratchOff + h * 256) * 4);
+    for (int h = 0; h < 3; ++h) acc[2] += lds_ld<f32x4>(lds0 + L.scr + h * 1024, kScratchOff * 4);
   }
   // Block-dependent work (model.py:84-88: CE1 / CE2 outputs are kept, and added to CD2 / CD1 AFTER the ReLU) sits behind
   // wave-uniform branches on blk; every tile is handled with compile-time indices so that the skip registers stay
   // individual registers (as runtime-indexed arrays hipcc copied them wholesale at every branch merge).
-  acc[0] += accb[0];
-  acc[1] += accb[1];
-  static_for<0, NEPI>([&](auto tc) {
+  static_for<0, 3>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
+    if (t == 2 && wave != 0) return;    // pair tile 16 belongs to wave 0
     f32x4 v = relu4(acc[t]);
     if (blk == 3) {
       v += skip_ce2[t];
@@ -805,7 +804,7 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
     constexpr int vb = t < 2 ? kVL3 + t : kVL3X;
     const bool gap = span_has_gap(32 * (t < 2 ? wave + 8 * t : 16), 32);   // wave-uniform: pair tiles 4, 8, 12, 16
     if (blk < 4) {
-      const unsigned wr = t < 2 ? L.wr3 : wrx;
+      const unsigned wr = t < 2 ? L.wr3 : L.wr3 + 16 * (32 * kB8S * 4);   // (t == 2: wave 0, pair tile 16)
       constexpr int off = t < 2 ? t * kT3W : 0;
       if (gap) {   // gap / past-the-tile pixels are never written: they stay zero
         if (vbit(L, vb)) {
@@ -831,14 +830,6 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
   });
 }
 
-template <int NMR, int NMX, int NR>
-__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, bool first, int wave, int xm, int xr1) {
-  if (first)
-    l1_stream<NMR, NMX, NR, true>(L, wbase, wave, xm, xr1);
-  else
-    l1_stream<NMR, NMX, NR, false>(L, wbase, wave, xm, xr1);
-}
-
 __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -861,8 +852,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   layer_end_sync();
 
   // extra tiles of this wave (see the assignment comment above)
-  const int xm = wave == 0 ? 32 : 31;                           // layer 1 main, waves 0 and 1
-  const int xr0 = wave == 7 ? 3 : wave - 4, xr1 = 4;            // layer 1 remainder, waves 4..7
+  const int xr0 = wave == 7 ? 3 : wave - 4;                     // layer 1 remainder tile of waves 4..7 (wave 7 also 4)
   const Lane L = make_lane(lds, wave, lane, xr0 < 0 ? 0 : xr0);
   const unsigned lds0 = lds_addr(lds);
 
@@ -886,10 +876,8 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
         const float* w = WREG(wcur);
         const unsigned wb = lds_addr(w);
-        if (wave < 2) layer1<4, 1, 0>(L, wb, blk == 0, wave, xm, 0);
-        else if (wave < 4) layer1<4, 0, 0>(L, wb, blk == 0, wave, 0, 0);
-        else if (wave < 7) layer1<4, 0, 1>(L, wb, blk == 0, wave, 0, 0);
-        else layer1<3, 0, 2>(L, wb, blk == 0, wave, 0, xr1);
+        if (blk == 0) layer1<true>(L, wb, wave);
+        else layer1<false>(L, wb, wave);
         wcur ^= 1;
 #if RCED_STAMPS
         const unsigned long long st_b_ = stamp();
@@ -905,12 +893,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane);
         const float* w = WREG(wcur);
         const unsigned tag2 = 0xC0000000u | (epoch + 1u);   // distinct from layer 3's tags (0x8.......)
-        const unsigned wb = lds_addr(w);
-        if (wave == 0) layer2<kL2Helper, 0>(L, lds0, wb, wave, tag2, P.err);
-        else if (wave == 1) layer2<kL2Helper, 1>(L, lds0, wb, wave, tag2, P.err);
-        else if (wave == 2) layer2<kL2Reducer, 0>(L, lds0, wb, wave, tag2, P.err);
-        else if (wave == 3) layer2<kL2Reducer, 1>(L, lds0, wb, wave, tag2, P.err);
-        else layer2<kL2Plain, 0>(L, lds0, wb, wave, tag2, P.err);
+        layer2(L, lds0, lds_addr(w), wave, tag2, P.err);
         wcur ^= 1;
         STAMP_MATH(1);
         layer_end_sync();
@@ -924,12 +907,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         const float* w = WREG(wcur);
         ++epoch;
         const unsigned tag = 0x80000000u | epoch;   // sign bit set: never the bits of a ReLU output
-        const unsigned wb = lds_addr(w);
-        if (wave == 0) layer3<kRoleReducer, 0>(P, L, lds0, wb, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
-        else if (wave == 1) layer3<kRoleHelper, 1>(P, L, lds0, wb, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
-        else if (wave == 2) layer3<kRoleHelper, 2>(P, L, lds0, wb, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
-        else if (wave == 3) layer3<kRoleHelper, 3>(P, L, lds0, wb, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
-        else layer3<kRolePlain, 0>(P, L, lds0, wb, blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        layer3(P, L, lds0, lds_addr(w), blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
         wcur ^= 1;
         STAMP_MATH(2);
         layer_end_sync();
