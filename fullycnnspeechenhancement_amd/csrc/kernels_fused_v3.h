@@ -546,21 +546,44 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave) 
     l1_job<FIRST, 1, false>(wa, rd + dt * G::kTileR, 0u, sh, acc);
     l1_store(L, acc[0], L.wr1 + dt * (16 * 18 * 4), 0, false, 0);
   }
-  // ---- pairs of regular tiles: (wave, wave+8), (wave+16, wave+24); wave 7 only the first
-  const int npair = wave == 7 ? 1 : 2;
-  unsigned rdA = rd, rdB = rdb, wr = L.wr1;
-  int T = wave;
-  vb = kVMain;
-#pragma unroll 1
-  for (int p = 0; p < npair; ++p) {
-    l1_job<FIRST, 2, false>(wa, rdA, rdB, sh, acc);
-    l1_store(L, acc[0], wr, 0, T > 0 && tile_has_gap(T), vb);           // tiles 8, 16, 24 (wave 0) have gap pixels
-    l1_store(L, acc[1], wr, kT1W, tile_has_gap(T + 8), vb + 1);
-    rdA += 2 * G::kTR;
-    rdB += 2 * G::kTR;
-    wr += 2 * kT1W;
-    T += 16;
-    vb += 2;
+  // ---- pairs of regular tiles: (wave, wave+8), (wave+16, wave+24) as one stream with pair 0's stores between pair 1's
+  //      MFMAs; wave 7 has only the first pair
+  if (wave == 7) {
+    l1_job<FIRST, 2, false>(wa, rd, rdb, sh, acc);
+    l1_store(L, acc[0], L.wr1, 0, false, 0);          // tiles 7, 15: no gap pixels
+    l1_store(L, acc[1], L.wr1, kT1W, false, 0);
+  } else {
+    constexpr int SM = G::SM, NT = 2 * SM, D = G::D, RING = D + 1;
+    f32x2 a[RING], b[RING][2];
+    f32x4 acc2[2][2];   // [pair][tile]
+    const bool g1 = tile_has_gap(wave + 8), g2 = tile_has_gap(wave + 16), g3 = tile_has_gap(wave + 24);   // tiles 8, 16, 24
+    run_job<NT, D>(
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, r = i % RING, p = i / SM, st = i % SM, aoff = st * G::kAStep * 4;
+          if constexpr (FIRST) {
+            a[r].x = lds_ld<float>(wa, aoff);
+            b[r][0].x = lds_ld<float>(rd, 2 * p * G::kTR + G::koff(st, 9));
+            b[r][1].x = lds_ld<float>(rdb, 2 * p * G::kTR + G::koff(st, 9));
+          } else {
+            a[r] = lds_ld<f32x2>(wa, aoff);
+            b[r][0] = lds_ld<f32x2>(rd, 2 * p * G::kTR + G::koff(st, 9));
+            b[r][1] = lds_ld<f32x2>(rdb, 2 * p * G::kTR + G::koff(st, 9));
+          }
+        },
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, r = i % RING, p = i / SM, st = i % SM;
+          if constexpr (st == 0) acc2[p][0] = acc2[p][1] = sh;
+          acc2[p][0] = mfma(a[r].x, b[r][0].x, acc2[p][0]);
+          acc2[p][1] = mfma(a[r].x, b[r][1].x, acc2[p][1]);
+          if constexpr (!FIRST) {
+            acc2[p][0] = mfma(a[r].y, b[r][0].y, acc2[p][0]);
+            acc2[p][1] = mfma(a[r].y, b[r][1].y, acc2[p][1]);
+          }
+          if constexpr (p == 1 && st == 1) l1_store(L, acc2[0][0], L.wr1, 0, false, kVMain);
+          if constexpr (p == 1 && st == 3) l1_store(L, acc2[0][1], L.wr1, kT1W, g1, kVMain + 1);
+        });
+    l1_store(L, acc2[1][0], L.wr1, 2 * kT1W, g2, kVMain + 2);
+    l1_store(L, acc2[1][1], L.wr1, 3 * kT1W, g3, kVMain + 3);
   }
 }
 
@@ -639,53 +662,53 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
       if (L.a4 == 0) lds_poke_a(lds0 + (kFlag2Off + wave) * 4, tag);
     }
   }
-  // ---- two pair jobs: tiles (wave, wave+8), (wave+16, wave+24)
-  unsigned rdA = L.rd2, rdB = L.rd2b, rdAt = L.rd2t, rdBt = L.rd2tb, wr = L.wr2;
-  int T = wave, vb = kVMain;
-#pragma unroll 1
-  for (int p = 0; p < 2; ++p) {
+  // ---- two pair jobs, tiles (wave, wave+8) and (wave+16, wave+24), as ONE stream: pair 0's stores ride between pair
+  //      1's MFMAs (LDS stores are slow, ~85 B/clk per CU: issued in one burst they delay the next operand reads)
+  {
+    constexpr int NT = 2 * NS;
     f32x2 a[RING][2], b[RING][2];
-    f32x4 acc[2][2] = {{sh[0], sh[1]}, {sh[0], sh[1]}};   // [tile][M-tile]
-    run_job<NS, D>(
+    f32x4 acc[2][2][2];   // [pair][tile][M-tile]
+    const bool g1 = tile_has_gap(wave + 8), g2 = tile_has_gap(wave + 16), g3 = tile_has_gap(wave + 24);   // tiles 8, 16, 24 (wave 0)
+    run_job<NT, D>(
         [&](auto ic) {
-          constexpr int i = decltype(ic)::value, r = i % RING;
-          if constexpr (i < kL2Steps) {
-            a[r][0] = lds_ld<f32x2>(wa, (i * 2 + 0) * 128 * 4);
-            a[r][1] = lds_ld<f32x2>(wa, (i * 2 + 1) * 128 * 4);
-            b[r][0] = lds_ld<f32x2>(rdA, 32 * i);
-            b[r][1] = lds_ld<f32x2>(rdB, 32 * i);
+          constexpr int i = decltype(ic)::value, r = i % RING, p = i / NS, st = i % NS;
+          if constexpr (st < kL2Steps) {
+            a[r][0] = lds_ld<f32x2>(wa, (st * 2 + 0) * 128 * 4);
+            a[r][1] = lds_ld<f32x2>(wa, (st * 2 + 1) * 128 * 4);
+            b[r][0] = lds_ld<f32x2>(L.rd2, 2 * p * kT2R + 32 * st);
+            b[r][1] = lds_ld<f32x2>(L.rd2b, 2 * p * kT2R + 32 * st);
           } else {
             a[r][0].x = lds_ld<float>(wt, (kL2Steps * 2 * 128) * 4);
             a[r][1].x = lds_ld<float>(wt, (kL2Steps * 2 * 128 + 64) * 4);
-            b[r][0].x = lds_ld<float>(rdAt, 0);
-            b[r][1].x = lds_ld<float>(rdBt, 0);
+            b[r][0].x = lds_ld<float>(L.rd2t, 2 * p * kT2R);
+            b[r][1].x = lds_ld<float>(L.rd2tb, 2 * p * kT2R);
           }
         },
         [&](auto ic) {
-          constexpr int i = decltype(ic)::value, r = i % RING;
-          acc[0][0] = mfma(a[r][0].x, b[r][0].x, acc[0][0]);
-          acc[0][1] = mfma(a[r][1].x, b[r][0].x, acc[0][1]);
-          acc[1][0] = mfma(a[r][0].x, b[r][1].x, acc[1][0]);
-          acc[1][1] = mfma(a[r][1].x, b[r][1].x, acc[1][1]);
-          if constexpr (i < kL2Steps) {
-            acc[0][0] = mfma(a[r][0].y, b[r][0].y, acc[0][0]);
-            acc[0][1] = mfma(a[r][1].y, b[r][0].y, acc[0][1]);
-            acc[1][0] = mfma(a[r][0].y, b[r][1].y, acc[1][0]);
-            acc[1][1] = mfma(a[r][1].y, b[r][1].y, acc[1][1]);
+          constexpr int i = decltype(ic)::value, r = i % RING, p = i / NS, st = i % NS;
+          if constexpr (st == 0) {
+            acc[p][0][0] = acc[p][1][0] = sh[0];
+            acc[p][0][1] = acc[p][1][1] = sh[1];
           }
+          acc[p][0][0] = mfma(a[r][0].x, b[r][0].x, acc[p][0][0]);
+          acc[p][0][1] = mfma(a[r][1].x, b[r][0].x, acc[p][0][1]);
+          acc[p][1][0] = mfma(a[r][0].x, b[r][1].x, acc[p][1][0]);
+          acc[p][1][1] = mfma(a[r][1].x, b[r][1].x, acc[p][1][1]);
+          if constexpr (st < kL2Steps) {
+            acc[p][0][0] = mfma(a[r][0].y, b[r][0].y, acc[p][0][0]);
+            acc[p][0][1] = mfma(a[r][1].y, b[r][0].y, acc[p][0][1]);
+            acc[p][1][0] = mfma(a[r][0].y, b[r][1].y, acc[p][1][0]);
+            acc[p][1][1] = mfma(a[r][1].y, b[r][1].y, acc[p][1][1]);
+          }
+          if constexpr (p == 1 && st == 1) l2_store<0>(L, acc[0][0][0], L.wr2, 0, false, kVMain);       // tile `wave`: no gap
+          if constexpr (p == 1 && st == 3) l2_store<1>(L, acc[0][0][1], L.wr2, 0, false, kVMain);
+          if constexpr (p == 1 && st == 5) l2_store<0>(L, acc[0][1][0], L.wr2, kT2W, g1, kVMain + 1);
+          if constexpr (p == 1 && st == 7) l2_store<1>(L, acc[0][1][1], L.wr2, kT2W, g1, kVMain + 1);
         });
-    const bool g0 = T > 0 && tile_has_gap(T), g1 = tile_has_gap(T + 8);   // tiles 8, 16, 24 (wave 0)
-    l2_store<0>(L, acc[0][0], wr, 0, g0, vb);
-    l2_store<1>(L, acc[0][1], wr, 0, g0, vb);
-    l2_store<0>(L, acc[1][0], wr, kT2W, g1, vb + 1);
-    l2_store<1>(L, acc[1][1], wr, kT2W, g1, vb + 1);
-    rdA += 2 * kT2R;
-    rdB += 2 * kT2R;
-    rdAt += 2 * kT2R;
-    rdBt += 2 * kT2R;
-    wr += 2 * kT2W;
-    T += 16;
-    vb += 2;
+    l2_store<0>(L, acc[1][0][0], L.wr2, 2 * kT2W, g2, kVMain + 2);
+    l2_store<1>(L, acc[1][0][1], L.wr2, 2 * kT2W, g2, kVMain + 2);
+    l2_store<0>(L, acc[1][1][0], L.wr2, 3 * kT2W, g3, kVMain + 3);
+    l2_store<1>(L, acc[1][1][1], L.wr2, 3 * kT2W, g3, kVMain + 3);
   }
   // ---- reducers: add the helper's share, store tile 32 (pixels 512..527: no gap inside)
   if (wave == 2 || wave == 3) {
@@ -853,6 +876,9 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
 
   // extra tiles of this wave (see the assignment comment above)
   const int xr0 = wave == 7 ? 3 : wave - 4;                     // layer 1 remainder tile of waves 4..7 (wave 7 also 4)
+#ifdef RCED_PRIO
+  if ((wave >= 4) == (RCED_PRIO > 0)) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for one half of the waves
+#endif
   const Lane L = make_lane(lds, wave, lane, xr0 < 0 ? 0 : xr0);
   const unsigned lds0 = lds_addr(lds);
 
