@@ -31,7 +31,7 @@
 #include "lds_dma.h"
 
 #ifndef RCED_D1
-#define RCED_D1 2   // operand prefetch depth (slots) of the layer-1 / layer-2 / layer-3 streams
+#define RCED_D1 1   // operand prefetch depth (slots) of the layer-1 / layer-2 / layer-3 jobs (1..4 measured: +-0.5 %)
 #endif
 #ifndef RCED_D2
 #define RCED_D2 2
@@ -152,15 +152,6 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
 
-// Volatile accesses to LDS words used for wave-to-wave signalling.  Through a generic pointer hipcc emits
-// flat_load/flat_store (both memory pipes, s_waitcnt vmcnt(0) in every poll); typed as LDS they are ds_read/ds_write.
-__device__ __forceinline__ unsigned lds_peek(const void* p) {
-  return *(volatile __attribute__((address_space(3))) const unsigned*)p;
-}
-__device__ __forceinline__ void lds_poke(void* p, unsigned v) {
-  *(volatile __attribute__((address_space(3))) unsigned*)p = v;
-}
-
 // hipcc hoists loop-invariant per-lane address arithmetic out of the tile loop -- every layer's, for every wave role --
 // and then keeps (or spills) dozens of VGPRs across all fifteen layers.  Each layer function therefore re-derives its
 // lane coordinates from a copy of the lane id the optimiser cannot see through: a handful of VALU per layer.
@@ -215,41 +206,6 @@ __device__ __forceinline__ bool px_valid(int px) {   // a real frequency bin (no
 __device__ __forceinline__ bool span_has_gap(int p0, int len) {
   const int fr = p0 / kS;
   return p0 + len > kNPX || (p0 - fr * kS) + len > kF;
-}
-
-// Epilogue of a P = 1 pass for one slot (rows = 16*mt + 4*kq + j output channels, column = pixel):
-// ReLU, zero the gap pixels, store [pixel][COUT] with 8-byte stores.
-template <int MT, int COUT>
-__device__ __forceinline__ void store_p1(float* out, const f32x4 (&acc)[MT], int px, int kq, bool gap) {
-  const bool ok = gap ? px_valid(px) : true;   // `gap` is wave-uniform
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int co0 = 16 * mt + 4 * kq;
-    f32x4 v = relu4(acc[mt]);
-    if (gap && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    float* p = out + px * COUT + co0;
-    if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
-    if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
-  }
-}
-
-// One M-tile of the same (used where a tile's two M-tiles belong to different waves).
-template <int COUT>
-__device__ __forceinline__ void store_p1_mt(float* out, f32x4 acc, int px, int kq, int mt) {
-  const int co0 = 16 * mt + 4 * kq;   // only used for tile 32 (pixels 512..527): no gap inside
-  f32x4 v = relu4(acc);
-  float* p = out + px * COUT + co0;
-  if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
-  if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
-}
-
-// Epilogue of the layer-1 remainder pass: rows 4*kq+j = (phase 2*kq + (j>>1), channel 16 + (j&1)),
-// column = pixel octet.  Two 8-byte stores per lane: channels 16,17 of two adjacent pixels.
-__device__ __forceinline__ void store_rem(float* b18, f32x4 acc, int px0, int kq, bool gap) {
-  const f32x4 v = relu4(acc);
-  const int pa = px0 + 2 * kq;
-  if (!gap || px_valid(pa)) *reinterpret_cast<f32x2*>(b18 + pa * 18 + 16) = f32x2{v.x, v.y};
-  if (!gap || px_valid(pa + 1)) *reinterpret_cast<f32x2*>(b18 + (pa + 1) * 18 + 16) = f32x2{v.z, v.w};
 }
 
 // The 11 input rows of a tile (frames t0-3 .. t0+7 of one utterance): 3 floats per thread, loaded one
