@@ -127,18 +127,19 @@ void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>*
     put_shift(dst + v3::kW3Data, 3 * blk + 2);
     dst += v3::kW3;
   }
-  // ---- decode_final as Toeplitz A-fragments: [s][m][lane][e]; row f = 16m + i; k = f'*8 + ci
+  // ---- decode_final (1x129, 8 -> 1): A fragments of the in-kernel GEMM, [u][lane][e]: row r = lane & 15 (pixel phase),
+  //      k = (window tap u, channel 2*kq + e), value W[u - r][c] (zero outside taps 0..128); then the bin-128 weights
+  //      W[t][c], t = 0..64 (kernels_fused_v3.h, "decode_final inside the kernel")
   const rced_layer_dev& lf = m->layers[15];
   fin->assign(v3::kFinPack, 0.f);
-  for (int s = 0; s < v3::kFinSteps; ++s)
-    for (int mt = 0; mt < v3::kFinMT; ++mt)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int e = 0; e < 2; ++e) {
-          const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
-          const int f = 16 * mt + i, fp = k / 8, ci = k % 8, tap = fp - f + 64;
-          (*fin)[((size_t)s * v3::kFinMT + mt) * 128 + lane * 2 + e] =
-              (f < 129 && tap >= 0 && tap < 129) ? wq(lf, tap, ci, 0, 8) : 0.f;
-        }
+  for (int u = 0; u < v3::kFinU; ++u)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < 2; ++e) {
+        const int r = lane & 15, c = 2 * (lane >> 4) + e, tap = u - r;
+        (*fin)[(size_t)u * 128 + lane * 2 + e] = (tap >= 0 && tap < 129) ? wq(lf, tap, c, 0, 8) : 0.f;
+      }
+  for (int t = 0; t <= 64; ++t)
+    for (int c = 0; c < 8; ++c) (*fin)[v3::kFinA + t * 8 + c] = wq(lf, t, c, 0, 8);
   *fin_bias = lf.host_shift[0];
 }
 
@@ -424,7 +425,8 @@ void fused_destroy(rced_model* m) {
 
 int fused_reserve(rced_model* m, int N, int T) {
   rced_fused* f = m->fused;
-  const int ch = m->variant == RCED_V3 ? v3::kHCh : (m->variant == RCED_V1 ? chain::NetV1::kFinalCh : chain::NetV2::kFinalCh);
+  if (m->variant == RCED_V3) return RCED_OK;   // decode_final runs inside the fused kernel: no hand-off tensor
+  const int ch = m->variant == RCED_V1 ? chain::NetV1::kFinalCh : chain::NetV2::kFinalCh;
   const size_t need = (size_t)N * T * v3::kF * ch * sizeof(float);
   if (need <= f->h_bytes) return RCED_OK;
   if (f->h) {
@@ -463,8 +465,10 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   v3::Params P;
   P.err = f->err_dev;
   P.x = x;
-  P.h = f->h;
+  P.y = y;
   P.wpack = f->wpack;
+  P.fin = f->fin_apack;
+  P.fin_bias = f->fin_bias;
   P.N = N;
   P.T = T;
   P.tiles_per_utt = (T + v3::kTF - 1) / v3::kTF;
@@ -472,21 +476,9 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   P.stamps = f->stamps;
   const int cus = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
   const int grid = std::min(P.total_tiles, cus);
-  m->prof_begin(RCED_K_FUSED, st);
+  m->prof_begin(RCED_K_FUSED, st);   // all 16 layers: decode_final is the kernel's last phase
   hipLaunchKernelGGL(v3::fused_v3_kernel, dim3(grid), dim3(v3::kThreads), v3::kLdsBytes, st, P);
   m->prof_end(RCED_K_FUSED, st);
-  HIP_TRY(hipGetLastError());
-  const int frames = N * T;
-  m->prof_begin(RCED_K_FINAL, st);
-  // LDS-staged B operand (0.41 ms at config 3; the direct-load kernel, RCED_FINAL_LDS=0, takes 0.56 ms)
-  if (final_lds_enabled())
-    hipLaunchKernelGGL((v3::final_gemm_lds_kernel<4, 32>), dim3((frames + 63) / 64), dim3(v3::kFinThreads), 0, st,
-                       (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y, frames);
-  else
-    hipLaunchKernelGGL(v3::final_gemm_kernel, dim3((frames + v3::kFinFrames - 1) / v3::kFinFrames),
-                       dim3(v3::kFinThreads), 0, st, (const float*)f->h, (const float*)f->fin_apack, f->fin_bias, y,
-                       frames);
-  m->prof_end(RCED_K_FINAL, st);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
 }
@@ -527,7 +519,7 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
     return RCED_OK;
   }
   if (!strcmp(key, "fused_final")) {   // 1: the 1x129 output layer runs inside the fused kernel (no hand-off tensor in HBM)
-    *value = 0;
+    *value = m->variant == RCED_V3;
     return RCED_OK;
   }
   if (!strcmp(key, "bf16")) {

@@ -72,7 +72,6 @@ constexpr int kS = 133;                      // pixel stride of a frame (129 + 4
 constexpr int kNPX = kTF * kS;               // 532 pixels per tile
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
-constexpr int kHCh = 8;                      // channels of the tensor handed to the final layer
 
 // ---- LDS map, in floats -----------------------------------------------------------------
 // B8 keeps its 8 channels at a pixel stride of 10 floats: with 8 channels one b64-step of the
@@ -123,6 +122,35 @@ constexpr int kW3 = kW3Data + kShiftPerLayer;
 constexpr int kWBlock = kW1 + kW2 + kW3;
 constexpr int kWTotal = 5 * kWBlock;
 
+// ---- decode_final (1x129, 8 -> 1, no BN, no ReLU; model.py:89-90) inside the kernel ----------------------------
+// The CD2 output of a tile never leaves the CU: block 4's layer 3 stores it to H, an LDS image that aliases the (by then
+// dead) B18 buffer: H pixel 193*i + 64 + f holds bin f of frame i, channel stride kHS; the 64 pixels in front of every
+// frame (and behind the last) are zero -- the SAME padding of the 129-tap kernel (64 taps each side).
+// GEMM: rows = 16 pixel phases r, columns = (frame i, block j) with output bin f = 16j + r (bins 0..127: 32 columns =
+// two column tiles: tile ct holds blocks 4ct..4ct+3 of all four frames, which spreads a read's 16 columns over more LDS
+// banks than 8 blocks of 2 frames), K = (144 window taps u) x 8 channels, window start = bin 16j - 64, A[r][(u, c)] = W[u - r][c]
+// (zero outside 0..128).  The 144 b64 K-steps are cut in 8 runs of 18, one per wave (both column tiles: 72 MFMAs per
+// wave); the eight partial sums meet in LDS scratch (B30 is dead) and waves 0 / 1 finish column tile 0 / 1 in a fixed
+// order (deterministic).  Bin 128 (one output per frame, 65 x 8 taps) is a dot product on the VALU of wave 2.
+// A fragments (73.7 KB) stream from L2 into registers, issued before block 4's layer 3 so that their latency hides.
+constexpr int kHS = 10;                                   // H channel stride (floats): 8-byte aligned b64 reads
+constexpr int kHFrame = 193;                              // H pixels per frame: 64 zero + 129 bins
+constexpr int kHPix = kTF * kHFrame + 64;                 // 836
+constexpr int kHOff = kB18Off + 1200;                     // behind layer 3's hand-off scratch (B18 floats 180..1134)
+static_assert(kHOff + kHPix * kHS <= kB30Off, "H fits inside B18");
+static_assert((kHOff % 2) == 0, "8-byte aligned");
+constexpr int kFinU = 144, kFinRun = kFinU / kWaves;      // window taps; K-steps per wave
+constexpr int kFinA = kFinU * 128;                        // floats of A fragments: [u][lane][2]
+constexpr int kFin128 = 65 * 8;                           // bin 128: W[f' - 64][c] for f' = 64..128
+constexpr int kFinPack = kFinA + 528;
+static_assert(kW1 + 528 <= kWRegion && (kW1 % 4) == 0, "the bin-128 weights fit behind a layer-1 packet in its LDS region");
+// partial sums: 8 waves x 256 floats per column tile, in two stretches of B30 (dead by then) that contain NO gap pixel
+// (B30's gap rows sit at floats 3990.., 7980.., 11970.. and must stay zero) and are clear of X0 (the next tile's input rows)
+constexpr int kFinScr0 = kB30Off + 4112, kFinScr1 = kB30Off + 8112;
+static_assert(kFinScr0 >= kX0Off + kX0Floats && (kFinScr0 % 4) == 0 && (kFinScr1 % 4) == 0, "16-byte aligned, clear of X0");
+static_assert(kFinScr0 >= kB30Off + (kB30Pad + kF + 4) * 30 && kFinScr0 + 2048 <= kB30Off + (kB30Pad + kS + kF) * 30, "no gap row");
+static_assert(kFinScr1 >= kB30Off + (kB30Pad + kS + kF + 4) * 30 && kFinScr1 + 2048 <= kB30Off + (kB30Pad + 2 * kS + kF) * 30, "no gap row");
+
 // ---- tile -> wave assignment ---------------------------------------------------------------
 // 16-pixel tiles 0..32 (pixels 0..527; 528..531 is gap): wave w owns tiles w + 8*slot, slot < 4
 // ("regular": one address register per wave, everything else immediates); tile 32 and, in layer 1,
@@ -138,8 +166,10 @@ constexpr int kWTotal = 5 * kWBlock;
 
 struct Params {
   const float* x;       // [N, T, 129]
-  float* h;             // [N*T, 129, 8]  output of CD2 (input of decode_final)
+  float* y;             // [N, T, 129]    the mask (output of decode_final)
   const float* wpack;   // kWTotal floats
+  const float* fin;     // kFinPack floats: decode_final's A fragments + its bin-128 weights (pack_v3)
+  float fin_bias;
   int N, T;
   int tiles_per_utt;    // ceil(T / kTF)
   int total_tiles;      // N * tiles_per_utt
@@ -306,6 +336,7 @@ struct Lane {
   unsigned rd1r, wr1r;     // layer 1 remainder tile xr0 (waves 4..7)
   unsigned rd2, rd2b, rd2t, rd2tb, wr2; // layer 2 tile `wave` (/ + 8): B18 window start (b64 steps / tail), B30 output
   unsigned rd3, rd3b, rd3t, rd3tb, wr3; // layer 3 pair tile `wave` (/ + 8): B30 window start (b64 steps / tail), B8 output
+  unsigned wh0, wh1, whx;  // block 4's layer 3: where this lane's output pixel of pair tile 0 / 1 / 16 goes in the H image
   unsigned scr;            // lane*16: offset inside a hand-off scratch area
   unsigned vbits;          // validity bits, see kV*
 };
@@ -340,6 +371,16 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   L.rd3 = B30 + 4 * ((2 * px0 - 4) * 30 + 2 * kq);          // px0 doubles as the pixel-PAIR index of layer 3
   L.rd3t = L.rd3 + 4 * (8 * kL3Steps - kq);                 // K = 300: tail k = 296 + kq, all four real
   L.wr3 = B8 + 4 * ((2 * px0 + (kq >> 1)) * kB8S + 4 * (kq & 1));
+  {
+    const unsigned H = lds_addr(lds + kHOff);
+    auto haddr = [&](int px) {   // px: tile-flat pixel of frame px / kS, bin px % kS
+      const int fr = px / kS, f = px - fr * kS;
+      return H + 4 * ((kHFrame * fr + 64 + f) * kHS + 4 * (kq & 1));
+    };
+    L.wh0 = haddr(2 * px0 + (kq >> 1));
+    L.wh1 = haddr(2 * (px0 + 128) + (kq >> 1));
+    L.whx = haddr(2 * (256 + n) + (kq >> 1));
+  }
   unsigned v = 0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) v |= (unsigned)px_valid(px0 + 128 * t) << (kVMain + t);
@@ -688,6 +729,7 @@ constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;   // pixels 8..51 o
 constexpr int kFlagOff = kScratchOff + 3 * 256;
 static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
 static_assert(8 + (3 * 256 + 3 + 17) / 18 <= kF, "scratch + flags stay inside frame 0's real pixels");
+static_assert(kFlagOff + 3 <= kHOff, "layer 3's hand-off scratch and the H image do not overlap");
 
 template <int S0, int S1>   // the share of pair tile 16: slots [S0, S1) (slot kL3Steps = the tail)
 __device__ __forceinline__ f32x4 l3_share(unsigned wa, unsigned wt, unsigned rdx, unsigned rdxt, f32x4 init) {
@@ -714,7 +756,7 @@ __device__ __forceinline__ f32x4 l3_share(unsigned wa, unsigned wt, unsigned rdx
 }
 
 __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned lds0, unsigned wbase, int blk, int wave,
-                                       int lane, unsigned tag, int utt, int t0, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
+                                       unsigned tag, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
   constexpr int D = RCED_D3, RING = D + 1, NS = kL3Steps + 1;
   const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
   const f32x4 sh = lds_ld<f32x4>(wbase + (L.kq16 & 16), kW3Data * 4);   // shift[4*(kq&1) ..]
@@ -794,19 +836,116 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
         lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
         lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
       }
-    } else {
-      const int n = lane & 15, kq = lane >> 4;
-      const int px = 2 * ((t < 2 ? 16 * wave + 128 * t : 256) + n) + (kq >> 1);
-      const int fr = px / kS, f = px - fr * kS;
-      if (vbit(L, vb) && t0 + fr < P.T) {
-        float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * kHCh + 4 * (kq & 1);
-        *reinterpret_cast<f32x4*>(hp) = v;
+    } else {   // block 4: the CD2 output goes to the H image (decode_final's input); gap lanes have no pixel
+      const unsigned wh = t == 0 ? L.wh0 : t == 1 ? L.wh1 : L.whx;
+      if (gap) {
+        if (vbit(L, vb)) {
+          lds_st<f32x2>(wh, 0, f32x2{v.x, v.y});
+          lds_st<f32x2>(wh, 8, f32x2{v.z, v.w});
+        }
+      } else {
+        lds_st<f32x2>(wh, 0, f32x2{v.x, v.y});
+        lds_st<f32x2>(wh, 8, f32x2{v.z, v.w});
       }
     }
     // keep CE1 / CE2 (values of gap lanes are whatever was computed: they only ever meet gap pixels again)
     skip_ce1[t] = blk == 0 ? v : skip_ce1[t];
     skip_ce2[t] = blk == 1 ? v : skip_ce2[t];
   });
+}
+
+// ---- decode_final inside the kernel (layout and decomposition: see kHS above) ---------------------------------
+struct FinA {
+  f32x2 a[kFinRun];   // this wave's 18 K-steps of A fragments
+};
+__device__ __forceinline__ void fin_prefetch(const Params& P, int wave, int lane, FinA& A) {
+  const f32x2* src = reinterpret_cast<const f32x2*>(P.fin) + (size_t)(kFinRun * wave) * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < kFinRun; ++s) A.a[s] = src[s * 64];
+}
+// zero the five 64-pixel pads of the H image (B18 holds layer-1 / layer-2 leftovers); block 4's layer 3 writes the bins
+__device__ __forceinline__ void fin_zero_pads(unsigned lds0, int tid) {
+  constexpr int kPadPairs = 64 * kHS / 2;   // b64 stores per pad
+#pragma unroll
+  for (int i = 0; i < (5 * kPadPairs + kThreads - 1) / kThreads; ++i) {
+    const int q = tid + i * kThreads, p = q / kPadPairs, e = q - p * kPadPairs;
+    if (q < 5 * kPadPairs) lds_st<f32x2>(lds0 + 4 * (kHOff + p * kHFrame * kHS + 2 * e), 0, f32x2{0.f, 0.f});
+  }
+}
+typedef f32x4 __attribute__((aligned(4))) f32x4_u;   // a [frame][129] row is only 4-byte aligned
+
+__device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsigned w128, int wave, int lane, int utt,
+                                            int t0, const FinA& A) {
+  const int n = lane & 15, kq = lane >> 4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  float* yt = P.y + ((size_t)utt * P.T + t0) * kF;   // the tile's first output row
+  const int nfr = P.T - t0 < kTF ? P.T - t0 : kTF;   // frames of the tile inside the utterance
+  if (wave == 2) {   // ---- bin 128 of the four frames (taps f' = 64..128, 8 channels each) on the VALU, FIRST: wave 6
+                     //      keeps the SIMD's matrix pipe busy meanwhile, and nothing waits for this wave at the end
+    const int fi = kq, sub = n;   // 16 lanes per frame; lane `sub` takes f' = 64 + sub + 16 m
+    const unsigned hb = lds0 + 4 * (kHOff + (kHFrame * fi + 64 + 64 + sub) * kHS);
+    const unsigned wb = w128 + sub * 32;   // bin-128 weights: LDS-DMA'd behind the next tile's first packet
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      if (sub + 16 * m <= 64) {
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+          const f32x2 hv = lds_ld<f32x2>(hb, (16 * m * kHS + c) * 4);
+          const f32x2 wv = lds_ld<f32x2>(wb, (16 * m * 8 + c) * 4);
+          sum = __builtin_fmaf(hv.x, wv.x, sum);
+          sum = __builtin_fmaf(hv.y, wv.y, sum);
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d, 16);   // over the frame's 16 lanes (same order for every lane)
+    if (sub == 0 && fi < nfr) yt[fi * kF + 128] = sum + P.fin_bias;
+  }
+  {  // ---- this wave's run of K-steps, both column tiles: column n of tile ct = (frame n >> 2, block 4*ct + (n & 3))
+    const unsigned rd0 = lds0 + 4 * (kHOff + ((kHFrame * (n >> 2) + 16 * (n & 3)) * kHS + 2 * kq)) + wave * (kFinRun * kHS * 4);
+    unsigned rd1 = rd0 + 64 * kHS * 4;
+    asm volatile("" : "+v"(rd1));   // a base of its own (see make_lane)
+    f32x4 acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
+    constexpr int D = 2, RING = D + 1;
+    f32x2 b[RING][2];
+    run_job<kFinRun, D>(
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, r = i % RING;
+          b[r][0] = lds_ld<f32x2>(rd0, i * kHS * 4);
+          b[r][1] = lds_ld<f32x2>(rd1, i * kHS * 4);
+        },
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, r = i % RING;
+          acc[0][0] = mfma(A.a[i].x, b[r][0].x, acc[0][0]);
+          acc[1][0] = mfma(A.a[i].x, b[r][1].x, acc[1][0]);
+          acc[0][1] = mfma(A.a[i].y, b[r][0].y, acc[0][1]);
+          acc[1][1] = mfma(A.a[i].y, b[r][1].y, acc[1][1]);
+        });
+    const unsigned scr = lds0 + wave * 1024 + lane * 16;
+    lds_st<f32x4>(scr, 4 * kFinScr0, acc[0][0] + acc[0][1]);
+    lds_st<f32x4>(scr, 4 * kFinScr1, acc[1][0] + acc[1][1]);
+  }
+  __syncthreads();
+  if (wave < 2) {   // ---- finish column tile `wave`: partial sums of waves 0..7, in that order, + bias
+    const unsigned scr = lds0 + 4 * (wave == 0 ? kFinScr0 : kFinScr1) + lane * 16;
+    f32x4 v = lds_ld<f32x4>(scr, 0);
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) v += lds_ld<f32x4>(scr, w * 1024);
+    v += f32x4{P.fin_bias, P.fin_bias, P.fin_bias, P.fin_bias};
+    const int fi = n >> 2, f0 = 16 * (4 * wave + (n & 3)) + 4 * kq;   // rows 4kq..4kq+3 = bins f0..f0+3 of frame fi
+    if (fi < nfr) *reinterpret_cast<f32x4_u*>(yt + fi * kF + f0) = v;
+  } else if (wave == 3) {
+    // The H image lay over B18, whose gap pixels (4 per frame, 18 channels) every layer relies on being zero and no
+    // layer ever writes: put the zeros back (every wave finished its H reads before the barrier above).
+    constexpr int kGapPairs = 4 * 18 / 2;   // b64 stores per gap
+#pragma unroll
+    for (int i = 0; i < (4 * kGapPairs + 63) / 64; ++i) {
+      const int q = lane + 64 * i, g = q / kGapPairs, e = q - g * kGapPairs;
+      if (q < 4 * kGapPairs)
+        lds_st<f32x2>(lds0 + 4 * (kB18Off + (kB18Pad + kF + kS * g) * 18 + 2 * e), 0, f32x2{0.f, 0.f});
+    }
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
@@ -826,7 +965,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   unsigned epoch = 0;   // layer-3 instances so far (tags the split-tile hand-offs)
   XStage xst = xstage_load(P, blockIdx.x, tid);
 #if RCED_STAMPS
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tfin = 0;
 #endif
   layer_end_sync();
 
@@ -847,6 +986,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
     __syncthreads();
 
     f32x4 skip_ce1[3], skip_ce2[3];
+    FinA finA;
 #pragma unroll
     for (int t = 0; t < 3; ++t) skip_ce1[t] = skip_ce2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* wsrc = P.wpack;
@@ -889,7 +1029,12 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         const float* w = WREG(wcur);
         ++epoch;
         const unsigned tag = 0x80000000u | epoch;   // sign bit set: never the bits of a ReLU output
-        layer3(P, L, lds0, lds_addr(w), blk, wave, lane, tag, utt, t0, skip_ce1, skip_ce2);
+        if (blk == 4) {
+          packet_dma<528>(P.fin + kFinA, WREG(wcur ^ 1) + kW1, wave, lane);   // decode_final's bin-128 weights ride along
+          fin_prefetch(P, wave, lane, finA);   // decode_final's A fragments: in flight during this layer
+          fin_zero_pads(lds0, tid);            // B18 is dead from here on (layer 3's own scratch sits below the H image)
+        }
+        layer3(P, L, lds0, lds_addr(w), blk, wave, tag, skip_ce1, skip_ce2);
         wcur ^= 1;
         STAMP_MATH(2);
         layer_end_sync();
@@ -897,193 +1042,22 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
       }
       wsrc += kWBlock;
     }
+#if RCED_STAMPS
+    const unsigned long long st_f_ = stamp();
+#endif
+    final_phase(P, lds0, lds_addr(WREG(wcur) + kW1), wave, lane, utt, t0, finA);   // no barrier at its end: the next tile's first one covers it
+#if RCED_STAMPS
+    tfin += stamp() - st_f_;
+#endif
   }
 #undef WREG
 #if RCED_STAMPS
   if (P.stamps && blockIdx.x == 0 && lane == 0)
     for (int i = 0; i < 8; ++i) P.stamps[wave * 8 + i] = tsum[i];
+  if (P.stamps && blockIdx.x == 0 && lane == 0) P.stamps[64 + wave * 3] = tfin;
 #endif
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// decode_final (1x129, 8->1, no BN, no ReLU; model.py:89-90) as a dense Toeplitz GEMM:
-//   y[frame, f] = b + sum_{f', ci} h[frame, f', ci] * W[f' - f + 64, ci]
-//   D[f (M: 9 tiles of 16), frame (N)] = sum_k A[f, k] * B[k, frame],  k = f'*8 + ci, K = 1032.
-// A (Toeplitz-expanded, A-fragment order) streams from L2; B is the h row of a frame, contiguous.
-// One workgroup = 3 waves = 64 frames; wave w owns M-tiles 3w..3w+2.
-// ---------------------------------------------------------------------------------------------
-constexpr int kFinK = kF * kHCh;          // 1032
-constexpr int kFinSteps = kFinK / 8;      // 129 b64-steps
-constexpr int kFinMT = 9;
-constexpr int kFinPack = kFinSteps * kFinMT * 128;   // floats
-constexpr int kFinFrames = 64;
-constexpr int kFinThreads = 192;
-
-__global__ __launch_bounds__(kFinThreads) void final_gemm_kernel(const float* __restrict__ h,
-                                                                  const float* __restrict__ apack, float bias,
-                                                                  float* __restrict__ y, int frames) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, kq = lane >> 4;
-  const int f0 = blockIdx.x * kFinFrames;
-  const f32x2* ap = reinterpret_cast<const f32x2*>(apack) + (wave * 3) * 64 + lane;
-  const float* bp[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    int fr = f0 + 16 * t + n;
-    if (fr >= frames) fr = frames - 1;   // clamp: computed, never stored
-    bp[t] = h + (size_t)fr * kFinK + 2 * kq;
-  }
-  f32x4 acc[4][3];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int m = 0; m < 3; ++m) acc[t][m] = f32x4{bias, bias, bias, bias};
-#pragma unroll 2
-  for (int s = 0; s < kFinSteps; ++s) {
-    f32x2 a[3], b[4];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) a[m] = ap[(s * kFinMT + m) * 64];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const f32x2*>(bp[t] + 8 * s);
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < 3; ++m) acc[t][m] = mfma(a[m][e], b[t][e], acc[t][m]);
-  }
-  // D row = f = 16*(3*wave+m) + 4*kq + j, column = frame
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int fr = f0 + 16 * t + n;
-    if (fr >= frames) continue;
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int f = 16 * (3 * wave + m) + 4 * kq;
-      float* yp = y + (size_t)fr * kF + f;
-      const f32x4 v = acc[t][m];
-      if (f + 0 < kF) yp[0] = v.x;
-      if (f + 1 < kF) yp[1] = v.y;
-      if (f + 2 < kF) yp[2] = v.z;
-      if (f + 3 < kF) yp[3] = v.w;
-    }
-  }
-}
-
-// The same GEMM with the B operand staged through LDS: the 64 frames' h rows arrive in chunks of 64 k as coalesced
-// 256-byte row pieces (read once per workgroup instead of once per wave, 16 cache lines per load before), one chunk
-// ahead in registers, into a two-buffer ping-pong with frame stride 66 floats (2 mod 32: the 16 frames of a
-// ds_read_b64 fall on 16 distinct bank pairs).  A still streams from L2, two steps ahead.
-template <int NT, int CHUNK>
-struct FinLds {
-  static constexpr int kFrames = 16 * NT;                             // frames per workgroup
-  static constexpr int kRow = CHUNK + 2;                              // 2 mod 32
-  static constexpr int kStepsPer = CHUNK / 8;
-  static constexpr int kChunks = (kFinK + CHUNK - 1) / CHUNK;
-  static constexpr int kPieces = CHUNK / 4;                           // float4 pieces per frame per chunk
-  static constexpr int kVec = kFrames * kPieces;
-  static constexpr int kPer = (kVec + kFinThreads - 1) / kFinThreads;
-  static_assert(kFinK % 4 == 0 && CHUNK % 8 == 0 && CHUNK % 32 == 0, "float4 pieces never straddle the end of a row");
-};
-
-template <int NT, int CHUNK>
-__global__ __launch_bounds__(kFinThreads) void final_gemm_lds_kernel(const float* __restrict__ h,
-                                                                      const float* __restrict__ apack, float bias,
-                                                                      float* __restrict__ y, int frames) {
-  using G = FinLds<NT, CHUNK>;
-  __shared__ __attribute__((aligned(16))) float bs[2][G::kFrames * G::kRow];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, kq = lane >> 4;
-  const int f0 = blockIdx.x * G::kFrames;
-  const f32x2* ap = reinterpret_cast<const f32x2*>(apack) + (wave * 3) * 64 + lane;
-  auto fetch = [&](int chunk, f32x4(&r)[G::kPer]) {
-#pragma unroll
-    for (int i = 0; i < G::kPer; ++i) {
-      const int q = tid + i * kFinThreads;
-      const int fr = f0 + q / G::kPieces, k = chunk * CHUNK + 4 * (q % G::kPieces);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (q < G::kVec && fr < frames && k < kFinK) v = *reinterpret_cast<const f32x4*>(h + (size_t)fr * kFinK + k);
-      r[i] = v;
-    }
-  };
-  auto commit = [&](int buf, const f32x4(&r)[G::kPer]) {
-#pragma unroll
-    for (int i = 0; i < G::kPer; ++i) {
-      const int q = tid + i * kFinThreads;
-      if (q < G::kVec) {
-        float* d = bs[buf] + (q / G::kPieces) * G::kRow + 4 * (q % G::kPieces);
-        *reinterpret_cast<f32x2*>(d) = f32x2{r[i].x, r[i].y};
-        *reinterpret_cast<f32x2*>(d + 2) = f32x2{r[i].z, r[i].w};
-      }
-    }
-  };
-  f32x4 acc[NT][3];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int m = 0; m < 3; ++m) acc[t][m] = f32x4{bias, bias, bias, bias};
-  f32x4 r[G::kPer];
-  fetch(0, r);
-  commit(0, r);
-  f32x2 a[3], an[3], an2[3];            // A fragments of steps S, S+1, S+2
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    a[m] = ap[m * 64];
-    an[m] = ap[(kFinMT + m) * 64];
-  }
-  __syncthreads();
-  for (int c = 0; c < G::kChunks; ++c) {
-    if (c + 1 < G::kChunks) fetch(c + 1, r);
-    const float* bb = bs[c & 1] + n * G::kRow + 2 * kq;
-    const int left = kFinSteps - G::kStepsPer * c;
-    const int ns = left < G::kStepsPer ? left : G::kStepsPer;
-#pragma unroll
-    for (int s = 0; s < G::kStepsPer; ++s) {
-      if (s < ns) {
-        const int S = G::kStepsPer * c + s;
-        if (S + 2 < kFinSteps) {
-#pragma unroll
-          for (int m = 0; m < 3; ++m) an2[m] = ap[((S + 2) * kFinMT + m) * 64];
-        }
-        f32x2 b[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x2*>(bb + 16 * t * G::kRow + 8 * s);
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int m = 0; m < 3; ++m) acc[t][m] = mfma(a[m][e], b[t][e], acc[t][m]);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          a[m] = an[m];
-          an[m] = an2[m];
-        }
-      }
-    }
-    if (c + 1 < G::kChunks) commit((c + 1) & 1, r);
-    __syncthreads();
-  }
-  // D row = f = 16*(3*wave+m) + 4*kq + j, column = frame
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int fr = f0 + 16 * t + n;
-    if (fr >= frames) continue;
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int f = 16 * (3 * wave + m) + 4 * kq;
-      float* yp = y + (size_t)fr * kF + f;
-      const f32x4 v = acc[t][m];
-      if (f + 0 < kF) yp[0] = v.x;
-      if (f + 1 < kF) yp[1] = v.y;
-      if (f + 2 < kF) yp[2] = v.z;
-      if (f + 3 < kF) yp[3] = v.w;
-    }
-  }
-}
 
 }  // namespace v3
 }  // namespace rced

@@ -16,7 +16,4 @@ print("wave   L1math  L2math  L3math | L1wait  L2wait  L3wait | L1first math/wai
 for w in range(8):
     v = [m.get_option("stamp%d" % (w * 8 + i)) for i in range(8)]
     print("%4d  %7d %7d %7d | %7d %7d %7d | %7d %7d   total %d" % (w, *v, sum(v)))
-print("layer 2 fine (kilo-cycles): wave  prologue  gemm  epilogue")
-for w in range(8):
-    v = [m.get_option("stamp%d" % (64 + w * 3 + i)) for i in range(3)]
-    print("%4d %8d %8d %8d" % (w, *v))
+print("decode_final phase (kilo-cycles) per wave:", [m.get_option("stamp%d" % (64 + w * 3)) for w in range(8)])
