@@ -21,6 +21,34 @@ using chain::f32x4;
 using chain::mfma;
 using chain::pin;
 
+// Where a wgrad kernel's per-wave partial sums go.  pstride == 0: atomicAdd into dW / dbias (fp32 atomics: the order of
+// the adds, hence the last bits of the result, changes from run to run).  pstride > 0 (the default, option
+// RCED_TRAIN_DET=0 turns it off): every (workgroup, wave[, pixel parity]) writes its sums to a slice of its own,
+// base[slice * pstride + idx], and wg_reduce adds the slices in a fixed order: the same bits every run.
+__device__ __forceinline__ void wg_put(float* base, unsigned pstride, int slice, int idx, float v) {
+  if (pstride) base[(size_t)slice * pstride + idx] = v;
+  else atomicAdd(base + idx, v);
+}
+// out[e] = sum over slices, in slice order: 16 slice-lanes per element (thread (e, p) adds slices p, p+16, ...), then
+// the 16 partial sums in order.  n = nW + nB elements per slice (dbias behind dW).
+static __global__ __launch_bounds__(1024) void wg_reduce(const float* __restrict__ part, int nslices, unsigned pstride, int nW,
+                                                        int nB, float* __restrict__ dW, float* __restrict__ dbias) {
+  __shared__ float red[16][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6, n = nW + nB;
+  float s = 0.f;
+  if (e < n)
+    for (int sl = p; sl < nslices; sl += 16) s += part[(size_t)sl * pstride + e];
+  red[p][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (p == 0 && e < n) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][threadIdx.x];
+    if (e < nW) dW[e] = t;
+    else if (dbias) dbias[e - nW] = t;
+  }
+}
+
 constexpr int kF = 129;
 constexpr int kTF = 2;                 // frames per tile (frame-of-element splits are written as one compare: keep it 2)
 constexpr int kWaves = 4, kThreads = 256;
@@ -707,7 +735,7 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
 template <int CIN, int TAPS, int COUT, bool XF, bool DZF, int PH = 1>
 __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const float* __restrict__ x, const float* __restrict__ dz,
                                                            float* __restrict__ dW, float* __restrict__ dbias, int frames,
-                                                           XformArgs xa, BnBwdArgs ba) {
+                                                           XformArgs xa, BnBwdArgs ba, unsigned pstride) {
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(CIN % 2 == 0 && COUT % 2 == 0, "wgrad1xk_mfma stages float4 / float2 pieces");
   static_assert(PH == 1 || (PH == 2 && COUT == 8 && G::kNPX % 2 == 0), "two pixel parities x 8 channels = 16 columns");
@@ -786,13 +814,14 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const flo
     for (int nt = 0; nt < NTo; ++nt) {
       const int co = PH == 2 ? (i & 7) : 16 * nt + i;
       const int ph = PH == 2 ? (i >> 3) : 0;
+      const int slice = ((int)blockIdx.x * kWaves + wave) * PH + ph;   // (the two parities hold the same dW entries)
       const float vv[4] = {acc[kt][nt].x, acc[kt][nt].y, acc[kt][nt].z, acc[kt][nt].w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = 16 * kt + 4 * kq + r;
         const int tapk = k / G::kCinP, ci = k - tapk * G::kCinP, tap = tapk - ph;
-        if (k < kRowsK && ci < CIN && co < COUT && tap >= 0 && tap < TAPS) atomicAdd(dW + (tap * CIN + ci) * COUT + co, vv[r]);
-        if (k == kRowsK && co < COUT && dbias) atomicAdd(dbias + co, vv[r]);
+        if (k < kRowsK && ci < CIN && co < COUT && tap >= 0 && tap < TAPS) wg_put(dW, pstride, slice, (tap * CIN + ci) * COUT + co, vv[r]);
+        if (k == kRowsK && co < COUT && dbias) wg_put(dbias, pstride, slice, co, vv[r]);
       }
     }
 }
@@ -833,7 +862,7 @@ template <int CIN, int TAPS, int COUT, bool XF, bool SUMS>
 __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __restrict__ x, const float* __restrict__ du,
                                                                const float* __restrict__ packet, float* __restrict__ dx,
                                                                float* __restrict__ dW, float* __restrict__ dbias, int frames,
-                                                               double* __restrict__ part, XformArgs xa, BnBwdArgs ba) {
+                                                               double* __restrict__ part, XformArgs xa, BnBwdArgs ba, unsigned pstride) {
   using B = BwdGeo<CIN, TAPS, COUT>;
   using GD = typename B::GD;
   using GW = typename B::GW;
@@ -920,13 +949,14 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
       for (int nt = 0; nt < NTo; ++nt) {
         const int co = PH == 2 ? (i & 7) : 16 * nt + i;
         const int ph = PH == 2 ? (i >> 3) : 0;
+        const int slice = ((int)blockIdx.x * 4 + (wave & 3)) * PH + ph;   // the four wgrad waves of the workgroup
         const float vv[4] = {acc[kt][nt].x, acc[kt][nt].y, acc[kt][nt].z, acc[kt][nt].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 16 * kt + 4 * kq + r;
           const int tapk = k / GW::kCinP, ci = k - tapk * GW::kCinP, tap = tapk - ph;
-          if (k < kRowsK && ci < CIN && co < COUT && tap >= 0 && tap < TAPS) atomicAdd(dW + (tap * CIN + ci) * COUT + co, vv[r]);
-          if (k == kRowsK && co < COUT && dbias) atomicAdd(dbias + co, vv[r]);
+          if (k < kRowsK && ci < CIN && co < COUT && tap >= 0 && tap < TAPS) wg_put(dW, pstride, slice, (tap * CIN + ci) * COUT + co, vv[r]);
+          if (k == kRowsK && co < COUT && dbias) wg_put(dbias, pstride, slice, co, vv[r]);
         }
       }
   }
@@ -1047,15 +1077,15 @@ __global__ __launch_bounds__(kFinThreads) void final_fwd(const float* __restrict
 constexpr int kFwPad = 80, kFwRow = 288;   // dzpad index = 80 + bin, reads span [-79, 195] around it
 template <int CH>
 __global__ __launch_bounds__(kThreads) void final_wgrad(const float* __restrict__ x, const float* __restrict__ dz,
-                                                         float* __restrict__ dW, float* __restrict__ dbias, int frames) {
+                                                         float* __restrict__ dW, float* __restrict__ dbias, int frames,
+                                                         unsigned pstride) {
   __shared__ float rows[kWaves][kFwRow];
-  __shared__ float red[9 * 16 * 16];
+  __shared__ float red[kWaves][9 * 16 * 16];   // one copy per wave, added in wave order (no LDS atomics: deterministic)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
   float* row = rows[wave];
   for (int e = lane; e < kFwRow; e += 64) row[e] = 0.f;
-  for (int e = tid; e < 9 * 256; e += kThreads) red[e] = 0.f;
   __syncthreads();
   f32x4 acc[9];
 #pragma unroll
@@ -1091,13 +1121,14 @@ __global__ __launch_bounds__(kThreads) void final_wgrad(const float* __restrict_
   for (int m = 0; m < 9; ++m) {
     const float vv[4] = {acc[m].x, acc[m].y, acc[m].z, acc[m].w};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * m + 4 * kq + r) * 16 + i], vv[r]);
+    for (int r = 0; r < 4; ++r) red[wave][(16 * m + 4 * kq + r) * 16 + i] = vv[r];
   }
   __syncthreads();
   for (int e = tid; e < 9 * 256; e += kThreads) {
     const int tap = e >> 4, c = e & 15;
-    if (tap < kF && c < CH) atomicAdd(dW + tap * CH + c, red[e]);
-    if (tap == 64 && c == CH && dbias) atomicAdd(dbias, red[e]);
+    const float v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    if (tap < kF && c < CH) wg_put(dW, pstride, blockIdx.x, tap * CH + c, v);
+    if (tap == 64 && c == CH && dbias) wg_put(dbias, pstride, blockIdx.x, 0, v);
   }
 }
 
@@ -1113,7 +1144,7 @@ __global__ __launch_bounds__(kThreads) void final_wgrad(const float* __restrict_
 template <int KW, int COUT, bool DZF>
 __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict__ x, const float* __restrict__ dz,
                                                          float* __restrict__ dW, float* __restrict__ dbias, int frames,
-                                                         int T, BnBwdArgs ba) {
+                                                         int T, BnBwdArgs ba, unsigned pstride) {
   constexpr int KH = 8, PT = 3, PL = (KW - 1) / 2, RS = kF + KW - 1, K1 = KH * KW;
   constexpr int KT = (K1 + 1 + 15) / 16, NTo = (COUT + 15) / 16;
   constexpr int kOneTile = K1 / 16, kOneRow = K1 % 16;
@@ -1210,8 +1241,8 @@ __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = 16 * kt + 4 * kq + r;
-        if (k < K1 && co < COUT) atomicAdd(dW + k * COUT + co, vv[r]);
-        if (k == K1 && co < COUT && dbias) atomicAdd(dbias + co, vv[r]);
+        if (k < K1 && co < COUT) wg_put(dW, pstride, (int)blockIdx.x * kWaves + wave, k * COUT + co, vv[r]);
+        if (k == K1 && co < COUT && dbias) wg_put(dbias, pstride, (int)blockIdx.x * kWaves + wave, co, vv[r]);
       }
     }
 }

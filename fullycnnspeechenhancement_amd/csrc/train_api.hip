@@ -71,6 +71,9 @@ struct rced_trainer {
   bool fuse_dz = true;         // RCED_TRAIN_FUSE_DZ=0: always materialise dz with bn_bwd_apply
   bool fuse_bwd = true;        // RCED_TRAIN_FUSE_BWD=0: separate wgrad and dgrad kernels everywhere
   bool fuse_sums = true;       // RCED_TRAIN_FUSE_SUMS=0: BatchNorm-backward sums of plain layers from bwd_route2, not from the dgrad
+  bool det = true;             // RCED_TRAIN_DET=0: weight gradients by fp32 atomics (the round-1 behaviour; not reproducible bit for bit)
+  float* wpart = nullptr;      // per-wave slices of the wgrad kernels' partial sums (deterministic mode; tmd::WgDet)
+  size_t wpart_floats = 0;
   std::vector<char> virt;      // virt[id]: tensor id (= relu(bn(z[id-1]))) is never materialised; its consumer rebuilds it
   float* pk_first = nullptr;   // A fragments of the 8xk first layer (rebuilt every step)
   float* pk_fin = nullptr, *pk_fin_bwd = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
@@ -84,7 +87,7 @@ struct rced_trainer {
   ~rced_trainer() {
     DeviceGuard g(device);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
-    fr(params); fr(grads); fr(m); fr(v); fr(trainable); fr(zero32); fr(part); fr(sums); fr(D);
+    fr(params); fr(grads); fr(m); fr(v); fr(trainable); fr(zero32); fr(part); fr(sums); fr(D); fr(wpart);
     for (auto* p : wf) fr(p);
     for (auto* p : wt) fr(p);
     for (auto* p : bias4) fr(p);
@@ -228,8 +231,10 @@ int first_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias,
   // persistent grid = what is resident (it was cus * 3 with two workgroups per CU resident: half of the second round idle)
   const dim3 grid(std::min(ntiles, ba ? rced::tmd::resident_grid(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, true>), lds, cus, occ_t)
                                       : rced::tmd::resident_grid(reinterpret_cast<const void*>(tmm::first_wgrad<KW, COUT, false>), lds, cus, occ_f)));
-  if (ba) hipLaunchKernelGGL((tmm::first_wgrad<KW, COUT, true>), grid, dim3(tmm::kThreads), lds, st, x, dz, dW, dbias, frames, T, *ba);
-  else hipLaunchKernelGGL((tmm::first_wgrad<KW, COUT, false>), grid, dim3(tmm::kThreads), lds, st, x, dz, dW, dbias, frames, T, nb);
+  rced::tmd::wg_launch([&](float* dw, float* db, unsigned ps) {
+    if (ba) hipLaunchKernelGGL((tmm::first_wgrad<KW, COUT, true>), grid, dim3(tmm::kThreads), lds, st, x, dz, dw, db, frames, T, *ba, ps);
+    else hipLaunchKernelGGL((tmm::first_wgrad<KW, COUT, false>), grid, dim3(tmm::kThreads), lds, st, x, dz, dw, db, frames, T, nb, ps);
+  }, (int)grid.x * tmm::kWaves, 8 * KW * COUT, COUT, dW, dbias, st);
   return 1;
 }
 int first_wgrad(const LayerSpec& s, const float* x, const float* dz, float* dW, float* dbias, int frames, int T, int cus,
@@ -300,8 +305,11 @@ int fin_dgrad(int ch, const float* dz, const float* w, float* pack, float* dx, i
 }
 int fin_wgrad(int ch, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus, hipStream_t st) {
   const dim3 grid(std::min((frames + tmm::kWaves - 1) / tmm::kWaves, cus * 2));
-#define X(CH) \
-  if (ch == CH) hipLaunchKernelGGL((tmm::final_wgrad<CH>), grid, dim3(tmm::kThreads), 0, st, x, dz, dW, dbias, frames);
+#define X(CH)                                                                                                              \
+  if (ch == CH)                                                                                                            \
+    rced::tmd::wg_launch([&](float* dw, float* db, unsigned ps) {                                                          \
+      hipLaunchKernelGGL((tmm::final_wgrad<CH>), grid, dim3(tmm::kThreads), 0, st, x, dz, dw, db, frames, ps);             \
+    }, (int)grid.x, 129 * CH, 1, dW, dbias, st);
   RCED_FIN_CH(X)
 #undef X
   return 1;
@@ -357,6 +365,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     if (const char* e = getenv("RCED_TRAIN_MFMA")) t->use_mfma = atoi(e);
     if (const char* e = getenv("RCED_TRAIN_FUSE_DZ")) t->fuse_dz = atoi(e) != 0;
     if (const char* e = getenv("RCED_TRAIN_FUSE_SUMS")) t->fuse_sums = atoi(e) != 0;
+    if (const char* e = getenv("RCED_TRAIN_DET")) t->det = atoi(e) != 0;
     if (const char* e = getenv("RCED_TRAIN_FUSE_BWD")) t->fuse_bwd = atoi(e) != 0;
   }
   const NetSpec* xnet = net;     // the reference's layout (what crosses the ABI)
@@ -550,6 +559,16 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
   const int L = net.n_layers, F = kFeatureDim, frames = N * T;
   const size_t P = (size_t)frames * F;
   if (int rc = ensure_acts(t, P)) return rc;
+  // deterministic weight gradients: the wgrad launchers of this thread write slices into t->wpart (tmd::WgDet)
+  struct WgScope {
+    explicit WgScope(rced_trainer* tr) { rced::tmd::g_wgdet = rced::tmd::WgDet{tr->det ? tr->wpart : nullptr, tr->wpart_floats}; }
+    ~WgScope() { rced::tmd::g_wgdet = rced::tmd::WgDet{}; }
+  };
+  if (t->det && !forward_only && !t->wpart) {
+    t->wpart_floats = (size_t)16 << 20;   // 64 MB: 4096 slices x up to 4096 floats (largest: 2048 x 2732, CR-CED 18 -> 30)
+    HIP_TRY(hipMalloc(&t->wpart, t->wpart_floats * sizeof(float)));
+  }
+  const WgScope wg_scope(t);
   auto blocks = [](size_t n) { return dim3((unsigned)std::min<size_t>((n + train::kThreads - 1) / train::kThreads, 65535)); };
   auto pair_grid = [&](int C) {   // channel-aligned kernels: rows = 256 / (C/2) pixels per workgroup pass
     const size_t rows = train::kThreads / (C / 2);

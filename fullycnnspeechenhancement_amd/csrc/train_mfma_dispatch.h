@@ -14,6 +14,29 @@ namespace tmd {
 
 constexpr int kPairGrid = 2048;     // workgroups of the channel-aligned elementwise kernels (and their partial sums)
 
+// Deterministic weight gradients (default): the wgrad kernels write per-wave slices into this buffer instead of adding to
+// dW with fp32 atomics, and tmm::wg_reduce sums the slices in a fixed order.  The training step points it at the
+// trainer's buffer for the duration of its backward pass (one caller thread per trainer); part == nullptr selects atomics.
+struct WgDet {
+  float* part = nullptr;
+  size_t cap_floats = 0;
+};
+inline thread_local WgDet g_wgdet;
+// Launch helper: `launch(dW_arg, dbias_arg, pstride)` launches the wgrad kernel; slices = partial-sum slices it writes.
+template <class F>
+inline int wg_launch(F&& launch, int slices, int nW, int nB, float* dW, float* dbias, hipStream_t st) {
+  const WgDet& d = g_wgdet;
+  const unsigned pstride = (unsigned)((nW + nB + 3) & ~3);
+  if (!d.part || (size_t)slices * pstride > d.cap_floats) {
+    launch(dW, dbias, 0u);          // atomics (not reproducible bit for bit)
+    return 0;
+  }
+  launch(d.part, d.part + nW, pstride);
+  hipLaunchKernelGGL(tmm::wg_reduce, dim3((nW + nB + 63) / 64), dim3(1024), 0, st, (const float*)d.part, slices, pstride, nW, nB,
+                     dW, dbias);
+  return 1;
+}
+
 // Kernels that want more than the default dynamic LDS need the attribute once per (kernel, device): `done` is that
 // kernel's bit mask over device ordinals (a process may hold trainers on several devices).
 inline void allow_lds(const void* kernel, size_t lds, unsigned long long& done) {
@@ -123,8 +146,10 @@ int tm_wgrad_launch1(const float* x, const float* dz, float* dW, float* dbias, i
   const void* kfn = reinterpret_cast<const void*>(tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF, PH>);
   allow_lds(kfn, lds, attr);
   const int grid = std::min(ntiles, resident_grid(kfn, lds, cus, occ));
-  hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF, PH>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dW,
-                     dbias, frames, xa, ba);
+  wg_launch([&](float* dw, float* db, unsigned ps) {
+    hipLaunchKernelGGL((tmm::wgrad1xk_mfma<CIN, TAPS, COUT, XF, DZF, PH>), dim3(grid), dim3(tmm::kThreads), lds, st, x, dz, dw, db,
+                       frames, xa, ba, ps);
+  }, grid * tmm::kWaves * PH, TAPS * CIN * COUT, COUT, dW, dbias, st);
   return 1;
 }
 // xa: x is the producer's z (see tm_conv); ba: dz is d_u, rebuilt through BatchNorm backward from (d_u, z)
@@ -151,8 +176,11 @@ int tm_bwd_fused_launch(const float* x, const float* du, const float* packet, fl
   const void* kfn = reinterpret_cast<const void*>(tmm::bwd_fused_mfma<CIN, TAPS, COUT, XF, SUMS>);
   allow_lds(kfn, lds, attr);
   const int grid = std::min(ntiles, std::min(resident_grid(kfn, lds, cus, occ, tmm::kBwdThreads), kPairGrid));
-  hipLaunchKernelGGL((tmm::bwd_fused_mfma<CIN, TAPS, COUT, XF, SUMS>), dim3(grid), dim3(tmm::kBwdThreads), lds, st, x, du, packet,
-                     dx, dW, dbias, frames, part, xa, ba);
+  constexpr int PH = COUT == 8 ? 2 : 1;
+  wg_launch([&](float* dw, float* db, unsigned ps) {
+    hipLaunchKernelGGL((tmm::bwd_fused_mfma<CIN, TAPS, COUT, XF, SUMS>), dim3(grid), dim3(tmm::kBwdThreads), lds, st, x, du, packet,
+                       dx, dw, db, frames, part, xa, ba, ps);
+  }, grid * 4 * PH, TAPS * CIN * COUT, COUT, dW, dbias, st);
   return grid;
 }
 
