@@ -71,6 +71,12 @@ class BatchShardedForward(object):
         # scatter (root -> peers) and gather (peers -> root) each get a communicator of their own
         self.scatter_group = dist.new_group(ranks=ranks) if self.world > 1 else group
         self.gather_group = dist.new_group(ranks=ranks) if self.world > 1 else group
+        if self.world > 1:
+            # The FIRST call on a group's communicator must involve all its ranks (torch.distributed.batch_isend_irecv:
+            # otherwise "the behavior is undefined" on NCCL/RCCL), and forward_from_root's transfers only ever pair the
+            # root with one peer: open both communicators with a collective here.
+            for g in (self.scatter_group, self.gather_group):
+                dist.all_reduce(torch.zeros(1, device=self.device), group=g)
 
     def _note(self, what, c):
         if self.trace is not None:
