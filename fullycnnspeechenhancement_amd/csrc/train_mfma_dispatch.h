@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "kernels_train_mfma.h"
 
@@ -39,8 +40,10 @@ inline int wg_launch(F&& launch, int slices, int nW, int nB, float* dW, float* d
 
 // Kernels that want more than the default dynamic LDS need the attribute once per (kernel, device): `done` is that
 // kernel's bit mask over device ordinals (a process may hold trainers on several devices).
+inline std::mutex g_launch_cache_mu;   // the per-kernel caches below are function-local statics shared by every trainer / thread
 inline void allow_lds(const void* kernel, size_t lds, unsigned long long& done) {
   if (lds <= 48 * 1024) return;
+  std::lock_guard<std::mutex> lock(g_launch_cache_mu);
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
@@ -53,6 +56,7 @@ inline void allow_lds(const void* kernel, size_t lds, unsigned long long& done) 
 // workgroups per CU, so every workgroup is resident from the start and walks the same number of tiles.
 // RCED_TM_GRID_MULT (experiments): oversubscribe by that factor.
 inline int resident_grid(const void* kernel, size_t lds, int cus, int& occ_cache, int threads = tmm::kThreads) {
+  std::lock_guard<std::mutex> lock(g_launch_cache_mu);
   if (occ_cache <= 0) {
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds) != hipSuccess || occ < 1) occ = 1;
