@@ -176,6 +176,20 @@ void pack_chain(const rced_model* m, std::vector<float>* wpack, std::vector<floa
         for (int mt = 0; mt < MT; ++mt)
           for (int lane = 0; lane < 64; ++lane)
             dst[NB * MT * 128 + (j * MT + mt) * 64 + lane] = wv(lane & 15, mt, 8 * NB + 4 * j + (lane >> 4));
+      if (G::R(l) > 0) {   // remainder pass: row i = (pixel phase i / R, channel 16 + i % R), k = (window tap u, ci), tap = u - phase
+        const int R = G::R(l), P = G::PH(l), KR = G::KR(l), NBR = KR / 8, NTR = (KR % 8 + 3) / 4;
+        float* rem = dst + G::main_data(l);
+        auto rv = [&](int i, int k) {
+          const int u = k / d.cinp, ci = k % d.cinp, tap = u - i / R;
+          return (i < P * R && k < KR && ci < d.cin && tap >= 0 && tap < d.taps) ? wq(L, tap, ci, 16 + i % R, d.cin) : 0.f;
+        };
+        for (int s = 0; s < NBR; ++s)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 2; ++e) rem[s * 128 + lane * 2 + e] = rv(lane & 15, 8 * s + 2 * (lane >> 4) + e);
+        for (int j = 0; j < NTR; ++j)
+          for (int lane = 0; lane < 64; ++lane) rem[NBR * 128 + j * 64 + lane] = rv(lane & 15, 8 * NBR + 4 * j + (lane >> 4));
+        for (int i = 0; i < P * R; ++i) dst[G::data(l) + 32 + i] = L.host_shift[16 + i % R];
+      }
     }
     for (int c = 0; c < d.cout; ++c) dst[G::data(l) + c] = L.host_shift[c];
     dst += G::packet(l);

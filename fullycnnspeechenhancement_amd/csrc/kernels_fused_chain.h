@@ -13,7 +13,10 @@
 //     resident, fully coalesced 1 KiB per wave-store); the matching decoder layer has the same cout,
 //     hence the same tile -> wave map and fragment layout, and simply loads them back (issued at the
 //     start of the layer, consumed in its epilogue).  A wave only ever re-reads its own stores.
-//   * no pixel-phase tricks (cout 10..32 fills one or two M-tiles reasonably).
+//   * layers with 17..24 output channels (V1: 20, 24; V2: 19, 21, 23) would fill two 16-row M-tiles 53-75 %: they run
+//     channels 0..15 as ONE M-tile (the main pass) plus a REMAINDER pass that computes channels 16.. for P adjacent
+//     pixels at once -- rows = (pixel phase p < P, channel 16 + c), P = 16 / (cout - 16), K = (taps + P - 1) * cin, one
+//     column per group of P pixels -- as the CR-CED kernel does for its ->18 layers: 16 % (V1) / 14 % (V2) fewer MFMAs.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -99,13 +102,24 @@ struct Geo {
   static constexpr int kXOff = 0;
   static constexpr int kYOff = kXOff + kRows * kChX;
   static constexpr int kWOff = ((kYOff + kRows * kChY + 3) / 4) * 4;
-  // packet of layer l (floats): b64 steps, b32 tails, 32 shifts
+  // remainder pass of layer l (0 = none): R channels past the first M-tile, P pixel phases per column, K, tiles
+  static constexpr int R(int l) {
+    const int c = N::layer[l].cout;
+    return (l > 0 && c > 16 && c - 16 <= 8) ? c - 16 : 0;
+  }
+  static constexpr int PH(int l) { return R(l) ? 16 / R(l) : 0; }
+  static constexpr int KR(int l) { return (N::layer[l].taps + PH(l) - 1) * N::layer[l].cinp; }
+  static constexpr int NRT(int l) { return R(l) ? (kNPX + 16 * PH(l) - 1) / (16 * PH(l)) : 0; }
+  static constexpr int kRemSlots = 2;                       // remainder tiles per wave, at most (waves 7..2 first, see rem_tile)
+  // packet of layer l (floats): main pass b64 steps, b32 tails; remainder pass likewise; 32 shifts; 16 remainder-row shifts
   static constexpr int K(int l) { return (l == 0 ? 8 : 1) * N::layer[l].taps * N::layer[l].cinp; }
-  static constexpr int MT(int l) { return (N::layer[l].cout + 15) / 16; }
+  static constexpr int MT(int l) { return R(l) ? 1 : (N::layer[l].cout + 15) / 16; }   // M-tiles of the MAIN pass
   static constexpr int NB64(int l) { return l == 0 ? 0 : K(l) / 8; }
   static constexpr int NTAIL(int l) { return l == 0 ? 2 * N::layer[0].taps : (K(l) % 8 + 3) / 4; }   // b32 steps
-  static constexpr int data(int l) { return NB64(l) * MT(l) * 128 + NTAIL(l) * MT(l) * 64; }
-  static constexpr int packet(int l) { return data(l) + 32; }
+  static constexpr int main_data(int l) { return NB64(l) * MT(l) * 128 + NTAIL(l) * MT(l) * 64; }
+  static constexpr int rem_data(int l) { return R(l) ? (KR(l) / 8) * 128 + ((KR(l) % 8 + 3) / 4) * 64 : 0; }
+  static constexpr int data(int l) { return main_data(l) + rem_data(l); }
+  static constexpr int packet(int l) { return data(l) + 32 + (R(l) ? 16 : 0); }
   static constexpr int packet_off(int l) {
     int o = 0;
     for (int i = 0; i < l; ++i) o += packet(i);
@@ -131,12 +145,17 @@ struct Geo {
   static constexpr int skip_unit(int l) {   // first unit index of saving layer l
     int u = 0;
     for (int i = 0; i < l; ++i)
-      if (N::layer[i].saves_skip) u += (kRegular + 1) * MT(i);
+      if (N::layer[i].saves_skip) u += (kRegular + 1) * MT(i) + (R(i) ? kRemSlots : 0);
     return u;
   }
+  static constexpr int skip_unit_rem(int l) { return skip_unit(l) + (kRegular + 1) * MT(l); }   // its remainder-tile units
   static constexpr int kSkipUnits = skip_unit(N::kLayers);
   static constexpr size_t kScratchFloatsPerWg = (size_t)kSkipUnits * kThreads * 4;
 };
+
+// Remainder tile j (0 / 1) of wave w: tiles 0..5 go to waves 7..2 (waves 0, 1 carry the two odd main tiles), tiles 6..11 to
+// waves 7..2 again, tile 12 to wave 1, tile 13 to wave 0; >= the layer's tile count: none.
+__device__ __forceinline__ int rem_tile(int wave, int j) { return wave >= 2 ? 7 - wave + 6 * j : (j == 0 ? 13 - wave : 99); }
 
 struct Params {
   const float* x;       // [N, T, 129]
@@ -393,6 +412,44 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
         float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * N::kFinalCh + co0;
         if (co0 + 1 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp) = f32x2{v.x, v.y};
         if (co0 + 3 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp + 2) = f32x2{v.z, v.w};
+      }
+    }
+  }
+  // ---- remainder pass: channels 16.. of P adjacent pixels per column (rows 4kq+j = (phase i / R, channel 16 + i % R))
+  if constexpr (G::R(L) > 0) {
+    static_assert(!kLast && MT == 1, "remainder layers are inner layers with one main M-tile");
+    constexpr int R = G::R(L), PHS = G::PH(L), KR = G::KR(L), NRT = G::NRT(L), padl = (D.taps - 1) / 2;
+    static_assert(NRT <= 14, "rem_tile hands out at most 14 remainder tiles");
+    const float* wr = w + G::main_data(L);
+    const f32x4 rsh = *reinterpret_cast<const f32x4*>(w + G::data(L) + 32 + 4 * kq);
+#pragma unroll 1
+    for (int jj = 0; jj < G::kRemSlots; ++jj) {
+      const int rt = rem_tile(wave, jj);            // wave-uniform
+      if (rt >= NRT) break;
+      const int pb = PHS * (16 * rt + n);           // first pixel of this lane's column
+      f32x4 sk = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (D.skip_from >= 0)
+        sk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                           scratch, tid * 16, (G::skip_unit_rem(D.skip_from) + jj) * kThreads * 16, 0));
+      f32x4 racc[1][1] = {{rsh}};
+      gemm_pass<1, 0, 1, KR, 0, RCED_CHAIN_DEPTH>(in, (pb - padl) * D.cinp + 2 * kq, 0, wr, lane, racc);
+      f32x4 v = racc[0][0];
+      if constexpr (D.skip_from >= 0) v += sk;      // module.py:30-31: before the ReLU
+      v = relu4(v);
+      const bool gap = span_has_gap<N>(16 * PHS * rt, 16 * PHS);   // wave-uniform
+      float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = 4 * kq + j, px = pb + i / R;
+        if (gap && !px_valid<N>(px)) vv[j] = 0.f;   // gap pixels hold zeros (the next layer's SAME padding)
+      }
+      if constexpr (D.saves_skip)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{vv[0], vv[1], vv[2], vv[3]}), scratch, tid * 16,
+                                               (G::skip_unit_rem(L) + jj) * kThreads * 16, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = 4 * kq + j, px = pb + i / R;
+        if (i < PHS * R && px < 16 * G::kTiles) out[px * D.coutp + 16 + i % R] = vv[j];   // rows past the tile are not allocated
       }
     }
   }

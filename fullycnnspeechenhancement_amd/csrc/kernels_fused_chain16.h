@@ -97,8 +97,15 @@ struct Geo {
   // fp32 input rows of the first layer alias buffer Y (dead until layer 1 writes it)
   static constexpr int kX0Off = kYOff + (kPad * kChY) / 2;
   static_assert((kPad * kChY) % 2 == 0 && G32::kX0Floats <= kYFloats - (kPad * kChY) / 2, "X0 fits in buffer Y");
-  static constexpr int skip_unit(int l) { return G32::skip_unit(l); }
-  static constexpr size_t kScratchFloatsPerWg = G32::kScratchFloatsPerWg;
+  // skip scratch: units = (layer that saves, slot, mt), each kThreads x float4 (this kernel's own M-tile counts: the
+  // fp32 kernel runs some layers as one M-tile + a remainder pass and numbers its units differently)
+  static constexpr int skip_unit(int l) {
+    int u = 0;
+    for (int i = 0; i < l; ++i)
+      if (N::layer[i].saves_skip) u += (kRegular + 1) * MT(i);
+    return u;
+  }
+  static constexpr size_t kScratchFloatsPerWg = (size_t)skip_unit(N::kLayers) * kThreads * 4;
 };
 
 __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) {
