@@ -153,9 +153,10 @@ struct Geo {
   static constexpr size_t kScratchFloatsPerWg = (size_t)kSkipUnits * kThreads * 4;
 };
 
-// Remainder tile j (0 / 1) of wave w: tiles 0..5 go to waves 7..2 (waves 0, 1 carry the two odd main tiles), tiles 6..11 to
-// waves 7..2 again, tile 12 to wave 1, tile 13 to wave 0; >= the layer's tile count: none.
-__device__ __forceinline__ int rem_tile(int wave, int j) { return wave >= 2 ? 7 - wave + 6 * j : (j == 0 ? 13 - wave : 99); }
+// Remainder tile j (0 / 1) of wave w: tiles 0..5 go to waves 7..2 (waves 0, 1 carry the two odd main tiles), tiles 6, 7 to
+// waves 0, 1, tiles 8..13 to waves 7..2 again; >= the layer's tile count: none.  (Per-SIMD MFMA counts, V1's 16 -> 20
+// layer: 148 / 94 / 108 / 108 on top of six main tiles each; the barrier that ends the layer waits for the fullest.)
+__device__ __forceinline__ int rem_tile(int wave, int j) { return wave >= 2 ? (j == 0 ? 7 - wave : 15 - wave) : (j == 0 ? 6 + wave : 99); }
 
 struct Params {
   const float* x;       // [N, T, 129]
