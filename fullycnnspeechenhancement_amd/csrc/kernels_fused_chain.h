@@ -211,6 +211,15 @@ __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, 
   const float* wt = w + NB64 * MT * 128 + lane;
   f32x2 a[RING][MT], b[RING][NT];
   float at[NTAIL == 0 ? 1 : NTAIL][MT], bt[NTAIL == 0 ? 1 : NTAIL][NT];
+  // One base register per tile, hidden from the optimiser: with one base and NT immediates hipcc fuses the tiles' reads
+  // of a step into ds_read2st64_b64 pairs, each of which needs a v_add for its re-based address -- VALU work that is
+  // not hidden behind fp32 MFMAs (they share the vector ALU) -- and takes the LDS cycles of two reads anyway.
+  int offs[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    offs[t] = t < NR ? off0 + t * STRIDE : offx;
+    asm volatile("" : "+v"(offs[t]));
+  }
 #pragma unroll
   for (int j = 0; j < NTAIL; ++j) {
     constexpr int dummy = 0;
@@ -221,15 +230,13 @@ __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) at[j][mt] = wt[(j * MT + mt) * 64];
 #pragma unroll
-    for (int t = 0; t < NR; ++t) bt[j][t] = act[off0 + t * STRIDE + d];
-    if constexpr (NX > 0) bt[j][NR] = act[offx + d];
+    for (int t = 0; t < NT; ++t) bt[j][t] = act[offs[t] + d];
   }
   auto load = [&](int s, f32x2(&as)[MT], f32x2(&bs)[NT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) as[mt] = wp[(s * MT + mt) * 64];
 #pragma unroll
-    for (int t = 0; t < NR; ++t) bs[t] = *reinterpret_cast<const f32x2*>(act + off0 + t * STRIDE + 8 * s);
-    if constexpr (NX > 0) bs[NR] = *reinterpret_cast<const f32x2*>(act + offx + 8 * s);
+    for (int t = 0; t < NT; ++t) bs[t] = *reinterpret_cast<const f32x2*>(act + offs[t] + 8 * s);
   };
 #pragma unroll
   for (int s = 0; s < DEPTH && s < NB64; ++s) load(s, a[s % RING], b[s % RING]);
@@ -391,8 +398,12 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
   for (int t = 0; t < NT; ++t) {
     const int tile = t < NR ? wave + kWaves * t : xtile;
     const int px = t < NR ? px0 + 128 * t : pxx;
-    const bool gap = span_has_gap<N>(16 * tile, 16);
-    const bool ok = gap ? px_valid<N>(px) : true;
+    const bool gap = span_has_gap<N>(16 * tile, 16);       // wave-uniform: 3 of the 26 tiles
+    bool ok = true;
+    if (gap) {
+      asm volatile("" ::: "memory");   // keeps this a wave-uniform BRANCH: as selects, every tile paid the validity arithmetic
+      ok = px_valid<N>(px);            // and four v_cndmask per fragment (VALU work is not hidden behind fp32 MFMAs)
+    }
     const int fr = px / G::kS, f = px - fr * G::kS;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -400,15 +411,18 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
       f32x4 v = acc[t][mt];
       if constexpr (D.skip_from >= 0) v += skip[t][mt];   // module.py:30-31: before the ReLU
       v = relu4(v);
-      if (gap && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (gap) {
+        asm volatile("" ::: "memory");
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       if constexpr (D.saves_skip)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), scratch, tid * 16,
                                                (G::skip_unit(L) + t * MT + mt) * kThreads * 16, 0);
       const int co0 = 16 * mt + 4 * kq;
       if constexpr (!kLast) {
         float* p = out + px * D.coutp + co0;
-        if (co0 + 1 < D.coutp) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
-        if (co0 + 3 < D.coutp) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
+        if (16 * mt + 16 <= D.coutp || co0 + 1 < D.coutp) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
+        if (16 * mt + 16 <= D.coutp || co0 + 3 < D.coutp) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
       } else if (ok && px < G::kNPX && f < kF && t0 + fr < P.T) {
         float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * N::kFinalCh + co0;
         if (co0 + 1 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp) = f32x2{v.x, v.y};
@@ -439,10 +453,13 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
       v = relu4(v);
       const bool gap = span_has_gap<N>(16 * PHS * rt, 16 * PHS);   // wave-uniform
       float vv[4] = {v.x, v.y, v.z, v.w};
+      if (gap) {
+        asm volatile("" ::: "memory");   // a wave-uniform branch (see the main epilogue)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = 4 * kq + j, px = pb + i / R;
-        if (gap && !px_valid<N>(px)) vv[j] = 0.f;   // gap pixels hold zeros (the next layer's SAME padding)
+        for (int j = 0; j < 4; ++j) {
+          const int i = 4 * kq + j, px = pb + i / R;
+          if (!px_valid<N>(px)) vv[j] = 0.f;   // gap pixels hold zeros (the next layer's SAME padding)
+        }
       }
       if constexpr (D.saves_skip)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{vv[0], vv[1], vv[2], vv[3]}), scratch, tid * 16,
