@@ -128,12 +128,17 @@ __device__ __forceinline__ void pass16(const __bf16* act, int off0, int offx, co
   constexpr int NT = NR + NX, RING = DEPTH + 1;
   const s16x4* wp = reinterpret_cast<const s16x4*>(w) + lane;
   s16x4 a[RING][MT], b[RING][NT];
+  int offs[NT];   // one hidden base register per tile: no ds_read2 fusing, no per-step re-basing adds (see chain::gemm_pass)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    offs[t] = t < NR ? off0 + t * STRIDE : offx;
+    asm volatile("" : "+v"(offs[t]));
+  }
   auto load = [&](int s, int buf) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a[buf][mt] = wp[(s * MT + mt) * 64];
 #pragma unroll
-    for (int t = 0; t < NR; ++t) b[buf][t] = *reinterpret_cast<const s16x4*>(act + off0 + t * STRIDE + 16 * s);
-    if constexpr (NX > 0) b[buf][NR] = *reinterpret_cast<const s16x4*>(act + offx + 16 * s);
+    for (int t = 0; t < NT; ++t) b[buf][t] = *reinterpret_cast<const s16x4*>(act + offs[t] + 16 * s);
   };
 #pragma unroll
   for (int s = 0; s < DEPTH && s < STEPS; ++s) load(s, s % RING);
@@ -201,15 +206,22 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
   for (int t = 0; t < NT; ++t) {
     const int tile = t < NR ? wave + kWaves * t : xtile;
     const int px = t < NR ? px0 + 128 * t : pxx;
-    const bool gap = chain::span_has_gap<N>(16 * tile, 16);
-    const bool ok = gap ? chain::px_valid<N>(px) : true;
+    const bool gap = chain::span_has_gap<N>(16 * tile, 16);   // wave-uniform: 3 of the 26 tiles
+    bool ok = true;
+    if (gap) {
+      asm volatile("" ::: "memory");   // a wave-uniform BRANCH, not selects (see chain::run_layer)
+      ok = chain::px_valid<N>(px);
+    }
     const int fr = px / G::kS, f = px - fr * G::kS;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       f32x4 v = acc[t][mt];
       if constexpr (D.skip_from >= 0) v += skip[t][mt];   // module.py:30-31: before the ReLU
       v = chain::relu4(v);
-      if (gap && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (gap) {
+        asm volatile("" ::: "memory");
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       const s16x4 h = to_bf16x4(v);                       // the layer's output IS this rounded value
       if constexpr (D.saves_skip || kLast) v = from_bf16x4(h);
       if constexpr (D.saves_skip)
