@@ -2,7 +2,7 @@
 """bf16 R-CED kernels vs their emulation (oracle.rced_np.forward_bf16) on a multi-workgroup ragged batch, both forms of
 the output layer; then config-2 timing.  tools/bf16_final_check.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from fullycnnspeechenhancement_amd import build_model

@@ -6,12 +6,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from fullycnnspeechenhancement_amd import audio, build_model
-from oracle import rced_np
+from fullycnnspeechenhancement_amd import weights as _weights
 
 N, T = 256, 512
 L = (T - 1) * 128 + 256
 pcm = torch.randn((N, L), device="cuda") * 0.1
-model = build_model("FullyCNNV3", False, weights=rced_np.make_weights("FullyCNNV3"))
+model = build_model("FullyCNNV3", False, weights=_weights.synthetic_weights(3, seed=42))
 
 
 def timed(fn, reps=10):

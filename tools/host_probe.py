@@ -2,8 +2,8 @@ import ctypes, os, sys, time, json
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from fullycnnspeechenhancement_amd import build_model, _lib
-from oracle import rced_np
-m = build_model("FullyCNNV3", False, weights=rced_np.make_weights("FullyCNNV3"))
+from fullycnnspeechenhancement_amd import weights as _weights
+m = build_model("FullyCNNV3", False, weights=_weights.synthetic_weights(3, seed=42))
 lib = _lib.load()
 x = np.abs(np.random.default_rng(0).standard_normal((256, 512, 129, 1))).astype(np.float32)
 y = np.zeros_like(x)
