@@ -142,11 +142,17 @@ def pmc_traffic(ge, variant, batch, frames, kernel):
     return None, "PMC capture is for another workload"
 
 
+def synthetic_magnitudes(shape, seed):
+    """x = |N(0,1)| float32 from numpy.random.default_rng(seed) (magnitude spectrograms are non-negative)."""
+    import numpy as np
+    x = np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+    return np.abs(x, out=x)
+
+
 def forward_line(args, torch, model, spec, _lib, variant, dtype, B, T, steps, warmup, world, rank, profile):
     """Time `steps` forwards of one resident batch; returns (elapsed_s, per-kind HIP-event times or None)."""
     import torch.distributed as dist
-    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    x = torch.randn((B, T, spec.FEATURE_DIM, 1), generator=g, device="cuda").abs_()   # |N(0,1)| magnitudes
+    x = torch.from_numpy(synthetic_magnitudes((B, T, spec.FEATURE_DIM, 1), 1234 + rank)).cuda()   # resident before the clock starts
     y = torch.empty_like(x)
     model.reserve(B, T)
     lib = _lib.load()
@@ -183,6 +189,22 @@ def forward_line(args, torch, model, spec, _lib, variant, dtype, B, T, steps, wa
     return elapsed, times, (x, y)
 
 
+def host_buffers_line(model, x, steps=5):
+    """The boundary as the reference calls it (tester.py:85-90): pageable numpy in, numpy out, through
+    rced_forward_host (chunked H2D / kernel / D2H on three streams).  PCIe-inclusive; reported beside `value`."""
+    xh = x.cpu().numpy()
+    model(xh)                      # pinned staging buffers are set up on the first call
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        yh = model(xh)
+    el = time.perf_counter() - t0
+    n, t = xh.shape[0], xh.shape[1]
+    return {"value": n * t * steps / el, "unit": "frames/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+            "bytes_each_way": int(xh.nbytes), "finite": bool(abs(float(yh.sum())) < float("inf")),
+            "note": "numpy [N,T,129,1] in -> numpy out through rced_forward_host: H2D + kernel + D2H per call, "
+                    "PCIe-inclusive (SURVEY 8(d2) 'with-H2D/D2H figure'); never `value`"}
+
+
 def from_root_line(args, torch, dist, model, spec, world, rank, local_rank, B, T):
     """The reference's single-host-process convention over RCCL: rank 0 holds the whole batch, scatters batch slices,
     every rank computes, the masks gather back (fullycnnspeechenhancement_amd/dist.py)."""
@@ -190,8 +212,7 @@ def from_root_line(args, torch, dist, model, spec, world, rank, local_rank, B, T
     eng = BatchShardedForward(model, device="cuda:%d" % local_rank, forward_into=lambda a, out: model(a, out=out))
     xr = None
     if rank == 0:
-        g = torch.Generator(device="cuda").manual_seed(99)
-        xr = torch.randn((world * B, T, spec.FEATURE_DIM, 1), generator=g, device="cuda").abs_()
+        xr = torch.from_numpy(synthetic_magnitudes((world * B, T, spec.FEATURE_DIM, 1), 1234)).cuda()
     for _ in range(2):
         eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks)
     torch.cuda.synchronize()
@@ -242,9 +263,8 @@ def secondary_config5(torch, ge, FullyCNNTrainer, spec, _weights, local_rank):
     B, T, steps, warmup = 256, 512, 20, 3
     w = _weights.synthetic_weights(3, seed=42)
     tr = FullyCNNTrainer("FullyCNNV3", batch_size=B, lr=1e-3, warmup_steps=4000.0, weights=w, device=local_rank)
-    g = torch.Generator(device="cuda").manual_seed(1234)
-    x = torch.randn((B, T, 129, 1), generator=g, device="cuda").abs_()
-    y = 0.5 * torch.randn((B, T, 129, 1), generator=g, device="cuda").abs_()
+    x = torch.from_numpy(synthetic_magnitudes((B, T, 129, 1), 1234)).cuda()      # SURVEY 8(d2), C5 = C3 + target seed 1235
+    y = torch.from_numpy(synthetic_magnitudes((B, T, 129, 1), 1235)).cuda()
     losses = []
     for _ in range(warmup):
         losses.append(tr.fit_step(x, y)[0])
@@ -342,6 +362,7 @@ def main():
                    "global_batch": world * B, "path": {0: "auto", 1: "layerwise", 2: "fused"}[model.get_option("path")],
                    "fused_available": bool(model.get_option("has_fused")), "parallelism": "batch-shard x%d" % world,
                    "rccl_world_size": rccl_world, "weights": "random-init (glorot, seed 42)",
+                   "input": "|N(0,1)| float32, numpy default_rng(1234 + rank), resident in HBM before the timed region",
                    "library": _lib.version()},
         "from_root": from_root,
     }
@@ -373,6 +394,13 @@ def main():
                         "note": "compute-bound path (7950 FLOP/B): peak = dense fp32 157.3 TFLOP/s, not HBM; "
                                 "algorithmic HBM bytes are 1032 B/frame"}
         out["roofline"] = roof
+    host_line = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        try:
+            host_line = host_buffers_line(model, x)
+        except Exception as e:
+            host_line = {"error": "%s: %s" % (type(e).__name__, e)}
+    out["host_buffers"] = host_line
     del x, y
     model.close()
     if rank == 0:
