@@ -57,10 +57,19 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define STAMP_BEGIN() const unsigned long long st_a_ = stamp()
 #define STAMP_MATH(i) const unsigned long long st_b_ = stamp(); tsum[i] += st_b_ - st_a_
 #define STAMP_WAIT(i) tsum[(i) + ((i) < 3 ? 3 : 1)] += stamp() - st_b_
+// finer stamps inside the layer functions: td[k] += cycles since the previous DET / DET_BEGIN of this function
+#define DET_ARG , unsigned long long (&td)[8]
+#define DET_PASS , tdet
+#define DET_BEGIN() unsigned long long dt_ = stamp()
+#define DET(k) do { const unsigned long long n_ = stamp(); td[k] += n_ - dt_; dt_ = n_; } while (0)
 #else
 #define STAMP_BEGIN()
 #define STAMP_MATH(i)
 #define STAMP_WAIT(i)
+#define DET_ARG
+#define DET_PASS
+#define DET_BEGIN()
+#define DET(k)
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -510,8 +519,9 @@ __device__ __forceinline__ void l1_store(const Lane& L, f32x4 acc4, unsigned wr,
 }
 
 template <bool FIRST>
-__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave) {
+__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave DET_ARG) {
   using G = L1Geo<FIRST>;
+  DET_BEGIN();
   const unsigned wa = wbase + (FIRST ? L.a4 : L.a8);     // A fragments: main [s][lane], remainder from kW1Main
   const f32x4 sh = lds_ld<f32x4>(wbase + L.kq16, kW1Data * 4);
   const f32x2 s2 = lds_ld<f32x2>(wbase, (kW1Data + 16) * 4);
@@ -536,6 +546,7 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave) 
     xr += 1;
     vb += 2;
   }
+  DET(4);
   // ---- the single main tile: waves 0 / 1 -> tile 32 / 31 (no gap pixels); wave 7 -> its third regular tile (23)
   const unsigned rd = FIRST ? L.rd0 : L.rd1, rdb = FIRST ? L.rd0b : L.rd1b;
   if (wave < 2 || wave == 7) {
@@ -543,6 +554,7 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave) 
     l1_job<FIRST, 1, false>(wa, rd + dt * G::kTileR, 0u, sh, acc);
     l1_store(L, acc[0], L.wr1 + dt * (16 * 18 * 4), 0, false, 0);
   }
+  DET(5);
   // ---- pairs of regular tiles: (wave, wave+8), (wave+16, wave+24) as one stream with pair 0's stores between pair 1's
   //      MFMAs; wave 7 has only the first pair
   if (wave == 7) {
@@ -582,6 +594,7 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave) 
     l1_store(L, acc2[1][0], L.wr1, 2 * kT1W, g2, kVMain + 2);
     l1_store(L, acc2[1][1], L.wr1, 3 * kT1W, g3, kVMain + 3);
   }
+  DET(6);
 }
 
 // ---- layer 2: 1x5, 18 -> 30 (two M-tiles) ------------------------------------------------------------
@@ -638,15 +651,17 @@ __device__ __forceinline__ void l2_store(const Lane& L, f32x4 acc4, unsigned wr,
   }
 }
 
-__device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wbase, int wave, unsigned tag, unsigned* err) {
+__device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wbase, int wave, unsigned tag, unsigned* err DET_ARG) {
   constexpr int D = RCED_D2, RING = D + 1, NS = kL2Steps + 1;
+  DET_BEGIN();
   const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
   f32x4 sh[2];
   sh[0] = lds_ld<f32x4>(wbase + L.kq16, kW2Data * 4);
   sh[1] = lds_ld<f32x4>(wbase + L.kq16, (kW2Data + 16) * 4);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // ---- the share of tile 32 (waves 0..3), first
-  f32x4 accx = zero4;
+  f32x4 accx = zero4, part = zero4;   // part / pflag: the reducers' copy of their helper's partial sums and flag word
+  unsigned pflag = 0u;
   if (wave < 4) {
     const unsigned rdx = L.rd2 + (32 - wave) * (16 * 18 * 4), rdxt = L.rd2t + (32 - wave) * (16 * 18 * 4);
     if (wave == 0) accx = l2_share<0, true>(wa, wt, rdx, rdxt, zero4);        // a helper's share starts from zero,
@@ -659,6 +674,7 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
       if (L.a4 == 0) lds_poke_a(lds0 + (kFlag2Off + wave) * 4, tag);
     }
   }
+  DET(7);
   // ---- two pair jobs, tiles (wave, wave+8) and (wave+16, wave+24), as ONE stream: pair 0's stores ride between pair
   //      1's MFMAs (LDS stores are slow, ~85 B/clk per CU: issued in one burst they delay the next operand reads)
   {
@@ -701,6 +717,13 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
           if constexpr (p == 1 && st == 3) l2_store<1>(L, acc[0][0][1], L.wr2, 0, false, kVMain);
           if constexpr (p == 1 && st == 5) l2_store<0>(L, acc[0][1][0], L.wr2, kT2W, g1, kVMain + 1);
           if constexpr (p == 1 && st == 7) l2_store<1>(L, acc[0][1][1], L.wr2, kT2W, g1, kVMain + 1);
+          if constexpr (p == 1 && st == 9) {   // reducers: the helper's flag and partial sums, fetched inside the stream (see layer 3)
+            if (wave == 2 || wave == 3) {
+              pflag = lds_peek_a(lds0 + (kFlag2Off + wave - 2) * 4);
+              cbar();
+              part = lds_ld<f32x4>(lds0 + L.scr + (wave - 2) * 1024, kScratch2Off * 4);
+            }
+          }
         });
     l2_store<0>(L, acc[1][0][0], L.wr2, 2 * kT2W, g2, kVMain + 2);
     l2_store<1>(L, acc[1][0][1], L.wr2, 2 * kT2W, g2, kVMain + 2);
@@ -710,8 +733,11 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
   // ---- reducers: add the helper's share, store tile 32 (pixels 512..527: no gap inside)
   if (wave == 2 || wave == 3) {
     const int xm = wave - 2;
-    flag_wait(lds0 + (kFlag2Off + xm) * 4, tag, err, 2u);
-    const f32x4 v = accx + lds_ld<f32x4>(lds0 + L.scr + xm * 1024, kScratch2Off * 4);
+    if (!__builtin_amdgcn_readfirstlane(pflag == tag)) {   // not there yet when fetched (not seen in practice)
+      flag_wait(lds0 + (kFlag2Off + xm) * 4, tag, err, 2u);
+      part = lds_ld<f32x4>(lds0 + L.scr + xm * 1024, kScratch2Off * 4);
+    }
+    const f32x4 v = accx + part;
     const unsigned wrx = L.wr2 + (32 - wave) * (16 * 30 * 4);
     if (xm == 0) l2_store<0>(L, v, wrx, 0, false, 0);
     else l2_store<1>(L, v, wrx, 0, false, 0);
@@ -725,6 +751,7 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
 // epilogue and the skip registers) and three helpers (waves 1..3: [10,19), [19,28), [28,37) + tail).  The share is each
 // wave's first job; partial sums go through 1-KiB scratch areas in the (dead during layer 3) B18 buffer + flag words.
 constexpr int kL3Cut1 = 10, kL3Cut2 = 19, kL3Cut3 = 28;
+constexpr int kL3Fetch = 24;   // slot of the reducer's regular job at which it fetches the helpers' flags and partial sums
 constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;   // pixels 8..51 of frame 0: always rewritten by layer 1
 constexpr int kFlagOff = kScratchOff + 3 * 256;
 static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
@@ -756,12 +783,15 @@ __device__ __forceinline__ f32x4 l3_share(unsigned wa, unsigned wt, unsigned rdx
 }
 
 __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned lds0, unsigned wbase, int blk, int wave,
-                                       unsigned tag, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3]) {
+                                       unsigned tag, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3] DET_ARG) {
   constexpr int D = RCED_D3, RING = D + 1, NS = kL3Steps + 1;
+  DET_BEGIN();
   const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
   const f32x4 sh = lds_ld<f32x4>(wbase + (L.kq16 & 16), kW3Data * 4);   // shift[4*(kq&1) ..]
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[3] = {sh, sh, zero4};   // [2]: pair tile 16 (wave 0)
+  f32x4 part[3] = {zero4, zero4, zero4};   // wave 0: the helpers' partial sums of pair tile 16 and their flag words
+  unsigned pflag[3];
   // ---- the share of pair tile 16 (waves 0..3), first
   if (wave < 4) {
     const unsigned rdx = L.rd3 + (16 - wave) * (16 * 60 * 4), rdxt = L.rd3t + (16 - wave) * (16 * 60 * 4);
@@ -775,10 +805,12 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
       if (L.a4 == 0) lds_poke_a(lds0 + (kFlagOff + wave - 1) * 4, tag);
     }
   }
+  DET(0);
   // ---- the two regular pair tiles
   {
     f32x2 a[RING], b[RING][2];
     f32x4 accb[2] = {zero4, zero4};   // second chain of each tile (the slot's second k-quad)
+    pflag[0] = pflag[1] = pflag[2] = 0u;
     run_job<NS, D>(
         [&](auto ic) {
           constexpr int i = decltype(ic)::value, r = i % RING;
@@ -800,16 +832,37 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
             accb[0] = mfma(a[r].y, b[r][0].y, accb[0]);
             accb[1] = mfma(a[r].y, b[r][1].y, accb[1]);
           }
+          // The helpers published their shares of pair tile 16 before their own regular tiles, i.e. long ago: the reducer
+          // fetches flags and partial sums HERE, as three more loads in its operand stream, instead of in three serial
+          // LDS round trips after its last MFMA, where every other wave of the workgroup waits for it at the barrier.
+          if constexpr (i == kL3Fetch) {
+            if (wave == 0) {
+#pragma unroll
+              for (int h = 0; h < 3; ++h) {
+                pflag[h] = lds_peek_a(lds0 + (kFlagOff + h) * 4);
+                cbar();
+                part[h] = lds_ld<f32x4>(lds0 + L.scr + h * 1024, kScratchOff * 4);
+              }
+            }
+          }
         });
     acc[0] += accb[0];
     acc[1] += accb[1];
   }
-  if (wave == 0) {   // collect the helpers' shares: published at the start of their passes
+  DET(1);
+  if (wave == 0) {   // collect the helpers' shares
+    const bool early = pflag[0] == tag && pflag[1] == tag && pflag[2] == tag;   // the same words in every lane
+    if (!__builtin_amdgcn_readfirstlane(early)) {   // not there yet at slot kL3Fetch (not seen in practice): wait, re-read
 #pragma unroll
-    for (int h = 0; h < 3; ++h) flag_wait(lds0 + (kFlagOff + h) * 4, tag, P.err, 4u);
+      for (int h = 0; h < 3; ++h) flag_wait(lds0 + (kFlagOff + h) * 4, tag, P.err, 4u);
 #pragma unroll
-    for (int h = 0; h < 3; ++h) acc[2] += lds_ld<f32x4>(lds0 + L.scr + h * 1024, kScratchOff * 4);
+      for (int h = 0; h < 3; ++h) part[h] = lds_ld<f32x4>(lds0 + L.scr + h * 1024, kScratchOff * 4);
+    }
+    acc[2] += part[0];   // fixed order: the result does not depend on which path was taken
+    acc[2] += part[1];
+    acc[2] += part[2];
   }
+  DET(2);
   // Block-dependent work (model.py:84-88: CE1 / CE2 outputs are kept, and added to CD2 / CD1 AFTER the ReLU) sits behind
   // wave-uniform branches on blk; every tile is handled with compile-time indices so that the skip registers stay
   // individual registers (as runtime-indexed arrays hipcc copied them wholesale at every branch merge).
@@ -852,6 +905,7 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
     skip_ce1[t] = blk == 0 ? v : skip_ce1[t];
     skip_ce2[t] = blk == 1 ? v : skip_ce2[t];
   });
+  DET(3);
 }
 
 // ---- decode_final inside the kernel (layout and decomposition: see kHS above) ---------------------------------
@@ -875,7 +929,7 @@ __device__ __forceinline__ void fin_zero_pads(unsigned lds0, int tid) {
 typedef f32x4 __attribute__((aligned(4))) f32x4_u;   // a [frame][129] row is only 4-byte aligned
 
 __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsigned w128, int wave, int lane, int utt,
-                                            int t0, const FinA& A) {
+                                            int t0, const FinA& A, const XStage& xnext, float* x0) {
   const int n = lane & 15, kq = lane >> 4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   float* yt = P.y + ((size_t)utt * P.T + t0) * kF;   // the tile's first output row
@@ -926,6 +980,10 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
     lds_st<f32x4>(scr, 4 * kFinScr0, acc[0][0] + acc[0][1]);
     lds_st<f32x4>(scr, 4 * kFinScr1, acc[1][0] + acc[1][1]);
   }
+  // The next tile's input rows (in registers since block 4's layer 3) go to X0 here: X0 aliases the start of B30, dead
+  // since the barrier that ended layer 3 and clear of the partial sums above.  The barrier below then also starts the
+  // next tile: waves 2..7 go straight into its first layer while waves 0, 1 finish this tile's masks.
+  xstage_store(xnext, x0, wave * 64 + lane);
   __syncthreads();
   if (wave < 2) {   // ---- finish column tile `wave`: partial sums of waves 0..7, in that order, + bias
     const unsigned scr = lds0 + 4 * (wave == 0 ? kFinScr0 : kFinScr1) + lane * 16;
@@ -965,7 +1023,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   unsigned epoch = 0;   // layer-3 instances so far (tags the split-tile hand-offs)
   XStage xst = xstage_load(P, blockIdx.x, tid);
 #if RCED_STAMPS
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tfin = 0;
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tfin = 0, tdet[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   layer_end_sync();
 
@@ -976,15 +1034,12 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
 #endif
   const Lane L = make_lane(lds, wave, lane, xr0 < 0 ? 0 : xr0);
   const unsigned lds0 = lds_addr(lds);
+  xstage_store(xst, lds + kX0Off, tid);   // the first tile's input rows; every later tile's are stored by final_phase
+  __syncthreads();
 
   for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
     const int utt = tile / P.tiles_per_utt;
     const int t0 = (tile - utt * P.tiles_per_utt) * kTF;   // first frame of the tile
-    // input rows prefetched during the previous tile -> X0 (B30 is dead: its last reader finished
-    // before the barrier that ended the previous tile)
-    xstage_store(xst, lds + kX0Off, tid);
-    __syncthreads();
-
     f32x4 skip_ce1[3], skip_ce2[3];
     FinA finA;
 #pragma unroll
@@ -998,8 +1053,8 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
         const float* w = WREG(wcur);
         const unsigned wb = lds_addr(w);
-        if (blk == 0) layer1<true>(L, wb, wave);
-        else layer1<false>(L, wb, wave);
+        if (blk == 0) layer1<true>(L, wb, wave DET_PASS);
+        else layer1<false>(L, wb, wave DET_PASS);
         wcur ^= 1;
 #if RCED_STAMPS
         const unsigned long long st_b_ = stamp();
@@ -1015,7 +1070,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane);
         const float* w = WREG(wcur);
         const unsigned tag2 = 0xC0000000u | (epoch + 1u);   // distinct from layer 3's tags (0x8.......)
-        layer2(L, lds0, lds_addr(w), wave, tag2, P.err);
+        layer2(L, lds0, lds_addr(w), wave, tag2, P.err DET_PASS);
         wcur ^= 1;
         STAMP_MATH(1);
         layer_end_sync();
@@ -1034,7 +1089,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
           fin_prefetch(P, wave, lane, finA);   // decode_final's A fragments: in flight during this layer
           fin_zero_pads(lds0, tid);            // B18 is dead from here on (layer 3's own scratch sits below the H image)
         }
-        layer3(P, L, lds0, lds_addr(w), blk, wave, tag, skip_ce1, skip_ce2);
+        layer3(P, L, lds0, lds_addr(w), blk, wave, tag, skip_ce1, skip_ce2 DET_PASS);
         wcur ^= 1;
         STAMP_MATH(2);
         layer_end_sync();
@@ -1045,7 +1100,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
 #if RCED_STAMPS
     const unsigned long long st_f_ = stamp();
 #endif
-    final_phase(P, lds0, lds_addr(WREG(wcur) + kW1), wave, lane, utt, t0, finA);   // no barrier at its end: the next tile's first one covers it
+    final_phase(P, lds0, lds_addr(WREG(wcur) + kW1), wave, lane, utt, t0, finA, xst, lds + kX0Off);   // no barrier at its end: layer 1's covers it
 #if RCED_STAMPS
     tfin += stamp() - st_f_;
 #endif
@@ -1055,6 +1110,8 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   if (P.stamps && blockIdx.x == 0 && lane == 0)
     for (int i = 0; i < 8; ++i) P.stamps[wave * 8 + i] = tsum[i];
   if (P.stamps && blockIdx.x == 0 && lane == 0) P.stamps[64 + wave * 3] = tfin;
+  if (P.stamps && blockIdx.x == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) P.stamps[88 + wave * 8 + i] = tdet[i];
 #endif
 }
 

@@ -17,3 +17,8 @@ for w in range(8):
     v = [m.get_option("stamp%d" % (w * 8 + i)) for i in range(8)]
     print("%4d  %7d %7d %7d | %7d %7d %7d | %7d %7d   total %d" % (w, *v, sum(v)))
 print("decode_final phase (kilo-cycles) per wave:", [m.get_option("stamp%d" % (64 + w * 3)) for w in range(8)])
+print("detail (kilo-cycles; the stamps themselves cost ~100 cycles each and serialise the wave): "
+      "L3 share / regular job / collect / epilogue | L1 remainder / single / pairs | L2 share")
+for w in range(8):
+    v = [m.get_option("stamp%d" % (88 + w * 8 + i)) for i in range(8)]
+    print("%4d  %7d %7d %7d %7d | %7d %7d %7d | %7d" % (w, *v))
