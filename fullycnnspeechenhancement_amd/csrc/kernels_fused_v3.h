@@ -507,12 +507,7 @@ __device__ __forceinline__ void l1_job(unsigned wa, unsigned rdA, unsigned rdB, 
 // [pixel][18] store of a main tile's channels 4kq..4kq+3 (masked: the tile has gap pixels; wave-uniform)
 __device__ __forceinline__ void l1_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
   const f32x4 v = relu4(acc4);
-  if (masked) {
-    if (vbit(L, vb)) {
-      lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
-      lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
-    }
-  } else {
+  if (!masked || vbit(L, vb)) {   // predication (exec mask from SGPRs), not a branch around two copies of the stores
     lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
     lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
   }
@@ -640,12 +635,7 @@ __device__ __forceinline__ f32x4 l2_share(unsigned wa, unsigned wt, unsigned rdx
 template <int MT>
 __device__ __forceinline__ void l2_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
   const f32x4 v = relu4(acc4);
-  if (masked) {
-    if (vbit(L, vb)) {
-      lds_st<f32x2>(wr, off + 64 * MT, f32x2{v.x, v.y});
-      if (MT == 0 || vbit(L, kVLt48)) lds_st<f32x2>(wr, off + 64 * MT + 8, f32x2{v.z, v.w});
-    }
-  } else {
+  if (!masked || vbit(L, vb)) {
     lds_st<f32x2>(wr, off + 64 * MT, f32x2{v.x, v.y});
     if (MT == 0 || vbit(L, kVLt48)) lds_st<f32x2>(wr, off + 64 * MT + 8, f32x2{v.z, v.w});
   }
@@ -782,6 +772,39 @@ __device__ __forceinline__ f32x4 l3_share(unsigned wa, unsigned wt, unsigned rdx
   return acc;
 }
 
+// Layer 3's epilogue for block BLK: ReLU, the block skips, stores.  Blocks 0 / 1 keep their outputs (CE1 / CE2) in the
+// skip registers, blocks 3 / 4 add CE2 / CE1 after the ReLU, block 4 stores to the H image (decode_final's input)
+// instead of B8.  Gap / past-the-tile pixels are never written (they stay zero): every store is predicated on the
+// lane's validity bit -- the compare is loop-invariant, hipcc keeps it as an exec mask in SGPRs -- rather than put
+// behind a wave-uniform "does this tile have a gap" branch.  Values of gap lanes in the skip registers are whatever was
+// computed: they only ever meet gap pixels again.
+template <int BLK>
+__device__ __forceinline__ void l3_epilogue(const Lane& L, int wave, f32x4 (&acc)[3], f32x4 (&skip_ce1)[3],
+                                            f32x4 (&skip_ce2)[3]) {
+  static_for<0, 3>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    if (t == 2 && wave != 0) return;    // pair tile 16 belongs to wave 0
+    f32x4 v = relu4(acc[t]);
+    if constexpr (BLK == 3) v += skip_ce2[t];
+    if constexpr (BLK == 4) v += skip_ce1[t];
+    if constexpr (BLK == 0) skip_ce1[t] = v;
+    if constexpr (BLK == 1) skip_ce2[t] = v;
+    constexpr int vb = t < 2 ? kVL3 + t : kVL3X;
+    unsigned wr;
+    int off = 0;
+    if constexpr (BLK < 4) {
+      wr = L.wr3;
+      off = t < 2 ? t * kT3W : 16 * (32 * kB8S * 4);
+    } else {
+      wr = t == 0 ? L.wh0 : t == 1 ? L.wh1 : L.whx;
+    }
+    if (vbit(L, vb)) {
+      lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
+      lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
+    }
+  });
+}
+
 __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned lds0, unsigned wbase, int blk, int wave,
                                        unsigned tag, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3] DET_ARG) {
   constexpr int D = RCED_D3, RING = D + 1, NS = kL3Steps + 1;
@@ -863,48 +886,15 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
     acc[2] += part[2];
   }
   DET(2);
-  // Block-dependent work (model.py:84-88: CE1 / CE2 outputs are kept, and added to CD2 / CD1 AFTER the ReLU) sits behind
-  // wave-uniform branches on blk; every tile is handled with compile-time indices so that the skip registers stay
-  // individual registers (as runtime-indexed arrays hipcc copied them wholesale at every branch merge).
-  static_for<0, 3>([&](auto tc) {
-    constexpr int t = decltype(tc)::value;
-    if (t == 2 && wave != 0) return;    // pair tile 16 belongs to wave 0
-    f32x4 v = relu4(acc[t]);
-    if (blk == 3) {
-      v += skip_ce2[t];
-    } else if (blk == 4) {
-      v += skip_ce1[t];
-    }
-    constexpr int vb = t < 2 ? kVL3 + t : kVL3X;
-    const bool gap = span_has_gap(32 * (t < 2 ? wave + 8 * t : 16), 32);   // wave-uniform: pair tiles 4, 8, 12, 16
-    if (blk < 4) {
-      const unsigned wr = t < 2 ? L.wr3 : L.wr3 + 16 * (32 * kB8S * 4);   // (t == 2: wave 0, pair tile 16)
-      constexpr int off = t < 2 ? t * kT3W : 0;
-      if (gap) {   // gap / past-the-tile pixels are never written: they stay zero
-        if (vbit(L, vb)) {
-          lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
-          lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
-        }
-      } else {
-        lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
-        lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
-      }
-    } else {   // block 4: the CD2 output goes to the H image (decode_final's input); gap lanes have no pixel
-      const unsigned wh = t == 0 ? L.wh0 : t == 1 ? L.wh1 : L.whx;
-      if (gap) {
-        if (vbit(L, vb)) {
-          lds_st<f32x2>(wh, 0, f32x2{v.x, v.y});
-          lds_st<f32x2>(wh, 8, f32x2{v.z, v.w});
-        }
-      } else {
-        lds_st<f32x2>(wh, 0, f32x2{v.x, v.y});
-        lds_st<f32x2>(wh, 8, f32x2{v.z, v.w});
-      }
-    }
-    // keep CE1 / CE2 (values of gap lanes are whatever was computed: they only ever meet gap pixels again)
-    skip_ce1[t] = blk == 0 ? v : skip_ce1[t];
-    skip_ce2[t] = blk == 1 ? v : skip_ce2[t];
-  });
+  // Block-dependent work (model.py:84-88: CE1 / CE2 outputs are kept, and added to CD2 / CD1 AFTER the ReLU): one
+  // wave-uniform switch on blk, then straight-line code.  This epilogue is every wave's tail in front of the layer's
+  // barrier -- nothing overlaps it -- so it is kept free of branches: as one generic body with `blk ==` tests inside
+  // it was ~40 scalar branches and 24 v_cndmask per wave (the skip registers were merged at every join).
+  if (blk == 0) l3_epilogue<0>(L, wave, acc, skip_ce1, skip_ce2);
+  else if (blk == 1) l3_epilogue<1>(L, wave, acc, skip_ce1, skip_ce2);
+  else if (blk == 2) l3_epilogue<2>(L, wave, acc, skip_ce1, skip_ce2);
+  else if (blk == 3) l3_epilogue<3>(L, wave, acc, skip_ce1, skip_ce2);
+  else l3_epilogue<4>(L, wave, acc, skip_ce1, skip_ce2);
   DET(3);
 }
 
