@@ -150,9 +150,9 @@ static_assert(kHOff + kHPix * kHS <= kB30Off, "H fits inside B18");
 static_assert((kHOff % 2) == 0, "8-byte aligned");
 constexpr int kFinU = 144, kFinRun = kFinU / kWaves;      // window taps; K-steps per wave
 constexpr int kFinA = kFinU * 128;                        // floats of A fragments: [u][lane][2]
-constexpr int kFin128 = 65 * 8;                           // bin 128: W[f' - 64][c] for f' = 64..128
-constexpr int kFinPack = kFinA + 528;
-static_assert(kW1 + 528 <= kWRegion && (kW1 % 4) == 0, "the bin-128 weights fit behind a layer-1 packet in its LDS region");
+constexpr int kFin128 = 80 * 8;                           // bin 128: W[t][c] for taps t = 0..64 (window bins 64..128), zero for t = 65..79
+constexpr int kFinPack = kFinA + kFin128;
+static_assert(kW1 + kFin128 <= kWRegion && (kW1 % 4) == 0, "the bin-128 weights fit behind a layer-1 packet in its LDS region");
 // partial sums: 8 waves x 256 floats per column tile, in two stretches of B30 (dead by then) that contain NO gap pixel
 // (B30's gap rows sit at floats 3990.., 7980.., 11970.. and must stay zero) and are clear of X0 (the next tile's input rows)
 constexpr int kFinScr0 = kB30Off + 4112, kFinScr1 = kB30Off + 8112;
@@ -917,6 +917,10 @@ __device__ __forceinline__ void fin_zero_pads(unsigned lds0, int tid) {
   }
 }
 typedef f32x4 __attribute__((aligned(4))) f32x4_u;   // a [frame][129] row is only 4-byte aligned
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 
 __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsigned w128, int wave, int lane, int utt,
                                             int t0, const FinA& A, const XStage& xnext, float* x0) {
@@ -925,25 +929,39 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
   float* yt = P.y + ((size_t)utt * P.T + t0) * kF;   // the tile's first output row
   const int nfr = P.T - t0 < kTF ? P.T - t0 : kTF;   // frames of the tile inside the utterance
   if (wave == 2) {   // ---- bin 128 of the four frames (taps f' = 64..128, 8 channels each) on the VALU, FIRST: wave 6
-                     //      keeps the SIMD's matrix pipe busy meanwhile, and nothing waits for this wave at the end
-    const int fi = kq, sub = n;   // 16 lanes per frame; lane `sub` takes f' = 64 + sub + 16 m
+                     //      keeps the SIMD's matrix pipe busy meanwhile
+    // 16 lanes per frame; lane `sub` takes taps t = sub + 16 m, m < 5.  Taps 65..79 carry zero weights (pack_v3) and meet
+    // the zero pad behind the frame, so there is no predicate and all loads of a batch are in flight together (as a
+    // predicated loop hipcc serialised it into ten LDS round trips in front of this wave's MFMA run, which every other
+    // wave then waited for at the barrier).
+    const int fi = kq, sub = n;
     const unsigned hb = lds0 + 4 * (kHOff + (kHFrame * fi + 64 + 64 + sub) * kHS);
     const unsigned wb = w128 + sub * 32;   // bin-128 weights: LDS-DMA'd behind the next tile's first packet
-    float sum = 0.f;
+    f32x4 hv[5][2], wv[5][2];
 #pragma unroll
-    for (int m = 0; m < 5; ++m) {
-      if (sub + 16 * m <= 64) {
+    for (int m = 0; m < 5; ++m)
 #pragma unroll
-        for (int c = 0; c < 8; c += 2) {
-          const f32x2 hv = lds_ld<f32x2>(hb, (16 * m * kHS + c) * 4);
-          const f32x2 wv = lds_ld<f32x2>(wb, (16 * m * 8 + c) * 4);
-          sum = __builtin_fmaf(hv.x, wv.x, sum);
-          sum = __builtin_fmaf(hv.y, wv.y, sum);
-        }
+      for (int c = 0; c < 2; ++c) {
+        const f32x2 h0 = lds_ld<f32x2>(hb, (16 * m * kHS + 4 * c) * 4), h1 = lds_ld<f32x2>(hb, (16 * m * kHS + 4 * c + 2) * 4);
+        hv[m][c] = f32x4{h0.x, h0.y, h1.x, h1.y};
+        wv[m][c] = lds_ld<f32x4>(wb, (16 * m * 8 + 4 * c) * 4);
       }
-    }
+    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d, 16);   // over the frame's 16 lanes (same order for every lane)
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        s4.x = __builtin_fmaf(hv[m][c].x, wv[m][c].x, s4.x);
+        s4.y = __builtin_fmaf(hv[m][c].y, wv[m][c].y, s4.y);
+        s4.z = __builtin_fmaf(hv[m][c].z, wv[m][c].z, s4.z);
+        s4.w = __builtin_fmaf(hv[m][c].w, wv[m][c].w, s4.w);
+      }
+    float sum = (s4.x + s4.y) + (s4.z + s4.w);
+    // over the frame's 16 lanes (one DPP row), the same order in every lane: quads, then half rows, then the row
+    sum += row_dpp<0xB1>(sum);    // quad_perm [1,0,3,2]
+    sum += row_dpp<0x4E>(sum);    // quad_perm [2,3,0,1]
+    sum += row_dpp<0x141>(sum);   // row_half_mirror
+    sum += row_dpp<0x140>(sum);   // row_mirror
     if (sub == 0 && fi < nfr) yt[fi * kF + 128] = sum + P.fin_bias;
   }
   {  // ---- this wave's run of K-steps, both column tiles: column n of tile ct = (frame n >> 2, block 4*ct + (n & 3))
@@ -1075,7 +1093,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         ++epoch;
         const unsigned tag = 0x80000000u | epoch;   // sign bit set: never the bits of a ReLU output
         if (blk == 4) {
-          packet_dma<528>(P.fin + kFinA, WREG(wcur ^ 1) + kW1, wave, lane);   // decode_final's bin-128 weights ride along
+          packet_dma<kFin128>(P.fin + kFinA, WREG(wcur ^ 1) + kW1, wave, lane);   // decode_final's bin-128 weights ride along
           fin_prefetch(P, wave, lane, finA);   // decode_final's A fragments: in flight during this layer
           fin_zero_pads(lds0, tid);            // B18 is dead from here on (layer 3's own scratch sits below the H image)
         }
