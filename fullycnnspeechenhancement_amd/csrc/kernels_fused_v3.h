@@ -39,6 +39,12 @@
 #ifndef RCED_D3
 #define RCED_D3 2
 #endif
+#ifndef RCED_LANE_OPAQUE
+#define RCED_LANE_OPAQUE 1   // all per-lane addresses hidden from the optimiser (A/B: -0.5 %)
+#endif
+#ifndef RCED_L3_CHAINS
+#define RCED_L3_CHAINS 2   // accumulation chains of layer 3's regular job: 4 = (tile, k-quad of the slot), 2 = one per tile (A/B: -0.3 %)
+#endif
 #ifndef RCED_STAMPS
 #define RCED_STAMPS 0     // diagnostic build: s_memtime stamps around every layer's math and barrier
 #endif
@@ -414,6 +420,12 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   L.rd2tb = L.rd2t + kT2R;
   L.rd3tb = L.rd3t + kT3R;
   asm volatile("" : "+v"(L.rd0b), "+v"(L.rd1b), "+v"(L.rd2b), "+v"(L.rd3b), "+v"(L.rd2tb), "+v"(L.rd3tb));
+#if RCED_LANE_OPAQUE
+  // every other address too: left visible, hipcc keeps only the lane-dependent part in a VGPR and re-adds the (scalar)
+  // buffer base at each use -- a v_add per job and per epilogue store
+  asm volatile("" : "+v"(L.rd0), "+v"(L.rd0r), "+v"(L.rd1), "+v"(L.wr1), "+v"(L.rd1r), "+v"(L.wr1r), "+v"(L.rd2), "+v"(L.rd2t));
+  asm volatile("" : "+v"(L.wr2), "+v"(L.rd3), "+v"(L.rd3t), "+v"(L.wr3), "+v"(L.wh0), "+v"(L.wh1), "+v"(L.whx));
+#endif
   return L;
 }
 __device__ __forceinline__ bool vbit(const Lane& L, int b) { return (L.vbits >> b) & 1u; }
@@ -852,8 +864,13 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
           acc[0] = mfma(a[r].x, b[r][0].x, acc[0]);
           acc[1] = mfma(a[r].x, b[r][1].x, acc[1]);
           if constexpr (i < kL3Steps) {
+#if RCED_L3_CHAINS == 4
             accb[0] = mfma(a[r].y, b[r][0].y, accb[0]);
             accb[1] = mfma(a[r].y, b[r][1].y, accb[1]);
+#else
+            acc[0] = mfma(a[r].y, b[r][0].y, acc[0]);
+            acc[1] = mfma(a[r].y, b[r][1].y, acc[1]);
+#endif
           }
           // The helpers published their shares of pair tile 16 before their own regular tiles, i.e. long ago: the reducer
           // fetches flags and partial sums HERE, as three more loads in its operand stream, instead of in three serial
@@ -869,8 +886,10 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
             }
           }
         });
+#if RCED_L3_CHAINS == 4
     acc[0] += accb[0];
     acc[1] += accb[1];
+#endif
   }
   DET(1);
   if (wave == 0) {   // collect the helpers' shares
