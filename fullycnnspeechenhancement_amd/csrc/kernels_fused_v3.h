@@ -456,9 +456,15 @@ __device__ __forceinline__ bool tile_has_gap(int T) { return span_has_gap(16 * T
 // tiles, the shares of the split tiles -- is base registers and wave-uniform branches around the shared code.  With
 // one unrolled stream per wave role (an earlier version) the kernel was 60 KB of code and ran 40 % slower than at
 // 52 KB: the instruction cache (64 KB for two CUs) no longer held what 16 waves were executing.
-template <int NSLOT, int D, class LoadF, class MathF>
-__device__ __forceinline__ void run_job(LoadF&& load, MathF&& math) {
+// `pre` runs once the job's first operand reads are in flight: a layer's first job issues the next weight packet's
+// LDS-DMA there (Once, below) -- ~30 mostly scalar instructions that used to sit between the barrier and the first LDS
+// read of the layer, where nothing overlaps them; here they run in the shadow of the reads' latency.
+template <int NSLOT, int D, class LoadF, class MathF, class Pre>
+__device__ __forceinline__ void run_job(LoadF&& load, MathF&& math, Pre&& pre) {
   static_for<0, (D < NSLOT ? D : NSLOT)>(load);
+  pin();
+  pre();
+  pin();
   static_for<0, NSLOT>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     if constexpr (i + D < NSLOT) load(IC<i + D>{});
@@ -467,6 +473,20 @@ __device__ __forceinline__ void run_job(LoadF&& load, MathF&& math) {
     pin();
   });
 }
+
+template <class F>
+struct Once {   // the wave's first job of a layer calls it; later jobs skip it (wave-uniform flag)
+  F f;
+  bool done = false;
+  __device__ __forceinline__ void operator()() {
+    if (!done) {
+      f();
+      done = true;
+    }
+  }
+};
+template <class F>
+__device__ __forceinline__ Once<F> once(F f) { return Once<F>{f}; }
 
 // ---- layer 1: 8x9, 1 -> 18 on the input rows (block 0, FIRST) / 1x9, 8 -> 18 on B8 (blocks 1..4) -----------
 // Blocks 1..4: a slot is a b64 K-step (two k-quads; k = tap*8 + ci): 9 slots per main tile (channels 0..15 of 16
@@ -485,8 +505,8 @@ struct L1Geo {
   static constexpr int koff(int st, int per) { return FIRST ? ((st / per) * 4 * kS + st % per) * 4 : kB8S * 4 * st; }
 };
 
-template <bool FIRST, int NT, bool REM>   // NT tiles in lockstep (1 or 2); REM: remainder tile (NT = 1)
-__device__ __forceinline__ void l1_job(unsigned wa, unsigned rdA, unsigned rdB, f32x4 init, f32x4 (&acc)[2]) {
+template <bool FIRST, int NT, bool REM, class Pre>   // NT tiles in lockstep (1 or 2); REM: remainder tile (NT = 1)
+__device__ __forceinline__ void l1_job(unsigned wa, unsigned rdA, unsigned rdB, f32x4 init, f32x4 (&acc)[2], Pre& pre) {
   using G = L1Geo<FIRST>;
   constexpr int NS = REM ? G::SR : G::SM, D = G::D, RING = D + 1, PER = REM ? 16 : 9;
   f32x2 a[RING], b[RING][NT];
@@ -513,7 +533,8 @@ __device__ __forceinline__ void l1_job(unsigned wa, unsigned rdA, unsigned rdB, 
           acc[0] = mfma(a[r].y, b[r][0].y, acc[0]);
           if constexpr (NT > 1) acc[1] = mfma(a[r].y, b[r][1].y, acc[1]);
         }
-      });
+      },
+      pre);
 }
 
 // [pixel][18] store of a main tile's channels 4kq..4kq+3 (masked: the tile has gap pixels; wave-uniform)
@@ -525,21 +546,22 @@ __device__ __forceinline__ void l1_store(const Lane& L, f32x4 acc4, unsigned wr,
   }
 }
 
-template <bool FIRST>
-__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave DET_ARG) {
+template <bool FIRST, class Dma>
+__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave, Dma dma DET_ARG) {
   using G = L1Geo<FIRST>;
   DET_BEGIN();
   const unsigned wa = wbase + (FIRST ? L.a4 : L.a8);     // A fragments: main [s][lane], remainder from kW1Main
   const f32x4 sh = lds_ld<f32x4>(wbase + L.kq16, kW1Data * 4);
   const f32x2 s2 = lds_ld<f32x2>(wbase, (kW1Data + 16) * 4);
   f32x4 acc[2];
+  auto pre = once(dma);
   // ---- remainder tiles: waves 4, 5, 6 -> tiles 0, 1, 2; wave 7 -> tiles 3 and 4
   const int nrem = wave < 4 ? 0 : wave == 7 ? 2 : 1;
   unsigned rdr = FIRST ? L.rd0r : L.rd1r, wrr = L.wr1r;
   int xr = wave == 7 ? 3 : wave - 4, vb = kVRem;
 #pragma unroll 1
   for (int r = 0; r < nrem; ++r) {
-    l1_job<FIRST, 1, true>(wa, rdr, 0u, f32x4{s2.x, s2.y, s2.x, s2.y}, acc);
+    l1_job<FIRST, 1, true>(wa, rdr, 0u, f32x4{s2.x, s2.y, s2.x, s2.y}, acc, pre);
     const f32x4 v = relu4(acc[0]);   // rows 4kq+jj = (phase 2kq + (jj>>1), channel 16 + (jj&1)): two pixels x channels 16,17
     if (xr > 0) {   // every remainder tile but tile 0 contains gap pixels (tile 4 also runs past the tile): never written
       if (vbit(L, vb)) lds_st<f32x2>(wrr, 0, f32x2{v.x, v.y});
@@ -558,14 +580,14 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave D
   const unsigned rd = FIRST ? L.rd0 : L.rd1, rdb = FIRST ? L.rd0b : L.rd1b;
   if (wave < 2 || wave == 7) {
     const int dt = wave == 0 ? 32 : wave == 1 ? 30 : 16;   // tiles away from regular tile `wave`
-    l1_job<FIRST, 1, false>(wa, rd + dt * G::kTileR, 0u, sh, acc);
+    l1_job<FIRST, 1, false>(wa, rd + dt * G::kTileR, 0u, sh, acc, pre);
     l1_store(L, acc[0], L.wr1 + dt * (16 * 18 * 4), 0, false, 0);
   }
   DET(5);
   // ---- pairs of regular tiles: (wave, wave+8), (wave+16, wave+24) as one stream with pair 0's stores between pair 1's
   //      MFMAs; wave 7 has only the first pair
   if (wave == 7) {
-    l1_job<FIRST, 2, false>(wa, rd, rdb, sh, acc);
+    l1_job<FIRST, 2, false>(wa, rd, rdb, sh, acc, pre);
     l1_store(L, acc[0], L.wr1, 0, false, 0);          // tiles 7, 15: no gap pixels
     l1_store(L, acc[1], L.wr1, kT1W, false, 0);
   } else {
@@ -597,7 +619,8 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave D
           }
           if constexpr (p == 1 && st == 1) l1_store(L, acc2[0][0], L.wr1, 0, false, kVMain);
           if constexpr (p == 1 && st == 3) l1_store(L, acc2[0][1], L.wr1, kT1W, g1, kVMain + 1);
-        });
+        },
+        pre);
     l1_store(L, acc2[1][0], L.wr1, 2 * kT1W, g2, kVMain + 2);
     l1_store(L, acc2[1][1], L.wr1, 3 * kT1W, g3, kVMain + 3);
   }
@@ -619,8 +642,8 @@ constexpr int kFlag2Off = kScratch2Off + 2 * 256;
 static_assert((kScratch2Off * 4) % 16 == 0, "scratch is read/written with b128");
 static_assert(8 + (2 * 256 + 2 + kB8S - 1) / kB8S <= kF, "layer-2 scratch stays inside frame 0's real pixels");
 
-template <int XM, bool HELPER>   // the share of tile 32: M-tile XM, slots [0, kL2Cut) (helper) or [kL2Cut, 11) + tail
-__device__ __forceinline__ f32x4 l2_share(unsigned wa, unsigned wt, unsigned rdx, unsigned rdxt, f32x4 init) {
+template <int XM, bool HELPER, class Pre>   // the share of tile 32: M-tile XM, slots [0, kL2Cut) (helper) or [kL2Cut, 11) + tail
+__device__ __forceinline__ f32x4 l2_share(unsigned wa, unsigned wt, unsigned rdx, unsigned rdxt, f32x4 init, Pre& pre) {
   constexpr int S0 = HELPER ? 0 : kL2Cut, NS = HELPER ? kL2Cut : kL2Steps + 1 - kL2Cut, D = RCED_D2, RING = D + 1;
   f32x2 a[RING], b[RING];
   f32x4 acc = init;
@@ -639,7 +662,8 @@ __device__ __forceinline__ f32x4 l2_share(unsigned wa, unsigned wt, unsigned rdx
         constexpr int i = decltype(ic)::value, r = i % RING;
         acc = mfma(a[r].x, b[r].x, acc);
         if constexpr (S0 + i < kL2Steps) acc = mfma(a[r].y, b[r].y, acc);
-      });
+      },
+      pre);
   return acc;
 }
 
@@ -653,7 +677,8 @@ __device__ __forceinline__ void l2_store(const Lane& L, f32x4 acc4, unsigned wr,
   }
 }
 
-__device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wbase, int wave, unsigned tag, unsigned* err DET_ARG) {
+template <class Dma>
+__device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wbase, int wave, unsigned tag, unsigned* err, Dma dma DET_ARG) {
   constexpr int D = RCED_D2, RING = D + 1, NS = kL2Steps + 1;
   DET_BEGIN();
   const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
@@ -664,12 +689,13 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
   // ---- the share of tile 32 (waves 0..3), first
   f32x4 accx = zero4, part = zero4;   // part / pflag: the reducers' copy of their helper's partial sums and flag word
   unsigned pflag = 0u;
+  auto pre = once(dma);
   if (wave < 4) {
     const unsigned rdx = L.rd2 + (32 - wave) * (16 * 18 * 4), rdxt = L.rd2t + (32 - wave) * (16 * 18 * 4);
-    if (wave == 0) accx = l2_share<0, true>(wa, wt, rdx, rdxt, zero4);        // a helper's share starts from zero,
-    else if (wave == 1) accx = l2_share<1, true>(wa, wt, rdx, rdxt, zero4);
-    else if (wave == 2) accx = l2_share<0, false>(wa, wt, rdx, rdxt, sh[0]);  // the reducer's from the shift
-    else accx = l2_share<1, false>(wa, wt, rdx, rdxt, sh[1]);
+    if (wave == 0) accx = l2_share<0, true>(wa, wt, rdx, rdxt, zero4, pre);        // a helper's share starts from zero,
+    else if (wave == 1) accx = l2_share<1, true>(wa, wt, rdx, rdxt, zero4, pre);
+    else if (wave == 2) accx = l2_share<0, false>(wa, wt, rdx, rdxt, sh[0], pre);  // the reducer's from the shift
+    else accx = l2_share<1, false>(wa, wt, rdx, rdxt, sh[1], pre);
     if (wave < 2) {   // publish (LDS operations of a wave execute in order: data, then flag)
       lds_st<f32x4>(lds0 + L.scr + wave * 1024, kScratch2Off * 4, accx);
       cbar();
@@ -726,7 +752,8 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
               part = lds_ld<f32x4>(lds0 + L.scr + (wave - 2) * 1024, kScratch2Off * 4);
             }
           }
-        });
+        },
+        pre);
     l2_store<0>(L, acc[1][0][0], L.wr2, 2 * kT2W, g2, kVMain + 2);
     l2_store<1>(L, acc[1][0][1], L.wr2, 2 * kT2W, g2, kVMain + 2);
     l2_store<0>(L, acc[1][1][0], L.wr2, 3 * kT2W, g3, kVMain + 3);
@@ -760,8 +787,8 @@ static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
 static_assert(8 + (3 * 256 + 3 + 17) / 18 <= kF, "scratch + flags stay inside frame 0's real pixels");
 static_assert(kFlagOff + 3 <= kHOff, "layer 3's hand-off scratch and the H image do not overlap");
 
-template <int S0, int S1>   // the share of pair tile 16: slots [S0, S1) (slot kL3Steps = the tail)
-__device__ __forceinline__ f32x4 l3_share(unsigned wa, unsigned wt, unsigned rdx, unsigned rdxt, f32x4 init) {
+template <int S0, int S1, class Pre>   // the share of pair tile 16: slots [S0, S1) (slot kL3Steps = the tail)
+__device__ __forceinline__ f32x4 l3_share(unsigned wa, unsigned wt, unsigned rdx, unsigned rdxt, f32x4 init, Pre& pre) {
   constexpr int NS = S1 - S0, D = RCED_D3, RING = D + 1;
   f32x2 a[RING], b[RING];
   f32x4 acc = init;
@@ -780,7 +807,8 @@ __device__ __forceinline__ f32x4 l3_share(unsigned wa, unsigned wt, unsigned rdx
         constexpr int i = decltype(ic)::value, r = i % RING;
         acc = mfma(a[r].x, b[r].x, acc);
         if constexpr (S0 + i < kL3Steps) acc = mfma(a[r].y, b[r].y, acc);
-      });
+      },
+      pre);
   return acc;
 }
 
@@ -817,8 +845,9 @@ __device__ __forceinline__ void l3_epilogue(const Lane& L, int wave, f32x4 (&acc
   });
 }
 
+template <class Dma>
 __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned lds0, unsigned wbase, int blk, int wave,
-                                       unsigned tag, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3] DET_ARG) {
+                                       unsigned tag, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3], Dma dma DET_ARG) {
   constexpr int D = RCED_D3, RING = D + 1, NS = kL3Steps + 1;
   DET_BEGIN();
   const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
@@ -827,13 +856,14 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
   f32x4 acc[3] = {sh, sh, zero4};   // [2]: pair tile 16 (wave 0)
   f32x4 part[3] = {zero4, zero4, zero4};   // wave 0: the helpers' partial sums of pair tile 16 and their flag words
   unsigned pflag[3];
+  auto pre = once(dma);
   // ---- the share of pair tile 16 (waves 0..3), first
   if (wave < 4) {
     const unsigned rdx = L.rd3 + (16 - wave) * (16 * 60 * 4), rdxt = L.rd3t + (16 - wave) * (16 * 60 * 4);
-    if (wave == 0) acc[2] = l3_share<0, kL3Cut1>(wa, wt, rdx, rdxt, sh);
-    else if (wave == 1) acc[2] = l3_share<kL3Cut1, kL3Cut2>(wa, wt, rdx, rdxt, zero4);
-    else if (wave == 2) acc[2] = l3_share<kL3Cut2, kL3Cut3>(wa, wt, rdx, rdxt, zero4);
-    else acc[2] = l3_share<kL3Cut3, kL3Steps + 1>(wa, wt, rdx, rdxt, zero4);
+    if (wave == 0) acc[2] = l3_share<0, kL3Cut1>(wa, wt, rdx, rdxt, sh, pre);
+    else if (wave == 1) acc[2] = l3_share<kL3Cut1, kL3Cut2>(wa, wt, rdx, rdxt, zero4, pre);
+    else if (wave == 2) acc[2] = l3_share<kL3Cut2, kL3Cut3>(wa, wt, rdx, rdxt, zero4, pre);
+    else acc[2] = l3_share<kL3Cut3, kL3Steps + 1>(wa, wt, rdx, rdxt, zero4, pre);
     if (wave > 0) {   // publish the partial sums
       lds_st<f32x4>(lds0 + L.scr + (wave - 1) * 1024, kScratchOff * 4, acc[2]);
       cbar();
@@ -885,7 +915,8 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
               }
             }
           }
-        });
+        },
+        pre);
 #if RCED_L3_CHAINS == 4
     acc[0] += accb[0];
     acc[1] += accb[1];
@@ -1002,7 +1033,8 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
           acc[1][0] = mfma(A.a[i].x, b[r][1].x, acc[1][0]);
           acc[0][1] = mfma(A.a[i].y, b[r][0].y, acc[0][1]);
           acc[1][1] = mfma(A.a[i].y, b[r][1].y, acc[1][1]);
-        });
+        },
+        [] {});
     const unsigned scr = lds0 + wave * 1024 + lane * 16;
     lds_st<f32x4>(scr, 4 * kFinScr0, acc[0][0] + acc[0][1]);
     lds_st<f32x4>(scr, 4 * kFinScr1, acc[1][0] + acc[1][1]);
@@ -1077,11 +1109,11 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
     for (int blk = 0; blk < 5; ++blk) {
       {  // ---- layer 1: (8x9, 1->18) for block 0, (1x9, 8->18) otherwise
         STAMP_BEGIN();
-        packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
         const float* w = WREG(wcur);
         const unsigned wb = lds_addr(w);
-        if (blk == 0) layer1<true>(L, wb, wave DET_PASS);
-        else layer1<false>(L, wb, wave DET_PASS);
+        auto dma = [&] { packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane); };   // next packet: layer 2's
+        if (blk == 0) layer1<true>(L, wb, wave, dma DET_PASS);
+        else layer1<false>(L, wb, wave, dma DET_PASS);
         wcur ^= 1;
 #if RCED_STAMPS
         const unsigned long long st_b_ = stamp();
@@ -1094,10 +1126,10 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
       }
       {  // ---- layer 2: (1x5, 18->30)
         STAMP_BEGIN();
-        packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane);
         const float* w = WREG(wcur);
         const unsigned tag2 = 0xC0000000u | (epoch + 1u);   // distinct from layer 3's tags (0x8.......)
-        layer2(L, lds0, lds_addr(w), wave, tag2, P.err DET_PASS);
+        auto dma = [&] { packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane); };
+        layer2(L, lds0, lds_addr(w), wave, tag2, P.err, dma DET_PASS);
         wcur ^= 1;
         STAMP_MATH(1);
         layer_end_sync();
@@ -1105,18 +1137,19 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
       }
       {  // ---- layer 3: (1x9, 30->8) on pixel pairs; block skips; hand-off
         STAMP_BEGIN();
-        // next packet: layer 1 of the next block, or of block 0 of the next tile (the stream wraps)
-        packet_dma<kW1>(blk == 4 ? P.wpack : wsrc + kWBlock, WREG(wcur ^ 1), wave, lane);
-        if (blk == 4) xst = xstage_load(P, tile + gridDim.x, tid);   // next tile's input rows
         const float* w = WREG(wcur);
         ++epoch;
         const unsigned tag = 0x80000000u | epoch;   // sign bit set: never the bits of a ReLU output
-        if (blk == 4) {
+        if (blk == 4) {   // once per tile: stays in front of the layer
+          xst = xstage_load(P, tile + gridDim.x, tid);   // next tile's input rows
           packet_dma<kFin128>(P.fin + kFinA, WREG(wcur ^ 1) + kW1, wave, lane);   // decode_final's bin-128 weights ride along
           fin_prefetch(P, wave, lane, finA);   // decode_final's A fragments: in flight during this layer
           fin_zero_pads(lds0, tid);            // B18 is dead from here on (layer 3's own scratch sits below the H image)
         }
-        layer3(P, L, lds0, lds_addr(w), blk, wave, tag, skip_ce1, skip_ce2 DET_PASS);
+        // next packet: layer 1 of the next block, or of block 0 of the next tile (the stream wraps)
+        const float* wnext = blk == 4 ? P.wpack : wsrc + kWBlock;
+        auto dma = [&] { packet_dma<kW1>(wnext, WREG(wcur ^ 1), wave, lane); };
+        layer3(P, L, lds0, lds_addr(w), blk, wave, tag, skip_ce1, skip_ce2, dma DET_PASS);
         wcur ^= 1;
         STAMP_MATH(2);
         layer_end_sync();
