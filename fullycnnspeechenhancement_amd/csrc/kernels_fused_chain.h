@@ -201,9 +201,14 @@ __device__ __forceinline__ void layer_end_sync() {
 // NT = NR regular slots (offsets off0 + t*STRIDE) + NX extra slot (offx), every M-tile.
 // Lanes whose tail k is past K re-read in-window data (their weights are zero).
 // XMT >= 0: the extra slot only computes M-tile XMT (the tile's other M-tile belongs to another wave).
-template <int NR, int NX, int MT, int K, int STRIDE, int DEPTH, int XMT = -1>
+// `pre` runs once the first operand reads are in flight: a layer's main pass issues the next packet's LDS-DMA there
+// (~30 mostly scalar instructions in the shadow of the reads' latency instead of between the barrier and the first read).
+struct NoPre {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int NR, int NX, int MT, int K, int STRIDE, int DEPTH, int XMT = -1, class Pre = NoPre>
 __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, const float* w, int lane,
-                                          f32x4 (&acc)[NR + NX][MT]) {
+                                          f32x4 (&acc)[NR + NX][MT], Pre pre = Pre()) {
   constexpr int NT = NR + NX, RING = DEPTH + 1;
   constexpr int NB64 = K / 8, NTAIL = (K % 8 + 3) / 4;
   const int kq = lane >> 4;
@@ -240,6 +245,9 @@ __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, 
   };
 #pragma unroll
   for (int s = 0; s < DEPTH && s < NB64; ++s) load(s, a[s % RING], b[s % RING]);
+  pin();
+  pre();
+  pin();
 #pragma unroll
   for (int s = 0; s < NB64; ++s) {
     if (s + DEPTH < NB64) load(s + DEPTH, a[(s + DEPTH) % RING], b[(s + DEPTH) % RING]);
@@ -264,9 +272,9 @@ __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, 
 
 // First layer: 8 x TAPS kernel on the 1-channel input, b32 steps; step s = ih*TAPS + j, lane kq <->
 // time tap 4*ih + kq.  x0 index of (input row r, bin f') is PADL + r*S + f'  =>  pixel + ti*S + j.
-template <int NR, int NX, int TAPS, int S, int DEPTH>
+template <int NR, int NX, int TAPS, int S, int DEPTH, class Pre>
 __device__ __forceinline__ void first_pass(const float* x0, int off0, int offx, const float* w, int lane,
-                                           f32x4 (&acc)[NR + NX][1]) {
+                                           f32x4 (&acc)[NR + NX][1], Pre pre) {
   constexpr int NT = NR + NX, RING = DEPTH + 1, STEPS = 2 * TAPS;
   const float* wp = w + lane;
   float a[RING], b[RING][NT];
@@ -279,6 +287,9 @@ __device__ __forceinline__ void first_pass(const float* x0, int off0, int offx, 
   };
 #pragma unroll
   for (int s = 0; s < DEPTH; ++s) load(s, s % RING);
+  pin();
+  pre();
+  pin();
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     if (s + DEPTH < STEPS) load(s + DEPTH, (s + DEPTH) % RING);
@@ -340,9 +351,9 @@ __device__ __forceinline__ void xstage_store(const XStage& st, float* x0, int ti
 }
 
 // One layer for one wave.  NX = 1 for the waves that own an extra tile (XMT < 0) or one M-tile of it (XMT = 0/1).
-template <class N, int L, int NX, int XMT = -1>
+template <class N, int L, int NX, int XMT = -1, class Dma>
 __device__ __forceinline__ void run_layer(const Params& P, float* lds, const float* w, __amdgpu_buffer_rsrc_t scratch,
-                                          int wave, int lane, int tid, int utt, int t0) {
+                                          int wave, int lane, int tid, int utt, int t0, Dma dma) {
   using G = Geo<N>;
   constexpr LayerDesc D = N::layer[L];
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::MT(L);
@@ -382,11 +393,11 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     for (int t = 0; t < NT; ++t) acc[t][mt] = sh;
   }
   if constexpr (L == 0) {
-    first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc);
+    first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc, dma);
   } else {
     constexpr int padl = (D.taps - 1) / 2;
     gemm_pass<NR, NX, MT, G::K(L), 128 * D.cinp, RCED_CHAIN_DEPTH, XMT>(in, (px0 - padl) * D.cinp + 2 * kq,
-                                                         (pxx - padl) * D.cinp + 2 * kq, w, lane, acc);
+                                                         (pxx - padl) * D.cinp + 2 * kq, w, lane, acc, dma);
   }
   // ---- epilogue: (+skip) -> ReLU -> zero the gap pixels -> LDS (or the hand-off tensor)
   // A layer that stores to global memory here (skip fragments, the hand-off tensor) waits NOW for the next packet's
@@ -481,16 +492,17 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
     float* const wbase = lds + G::kWOff;
     // next packet: layer L+1, or layer 0 for the next tile (the stream wraps)
     constexpr int nxt = (L + 1 < N::kLayers) ? L + 1 : 0;
-    packet_dma<G::packet(nxt)>(P.wpack + G::packet_off(nxt), wbase + (wcur ^ 1) * G::kWRegion, wave, lane);
+    float* const wdst = wbase + (wcur ^ 1) * G::kWRegion;
+    auto dma = [&] { packet_dma<G::packet(nxt)>(P.wpack + G::packet_off(nxt), wdst, wave, lane); };   // issued inside the main pass
     if constexpr (L == N::kLayers - 1) xst = xstage_load<N>(P, tile + gridDim.x, tid);
     const float* w = wbase + wcur * G::kWRegion;
     if constexpr (L > 0 && G::MT(L) == 2 && G::kSplitExtra) {
-      if (wave < G::kExtra) run_layer<N, L, 1, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
-      else if (wave < 2 * G::kExtra) run_layer<N, L, 1, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0);
-      else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+      if (wave < G::kExtra) run_layer<N, L, 1, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
+      else if (wave < 2 * G::kExtra) run_layer<N, L, 1, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
+      else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
     } else {
-      if (wave < G::kExtra) run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0);
-      else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+      if (wave < G::kExtra) run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
+      else run_layer<N, L, 0, -1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
     }
     wcur ^= 1;
     if constexpr (N::layer[L].saves_skip || L == N::kLayers - 1) __syncthreads();

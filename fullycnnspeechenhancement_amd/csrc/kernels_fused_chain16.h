@@ -179,7 +179,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     for (int t = 0; t < NT; ++t) acc[t][mt] = sh;
   }
   if constexpr (L == 0) {
-    chain::first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc);
+    chain::first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc, chain::NoPre());
   } else {
     constexpr int padl = (D.taps - 1) / 2, cpi = G::cp(L - 1);
     pass16<NR, NX, MT, G::steps(L), 128 * cpi, RCED_C16_DEPTH>(in, (px0 - padl) * cpi + 4 * kq, (pxx - padl) * cpi + 4 * kq, w, lane, acc);
