@@ -122,9 +122,10 @@ __device__ __forceinline__ f32x4 from_bf16x4(s16x4 s) {
 }
 
 // Implicit-GEMM pass on bf16: STEPS steps of K = 16 (lane kq supplies k = 16 s + 4 kq .. +3), NT = NR + NX slots.
-template <int NR, int NX, int MT, int STEPS, int STRIDE, int DEPTH>
+// `pre` runs once the first operand reads are in flight (the next packet's LDS-DMA: see chain::gemm_pass).
+template <int NR, int NX, int MT, int STEPS, int STRIDE, int DEPTH, class Pre>
 __device__ __forceinline__ void pass16(const __bf16* act, int off0, int offx, const float* w, int lane,
-                                       f32x4 (&acc)[NR + NX][MT]) {
+                                       f32x4 (&acc)[NR + NX][MT], Pre pre) {
   constexpr int NT = NR + NX, RING = DEPTH + 1;
   const s16x4* wp = reinterpret_cast<const s16x4*>(w) + lane;
   s16x4 a[RING][MT], b[RING][NT];
@@ -142,6 +143,9 @@ __device__ __forceinline__ void pass16(const __bf16* act, int off0, int offx, co
   };
 #pragma unroll
   for (int s = 0; s < DEPTH && s < STEPS; ++s) load(s, s % RING);
+  pin();
+  pre();
+  pin();
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     if (s + DEPTH < STEPS) load(s + DEPTH, (s + DEPTH) % RING);
@@ -154,9 +158,9 @@ __device__ __forceinline__ void pass16(const __bf16* act, int off0, int offx, co
   }
 }
 
-template <class N, int L, int NX>
+template <class N, int L, int NX, class Dma>
 __device__ __forceinline__ void run_layer(const Params& P, float* lds, const float* w, __amdgpu_buffer_rsrc_t scratch,
-                                          int wave, int lane, int tid, int utt, int t0) {
+                                          int wave, int lane, int tid, int utt, int t0, Dma dma) {
   using G = Geo<N>;
   constexpr LayerDesc D = N::layer[L];
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::MT(L);
@@ -179,10 +183,10 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     for (int t = 0; t < NT; ++t) acc[t][mt] = sh;
   }
   if constexpr (L == 0) {
-    chain::first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc, chain::NoPre());
+    chain::first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc, dma);
   } else {
     constexpr int padl = (D.taps - 1) / 2, cpi = G::cp(L - 1);
-    pass16<NR, NX, MT, G::steps(L), 128 * cpi, RCED_C16_DEPTH>(in, (px0 - padl) * cpi + 4 * kq, (pxx - padl) * cpi + 4 * kq, w, lane, acc);
+    pass16<NR, NX, MT, G::steps(L), 128 * cpi, RCED_C16_DEPTH>(in, (px0 - padl) * cpi + 4 * kq, (pxx - padl) * cpi + 4 * kq, w, lane, acc, dma);
   }
   // skip fragments of the matching encoder layer (own stores of an earlier layer; L2-resident).  Loaded here, not
   // before the pass: 32 fewer live VGPRs during the pass keep the kernel at 128 and two workgroups on a CU, whose
@@ -257,11 +261,12 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
   if constexpr (L < N::kLayers) {
     float* const wbase = lds + G::kWOff;
     constexpr int nxt = (L + 1 < N::kLayers) ? L + 1 : 0;
-    packet_dma<G::packet(nxt)>(P.wpack + G::packet_off(nxt), wbase + (wcur ^ 1) * G::kWRegion, wave, lane);
+    float* const wdst = wbase + (wcur ^ 1) * G::kWRegion;
+    auto dma = [&] { packet_dma<G::packet(nxt)>(P.wpack + G::packet_off(nxt), wdst, wave, lane); };   // issued inside the pass
     if constexpr (L == N::kLayers - 1) xst = chain::xstage_load<N>(P, tile + gridDim.x, tid);
     const float* w = wbase + wcur * G::kWRegion;
-    if (wave < G::kExtra) chain16::run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0);
-    else chain16::run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0);
+    if (wave < G::kExtra) chain16::run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
+    else chain16::run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
     wcur ^= 1;
     if constexpr (N::layer[L].saves_skip || L == N::kLayers - 1) __syncthreads();
     else chain::layer_end_sync();
