@@ -178,7 +178,10 @@ __device__ __forceinline__ float relu1(float v) {   // integer max: see kernels_
 }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
 
-template <int NFLOATS>
+// SBASE: chunk base in SGPRs + one 32-bit lane offset (lds_dma16s) instead of a 64-bit address per lane and chunk.  It
+// frees ~45 VGPRs here but the per-layer chunk bases then live in (spilled) SGPRs: A/B -1 % (V1), -2 % (V2), -0.3 %
+// (CR-CED); only the bf16 kernel, capped at 128 VGPRs for two workgroups per CU, gains (no scratch any more, +0.5-1 %).
+template <int NFLOATS, bool SBASE = false>
 __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float* dst, int wave, int lane) {
   constexpr int n4 = NFLOATS / 4;
   constexpr int chunks = (n4 + 63) / 64;
@@ -188,7 +191,8 @@ __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float*
     if (c < chunks) {
       const int idx = c * 64 + lane;
       if (idx < n4)
-        lds_dma16(src + (size_t)idx * 4, dst + c * 256);
+        if constexpr (SBASE) lds_dma16s(src + c * 256, (unsigned)lane * 16u, dst + c * 256);
+        else lds_dma16(src + (size_t)idx * 4, dst + c * 256);
     }
   }
 }

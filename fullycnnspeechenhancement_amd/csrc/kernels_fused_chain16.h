@@ -251,7 +251,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
 
 template <int NFLOATS>
 __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float* dst, int wave, int lane) {
-  chain::packet_dma<NFLOATS>(src, dst, wave, lane);
+  chain::packet_dma<NFLOATS, true>(src, dst, wave, lane);
 }
 
 template <class N, int L>

@@ -27,4 +27,21 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc_lane, float* lds_dst
       : "memory");
 }
 
+// The same with a wave-uniform base address in SGPRs and ONE 32-bit per-lane byte offset (lane * 16 for every chunk of
+// every packet): a 64-bit per-lane address per chunk cost a v_lshl_add_u64 per transfer and VGPR pairs that stayed live
+// across the tile loop (the bf16 R-CED kernel, capped at 128 VGPRs for two workgroups per CU, spilled them).
+__device__ __forceinline__ void lds_dma16s(const float* gsrc_wave, unsigned lane_byte_off, float* lds_dst_wave) {
+  const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_dst_wave;
+  unsigned saved;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(saved)
+      : "v"(lane_byte_off), "s"(gsrc_wave), "s"(m0v)
+      : "memory");
+}
+
 }  // namespace rced
