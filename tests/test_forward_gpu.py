@@ -225,12 +225,14 @@ def test_batch_and_time_shard_invariance(net_work, tag, variant, built):
     assert np.abs(b[:, 3:] - y[:, 24:]).max() <= 1e-5 * scale
 
 
-def test_full_size_config3_sampled_against_oracle(built):
-    """BASELINE config 3 (CR-CED, batch 256, 129x512) on the device path; a random sample of output
-    frames is checked against the oracle run on each frame's 8-frame receptive field."""
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_full_size_config3_sampled_against_oracle(net_work, tag, variant, built):
+    """BASELINE config 3 (CR-CED, batch 256, 129x512) on the device path -- and the two R-CED nets at the same size
+    (every persistent workgroup walks 128-171 tiles); a random sample of output frames is checked against the oracle
+    run on each frame's 8-frame receptive field."""
     import torch
-    w = rced_np.make_weights("FullyCNNV3", seed=42)
-    m = make_model(3, w)
+    w = rced_np.make_weights(net_work, seed=42)
+    m = make_model(variant, w)
     g = torch.Generator(device="cuda").manual_seed(1234)
     x = torch.randn((256, 512, 129, 1), generator=g, device="cuda").abs_()
     y = m(x)
@@ -243,9 +245,9 @@ def test_full_size_config3_sampled_against_oracle(built):
     for n, t in picks:
         lo, hi = max(t - 3, 0), min(t + 5, 512)
         win = x[n:n + 1, lo:hi].cpu().numpy()
-        ref = rced_c.forward("FullyCNNV3", w, win, np.float64)[0, t - lo]
+        ref = rced_c.forward(net_work, w, win, np.float64)[0, t - lo]
         got = y[n, t].cpu().numpy()
-        assert np.abs(got - ref).max() <= RTOL * scale, (n, t)
+        assert np.abs(got - ref).max() <= RTOL * scale, (net_work, n, t)
     # utterances are independent: rerunning a slice of the batch reproduces it bit for bit
     assert torch.equal(m(x[100:104].contiguous()), y[100:104])
 
