@@ -58,8 +58,11 @@ __global__ __launch_bounds__(kThreads) void chan_reduce(const float* __restrict_
 }
 
 // sums[c][2] = sum over partials.  One workgroup per output (launch with 2*C workgroups).
+// only_if: a device flag; the launch is a no-op when it is given and zero (the conditional exact recomputation behind
+// sums_fix_x, train_api.hip).
 __global__ __launch_bounds__(kThreads) void reduce_finish(const double* __restrict__ part, int nparts, int C,
-                                                           double* __restrict__ sums) {
+                                                           double* __restrict__ sums, const int* __restrict__ only_if = nullptr) {
+  if (only_if && *only_if == 0) return;
   __shared__ double s[kThreads];
   const int tid = threadIdx.x, n = 2 * C, i = blockIdx.x;
   double t = 0.0;
@@ -223,7 +226,9 @@ __global__ __launch_bounds__(kThreads) void bwd_route2(const float2* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float2* __restrict__ skip_pre, int use_act, size_t P, int C,
                                                         float2* __restrict__ g_skip_pre, float2* __restrict__ g_skip_post,
-                                                        float2* __restrict__ d, double* __restrict__ part) {
+                                                        float2* __restrict__ d, double* __restrict__ part,
+                                                        const int* __restrict__ only_if = nullptr) {
+  if (only_if && *only_if == 0) return;   // wave-uniform: see reduce_finish
   __shared__ double red[kThreads * 4];
   const PairLane L(C, threadIdx.x);
   double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [k][S1, S2]

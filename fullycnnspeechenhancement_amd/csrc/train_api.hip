@@ -79,6 +79,7 @@ struct rced_trainer {
   float* pk_fin = nullptr, *pk_fin_bwd = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
   float* zero32 = nullptr;
   double *part = nullptr, *sums = nullptr;
+  int* redo = nullptr;         // device flag behind `sums` (same allocation): sums_fix_x asks for the exact recomputation
   // activations for P pixels
   size_t cap_px = 0;
   std::vector<float*> out, z, G;   // out/G indexed by tensor id (0 unused), z by layer
@@ -321,15 +322,26 @@ __global__ void sums_fix(double* __restrict__ sums, const float* __restrict__ mu
   if (c < C) sums[2 * c + 1] = (double)rstd[c] * (sums[2 * c + 1] - (double)mu[c] * sums[2 * c]);
 }
 
-// (sum d_u, sum d_u * x), x = relu(a z + b), from the fused backward kernel -> (S1, S2): where d_u != 0, z = (x - b) / a
+// (sum d_u, sum d_u * x), x = relu(a z + b), from the fused backward kernel -> (S1, S2): where d_u != 0, z = (x - b) / a.
+// That division is exact enough only while |gamma| is not tiny (x was rounded to fp32: zhat comes back with an error of
+// eps |x| / |gamma|), and meaningless for gamma = 0 -- where S2 is still needed: it is gamma's own gradient, and TF's
+// d gamma = sum dy * zhat does not vanish with gamma.  So the kernel also raises *redo when any channel of the layer has
+// |gamma| < kTinyGamma, and the step then recomputes the layer's sums exactly from (g, z) with bwd_route2 -- launched
+// every step with this flag as its only_if, i.e. as a no-op in every step a real training run ever takes.
+constexpr float kTinyGamma = 1e-3f;
 __global__ void sums_fix_x(double* __restrict__ sums, const float* __restrict__ mu, const float* __restrict__ rstd,
-                           const float* __restrict__ gamma, const float* __restrict__ beta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float a = gamma[c] * rstd[c];                 // the folded forward, exactly as xform_table_fill forms it
-  const float b = beta[c] - a * mu[c];
-  const double s1 = sums[2 * c], sx = sums[2 * c + 1];
-  sums[2 * c + 1] = a != 0.f ? (double)rstd[c] * ((sx - (double)b * s1) / (double)a - (double)mu[c] * s1) : 0.0;   // a = 0: dz = 0 anyway
+                           const float* __restrict__ gamma, const float* __restrict__ beta, int C, int* __restrict__ redo) {
+  const int c = threadIdx.x;     // one workgroup of >= C threads
+  bool tiny = false;
+  if (c < C) {
+    const float a = gamma[c] * rstd[c];                 // the folded forward, exactly as xform_table_fill forms it
+    const float b = beta[c] - a * mu[c];
+    const double s1 = sums[2 * c], sx = sums[2 * c + 1];
+    tiny = !(fabsf(gamma[c]) >= kTinyGamma);
+    sums[2 * c + 1] = a != 0.f ? (double)rstd[c] * ((sx - (double)b * s1) / (double)a - (double)mu[c] * s1) : 0.0;
+  }
+  const int any = __syncthreads_or(tiny);
+  if (threadIdx.x == 0) *redo = any;
 }
 
 __global__ void sums_to_float(const double* __restrict__ sums, int C, int which, float* __restrict__ dst) {
@@ -445,7 +457,9 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
   TRY_OR_FREE(hipMalloc(&t->zero32, 64 * sizeof(float)));
   TRY_OR_FREE(hipMemset(t->zero32, 0, 64 * sizeof(float)));
   TRY_OR_FREE(hipMalloc(&t->part, (size_t)std::max(kReduceGrid, kPairGrid) * train::kMaxC * 2 * sizeof(double)));
-  TRY_OR_FREE(hipMalloc(&t->sums, train::kMaxC * 2 * sizeof(double)));
+  TRY_OR_FREE(hipMalloc(&t->sums, (train::kMaxC * 2 + 2) * sizeof(double)));
+  t->redo = reinterpret_cast<int*>(t->sums + train::kMaxC * 2);
+  TRY_OR_FREE(hipMemset(t->redo, 0, 2 * sizeof(double)));
   t->wf.assign(L, nullptr); t->wt.assign(L, nullptr); t->bias4.assign(L, nullptr);
   t->mu.assign(L, nullptr); t->rstd.assign(L, nullptr);
   t->pk_fwd.assign(L, nullptr); t->pk_bwd.assign(L, nullptr);
@@ -732,10 +746,18 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     if (lazy_mask && fused_sums[l] > 0) {
       hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part,
                          fused_sums[l], s.cout, t->sums);
-      if (sums_from_x[l])
+      if (sums_from_x[l]) {
         hipLaunchKernelGGL(sums_fix_x, dim3(1), dim3(64), 0, st, t->sums, (const float*)mu, (const float*)t->rstd[l],
-                           (const float*)(t->params + f.gamma), (const float*)(t->params + f.beta), s.cout);
-      else
+                           (const float*)(t->params + f.gamma), (const float*)(t->params + f.beta), s.cout, t->redo);
+        // |gamma| tiny somewhere in this layer: the sums again, exactly, from (g, z) (no-ops otherwise; see sums_fix_x)
+        const dim3 grid = pair_grid(s.cout);
+        hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
+                           (const float2*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
+                           (const float*)(t->params + f.beta), (const float2*)nullptr, s.use_act, P, s.cout, (float2*)nullptr,
+                           (float2*)nullptr, (float2*)nullptr, t->part, (const int*)t->redo);
+        hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part,
+                           (int)grid.x, s.cout, t->sums, (const int*)t->redo);
+      } else
         hipLaunchKernelGGL(sums_fix, dim3(1), dim3(64), 0, st, t->sums, (const float*)mu, (const float*)t->rstd[l], s.cout);
     } else if (pairs) {
       const dim3 grid = pair_grid(s.cout);

@@ -322,6 +322,43 @@ def test_all_gradients_tight_on_inputs_without_relu_ties(net_work, tag, variant,
     tr.close()
 
 
+def test_gamma_zero_and_tiny_gamma_get_their_true_gradients(built, capsys):
+    """A BatchNorm channel with gamma = 0 (and beta > 0) still has d gamma = sum dy * zhat != 0 (module.py:29,
+    tf.layers.batch_normalization).  The fused backward kernel recovers zhat from the transformed activations by dividing
+    by gamma * rstd, which cannot work there: the step must notice and recompute that layer's sums from (g, z).  Channels
+    of an 18- and a 30-channel layer (the tensors whose sums come from the fused kernel) with gamma = 0 and 2e-4."""
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer
+    w = {k: v.copy() for k, v in rced_np.make_weights("FullyCNNV3", seed=11).items()}
+    edits = (("CE2_encode_1", 5, 0.0, 0.3), ("CD1_encode_2", 17, 0.0, 0.2), ("CE3_encode_2", 3, 2e-4, 0.25),
+             ("CD2_encode_1", 11, -3e-4, 0.4))
+    for scope, c, gam, bet in edits:
+        w[scope + "/batch_norm/gamma"][c] = gam
+        w[scope + "/batch_norm/beta"][c] = bet
+    ref = train_ref.TrainRef("FullyCNNV3", w, batch_size=4)
+    x, seed = screened_input(ref, 2, 3, 9100)
+    y = rced_np.make_input(2, 3, seed=78)
+    loss_ref, grads_ref, _ = ref.loss_and_grads(x, y)
+    tr = FullyCNNTrainer("FullyCNNV3", batch_size=4, lr=1e-4, weights=w)
+    loss, _, _ = tr.train_step(x, y)
+    assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref)
+    g = tr.gradients()
+    worst = 0.0
+    for name, gr in grads_ref.items():
+        gr = gr.numpy()
+        if name.endswith("/bias") and (name[:-5] + "/batch_norm/gamma") in grads_ref:
+            continue
+        err = np.abs(g[name].astype(np.float64) - gr).max() / np.abs(gr).max()
+        worst = max(worst, err)
+        assert err < TIGHT, (name, err)
+    for scope, c, gam, bet in edits:      # the edited channels themselves: gamma's gradient is there and right
+        gr = grads_ref[scope + "/batch_norm/gamma"].numpy()
+        assert abs(gr[c]) > 1e-3 * np.abs(gr).max(), (scope, "the case is vacuous: d gamma ~ 0")
+        assert abs(g[scope + "/batch_norm/gamma"][c] - gr[c]) <= TIGHT * np.abs(gr).max(), (scope, c)
+    with capsys.disabled():
+        print("\n[train parity] gamma = 0 / tiny gamma channels: worst gradient error %.2e of its tensor's max" % worst)
+    tr.close()
+
+
 @pytest.mark.parametrize("net_work,tag,variant", NETS)
 def test_model_is_training_true_is_the_training_graph(net_work, tag, variant, built):
     """trainer.py:165-172 builds `Model(is_training=True)`; model(x) then normalises with the statistics of the batch
