@@ -272,6 +272,26 @@ def test_repeated_launches_are_bit_identical(net_work, tag, variant, built):
             assert np.array_equal(m(x), y0)
 
 
+def test_out_argument_for_host_and_device_buffers(built):
+    """model(x, out=buf): the caller's buffer is written and returned, for ndarray and for cuda tensors; a buffer of the
+    wrong kind, shape or dtype is refused."""
+    import torch
+    w = rced_np.make_weights("FullyCNNV3", seed=3)
+    m = make_model(3, w)
+    x = rced_np.make_input(3, 10, seed=4)
+    y = m(x)
+    buf = np.full_like(x, -7.0)
+    assert m(x, out=buf) is buf and np.array_equal(buf, y)
+    xt = torch.from_numpy(x).cuda()
+    bt = torch.full_like(xt, -7.0)
+    assert m(xt, out=bt) is bt and np.array_equal(bt.cpu().numpy(), y)
+    for bad in (np.zeros((3, 10, 129), np.float32), np.zeros(x.shape, np.float64), bt, np.zeros(x.shape, np.float32)[:, ::-1]):
+        with pytest.raises(ValueError):
+            m(x, out=bad)
+    with pytest.raises(ValueError):
+        m(xt, out=buf)
+
+
 def test_single_op_conv_bn_relu_known_answers(built):
     """rced_conv_bn_relu against the analytic cases of test_oracle.py, and against the oracle op."""
     import torch
