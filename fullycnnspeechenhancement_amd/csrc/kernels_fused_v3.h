@@ -775,12 +775,19 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
 
 // ---- layer 3: 1x9, 30 -> 8 on pixel pairs ------------------------------------------------------------
 // Rows = 2 pixel phases x 8 channels, K = 10 taps x 30 = 300 (37 b64 slots + the b32 tail).  Every wave has two regular
-// pair tiles, run in lockstep (one A fragment per slot for both, four accumulation chains: tile x k-quad of the slot).
-// Pair tile 16 is split ALONG K in four, one part per SIMD (waves 0..3): the reducer (wave 0: slots [0,10), owns the
-// epilogue and the skip registers) and three helpers (waves 1..3: [10,19), [19,28), [28,37) + tail).  The share is each
+// pair tiles, run in lockstep (one A fragment per slot for both, one accumulation chain per tile).
+// Pair tile 16 is split ALONG K in four, one part per SIMD (waves 0..3): the reducer (wave 0: slots [0,8), owns the
+// epilogue and the skip registers) and three helpers (waves 1..3: [8,18), [18,28), [28,37) + tail).  The share is each
 // wave's first job; partial sums go through 1-KiB scratch areas in the (dead during layer 3) B18 buffer + flag words.
-constexpr int kL3Cut1 = 10, kL3Cut2 = 19, kL3Cut3 = 28;
-constexpr int kL3Fetch = 24;   // slot of the reducer's regular job at which it fetches the helpers' flags and partial sums
+#ifndef RCED_L3_CUTS
+#define RCED_L3_CUTS 8, 18, 28   // the reducer (wave 0) takes the smallest share: it also collects and stores the tile (A/B: -0.25 %)
+#endif
+#ifndef RCED_L3_FETCH
+#define RCED_L3_FETCH 24
+#endif
+constexpr int kL3CutsArr[3] = {RCED_L3_CUTS};
+constexpr int kL3Cut1 = kL3CutsArr[0], kL3Cut2 = kL3CutsArr[1], kL3Cut3 = kL3CutsArr[2];
+constexpr int kL3Fetch = RCED_L3_FETCH;   // slot of the reducer's regular job at which it fetches the helpers' flags and partial sums
 constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;   // pixels 8..51 of frame 0: always rewritten by layer 1
 constexpr int kFlagOff = kScratchOff + 3 * 256;
 static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
