@@ -636,7 +636,10 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave, 
 // publishes it through LDS scratch + a tagged flag word before its regular tiles, and the reducer picks it up after
 // its last job, when it has long been there.  Scratch: in the B8 buffer, which is dead during layer 2 (layer 3
 // rewrites every real pixel of it).
-constexpr int kL2Cut = 6;
+#ifndef RCED_L2_CUT
+#define RCED_L2_CUT 6
+#endif
+constexpr int kL2Cut = RCED_L2_CUT;
 constexpr int kScratch2Off = kB8Off + kB8Pad * kB8S + 8 * kB8S;   // B8 rows 8.. of frame 0 (2 x 256 floats + 2 flags)
 constexpr int kFlag2Off = kScratch2Off + 2 * 256;
 static_assert((kScratch2Off * 4) % 16 == 0, "scratch is read/written with b128");
