@@ -409,40 +409,43 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
   // across the barrier instead of exposing their latency in front of it (vmcnt counts loads and stores alike).  Nobody
   // reads them before a later layer's vmcnt(0) has retired them.  The other layers wait at their end (layer_end_sync).
   if constexpr (D.saves_skip || kLast) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // One fragment (tile slot t, M-tile mt): (+skip) -> ReLU -> (gap pixels: zero) -> skip scratch -> LDS / the hand-off tensor
+  auto fragment = [&](int t, int mt, int px, bool masked, bool ok) {
+    if (t >= NR && XMT >= 0 && mt != XMT) return;          // the other M-tile of the split extra tile is another wave's
+    const int fr = px / G::kS, f = px - fr * G::kS;
+    f32x4 v = acc[t][mt];
+    if constexpr (D.skip_from >= 0) v += skip[t][mt];   // module.py:30-31: before the ReLU
+    v = relu4(v);
+    if (masked && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (D.saves_skip)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), scratch, tid * 16,
+                                             (G::skip_unit(L) + t * MT + mt) * kThreads * 16, 0);
+    const int co0 = 16 * mt + 4 * kq;
+    if constexpr (!kLast) {
+      float* p = out + px * D.coutp + co0;
+      if (16 * mt + 16 <= D.coutp || co0 + 1 < D.coutp) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
+      if (16 * mt + 16 <= D.coutp || co0 + 3 < D.coutp) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
+    } else if (ok && px < G::kNPX && f < kF && t0 + fr < P.T) {
+      float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * N::kFinalCh + co0;
+      if (co0 + 1 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp) = f32x2{v.x, v.y};
+      if (co0 + 3 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp + 2) = f32x2{v.z, v.w};
+    }
+  };
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int tile = t < NR ? wave + kWaves * t : xtile;
     const int px = t < NR ? px0 + 128 * t : pxx;
-    const bool gap = span_has_gap<N>(16 * tile, 16);       // wave-uniform: 3 of the 26 tiles
-    bool ok = true;
-    if (gap) {
-      asm volatile("" ::: "memory");   // keeps this a wave-uniform BRANCH: as selects, every tile paid the validity arithmetic
-      ok = px_valid<N>(px);            // and four v_cndmask per fragment (VALU work is not hidden behind fp32 MFMAs)
-    }
-    const int fr = px / G::kS, f = px - fr * G::kS;
+    // Wave-uniform: 3 of the 26 tiles contain gap pixels.  ONE branch per tile with the tile's fragments in both arms
+    // (as selects, every tile paid the validity arithmetic and four v_cndmask per fragment; as a branch per fragment the
+    // condition went through a VGPR and back at every join).
+    if (span_has_gap<N>(16 * tile, 16)) {
+      asm volatile("");   // keeps the arms apart
+      const bool ok = px_valid<N>(px);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (t >= NR && XMT >= 0 && mt != XMT) continue;      // the other M-tile of the split extra tile is another wave's
-      f32x4 v = acc[t][mt];
-      if constexpr (D.skip_from >= 0) v += skip[t][mt];   // module.py:30-31: before the ReLU
-      v = relu4(v);
-      if (gap) {
-        asm volatile("" ::: "memory");
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      if constexpr (D.saves_skip)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), scratch, tid * 16,
-                                               (G::skip_unit(L) + t * MT + mt) * kThreads * 16, 0);
-      const int co0 = 16 * mt + 4 * kq;
-      if constexpr (!kLast) {
-        float* p = out + px * D.coutp + co0;
-        if (16 * mt + 16 <= D.coutp || co0 + 1 < D.coutp) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
-        if (16 * mt + 16 <= D.coutp || co0 + 3 < D.coutp) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
-      } else if (ok && px < G::kNPX && f < kF && t0 + fr < P.T) {
-        float* hp = P.h + (((size_t)utt * P.T + t0 + fr) * kF + f) * N::kFinalCh + co0;
-        if (co0 + 1 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp) = f32x2{v.x, v.y};
-        if (co0 + 3 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp + 2) = f32x2{v.z, v.w};
-      }
+      for (int mt = 0; mt < MT; ++mt) fragment(t, mt, px, true, ok);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fragment(t, mt, px, false, true);
     }
   }
   // ---- remainder pass: channels 16.. of P adjacent pixels per column (rows 4kq+j = (phase i / R, channel 16 + i % R))
