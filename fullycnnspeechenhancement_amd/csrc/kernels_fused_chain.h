@@ -354,11 +354,35 @@ __device__ __forceinline__ void xstage_store(const XStage& st, float* x0, int ti
   if (tid + 3 * kThreads < G::kX0Floats) x0[tid + 3 * kThreads] = st.v3;
 }
 
+// Per-lane window / output offsets of a wave's regular tile `wave`, every layer's, computed ONCE per kernel and kept in
+// registers: re-derived in every layer they were ~20 VALU instructions in front of each layer's first LDS read, and VALU
+// work is not hidden behind fp32 MFMAs.  A layer takes its two values through an opaque copy, so that nothing DERIVED from
+// them is hoisted out of the tile loop as well (hoisted wholesale, the layers' address arithmetic spilled).
+template <class N>
+struct LaneTab {
+  int in[N::kLayers];    // (px0 - padl) * cinp + 2 kq: B-operand window start
+  int out[N::kLayers];   // px0 * coutp + 4 kq: this lane's output channels 4kq.. of pixel px0 (M-tile 0)
+};
+template <class N>
+__device__ __forceinline__ LaneTab<N> make_lane_tab(int wave, int lane) {
+  LaneTab<N> T;
+  const int n = lane & 15, kq = lane >> 4, px0 = 16 * wave + n;
+#pragma unroll
+  for (int l = 0; l < N::kLayers; ++l) {
+    T.in[l] = (px0 - (N::layer[l].taps - 1) / 2) * N::layer[l].cinp + 2 * kq;
+    T.out[l] = px0 * N::layer[l].coutp + 4 * kq;
+    asm volatile("" : "+v"(T.in[l]), "+v"(T.out[l]));
+  }
+  return T;
+}
+
 // One layer for one wave.  NX = 1 for the waves that own an extra tile (XMT < 0) or one M-tile of it (XMT = 0/1).
 template <class N, int L, int NX, int XMT = -1, class Dma>
 __device__ __forceinline__ void run_layer(const Params& P, float* lds, const float* w, __amdgpu_buffer_rsrc_t scratch,
-                                          int wave, int lane, int tid, int utt, int t0, Dma dma) {
+                                          int wave, int lane, int tid, int utt, int t0, Dma dma, const LaneTab<N>& LT) {
   using G = Geo<N>;
+  int lt_in = LT.in[L], lt_out = LT.out[L];
+  asm volatile("" : "+v"(lt_in), "+v"(lt_out));
   constexpr LayerDesc D = N::layer[L];
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::MT(L);
   constexpr bool kLast = (L == N::kLayers - 1);
@@ -399,9 +423,8 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
   if constexpr (L == 0) {
     first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc, dma);
   } else {
-    constexpr int padl = (D.taps - 1) / 2;
-    gemm_pass<NR, NX, MT, G::K(L), 128 * D.cinp, RCED_CHAIN_DEPTH, XMT>(in, (px0 - padl) * D.cinp + 2 * kq,
-                                                         (pxx - padl) * D.cinp + 2 * kq, w, lane, acc, dma);
+    gemm_pass<NR, NX, MT, G::K(L), 128 * D.cinp, RCED_CHAIN_DEPTH, XMT>(in, lt_in, lt_in + 16 * (xtile - wave) * D.cinp,
+                                                                        w, lane, acc, dma);
   }
   // ---- epilogue: (+skip) -> ReLU -> zero the gap pixels -> LDS (or the hand-off tensor)
   // A layer that stores to global memory here (skip fragments, the hand-off tensor) waits NOW for the next packet's
@@ -422,7 +445,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
                                              (G::skip_unit(L) + t * MT + mt) * kThreads * 16, 0);
     const int co0 = 16 * mt + 4 * kq;
     if constexpr (!kLast) {
-      float* p = out + px * D.coutp + co0;
+      float* p = out + lt_out + (t < NR ? 128 * t : 16 * (xtile - wave)) * D.coutp + 16 * mt;
       if (16 * mt + 16 <= D.coutp || co0 + 1 < D.coutp) *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
       if (16 * mt + 16 <= D.coutp || co0 + 3 < D.coutp) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z, v.w};
     } else if (ok && px < G::kNPX && f < kF && t0 + fr < P.T) {
@@ -493,7 +516,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
 
 template <class N, int L>
 __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu_buffer_rsrc_t scratch, int& wcur, XStage& xst,
-                                           int tile, int wave, int lane, int tid, int utt, int t0) {
+                                           int tile, int wave, int lane, int tid, int utt, int t0, const LaneTab<N>& LT) {
   using G = Geo<N>;
   if constexpr (L < N::kLayers) {
     float* const wbase = lds + G::kWOff;
@@ -504,17 +527,17 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
     if constexpr (L == N::kLayers - 1) xst = xstage_load<N>(P, tile + gridDim.x, tid);
     const float* w = wbase + wcur * G::kWRegion;
     if constexpr (L > 0 && G::MT(L) == 2 && G::kSplitExtra) {
-      if (wave < G::kExtra) run_layer<N, L, 1, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
-      else if (wave < 2 * G::kExtra) run_layer<N, L, 1, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
-      else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
+      if (wave < G::kExtra) run_layer<N, L, 1, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
+      else if (wave < 2 * G::kExtra) run_layer<N, L, 1, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
+      else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
     } else {
-      if (wave < G::kExtra) run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
-      else run_layer<N, L, 0, -1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma);
+      if (wave < G::kExtra) run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
+      else run_layer<N, L, 0, -1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
     }
     wcur ^= 1;
     if constexpr (N::layer[L].saves_skip || L == N::kLayers - 1) __syncthreads();
     else layer_end_sync();
-    run_layers<N, L + 1>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0);
+    run_layers<N, L + 1>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0, LT);
   }
 }
 
@@ -534,13 +557,14 @@ __global__ __launch_bounds__(kThreads) void fused_chain_kernel(Params P) {
   XStage xst = xstage_load<N>(P, blockIdx.x, tid);
   const __amdgpu_buffer_rsrc_t scratch = __builtin_amdgcn_make_buffer_rsrc(
       P.scratch + (size_t)blockIdx.x * G::kScratchFloatsPerWg, 0, (int)(G::kScratchFloatsPerWg * 4), 0x00020000);
+  const LaneTab<N> LT = make_lane_tab<N>(wave, lane);
   layer_end_sync();
   for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
     const int utt = tile / P.tiles_per_utt;
     const int t0 = (tile - utt * P.tiles_per_utt) * N::kTF;
     xstage_store<N>(xst, lds + G::kX0Off, tid);   // buffer Y is dead: its last reader finished before the last barrier
     __syncthreads();
-    run_layers<N, 0>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0);
+    run_layers<N, 0>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0, LT);
   }
 }
 
