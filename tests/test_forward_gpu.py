@@ -170,6 +170,26 @@ def test_full_size_config2_bf16_sampled_against_its_emulation(built, capsys):
     assert torch.equal(m(x[10:12].contiguous()), y[10:12])      # utterances are independent, launches deterministic
 
 
+@pytest.mark.parametrize("net_work,dtype,batch", [("FullyCNN", "bfloat16", 64), ("FullyCNNV2", "bfloat16", 64),
+                                                  ("FullyCNNV2", "float32", 128), ("FullyCNNV3", "float32", 128)])
+def test_full_batch_and_random_slices_bit_for_bit(net_work, dtype, batch, built):
+    """Race screen at full occupancy (the bf16 kernels run two workgroups per CU): rerunning the batch, and rerunning
+    random slices of it (other tile -> workgroup maps, other neighbours in LDS), reproduces every mask bit for bit.
+    (An experimental restructuring of the bf16 epilogue that was semantically the same code failed exactly this on V2.)"""
+    import torch
+    from fullycnnspeechenhancement_amd import build_model
+    m = build_model(net_work, False, weights=rced_np.make_weights(net_work, seed=42), dtype=dtype)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn((batch, 512, 129, 1), generator=g, device="cuda").abs_()
+    y = m(x).clone()
+    rng = np.random.default_rng(0)
+    for _ in range(8):
+        assert torch.equal(m(x), y)
+        a = int(rng.integers(0, batch - 1))
+        b = int(rng.integers(a + 1, min(batch, a + 9) + 1))
+        assert torch.equal(m(x[a:b].contiguous()), y[a:b]), (a, b)
+
+
 def test_bf16_is_refused_for_cr_ced(built):
     from fullycnnspeechenhancement_amd import build_model
     w, _ = load_golden("v3")
