@@ -30,13 +30,18 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc_lane, float* lds_dst
 // The same with a wave-uniform base address in SGPRs and ONE 32-bit per-lane byte offset (lane * 16 for every chunk of
 // every packet): a 64-bit per-lane address per chunk cost a v_lshl_add_u64 per transfer and VGPR pairs that stayed live
 // across the tile loop (the bf16 R-CED kernel, capped at 128 VGPRs for two workgroups per CU, spilled them).
+// HAZARD: hipcc pads no wait states for instructions inside inline asm.  The SGPR base may have been written by a VALU
+// instruction right in front of the statement (v_readlane of a spilled SGPR, v_readfirstlane), and "VALU writes SGPR ->
+// VMEM reads that SGPR" needs 5 wait states on this part: the two s_mov + s_nop 3 provide 6 (and cover the 1 wait state
+// "SALU writes M0 -> LDS-DMA").  Without them the transfer could read a stale base -- seen as run-to-run differences of
+// the bf16 R-CED V2 kernel in some builds, never as a fault.
 __device__ __forceinline__ void lds_dma16s(const float* gsrc_wave, unsigned lane_byte_off, float* lds_dst_wave) {
   const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_dst_wave;
   unsigned saved;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
+      "s_nop 3\n\t"
       "global_load_lds_dwordx4 %1, %2\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(saved)
