@@ -441,8 +441,11 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     v = relu4(v);
     if (masked && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (D.saves_skip)
+    {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), scratch, tid * 16,
                                              (G::skip_unit(L) + t * MT + mt) * kThreads * 16, 0);
+      store_wait_state();
+    }
     const int co0 = 16 * mt + 4 * kq;
     if constexpr (!kLast) {
       float* p = out + lt_out + (t < NR ? 128 * t : 16 * (xtile - wave)) * D.coutp + 16 * mt;
@@ -503,8 +506,11 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
         }
       }
       if constexpr (D.saves_skip)
+      {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{vv[0], vv[1], vv[2], vv[3]}), scratch, tid * 16,
                                                (G::skip_unit_rem(L) + jj) * kThreads * 16, 0);
+        store_wait_state();
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = 4 * kq + j, px = pb + i / R;

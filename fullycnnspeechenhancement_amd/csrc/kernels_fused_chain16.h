@@ -229,8 +229,11 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
       const s16x4 h = to_bf16x4(v);                       // the layer's output IS this rounded value
       if constexpr (D.saves_skip || kLast) v = from_bf16x4(h);
       if constexpr (D.saves_skip)
+      {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), scratch, tid * 16,
                                                (G::skip_unit(L) + t * MT + mt) * kThreads * 16, 0);
+        store_wait_state();
+      }
       const int co0 = 16 * mt + 4 * kq;
       if constexpr (!kLast) {
         if (co0 < cpo) *reinterpret_cast<s16x4*>(out + px * cpo + co0) = h;

@@ -1061,7 +1061,10 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
     for (int w = 1; w < kWaves; ++w) v += lds_ld<f32x4>(scr, w * 1024);
     v += f32x4{P.fin_bias, P.fin_bias, P.fin_bias, P.fin_bias};
     const int fi = n >> 2, f0 = 16 * (4 * wave + (n & 3)) + 4 * kq;   // rows 4kq..4kq+3 = bins f0..f0+3 of frame fi
-    if (fi < nfr) *reinterpret_cast<f32x4_u*>(yt + fi * kF + f0) = v;
+    if (fi < nfr) {
+      *reinterpret_cast<f32x4_u*>(yt + fi * kF + f0) = v;
+      store_wait_state();   // see lds_dma.h
+    }
   } else if (wave == 3) {
     // The H image lay over B18, whose gap pixels (4 per frame, 18 channels) every layer relies on being zero and no
     // layer ever writes: put the zeros back (every wave finished its H reads before the barrier above).
