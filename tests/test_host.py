@@ -104,3 +104,27 @@ def test_package_synthetic_weights_match_the_oracle_generator():
         assert set(a) == set(b)
         for k in a:
             assert a[k].dtype == np.float32 and np.array_equal(a[k], b[k]), k
+
+
+def test_compiled_kernels_are_free_of_the_two_measured_hazard_sequences(built):
+    """tools/isa_lint.py over the gfx950 code of every object of the library: (A) VALU writes VCC / vector-memory
+    instruction / SALU reads VCC, (B) an SGPR-base LDS-DMA closer than 5 wait states behind the VALU write of its base.
+    Both compile without complaint and both misbehaved on MI355X; the sources avoid them with explicit wait
+    states, and this test notices when a new build brings one back.  Also checks that the lint itself still sees them."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import glob
+    import isa_lint
+    bad_a = ["v_cmp_gt_i32_e32 vcc, 24, v22", "buffer_store_dwordx4 v[30:33], v24, s[44:47], s78 offen",
+             "s_and_saveexec_b64 s[0:1], vcc"]
+    assert [f[0] for f in isa_lint.lint_function("f", bad_a)] == ["A"]
+    assert not isa_lint.lint_function("f", bad_a[:2] + ["s_nop 0"] + bad_a[2:])
+    bad_b = ["v_readlane_b32 s21, v95, 3", "s_mov_b32 s16, m0", "s_mov_b32 m0, s3", "s_nop 0",
+             "global_load_lds_dwordx4 v71, s[20:21]"]
+    assert [f[0] for f in isa_lint.lint_function("f", bad_b)] == ["B"]
+    assert not isa_lint.lint_function("f", bad_b[:3] + ["s_nop 3"] + bad_b[4:])
+    objs = sorted(glob.glob(os.path.join(isa_lint.ROOT, "build", "*.o")))
+    assert len(objs) >= 5, "the library's objects (build/*.o) exist after __graft_entry__.build()"
+    found, nfn, nins = isa_lint.lint(objs)
+    assert nfn > 100 and nins > 100000, (nfn, nins)
+    assert not found, found[:3]
