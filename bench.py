@@ -14,7 +14,7 @@ A "step" = one forward of the hot path (model_utils/model.py:93-96 via the C ABI
 B x T x 129 synthetic magnitude frames already resident in HBM.
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel vs the fp32 MFMA/VALU peak, HIP events inside
 the timed region), `cpu_baseline` (the CPU restatement timed on this box's cores) and, at N = 1, `secondary`
-(BASELINE configs 2 and 5 under the same clock).
+(BASELINE configs 2, 5 and 1, R-CED V1 / V2 in fp32 at config 3's shape, and the PCM -> PCM pipeline, under the same clock).
 """
 
 import argparse
@@ -83,25 +83,32 @@ def launch_ranks(args):
 
 def cpu_baseline(variant, weights, frames_t, budget_s):
     """The oracle's torch-CPU fp32 restatement (kind "port": TF 1.14 itself cannot run here) on a
-    bounded sample of the same workload: batches of 8 utterances x T frames until ~budget_s.  oneDNN does
-    not always scale to every hardware thread, so a short probe picks the fastest thread count first."""
+    bounded sample of the same workload: batches of 8 or 32 utterances x T frames until ~budget_s.  oneDNN does
+    not always scale to every hardware thread, so a short probe over (batch, threads) picks the fastest pair first;
+    the probe table is part of `sample`."""
     import torch
     from oracle import rced_np, torch_ref
     ref = torch_ref.TorchRef(NET_WORK[variant], weights)
-    x = torch.from_numpy(rced_np.make_input(8, frames_t, seed=1234))
+    x32 = torch.from_numpy(rced_np.make_input(32, frames_t, seed=1234))
     ncpu = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
     cands = sorted({default_threads} | {c for c in (8, 16, 32, 64, 128, 256) if c <= ncpu})
-    probe, best = {}, default_threads
-    for c in cands:
-        torch.set_num_threads(c)
-        ref(x[:1])
-        t0 = time.perf_counter()
-        ref(x)
-        probe[c] = x.shape[0] * x.shape[1] / (time.perf_counter() - t0)
-        if probe[c] > probe.get(best, 0):
-            best = c
-    torch.set_num_threads(best)
+    probe, best = {}, (8, default_threads)
+    for nb in (8, 32):
+        x = x32[:nb]
+        for c in cands:
+            if nb == 32 and c < 16 and len(cands) > 2:
+                continue              # a big batch on few threads only costs probe time
+            torch.set_num_threads(c)
+            ref(x[:1])
+            t0 = time.perf_counter()
+            ref(x)
+            probe[(nb, c)] = x.shape[0] * x.shape[1] / (time.perf_counter() - t0)
+            if probe[(nb, c)] > probe.get(best, 0):
+                best = (nb, c)
+    nb, threads = best
+    x = x32[:nb]
+    torch.set_num_threads(threads)
     ref(x[:1])  # warm-up (oneDNN primitive creation)
     done, t0 = 0, time.perf_counter()
     while True:
@@ -111,34 +118,39 @@ def cpu_baseline(variant, weights, frames_t, budget_s):
         if el >= budget_s:
             break
     torch.set_num_threads(default_threads)
-    return {"value": done / el, "unit": "frames/s", "cores": int(best), "kind": "port",
-            "sample": "torch-CPU fp32 restatement (oracle/torch_ref.py), %d frames = %d batches of [8,%d,129,1] in %.1f s "
-                      "on %d threads (fastest of %s); host has %d logical cpus"
-                      % (done, done // (8 * frames_t), frames_t, el, best, sorted(probe), ncpu)}
+    table = ", ".join("b%d/t%d: %.0f" % (k[0], k[1], v) for k, v in sorted(probe.items()))
+    return {"value": done / el, "unit": "frames/s", "cores": int(threads), "kind": "port",
+            "sample": "torch-CPU fp32 restatement (oracle/torch_ref.py), %d frames = %d batches of [%d,%d,129,1] in %.1f s "
+                      "on %d threads; probe (batch/threads: frames/s): %s; host has %d logical cpus"
+                      % (done, done // (nb * frames_t), nb, frames_t, el, threads, table, ncpu)}
 
 
-def pmc_record(name, kernel_hash):
-    """A committed rocprofv3 PMC capture (profiles/<name>), or None when it was taken on other kernel code than the
-    one being run: every capture records the hash of the sources that define the kernels and their packed-weight /
-    LDS layouts (__graft_entry__.forward_kernel_hash / train_kernel_hash)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", name)) as fh:
-            d = json.load(fh)
-        return d if d.get("kernel_hash") == kernel_hash else None
-    except Exception:
-        return None
+def pmc_record(suffix, kernel_hash):
+    """The newest committed rocprofv3 PMC capture profiles/rNN_<suffix> that was taken on exactly the kernel code being
+    run, or (None, None): every capture records the hash of the sources that define the kernels and their packed-weight /
+    LDS layouts (__graft_entry__.forward_kernel_hash / train_kernel_hash); a stale capture is never attached."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)), reverse=True):
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+        except Exception:
+            continue
+        if d.get("kernel_hash") == kernel_hash:
+            return d, "profiles/" + os.path.basename(path)
+    return None, None
 
 
 def pmc_traffic(ge, variant, batch, frames, kernel):
     """HBM bytes per launch of the dominant kernel (FETCH_SIZE + WRITE_SIZE, separate passes, corrected as
     MI355X_MICROARCH.md prescribes; collected by tools/profile.sh on this same command)."""
-    d = pmc_record("r02_pmc_traffic.json", ge.forward_kernel_hash())
+    d, src = pmc_record("pmc_traffic.json", ge.forward_kernel_hash())
     if not d:
-        return None, "no PMC capture for this kernel build (profiles/r02_pmc_traffic.json records another kernel_hash)"
+        return None, "no PMC capture for this kernel build (every profiles/r*_pmc_traffic.json records another kernel_hash)"
     wl = d["workload"]
     key = {"rced_fused": "fused_v3_kernel", "rced_final_gemm": "final_gemm_kernel"}.get(kernel)
     if key in d and (wl["variant"], wl["batch"], wl["frames"]) == (variant, batch, frames):
-        return 1024 * (d[key]["fetch_kib"] + d[key]["write_kib"]), "profiles/r02_pmc_traffic.json (kernel_hash %s)" % d["kernel_hash"]
+        return 1024 * (d[key]["fetch_kib"] + d[key]["write_kib"]), "%s (kernel_hash %s)" % (src, d["kernel_hash"])
     return None, "PMC capture is for another workload"
 
 
@@ -236,13 +248,36 @@ def from_root_line(args, torch, dist, model, spec, world, rank, local_rank, B, T
     tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     el = float(tmax.item())
+    # compute-free passes: what the links alone take per direction, so that the overlap shows as
+    # ms_per_step ~ max(compute, transfer) instead of being inferred
+    probe = {}
+    for direction in ("scatter", "gather"):
+        try:
+            eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks, direction=direction)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks, direction=direction)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tp = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            probe[direction + "_only_ms"] = 1e3 * float(tp.item()) / 3
+        except Exception as e:
+            probe[direction + "_only_ms"] = "%s: %s" % (type(e).__name__, e)
+    eng.close()
     return {"value": world * B * T * args.from_root_steps / el, "unit": "frames/s",
             "ms_per_step": 1e3 * el / args.from_root_steps, "steps": args.from_root_steps,
             "chunks": args.from_root_chunks, "global_batch": world * B,
             "bytes_per_peer_each_way": B * T * spec.FEATURE_DIM * 4,
+            "transfer_only": probe,
             "note": "BatchShardedForward.forward_from_root: rank 0 holds [N*B,T,129,1] in HBM, scatters batch "
                     "slices over RCCL send/recv (one peer per xGMI link), every rank computes, masks gather back "
-                    "to rank 0; chunked so that transfer overlaps compute.  Reported beside `value`, not as it."}
+                    "to rank 0; chunked so that transfer overlaps compute.  Reported beside `value`, not as it.  "
+                    "transfer_only: the same call with no compute, one direction at a time (3 calls each): with the "
+                    "overlap working, ms_per_step ~ max(resident ms_per_step, scatter_only_ms, gather_only_ms) + "
+                    "one chunk's transfer at each end."}
 
 
 def secondary_config2(torch, build_model, spec, _lib, _weights, local_rank):
@@ -287,7 +322,7 @@ def secondary_config5(torch, ge, FullyCNNTrainer, spec, _weights, local_rank):
     ms = 1e3 * elapsed / steps
     flops = 3 * spec.flops_per_frame(3) * B * T                 # forward + dgrad + wgrad, nominal
     free, total = torch.cuda.mem_get_info()
-    pmc = pmc_record("r02_pmc_train.json", ge.train_kernel_hash())
+    pmc, pmc_src = pmc_record("pmc_train.json", ge.train_kernel_hash())
     out = {"config": "CR-CED V3 training step (fwd+bwd+Adam), batch 256, 129x512, fp32 (BASELINE configs[4])",
            "metric": "training step time", "value": ms, "unit": "ms/step", "higher_is_better": False,
            "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "f32",
@@ -297,10 +332,151 @@ def secondary_config5(torch, ge, FullyCNNTrainer, spec, _weights, local_rank):
                         "note": "3 x forward FLOPs (nominal) over wall time per step; the step is layer-by-layer and also "
                                 "HBM-heavy (hbm_gb_per_step)"},
            "hbm_gb_per_step": (pmc or {}).get("hbm_gb_per_step"),
-           "hbm_note": ("rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE summed over the step's kernels, profiles/r02_pmc_train.json"
+           "hbm_note": ("rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE summed over the step's kernels, %s" % pmc_src
                         if pmc else "no PMC capture for this kernel build"),
            "loss_first": losses[0], "loss_last": losses[-1], "device_mem_gb": (total - free) / 1e9}
     tr.close()
+    return out
+
+
+def secondary_rced_fp32(torch, build_model, spec, _lib, _weights, local_rank, variant):
+    """R-CED V1 / V2 forward in fp32 at config 3's shape (batch 256, 129x512; model_utils/model.py:6-61): the other two
+    nets of the path under the driver's clock, with one roofline entry per kernel."""
+    B, T, steps, warmup = 256, 512, 30, 5
+    name = NET_WORK[variant]
+    w = _weights.synthetic_weights(variant, seed=42)
+    model = build_model(name, False, weights=w, device=local_rank)
+    elapsed, times, _ = forward_line(None, torch, model, spec, _lib, variant, "f32", B, T, steps, warmup, 1, 0, True)
+    ms = 1e3 * elapsed / steps
+    flops = spec.flops_per_frame(variant)
+    final = 2 * spec.FEATURE_DIM * sum(l.kh * l.kw * l.cin * l.cout for l in spec.layers(variant)[-1:])
+    per_kernel = {}
+    for k, (tot, launches) in times.items():
+        if not launches:
+            continue
+        kf = final if k == "rced_final_gemm" else flops - final
+        ach = kf * B * T * steps / (tot * 1e-3) / 1e12
+        per_kernel[k] = {"avg_launch_ms": tot / launches, "launches": launches, "flop_per_frame": kf,
+                         "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS}
+    out = {"config": "%s (%d-layer R-CED) forward, batch 256, 129x512, fp32 (config 3's shape; model.py:%s)"
+                     % (name, len(spec.layers(variant)), "6-29" if variant == 1 else "32-61"),
+           "metric": "spectrogram frames/sec (%s fwd, 129-bin)" % name, "value": B * T * steps / elapsed, "unit": "frames/s",
+           "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "f32",
+           "tflops": flops * B * T / (ms * 1e-3) / 1e12,
+           "roofline": {"bound": "mfma", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "achieved": flops * B * T / (ms * 1e-3) / 1e12,
+                        "frac": flops * B * T / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                        "note": "whole forward over wall time per step; per kernel (HIP events on the launch stream) below"},
+           "kernels": per_kernel}
+    model.close()
+    return out
+
+
+def secondary_config1_latency(torch, build_model, spec, _lib, _weights, local_rank):
+    """BASELINE configs[0]: R-CED V1 forward on ONE 129x256 spectrogram the way infer.py calls it (infer.py:62-65):
+    numpy in, numpy out through rced_forward_host -- a latency, not a throughput."""
+    import numpy as np
+    T, reps = 256, 200
+    model = build_model("FullyCNN", False, weights=_weights.synthetic_weights(1, seed=42), device=local_rank)
+    xh = synthetic_magnitudes((1, T, spec.FEATURE_DIM, 1), 1234)
+    for _ in range(10):
+        yh = model(xh)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        yh = model(xh)
+    host_ms = 1e3 * (time.perf_counter() - t0) / reps
+    xd = torch.from_numpy(xh).cuda()
+    for _ in range(10):
+        model(xd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        model(xd)
+    torch.cuda.synchronize()
+    dev_ms = 1e3 * (time.perf_counter() - t0) / reps
+    model.close()
+    return {"config": "R-CED V1 (10-layer) forward on one 129x256 spectrogram, numpy in -> numpy out (BASELINE configs[0], "
+                      "infer.py:62-65)",
+            "metric": "latency per utterance", "value": host_ms, "unit": "ms", "higher_is_better": False,
+            "ms_per_step": host_ms, "steps": reps, "dtype": "f32", "frames_per_s": T / (host_ms * 1e-3),
+            "device_resident_ms": dev_ms, "finite": bool(np.isfinite(yh).all()),
+            "note": "host path = H2D + fused kernel + final GEMM + D2H + synchronise per call; device_resident_ms = the two "
+                    "launches alone, back to back (one tile's trip through all layers: launch-bound, no roofline claim)"}
+
+
+def secondary_pipeline(torch, build_model, spec, _lib, _weights, local_rank, cpu_seconds):
+    """PCM -> STFT -> CR-CED -> ISTFT -> PCM at config-3 scale (infer.py:54-71 as a batch; data_utils/audio_feature.py:22-44,
+    model_utils/utils.py:171-183): rced_stft / rced_forward / rced_istft device-resident, the three kernel times, and the
+    CPU leg for the two audio stages (the reference's own numpy algorithm, oracle/audio_np) beside them."""
+    import numpy as np
+    from fullycnnspeechenhancement_amd import audio
+    N, T, reps = 256, 512, 10
+    L = (T - 1) * 128 + 256
+    rng = np.random.default_rng(4321)
+    pcm_h = (rng.standard_normal((N, L), dtype=np.float32) * np.float32(0.1))
+    pcm = torch.from_numpy(pcm_h).cuda()
+    model = build_model("FullyCNNV3", False, weights=_weights.synthetic_weights(3, seed=42), device=local_rank)
+    model.reserve(N, T)
+
+    def timed(fn):
+        for _ in range(3):
+            out = fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # the kernels run on torch's current stream
+        a.record()
+        for _ in range(reps):
+            out = fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps, out
+
+    t_stft, (mag, ph) = timed(lambda: audio.stft_batch(pcm))
+    assert int(mag.shape[1]) == T
+    t_cnn, pred = timed(lambda: model(mag))
+    t_istft, wav = timed(lambda: audio.istft_batch(pred, ph))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m2, p2 = audio.stft_batch(pcm)
+        wav = audio.istft_batch(model(m2), p2)
+    torch.cuda.synchronize()
+    whole = 1e3 * (time.perf_counter() - t0) / reps
+    frames = N * T
+    flop_dft = 2 * 256 * 258
+    out = {"config": "PCM -> STFT -> CR-CED V3 -> ISTFT -> PCM, 256 utterances x 65,664 samples (512 frames), device-resident "
+                     "(SURVEY 8(f) N1 + a5 + N2; infer.py:54-71)",
+           "metric": "spectrogram frames/sec through the whole pipeline", "value": frames / (whole * 1e-3), "unit": "frames/s",
+           "ms_per_step": whole, "steps": reps, "dtype": "f32",
+           "kernels_ms": {"rced_stft": t_stft, "rced_forward": t_cnn, "rced_istft": t_istft},
+           "stft": {"tflops": frames * flop_dft / t_stft / 1e9, "frac_fp32_peak": frames * flop_dft / t_stft / 1e9 / FP32_PEAK_TFLOPS,
+                    "algorithmic_gbps": (N * L * 4 + frames * 129 * 12) / t_stft / 1e6,
+                    "frac_hbm_8tbs": (N * L * 4 + frames * 129 * 12) / t_stft / 1e6 / 8000.0},
+           "istft": {"tflops": frames * flop_dft / t_istft / 1e9, "frac_fp32_peak": frames * flop_dft / t_istft / 1e9 / FP32_PEAK_TFLOPS,
+                     "algorithmic_gbps": (frames * 129 * 12 + N * (T + 1) * 128 * 4) / t_istft / 1e6,
+                     "frac_hbm_8tbs": (frames * 129 * 12 + N * (T + 1) * 128 * 4) / t_istft / 1e6 / 8000.0},
+           "finite": bool(torch.isfinite(wav).all()),
+           "note": "dense-DFT GEMMs (K = 256 / 258) on the fp32 MFMA: bounded by neither roofline at this size (0.3 ms "
+                   "kernels); reported against both"}
+    if cpu_seconds > 0:
+        from oracle import audio_np
+        done, t_st, t_is = 0, 0.0, 0.0
+        t_begin = time.perf_counter()
+        while time.perf_counter() - t_begin < cpu_seconds and done < N:
+            t0 = time.perf_counter()
+            mg, phs = audio_np.stft(pcm_h[done])
+            t1 = time.perf_counter()
+            audio_np.rebuild(mg, phs, nfft=512)
+            t2 = time.perf_counter()
+            t_st += t1 - t0
+            t_is += t2 - t1
+            done += 1
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "unit": "frames/s",
+                               "stft": done * T / t_st, "istft": done * T / t_is, "value": done * T / (t_st + t_is),
+                               "sample": "oracle/audio_np.py (numpy restatement of audio_feature.py:22-44 and utils.py:171-183, "
+                                         "pinned to the reference's own outputs; its de-emphasis is the reference's per-sample "
+                                         "Python loop) on %d utterances of %d samples, one thread: %.2f s STFT, %.2f s rebuild"
+                                         % (done, L, t_st, t_is)}
+    model.close()
     return out
 
 
@@ -322,6 +498,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1:   # before anything can fail: the launcher test reads this line (each rank prints its own)
+        print("[bench] rank %d of WORLD_SIZE=%d started" % (rank, world), file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     if world != max(args.gpus, 1):
@@ -420,7 +598,12 @@ def main():
         if world == 1 and not args.no_secondary:
             sec = []
             for fn, a in ((secondary_config2, (torch, build_model, spec, _lib, _weights, local_rank)),
-                          (secondary_config5, (torch, ge, FullyCNNTrainer, spec, _weights, local_rank))):
+                          (secondary_config5, (torch, ge, FullyCNNTrainer, spec, _weights, local_rank)),
+                          (secondary_rced_fp32, (torch, build_model, spec, _lib, _weights, local_rank, 1)),
+                          (secondary_rced_fp32, (torch, build_model, spec, _lib, _weights, local_rank, 2)),
+                          (secondary_config1_latency, (torch, build_model, spec, _lib, _weights, local_rank)),
+                          (secondary_pipeline, (torch, build_model, spec, _lib, _weights, local_rank,
+                                                min(args.cpu_seconds, 6.0)))):
                 try:
                     sec.append(fn(*a))
                 except Exception as e:      # a failing secondary must not take the headline line down with it

@@ -28,11 +28,13 @@ SYMBOLS = {
     "rced_create": (ctypes.c_int, [ctypes.c_int, _c_float_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(_vp)]),
     "rced_destroy": (None, [_vp]),
     "rced_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "rced_check": (ctypes.c_int, [_vp]),
     "rced_forward_host": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     "rced_reserve": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "rced_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
     "rced_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _c_int_p]),
     "rced_conv_bn_relu": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 9 + [_vp]),
+    "rced_conv_bn_relu_train": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 8 + [_vp, ctypes.c_int, _vp]),
     "rced_stft_num_frames": (ctypes.c_int, [ctypes.c_int]),
     "rced_stft": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
     "rced_istft": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),

@@ -513,6 +513,11 @@ int fused_set_option(rced_model* m, const char* key, int value) {
     m->fused->bf16 = value != 0;
     return RCED_OK;
   }
+  if (!strcmp(key, "inject_handoff_error")) {   // test hook: write `value` into the sticky error word as the kernel would
+    if (!m->fused->err_host) return rced_fail(RCED_ERR_ARG, "this variant's fused kernel has no hand-off error word");
+    *reinterpret_cast<volatile unsigned*>(m->fused->err_host) = (unsigned)value;
+    return RCED_OK;
+  }
   return RCED_ERR_ARG;
 }
 

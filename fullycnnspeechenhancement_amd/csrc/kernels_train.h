@@ -93,6 +93,18 @@ __global__ void bn_stats_finish(const double* __restrict__ sums, double P, int C
   moving_var[c] = (float)(momentum * (double)moving_var[c] + (1.0 - momentum) * unbiased);
 }
 
+// (mean, biased variance) of the batch from (sum z, sum z^2): out[c] = mean, out[C + c] = variance -- what TF's UPDATE_OPS
+// would fold into the moving statistics (rced_conv_bn_relu_train hands them to the caller).
+__global__ void batch_mean_var(const double* __restrict__ sums, double P, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[2 * c] / P;
+  double var = sums[2 * c + 1] / P - m * m;
+  if (var < 0.0) var = 0.0;
+  out[c] = (float)m;
+  out[C + c] = (float)var;
+}
+
 // ---- forward elementwise: out = act(gamma*(z-mu)*rstd + beta + skip_pre) + skip_post -------------
 __global__ __launch_bounds__(kThreads) void bn_act_fwd(const float* __restrict__ z, const float* __restrict__ mu,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,

@@ -540,6 +540,11 @@ int rced_conv_bn_relu(const float* x, float* y, const float* kernel, const float
   return rc;
 }
 
+int rced_check(rced_model* m) {
+  if (!m) return fail(RCED_ERR_ARG, "model is NULL");
+  return fused_check(m);   // reads pinned host memory: no device call, no synchronisation
+}
+
 float rced_last_kernel_ms(rced_model* m) {
   if (!m) return -1.f;
   return m->prof_dominant_ms(nullptr, nullptr);

@@ -74,6 +74,7 @@ struct rced_trainer {
   bool det = true;             // RCED_TRAIN_DET=0: weight gradients by fp32 atomics (the round-1 behaviour; not reproducible bit for bit)
   float* wpart = nullptr;      // per-wave slices of the wgrad kernels' partial sums (deterministic mode; tmd::WgDet)
   size_t wpart_floats = 0;
+  int wg_error = 0;            // tmd::wg_launch could not grow wpart: the step fails instead of using atomics
   std::vector<char> virt;      // virt[id]: tensor id (= relu(bn(z[id-1]))) is never materialised; its consumer rebuilds it
   float* pk_first = nullptr;   // A fragments of the 8xk first layer (rebuilt every step)
   float* pk_fin = nullptr, *pk_fin_bwd = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
@@ -575,11 +576,16 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
   if (int rc = ensure_acts(t, P)) return rc;
   // deterministic weight gradients: the wgrad launchers of this thread write slices into t->wpart (tmd::WgDet)
   struct WgScope {
-    explicit WgScope(rced_trainer* tr) { rced::tmd::g_wgdet = rced::tmd::WgDet{tr->det ? tr->wpart : nullptr, tr->wpart_floats}; }
+    explicit WgScope(rced_trainer* tr) {
+      tr->wg_error = 0;
+      rced::tmd::g_wgdet = tr->det ? rced::tmd::WgDet{&tr->wpart, &tr->wpart_floats, &tr->wg_error} : rced::tmd::WgDet{};
+    }
     ~WgScope() { rced::tmd::g_wgdet = rced::tmd::WgDet{}; }
   };
   if (t->det && !forward_only && !t->wpart) {
-    t->wpart_floats = (size_t)16 << 20;   // 64 MB: 4096 slices x up to 4096 floats (largest: 2048 x 2732, CR-CED 18 -> 30)
+    // start value: 64 MB = 4096 slices x up to 4096 floats (largest of CR-CED: 2048 x 2732, the 18 -> 30 layer); a launcher
+    // whose occupancy-sized grid needs more grows it (tmd::wg_launch)
+    t->wpart_floats = (size_t)16 << 20;
     HIP_TRY(hipMalloc(&t->wpart, t->wpart_floats * sizeof(float)));
   }
   const WgScope wg_scope(t);
@@ -856,7 +862,13 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       }
     }
   }
+  if (t->wg_error) return rced_fail(RCED_ERR_ALLOC, "deterministic weight gradients: the per-wave slice buffer could not be grown");
   // ---- Adam (TF form), trainer.py:175-179
+  // global_step: the reference fetches it in the same sess.run as train_op (trainer.py:186-191); TF1 orders a read and an
+  // assign_add in one run only through control dependencies, and slim.learning.create_train_op makes train_op =
+  // (increment global_step, then return the loss), so the fetched value is unordered against the increment in principle.
+  // This library returns the POST-increment value, deterministically: after the first step train_step returns 1 and
+  // the loop's next learning rate is noam(1) (trainer.py:215, step = global_step + 1 = 2).  See DESIGN.md 3.6.
   t->global_step += 1;
   const double tt = (double)t->global_step;
   const float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)kAdamB2, tt)) / (1.0 - std::pow((double)kAdamB1, tt)));
@@ -883,6 +895,57 @@ int rced_train_step(rced_trainer* t, const float* x_dev, const float* y_dev, int
 int rced_train_forward(rced_trainer* t, const float* x_dev, float* pred_dev, int N, int T, void* stream) {
   if (!pred_dev) return rced_fail(RCED_ERR_ARG, "bad batch");
   return train_run(t, x_dev, nullptr, pred_dev, N, T, 0.f, nullptr, stream);
+}
+
+// module.py:11-34 with is_training=True, as ONE op on device pointers: z = conv(x) + bias; BatchNorm with the statistics of
+// this batch (mean and biased variance over N*T*F, eps 1e-3 -- tf.layers.batch_normalization(training=True)); + skip; ReLU.
+// The layerwise kernels of the training step (direct convolution, fp64 channel sums), not the MFMA path: a single op has
+// no packed-weight state to keep between calls.
+int rced_conv_bn_relu_train(const float* x, float* y, const float* kernel, const float* bias, const float* gamma_beta,
+                            const float* skip_input, int use_act, int N, int T, int F, int cin, int cout, int kh, int kw,
+                            float* batch_mean_var_out, int device, void* stream) {
+  if (N < 0 || T < 0 || F <= 0 || cin <= 0 || cout <= 0 || cout > train::kThreads || kh <= 0 || kw <= 0)
+    return rced_fail(RCED_ERR_ARG, "bad shape");
+  if (N == 0 || T == 0) return RCED_OK;
+  if (!x || !y || !kernel || !bias || !gamma_beta) return rced_fail(RCED_ERR_ARG, "null pointer");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return rced_fail(RCED_ERR_HIP, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return rced_fail(RCED_ERR_ARG, "device %d out of range", device);
+  DeviceGuard g(device);
+  if (!g.ok) return rced_fail(RCED_ERR_HIP, "hipSetDevice(%d) failed", device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int frames = N * T, K = kh * kw * cin, cout4 = (cout + 3) & ~3;
+  const size_t P = (size_t)frames * F, n = P * cout;
+  // one scratch allocation: z | repacked kernel | bias4 | mu | rstd | two dummies for the moving statistics | partial sums | sums
+  const size_t fl = n + (size_t)K * cout4 + cout4 + 4 * (size_t)cout;
+  const size_t dbl = (size_t)kReduceGrid * cout * 2 + 2 * (size_t)cout;
+  float* buf = nullptr;
+  HIP_TRY(hipMalloc(&buf, ((fl + 1) & ~(size_t)1) * sizeof(float) + dbl * sizeof(double)));
+  float *z = buf, *wf = z + n, *b4 = wf + (size_t)K * cout4, *mu = b4 + cout4, *rstd = mu + cout, *mm = rstd + cout, *mv = mm + cout;
+  double* part = reinterpret_cast<double*>(buf + ((fl + 1) & ~(size_t)1));
+  double* sums = part + (size_t)kReduceGrid * cout * 2;
+  int rc = RCED_OK;
+  hipLaunchKernelGGL(train::repack_fwd, dim3((K * cout4 + 255) / 256), dim3(256), 0, st, kernel, K, cout, cout4, wf);
+  hipLaunchKernelGGL(train::repack_fwd, dim3(1), dim3(256), 0, st, bias, 1, cout, cout4, b4);
+  rc = launch_conv(x, z, wf, b4, nullptr, frames, T, F, cin, cout, cout4, kh, kw, (kh - 1) / 2, (kw - 1) / 2, st);
+  if (rc == RCED_OK) {
+    hipLaunchKernelGGL(train::chan_reduce, dim3(kReduceGrid), dim3(train::kThreads), 0, st, (const float*)z, (const float*)z,
+                       (const float*)nullptr, (const float*)nullptr, P, cout, part);
+    hipLaunchKernelGGL(train::reduce_finish, dim3(2 * cout), dim3(train::kThreads), 0, st, (const double*)part, kReduceGrid, cout, sums);
+    hipLaunchKernelGGL(train::bn_stats_finish, dim3((cout + 63) / 64), dim3(64), 0, st, (const double*)sums, (double)P, cout, kBnEps,
+                       1.f, mu, rstd, mm, mv);    // momentum 1: the two dummies are left alone
+    if (batch_mean_var_out)
+      hipLaunchKernelGGL(train::batch_mean_var, dim3((cout + 63) / 64), dim3(64), 0, st, (const double*)sums, (double)P, cout,
+                         batch_mean_var_out);
+    auto blocks = dim3((unsigned)std::min<size_t>((n + train::kThreads - 1) / train::kThreads, 65535));
+    hipLaunchKernelGGL(train::bn_act_fwd, blocks, dim3(train::kThreads), 0, st, (const float*)z, (const float*)mu, (const float*)rstd,
+                       gamma_beta, gamma_beta + cout, skip_input, (const float*)nullptr, use_act, n, cout, y);
+    if (hipGetLastError() != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "single-op training launch failed");
+  }
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(buf);
+  return rc;
 }
 
 }  // extern "C"

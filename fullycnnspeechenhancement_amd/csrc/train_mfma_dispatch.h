@@ -19,21 +19,38 @@ constexpr int kPairGrid = 2048;     // workgroups of the channel-aligned element
 // dW with fp32 atomics, and tmm::wg_reduce sums the slices in a fixed order.  The training step points it at the
 // trainer's buffer for the duration of its backward pass (one caller thread per trainer); part == nullptr selects atomics.
 struct WgDet {
-  float* part = nullptr;
-  size_t cap_floats = 0;
+  float** part = nullptr;         // the trainer's slice buffer, grown on demand; nullptr selects atomics (RCED_TRAIN_DET=0)
+  size_t* cap_floats = nullptr;
+  int* error = nullptr;           // raised when the buffer cannot be grown: the step then fails (RCED_ERR_ALLOC) -- a
+                                  // deterministic trainer never falls back to atomics silently
 };
 inline thread_local WgDet g_wgdet;
-// Launch helper: `launch(dW_arg, dbias_arg, pstride)` launches the wgrad kernel; slices = partial-sum slices it writes.
+// Launch helper: `launch(dW_arg, dbias_arg, pstride)` launches the wgrad kernel; slices = partial-sum slices it writes
+// (grid x waves x parities: the grid comes from the runtime's occupancy answer, so the size is only known here).
 template <class F>
 inline int wg_launch(F&& launch, int slices, int nW, int nB, float* dW, float* dbias, hipStream_t st) {
   const WgDet& d = g_wgdet;
   const unsigned pstride = (unsigned)((nW + nB + 3) & ~3);
-  if (!d.part || (size_t)slices * pstride > d.cap_floats) {
-    launch(dW, dbias, 0u);          // atomics (not reproducible bit for bit)
+  if (!d.part) {
+    launch(dW, dbias, 0u);          // atomics (not reproducible bit for bit): asked for with RCED_TRAIN_DET=0
     return 0;
   }
-  launch(d.part, d.part + nW, pstride);
-  hipLaunchKernelGGL(tmm::wg_reduce, dim3((nW + nB + 63) / 64), dim3(1024), 0, st, (const float*)d.part, slices, pstride, nW, nB,
+  const size_t need = (size_t)slices * pstride;
+  if (need > *d.cap_floats) {       // first step, or a launcher whose grid grew: earlier launches still read the old buffer
+    (void)hipStreamSynchronize(st);
+    if (*d.part) (void)hipFree(*d.part);
+    *d.part = nullptr;
+    *d.cap_floats = 0;
+    const size_t want = need + need / 4;
+    if (hipMalloc(reinterpret_cast<void**>(d.part), want * sizeof(float)) != hipSuccess) {
+      *d.part = nullptr;
+      if (d.error) *d.error = 1;
+      return -1;                    // nothing launched: the caller's step reports the failure before Adam runs
+    }
+    *d.cap_floats = want;
+  }
+  launch(*d.part, *d.part + nW, pstride);
+  hipLaunchKernelGGL(tmm::wg_reduce, dim3((nW + nB + 63) / 64), dim3(1024), 0, st, (const float*)*d.part, slices, pstride, nW, nB,
                      dW, dbias);
   return 1;
 }

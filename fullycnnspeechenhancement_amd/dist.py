@@ -22,7 +22,15 @@ Two things make that real on RCCL and not only on gloo:
     serial scatter -> compute -> gather per chunk.
 The same code runs on the "gloo" backend with CPU tensors, which is how tests/ cover the
 world_size > 1 logic without GPUs.
+
+Failures.  A forward that raises on one rank must not leave the others waiting for transfers that never come: the
+failing rank finishes the protocol with zero-filled results, every call ends with one status all-reduce on `group`, and
+then EVERY rank raises (the failing one its own exception, the others a RuntimeError naming the rank).  `timeout_s`
+bounds each wait on a transfer where the backend supports it (gloo; on RCCL a wait only orders the stream, and the
+process group's own timeout / watchdog applies).
 """
+
+import datetime
 
 import torch
 import torch.distributed as dist
@@ -48,17 +56,28 @@ def chunk_bounds(lo, hi, chunks):
     return [(lo + a, lo + b) for a, b in shard_bounds(n, c) if b > a]
 
 
+class PeerForwardError(RuntimeError):
+    """forward_from_root: the forward of another rank raised; this rank's result is incomplete."""
+
+
 class BatchShardedForward(object):
     """forward: callable mapping a [n, T, 129, 1] tensor on this rank's device to the same shape
     (a fullycnnspeechenhancement_amd model on GPU; any stand-in under gloo in tests).
 
-    Construction is collective (every rank of `group` must construct it): it creates the two
-    direction groups.  `trace`, if given, is a list that receives ("recv"|"fwd"|"send"|"result", chunk)
-    events in the order this rank passed them (tests use it to check the pipeline order)."""
+    Construction is COLLECTIVE OVER THE DEFAULT PROCESS GROUP unless `scatter_group` / `gather_group` are handed in:
+    it creates the two direction groups with torch.distributed.new_group, which every process of the default group
+    must enter -- also those that are not members of `group`.  With a real subgroup either construct the object on all
+    processes (non-members pass the same `group` and never call the forward methods), or create the two groups yourself
+    (collectively) and pass them.  `close()` destroys the groups this object created (their communicators hold device
+    memory on RCCL).  `trace`, if given, is a list that receives ("recv"|"fwd"|"send"|"result", chunk) events in the
+    order this rank passed them (tests use it to check the pipeline order)."""
 
-    def __init__(self, forward, group=None, device=None, trace=None, forward_into=None):
+    def __init__(self, forward, group=None, device=None, trace=None, forward_into=None, scatter_group=None,
+                 gather_group=None, timeout_s=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (one process per GPU)")
+        if (scatter_group is None) != (gather_group is None):
+            raise ValueError("pass both scatter_group and gather_group, or neither")
         self.forward = forward
         self.forward_into = forward_into     # optional (x, out) -> None: writes the result in place (no copy on the root)
         self.group = group
@@ -66,30 +85,75 @@ class BatchShardedForward(object):
         self.world = dist.get_world_size(group)
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.trace = trace
+        self.timeout = datetime.timedelta(seconds=timeout_s) if timeout_s else None
         ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
         self._ranks = ranks
+        self._own_groups = []
         # scatter (root -> peers) and gather (peers -> root) each get a communicator of their own
-        self.scatter_group = dist.new_group(ranks=ranks) if self.world > 1 else group
-        self.gather_group = dist.new_group(ranks=ranks) if self.world > 1 else group
-        if self.world > 1:
+        if scatter_group is not None:
+            self.scatter_group, self.gather_group = scatter_group, gather_group
+        elif self.world > 1:
+            self.scatter_group = dist.new_group(ranks=ranks)
+            self.gather_group = dist.new_group(ranks=ranks)
+            self._own_groups = [self.scatter_group, self.gather_group]
+        else:
+            self.scatter_group = self.gather_group = group
+        if self.world > 1 and self.rank >= 0:
             # The FIRST call on a group's communicator must involve all its ranks (torch.distributed.batch_isend_irecv:
             # otherwise "the behavior is undefined" on NCCL/RCCL), and forward_from_root's transfers only ever pair the
             # root with one peer: open both communicators with a collective here.
             for g in (self.scatter_group, self.gather_group):
                 dist.all_reduce(torch.zeros(1, device=self.device), group=g)
 
+    def close(self):
+        """Destroy the two direction groups this object created (collective over their ranks on some backends: call it
+        on every rank).  Groups handed in by the caller are the caller's."""
+        groups, self._own_groups = self._own_groups, []
+        for g in groups:
+            try:
+                dist.destroy_process_group(g)
+            except Exception:
+                pass
+
     def _note(self, what, c):
         if self.trace is not None:
             self.trace.append((what, c))
+
+    def _wait(self, works):
+        for w in works:
+            if self.timeout is not None:
+                w.wait(timeout=self.timeout)
+            else:
+                w.wait()
+
+    def _finish(self, err):
+        """End of a forward_from_root call on every rank: one status all-reduce (MAX over 1 + failing rank), then raise
+        where something failed."""
+        if self.world > 1:
+            flag = torch.tensor([0 if err is None else self.rank + 1], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            bad = int(flag.item())
+        else:
+            bad = 0 if err is None else self.rank + 1
+        if err is not None:
+            raise err
+        if bad:
+            raise PeerForwardError("forward_from_root: the forward of rank %d raised; the gathered result is incomplete"
+                                   % (bad - 1))
 
     # -- every rank already holds its own utterances: no data-path collective -----------------
     def forward_resident(self, x_local):
         return self.forward(x_local)
 
     # -- one rank holds the whole batch (the reference's calling convention) -------------------
-    def forward_from_root(self, x_root, root=0, chunks=1):
+    def forward_from_root(self, x_root, root=0, chunks=1, direction="both"):
         """x_root: [N, T, 129, 1] on `root` (ignored elsewhere).  Returns [N, T, 129, 1] on root, None
-        on the other ranks.  `root` is a rank of `group`.  chunks > 1 pipelines each peer's slice."""
+        on the other ranks.  `root` is a rank of `group`.  chunks > 1 pipelines each peer's slice.
+        direction (measurement only): "scatter" = the peers receive their slices and nothing else happens, "gather" =
+        the peers send zero-filled results of the right shape and nothing else happens -- the compute-free transfer
+        times bench.py reports next to the pipelined figure; the returned tensor is then meaningless."""
+        if direction not in ("both", "scatter", "gather"):
+            raise ValueError("direction must be 'both', 'scatter' or 'gather'")
         meta = [None]
         if self.rank == root:
             if x_root.dim() != 4 or x_root.shape[2] != 129 or x_root.shape[3] != 1:
@@ -102,6 +166,8 @@ class BatchShardedForward(object):
         n, t = shape[0], shape[1]
         bounds = shard_bounds(n, self.world)
         groot = self._ranks[root]            # P2POp peers are global ranks
+        do_scatter, do_gather, do_compute = direction != "gather", direction != "scatter", direction == "both"
+        err = None
 
         if self.rank == root:
             x_root = x_root.contiguous()
@@ -114,39 +180,56 @@ class BatchShardedForward(object):
                          for r, p in pieces.items() if c < len(p)]
                 recvs = [dist.P2POp(dist.irecv, y[p[c][0]:p[c][1]], self._ranks[r], self.gather_group)
                          for r, p in pieces.items() if c < len(p)]
-                send_works.append(dist.batch_isend_irecv(sends))
-                recv_works.append(dist.batch_isend_irecv(recvs))
+                send_works.append(dist.batch_isend_irecv(sends) if do_scatter else [])
+                recv_works.append(dist.batch_isend_irecv(recvs) if do_gather else [])
             lo, hi = bounds[root]
-            if hi > lo:   # the root's own slice computes while its links carry the others'
-                for i, (a, b) in enumerate(chunk_bounds(lo, hi, chunks)):
-                    if self.forward_into is not None:
-                        self.forward_into(x_root[a:b], y[a:b])
-                    else:
-                        y[a:b] = self.forward(x_root[a:b])
-                    self._note("fwd", i)
+            if hi > lo and do_compute:   # the root's own slice computes while its links carry the others'
+                try:
+                    for i, (a, b) in enumerate(chunk_bounds(lo, hi, chunks)):
+                        if self.forward_into is not None:
+                            self.forward_into(x_root[a:b], y[a:b])
+                        else:
+                            y[a:b] = self.forward(x_root[a:b])
+                        self._note("fwd", i)
+                except Exception as e:   # the transfers in flight are still drained: the peers must not be left waiting
+                    err = e
             for c in range(depth):       # results stream back chunk by chunk
-                for w in send_works[c] + recv_works[c]:
-                    w.wait()
+                self._wait(send_works[c] + recv_works[c])
                 self._note("result", c)
+            self._finish(err)
             return y
 
         lo, hi = bounds[self.rank]
         pieces = chunk_bounds(lo, hi, chunks)
         if not pieces:
+            self._finish(None)
             return None
-        bufs = [torch.empty((b - a, t) + tuple(shape[2:]), dtype=dtype, device=self.device) for a, b in pieces]
+        alloc = torch.empty if do_scatter else torch.zeros
+        bufs = [alloc((b - a, t) + tuple(shape[2:]), dtype=dtype, device=self.device) for a, b in pieces]
         # every receive is posted up front, each as a batch of its own: chunk c+1 lands while chunk c computes
-        recv_works = [dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, groot, self.scatter_group)]) for buf in bufs]
+        recv_works = [dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, groot, self.scatter_group)]) if do_scatter else []
+                      for buf in bufs]
         send_works, outs = [], []
         for c, buf in enumerate(bufs):
-            for w in recv_works[c]:
-                w.wait()                 # nccl: the current stream waits for THIS chunk only
+            self._wait(recv_works[c])    # nccl: the current stream waits for THIS chunk only
             self._note("recv", c)
-            out = self.forward(buf).contiguous()
-            self._note("fwd", c)
-            outs.append(out)             # keep alive until sent
-            send_works += dist.batch_isend_irecv([dist.P2POp(dist.isend, out, groot, self.gather_group)])
-            self._note("send", c)
-        for w in send_works:
-            w.wait()
+            out = buf
+            if do_compute:
+                if err is None:
+                    try:
+                        out = self.forward(buf).contiguous()
+                        if out.shape != buf.shape or out.dtype != buf.dtype:
+                            raise ValueError("forward returned %s %s for an input of %s %s"
+                                             % (tuple(out.shape), out.dtype, tuple(buf.shape), buf.dtype))
+                    except Exception as e:
+                        err = e
+                if err is not None:      # finish the protocol with zeros: the root is waiting for this chunk
+                    out = torch.zeros_like(buf)
+                self._note("fwd", c)
+            if do_gather:
+                outs.append(out)         # keep alive until sent
+                send_works += dist.batch_isend_irecv([dist.P2POp(dist.isend, out, groot, self.gather_group)])
+                self._note("send", c)
+        self._wait(send_works)
+        self._finish(err)
         return None

@@ -56,6 +56,10 @@ class _RcedNet(object):
         h = ctypes.c_void_p()
         fp = blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
         if self.is_training:
+            # A new library object: variables = `weights`, Adam slots and global_step start from zero -- what
+            # Saver.restore of a checkpoint WITHOUT optimizer slots gives.  FullyCNNTrainer looks the handle up on every
+            # call (it never caches the pointer), so trainer.model.restore(w) is safe; to carry optimizer state over use
+            # FullyCNNTrainer.optimizer_state() / load_optimizer_state() or from_checkpoint().
             _lib.check(lib.rced_train_create(self.variant, fp, blob.size, self.batch_size, self.device, ctypes.byref(h)))
             self._release()
             self._train = h
@@ -71,7 +75,25 @@ class _RcedNet(object):
 
     @property
     def weights(self):
+        """The model's TF variables by name.  Inference graph: what was restored.  Training graph: read back from the
+        device, i.e. the CURRENT values after whatever train steps ran on this handle (rced_train_get_variables)."""
+        if self.is_training and self._train is not None:
+            buf = np.empty(spec.num_weights(self.variant), np.float32)
+            _lib.check(_lib.load().rced_train_get_variables(self._train, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), buf.size))
+            out, o = {}, 0
+            for name, shape in spec.variable_shapes(self.variant):
+                k = int(np.prod(shape))
+                out[name] = buf[o:o + k].reshape(shape).copy()
+                o += k
+            return out
         return self._weights
+
+    def check(self):
+        """rced_check: after the caller has synchronised a device-resident `model(x)` itself, was that launch valid?
+        Raises RcedError(RCED_ERR_STATE) if the fused kernel recorded a hand-off time-out (include/rced.h)."""
+        if self._handle is not None:
+            _lib.check(_lib.load().rced_check(self._handle))
+        return True
 
     def param_count(self):
         """BaseTester.param_count (tester.py:41-47): trainable scalars."""
@@ -231,10 +253,13 @@ def conv_bn_relu(inputs, out_channels, kernel_size, stride=(1, 1), is_training=F
     inputs: torch.cuda float32 [N,T,F,cin]; params: dict with "{scope}/kernel", "{scope}/bias" and, if
     use_norm, "{scope}/batch_norm/{gamma,beta,moving_mean,moving_variance}" (numpy or torch).
     Returns a torch.cuda tensor [N,T,F,out_channels].
+
+    is_training=True (module.py:29 `training=is_training`): BatchNorm normalises with the mean / biased variance of this
+    batch (rced_conv_bn_relu_train); the moving statistics in `params` are neither read nor changed -- in TF they change
+    only when the UPDATE_OPS run, which belongs to train_op (trainer.py:175-179).  With use_norm=False the flag has no
+    effect, as in the reference.
     """
     import torch
-    if is_training:
-        raise NotImplementedError("is_training=True is not built (SURVEY 8f N3)")
     if tuple(stride) != (1, 1) or padding != "SAME":
         raise ValueError("only stride (1,1), padding 'SAME' (all the reference ever passes)")
     if params is None:
@@ -256,6 +281,21 @@ def conv_bn_relu(inputs, out_channels, kernel_size, stride=(1, 1), is_training=F
     k = dev_t(params[scope + "/kernel"], (kh, kw, cin, out_channels))
     b = dev_t(params[scope + "/bias"], (out_channels,))
     bn = None
+    if use_norm and is_training:
+        p = scope + "/batch_norm/"
+        gb = torch.cat([dev_t(params[p + v], (out_channels,)) for v in ("gamma", "beta")])
+        skip = None
+        if skip_input is not None:
+            skip = skip_input.float().contiguous()
+            if tuple(skip.shape) != (n, t, f, out_channels):
+                raise ValueError("skip_input shape %s, expected %s" % (tuple(skip.shape), (n, t, f, out_channels)))
+        y = torch.empty((n, t, f, out_channels), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.load().rced_conv_bn_relu_train(
+            x.data_ptr(), y.data_ptr(), k.data_ptr(), b.data_ptr(), gb.data_ptr(),
+            skip.data_ptr() if skip is not None else None, 1 if use_act else 0, n, t, f, cin, out_channels, kh, kw,
+            None, dev.index, st))
+        return y
     if use_norm:
         p = scope + "/batch_norm/"
         bn = torch.cat([dev_t(params[p + v], (out_channels,)) for v in ("gamma", "beta", "moving_mean", "moving_variance")])

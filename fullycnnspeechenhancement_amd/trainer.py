@@ -15,6 +15,8 @@ from . import _lib, model as _model, spec, weights as _weights
 
 
 class FullyCNNTrainer(object):
+    model = None
+
     def __init__(self, net_work="FullyCNNV3", batch_size=1, lr=1e-3, warmup_steps=4000.0, weights=None, device=0,
                  seed=None):
         self.net_work = net_work
@@ -29,7 +31,15 @@ class FullyCNNTrainer(object):
         # creat_graph (trainer.py:165-172): self.model = Model(is_training=True); self.pred = self.model(self.input_x).
         # The model object owns the library's training handle; train_step runs on the same one.
         self.model = _model.build_model(net_work, True, weights=w, device=self.device, batch_size=self.batch_size)
-        self._h = self.model._train
+
+    @property
+    def _h(self):
+        """The library's training handle, looked up on every call: the model object owns it, and
+        `trainer.model.restore(w)` / `trainer.model.close()` replace / free it (a cached pointer would dangle)."""
+        h = self.model._train if self.model is not None else None
+        if h is None:
+            raise RuntimeError("the trainer's model is closed")
+        return h
 
     def noam_scheme(self, global_step, warmup_steps=None):
         """trainer.py:68-76."""
@@ -157,10 +167,19 @@ class FullyCNNTrainer(object):
         tr.load_optimizer_state(adam_m, adam_v, step)
         return tr
 
+    def restore(self, weights, keep_optimizer=True):
+        """Saver.restore of model variables into a running trainer (trainer.py:59-65).  keep_optimizer: the Adam slots and
+        global_step survive (a TF restore of a checkpoint that holds only model variables leaves them as they are);
+        False resets them, which is what `trainer.model.restore(weights)` alone does."""
+        state = self.optimizer_state() if keep_optimizer else None
+        self.model.restore(weights)
+        if state is not None:
+            self.load_optimizer_state(*state)
+        return self
+
     def close(self):
-        if self._h is not None:
+        if self.model is not None:
             self.model.close()     # the model owns the handle
-            self._h = None
 
     def __del__(self):
         try:

@@ -73,6 +73,13 @@ void rced_destroy(rced_model* m);
  * after enqueueing.  Replaces sess.run(self.pred, ...) with device-resident tensors. */
 int rced_forward(rced_model* m, const float* x_dev, float* y_dev, int N, int T, void* stream);
 
+/* State of the model AFTER work the caller has synchronised itself.  rced_forward only enqueues; the fused CR-CED kernel
+ * records a wave-to-wave hand-off that timed out in a sticky word in pinned host memory, which the library looks at before
+ * the NEXT launch and in its synchronising entry points (rced_forward_host, rced_profile_query) -- a caller that enqueues
+ * one forward, synchronises its own stream and reads y calls this to learn that y is valid: RCED_OK, or RCED_ERR_STATE
+ * (the masks of that launch are wrong; destroy and recreate the model).  No device call, no synchronisation. */
+int rced_check(rced_model* m);
+
 /* Same with HOST pointers (the reference boundary hands numpy arrays: tester.py:85-90).
  * Copies H2D, runs, copies D2H, synchronises.  Batches >= 8 MB are split into "host_chunks" utterance chunks and
  * the three legs are overlapped on internal streams (a helper thread issues the downloads). */
@@ -89,6 +96,8 @@ int rced_reserve(rced_model* m, int N, int T);
  *   "fused_grid"  workgroups of the persistent fused kernel (0 = one per CU)
  *   "bf16"        R-CED V1 / V2 only: 1 = bf16 activations + inner-layer weights, fp32 accumulation (BASELINE config 2;
  *                 ~6e-3 of the largest output away from the fp32 result -- opt-in)
+ *   "inject_handoff_error"  set only, CR-CED: writes the value into the sticky hand-off error word as the kernel would on a
+ *                 time-out (0 clears it) -- a test hook for rced_check / RCED_ERR_STATE handling
  *   "has_fused", "num_cus", "fused_final"  get only ("fused_final": the 1x129 output layer runs inside the fused kernel)
  * Environment: RCED_FINAL_LDS=0 (the last layer's GEMM without LDS staging; read at the first forward); for rced_train_create RCED_TRAIN_MFMA=0 (direct-conv
  * kernels only), RCED_TRAIN_FUSE_ACT=0, RCED_TRAIN_FUSE_DZ=0 (materialise activations / dz). */
@@ -161,6 +170,16 @@ int rced_train_get_gradients(rced_trainer* t, float* blob_host, size_t n_floats)
 int rced_train_get_state(rced_trainer* t, float* m_blob_host, float* v_blob_host, size_t n_floats, long long* global_step);
 int rced_train_set_state(rced_trainer* t, const float* m_blob_host, const float* v_blob_host, size_t n_floats,
                          long long global_step);
+
+/* The single op with is_training=True (module.py:29 `training=is_training`): BatchNorm normalises with the mean and the
+ * BIASED variance of this batch over N*T*F (eps 1e-3), then + skip_input, then ReLU.  gamma_beta: gamma[cout], beta[cout]
+ * (device).  batch_mean_var_out: NULL, or device [2*cout] receiving (mean, biased variance) -- what TF's UPDATE_OPS fold
+ * into moving_mean / moving_variance (momentum 0.99; the variance Bessel-corrected by the fused kernel); the op itself
+ * updates nothing, as the TF op does not unless the UPDATE_OPS are run.  use_norm=False has no training form: use
+ * rced_conv_bn_relu with bn = NULL.  Direct-convolution kernels; synchronises the stream. */
+int rced_conv_bn_relu_train(const float* x, float* y, const float* kernel, const float* bias, const float* gamma_beta,
+                            const float* skip_input, int use_act, int N, int T, int F, int cin, int cout, int kh, int kw,
+                            float* batch_mean_var_out, int device, void* stream);
 
 /* Average device time (ms) of the dominant kernel of the last rced_forward, measured with HIP
  * events on the launch stream when profiling is on ("profile" option = 1).  <0 if none. */

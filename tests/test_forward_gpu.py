@@ -253,8 +253,8 @@ def test_full_size_config3_sampled_against_oracle(net_work, tag, variant, built)
     import torch
     w = rced_np.make_weights(net_work, seed=42)
     m = make_model(variant, w)
-    g = torch.Generator(device="cuda").manual_seed(1234)
-    x = torch.randn((256, 512, 129, 1), generator=g, device="cuda").abs_()
+    import bench
+    x = torch.from_numpy(bench.synthetic_magnitudes((256, 512, 129, 1), 1234)).cuda()   # bench.py's own input
     y = m(x)
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
@@ -444,3 +444,56 @@ def test_from_root_on_rccl_world_size_1(built):
         assert torch.equal(eng.forward_resident(x), y)
     finally:
         dist.destroy_process_group()
+
+
+def test_rced_check_reports_the_sticky_handoff_error(built):
+    """include/rced.h rced_check: a caller that enqueues one device-resident forward and synchronises its own stream
+    asks the model whether that launch was valid.  The error word is forced through the documented test hook."""
+    import torch
+    from fullycnnspeechenhancement_amd import _lib
+    w = rced_np.make_weights("FullyCNNV3", seed=7)
+    m = make_model(3, w)
+    x = torch.from_numpy(rced_np.make_input(2, 16, seed=3)).cuda()
+    y = m(x)
+    torch.cuda.synchronize()
+    assert m.check() is True and _lib.load().rced_check(m._handle) == _lib.RCED_OK
+    m.set_option("inject_handoff_error", 2)
+    del m._options["inject_handoff_error"]          # a test hook, not a setting to replay on restore()
+    assert _lib.load().rced_check(m._handle) == _lib.RCED_ERR_STATE
+    with pytest.raises(_lib.RcedError) as ei:
+        m.check()
+    assert ei.value.code == _lib.RCED_ERR_STATE and "hand-off" in str(ei.value)
+    with pytest.raises(_lib.RcedError):             # ... and the model refuses further launches
+        m(x)
+    m.set_option("inject_handoff_error", 0)
+    del m._options["inject_handoff_error"]
+    assert m.check() is True
+    assert torch.equal(m(x), y)
+    assert _lib.load().rced_check(None) == _lib.RCED_ERR_ARG
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 129, 1, 18, 8, 9), (3, 5, 129, 8, 30, 1, 5), (1, 4, 129, 6, 7, 1, 3)])
+@pytest.mark.parametrize("use_act,with_skip", [(True, False), (True, True), (False, True)])
+def test_single_op_conv_bn_relu_training_mode(shape, use_act, with_skip, built):
+    """module.py:11-34 with is_training=True: BatchNorm with the statistics of the batch (biased variance, eps 1e-3),
+    then + skip, then ReLU -- against the numpy fp64 restatement of the same op (oracle/rced_np.conv_bn_relu with the
+    batch's own mean / variance as the 'moving' statistics)."""
+    import torch
+    from fullycnnspeechenhancement_amd.model import conv_bn_relu
+    n, t, f, cin, cout, kh, kw = shape
+    rng = np.random.default_rng(hash(shape) % 1000)
+    x = rng.standard_normal((n, t, f, cin)).astype(np.float32)
+    k = (rng.standard_normal((kh, kw, cin, cout)) * 0.2).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    beta = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+    skip = rng.standard_normal((n, t, f, cout)).astype(np.float32) if with_skip else None
+    z = rced_np.conv_bn_relu(x, k, b, None, None, use_act=False)                 # conv + bias, fp64
+    mean, var = z.mean(axis=(0, 1, 2)), z.var(axis=(0, 1, 2))                    # biased variance
+    ref = rced_np.conv_bn_relu(x, k, b, (gamma, beta, mean, var), skip, use_act=use_act)
+    params = {"c/kernel": k, "c/bias": b, "c/batch_norm/gamma": gamma, "c/batch_norm/beta": beta,
+              "c/batch_norm/moving_mean": np.full(cout, 7.0, np.float32),        # must be ignored in training mode
+              "c/batch_norm/moving_variance": np.full(cout, 9.0, np.float32)}
+    y = conv_bn_relu(torch.from_numpy(x).cuda(), cout, (kh, kw), is_training=True, use_act=use_act, scope="c",
+                     skip_input=torch.from_numpy(skip).cuda() if with_skip else None, params=params)
+    check_parity(y.cpu().numpy(), ref, what="conv_bn_relu(is_training=True) %s" % (shape,))

@@ -70,8 +70,12 @@ def test_bench_gpus_n_without_a_launcher_starts_n_ranks(built):
     env["CUDA_VISIBLE_DEVICES"] = ""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=300)
+    # What is deterministic: the parent relays the child's failure, no JSON line is invented, and at least one rank saw
+    # WORLD_SIZE=2 (every rank prints that line BEFORE the GPU check; torchrun kills the surviving rank as soon as the
+    # first one exits, so how many of the later "needs a GPU" messages appear is a race and is not asserted).
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    assert "of WORLD_SIZE=2 started" in r.stderr, r.stderr[-2000:]
+    assert "bench.py needs a GPU" in r.stderr, r.stderr[-2000:]
     assert r.stdout.strip() == ""            # no JSON line was produced, none was invented
 
 
@@ -113,7 +117,6 @@ def test_compiled_kernels_are_free_of_the_two_measured_hazard_sequences(built):
     states, and this test notices when a new build brings one back.  Also checks that the lint itself still sees them."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import glob
     import isa_lint
     bad_a = ["v_cmp_gt_i32_e32 vcc, 24, v22", "buffer_store_dwordx4 v[30:33], v24, s[44:47], s78 offen",
              "s_and_saveexec_b64 s[0:1], vcc"]
@@ -123,8 +126,11 @@ def test_compiled_kernels_are_free_of_the_two_measured_hazard_sequences(built):
              "global_load_lds_dwordx4 v71, s[20:21]"]
     assert [f[0] for f in isa_lint.lint_function("f", bad_b)] == ["B"]
     assert not isa_lint.lint_function("f", bad_b[:3] + ["s_nop 3"] + bad_b[4:])
-    objs = sorted(glob.glob(os.path.join(isa_lint.ROOT, "build", "*.o")))
-    assert len(objs) >= 5, "the library's objects (build/*.o) exist after __graft_entry__.build()"
+    bad_a2 = ["v_cmp_gt_i32_e64 s[0:1], 24, v22", "global_store_dwordx4 v[30:31], v[2:5], off", "s_and_saveexec_b64 s[2:3], s[0:1]"]
+    assert [f[0] for f in isa_lint.lint_function("f", bad_a2)] == ["A"]
+    assert not isa_lint.lint_function("f", bad_a2[:2] + ["s_and_saveexec_b64 s[2:3], s[4:5]"])
+    objs = isa_lint.default_objects()     # the .so the package loads: what runs, not build/*.o that may be stale
+    assert objs, "librced_hip.so exists after __graft_entry__.build()"
     found, nfn, nins = isa_lint.lint(objs)
     assert nfn > 100 and nins > 100000, (nfn, nins)
     assert not found, found[:3]

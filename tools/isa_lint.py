@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""Lint of the compiled gfx950 kernels (build/*.o) for two instruction sequences that hipcc emits without complaint and
+"""Lint of the compiled gfx950 kernels (the shipped librced_hip.so by default) for two instruction sequences that hipcc emits without complaint and
 that misbehaved on MI355X in this project ("Things that did not pay" / the reproducibility hunt):
 
   A. VALU writes VCC  /  vector-memory instruction  /  SALU reads VCC   (three consecutive instructions).
      Measured: `v_cmp_gt_i32 vcc` / `buffer_store_dwordx4` / `s_and_saveexec_b64 s[0:1], vcc` lost lanes of the LDS store
      the mask guards (run-to-run differences, two workgroups per CU); one wait state between store and SALU cures it.
+     Also the same shape through an SGPR pair instead of VCC: `v_cmp_*_e64 s[a:b]` / vector-memory / SALU reads s[a:b]
+     (s_and_saveexec_b64, s_mov_b64 exec, ...) -- which register the compare lands in is the allocator's choice.
   B. An LDS-DMA with an SGPR base (`global_load_lds_* v, s[a:b]`, issued from inline asm, where hipcc pads no hazard wait
      states) fewer than 5 wait states behind a VALU instruction that wrote s[a] or s[b] (v_readlane of a spilled SGPR,
      v_readfirstlane).
 
-Usage: tools/isa_lint.py [object files...]   (default: build/*.o of the repo; needs them built).  Exit status 1 and a
+Usage: tools/isa_lint.py [object or shared-object files...]   (default: the library the package loads,
+fullycnnspeechenhancement_amd/librced_hip.so -- the code that actually runs, not objects that may be stale or absent).  Exit status 1 and a
 listing when a sequence is found.  tests/test_host.py runs it on every build."""
 import glob
 import os
@@ -25,6 +28,8 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 VALU_WRITES_VCC = re.compile(r"^v_cmpx?_\w+_e32\b|^v_\w+\s+(v\d+|v\[\d+:\d+\]), vcc\b|^v_cmpx?_\w+\s+vcc\b")
 VMEM = re.compile(r"^(buffer_|global_|flat_|scratch_)")
 SALU_READS_VCC = re.compile(r"^s_\w+\s+[^,]+,.*\bvcc\b|^s_cbranch_vcc")
+VALU_WRITES_SPAIR = re.compile(r"^v_cmpx?_\w+\s+s\[(\d+):(\d+)\]")
+SALU_READS_SPAIR = re.compile(r"^s_\w+\s+[^,]+,.*\bs\[(\d+):(\d+)\]")
 DMA_SBASE = re.compile(r"^global_load_lds_\w+\s+v\d+, s\[(\d+):(\d+)\]")
 VALU_WRITES_SGPR = re.compile(r"^v_(readlane|readfirstlane)_b32\s+s(\d+)\b")
 NOP = re.compile(r"^s_nop\s+(\d+)")
@@ -65,6 +70,13 @@ def lint_function(fn, ins):
     for i in range(len(ins) - 2):
         if VALU_WRITES_VCC.search(ins[i]) and VMEM.search(ins[i + 1]) and SALU_READS_VCC.search(ins[i + 2]):
             found.append(("A", fn, i, ins[i:i + 3]))
+            continue
+        w = VALU_WRITES_SPAIR.match(ins[i])
+        if w and VMEM.search(ins[i + 1]):
+            r = SALU_READS_SPAIR.match(ins[i + 2])
+            # the SALU instruction's SOURCE operands: everything behind the first comma
+            if r and ("s[%s:%s]" % w.groups()) in ins[i + 2].split(",", 1)[1]:
+                found.append(("A", fn, i, ins[i:i + 3]))
     for i, s in enumerate(ins):
         m = DMA_SBASE.match(s)
         if not m:
@@ -94,10 +106,15 @@ def lint(objs):
     return found, nfn, nins
 
 
+def default_objects():
+    so = os.path.join(ROOT, "fullycnnspeechenhancement_amd", "librced_hip.so")
+    return [so] if os.path.exists(so) else []
+
+
 def main():
-    objs = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "build", "*.o")))
+    objs = sys.argv[1:] or default_objects()
     if not objs:
-        print("isa_lint: no objects (run __graft_entry__.build() first)")
+        print("isa_lint: no library (run __graft_entry__.build() first)")
         return 2
     found, nfn, nins = lint(objs)
     for kind, fn, i, seq in found:
