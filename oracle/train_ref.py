@@ -51,41 +51,66 @@ class TrainRef:
         self.v = {k: torch.zeros_like(self.vars[k]) for k in trainable_names(net_work)}
         self.global_step = 0
 
-    def _forward_train_taps(self, x, keep_preact=False):
-        """The same graph on NHWC tensors with tap-wise matmuls (module.py:27 `SAME`: (k-1)//2 before, the rest after)."""
+    def _forward_train_taps(self, x, keep_preact=False, leaf_after=None):
+        """The same graph on NHWC tensors with tap-wise matmuls (module.py:27 `SAME`: (k-1)//2 before, the rest after).
+        leaf_after = a layer scope: everything up to and including that layer runs without autograd, its output becomes a
+        leaf that requires grad (self.mid = (leaf, normalised pre-activation zhat, BatchNorm output u) of that layer), and
+        the rest of the net is recorded -- d loss / d leaf then gives that layer's d beta = sum g [u > 0] and
+        d gamma = sum g [u > 0] zhat without holding the whole net's graph (used at BASELINE config 5's full size)."""
         tens = [torch.as_tensor(x).to(device=self.device, dtype=self.dtype)]
         stats, pre = [], []
+        recording = leaf_after is None
+        self.mid = None
         for l in self.layers:
-            k = self.vars[l.scope + "/kernel"]                                    # HWIO
-            pt, pb = (l.kh - 1) // 2, (l.kh - 1) - (l.kh - 1) // 2
-            pl, pr = (l.kw - 1) // 2, (l.kw - 1) - (l.kw - 1) // 2
-            src = tens[l.src]
-            n, t, f, _ = src.shape
-            xp = Fn.pad(src, (0, 0, pl, pr, pt, pb))
-            y = None
-            for i in range(l.kh):
-                for j in range(l.kw):
-                    term = xp[:, i:i + t, j:j + f, :] @ k[i, j]
-                    y = term if y is None else y.add_(term)
-            del xp
-            y = y + self.vars[l.scope + "/bias"]
-            if l.use_norm:
-                p = l.scope + "/batch_norm/"
-                mean = y.mean(dim=(0, 1, 2))
-                var = ((y - mean) ** 2).mean(dim=(0, 1, 2))
-                y = (y - mean) / torch.sqrt(var + L.BN_EPS) * self.vars[p + "gamma"] + self.vars[p + "beta"]
-                stats.append((l.scope, mean.detach(), var.detach(), y.numel() // y.shape[-1]))
-            if l.skip_pre >= 0:
-                y = y + tens[l.skip_pre]
-            if l.use_act:
-                if keep_preact:
-                    pre.append(float(y.detach().abs().min()))
-                y = torch.relu(y)
-            if l.skip_post >= 0:
-                y = y + tens[l.skip_post]
+            with torch.set_grad_enabled(recording and torch.is_grad_enabled()):
+                k = self.vars[l.scope + "/kernel"]                                    # HWIO
+                pt, pb = (l.kh - 1) // 2, (l.kh - 1) - (l.kh - 1) // 2
+                pl, pr = (l.kw - 1) // 2, (l.kw - 1) - (l.kw - 1) // 2
+                src = tens[l.src]
+                n, t, f, _ = src.shape
+                xp = Fn.pad(src, (0, 0, pl, pr, pt, pb))
+                y = None
+                for i in range(l.kh):
+                    for j in range(l.kw):
+                        term = xp[:, i:i + t, j:j + f, :] @ k[i, j]
+                        y = term if y is None else y.add_(term)
+                del xp
+                y = y + self.vars[l.scope + "/bias"]
+                zhat = None
+                if l.use_norm:
+                    p = l.scope + "/batch_norm/"
+                    mean = y.mean(dim=(0, 1, 2))
+                    var = ((y - mean) ** 2).mean(dim=(0, 1, 2))
+                    zhat = (y - mean) / torch.sqrt(var + L.BN_EPS)
+                    y = zhat * self.vars[p + "gamma"] + self.vars[p + "beta"]
+                    stats.append((l.scope, mean.detach(), var.detach(), y.numel() // y.shape[-1]))
+                if l.skip_pre >= 0:
+                    y = y + tens[l.skip_pre]
+                u = y
+                if l.use_act:
+                    if keep_preact:
+                        pre.append(float(y.detach().abs().min()))
+                    y = torch.relu(y)
+                if l.skip_post >= 0:
+                    y = y + tens[l.skip_post]
+            if leaf_after is not None and l.scope == leaf_after:
+                y = y.detach().requires_grad_(True)
+                self.mid = (y, zhat.detach(), u.detach())
+                recording = True
             tens.append(y)
         self.last_hidden = tens[-2]
         return (tens[-1], stats, pre) if keep_preact else (tens[-1], stats)
+
+    def mid_layer_bn_grads(self, x, target, scope):
+        """(d beta, d gamma) of the plain conv+BN+ReLU layer `scope` (no skip in or out), from the gradient that reaches
+        its output through the rest of the net: d beta = sum g [u > 0], d gamma = sum g [u > 0] zhat
+        (module.py:28-33; tf.layers.batch_normalization's own backward).  Also returns the loss."""
+        pred, _ = self._forward_train_taps(x, leaf_after=scope)
+        loss = ((torch.as_tensor(target).to(device=pred.device, dtype=self.dtype) - pred) ** 2).sum() / self.batch_size
+        leaf, zhat, u = self.mid
+        (g,) = torch.autograd.grad(loss, leaf)
+        du = g * (u > 0)
+        return du.sum(dim=(0, 1, 2)), (du * zhat).sum(dim=(0, 1, 2)), float(loss.detach())
 
     def min_abs_preactivation(self, x):
         """Smallest |value entering a ReLU| over the whole net for this input: a ReLU whose input is within fp32

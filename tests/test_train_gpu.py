@@ -478,3 +478,76 @@ def test_atomic_wgrad_option_agrees_with_the_ordered_reduction(built, monkeypatc
         if "moving_" in name or (name.endswith("/bias") and not name.startswith("decode_final")):
             continue
         assert rel(out["1"][name], g0) < 1e-5, name
+
+
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_every_gradient_on_the_multi_tile_ragged_batch_against_fp64_autograd(net_work, tag, variant, built, capsys):
+    """The multi-tile bar.  4847 frames (37 x 131, odd) = 2424 two-frame tiles: every persistent training kernel walks its
+    prefetch-next-tile loop, ends on a half-empty tile, and the weight gradients go through the per-wave slices and
+    wg_reduce.  EVERY gradient of every layer against the fp64 autograd restatement run on the same GPU with plain torch
+    matmuls (oracle/train_ref.py, conv="taps"; trainer.py:146-147 loss, module.py:27-33 layers) -- not against this
+    repo's own direct-convolution kernels.  Bound 2e-3 of the tensor's largest entry = the restatement's own fp32-vs-fp64
+    figure (ReLU masks recomputed in fp32 flip on pre-activations within rounding of zero); measured values are printed."""
+    import torch
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer
+    w = rced_np.make_weights(net_work, seed=27)
+    x = rced_np.make_input(37, 131, seed=41)
+    y = rced_np.make_input(37, 131, seed=42)
+    tr = FullyCNNTrainer(net_work, batch_size=37, lr=1e-3, weights=w)
+    loss, _, _ = tr.train_step(x, y)
+    g = tr.gradients()
+    tr.close()
+    torch.cuda.empty_cache()
+    ref = train_ref.TrainRef(net_work, w, batch_size=37, device="cuda", conv="taps")
+    loss_ref, grads_ref, _ = ref.loss_and_grads(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref), (loss, loss_ref)
+    worst = {}
+    for name, gr in grads_ref.items():
+        gr = gr.cpu().numpy()
+        if name.endswith("/bias") and (name[:-5] + "/batch_norm/gamma") in grads_ref:
+            # a bias in front of BatchNorm: the true gradient is exactly 0 (the batch mean removes it)
+            assert np.abs(g[name]).max() <= 1e-3 * max(np.abs(g[name[:-5] + "/kernel"]).max(), 1e-30), name
+            continue
+        err = np.abs(g[name].astype(np.float64) - gr).max() / np.abs(gr).max()
+        worst[name] = err
+        assert err < 2e-3, (name, err)
+        assert cosine(g[name], gr) > 1 - 1e-5, name     # |error| <= 2e-3 of the max bounds 1 - cos at ~4e-6
+    del ref, grads_ref
+    torch.cuda.empty_cache()
+    with capsys.disabled():
+        k = max(worst, key=worst.get)
+        print("\n[train parity, 37 x 131] %s: loss rel err %.2e; worst gradient %s %.2e of its max; median %.2e (%d tensors)" % (
+            net_work, abs(loss - loss_ref) / abs(loss_ref), k, worst[k], float(np.median(list(worst.values()))), len(worst)))
+
+
+def test_full_size_config5_mid_network_bn_gradients(built, capsys):
+    """BASELINE configs[4] at full size, a DEEP layer: d beta and d gamma of CD1_encode_2 (18 -> 30 channels, block 4) --
+    they are the BatchNorm-backward sums S1, S2 the fused backward kernel forms from its transformed x tile, after the
+    gradient has come back through CD2's three layers and CD1_decode (prefetch-next-tile loops, bwd_fused_mfma,
+    wg_reduce at 128 tiles per workgroup).  The fp64 restatement runs the net up to that layer without autograd and
+    records only the five layers behind it (oracle/train_ref.py mid_layer_bn_grads)."""
+    import torch
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer
+    import bench
+    B, T = 256, 512
+    w = rced_np.make_weights("FullyCNNV3", seed=42)
+    x = torch.from_numpy(bench.synthetic_magnitudes((B, T, 129, 1), 1234)).cuda()    # SURVEY 8(d2) C5
+    y = torch.from_numpy(bench.synthetic_magnitudes((B, T, 129, 1), 1235)).cuda()
+    tr = FullyCNNTrainer("FullyCNNV3", batch_size=B, lr=1e-3, weights=w)
+    loss, _, _ = tr.train_step(x, y)
+    grads = tr.gradients()
+    tr.close()
+    torch.cuda.empty_cache()
+    ref = train_ref.TrainRef("FullyCNNV3", w, B, device="cuda", conv="taps")
+    dbeta, dgamma, loss_ref = ref.mid_layer_bn_grads(x, y, "CD1_encode_2")
+    assert abs(loss - loss_ref) <= 1e-5 * loss_ref
+    e = {}
+    for name, gr in (("CD1_encode_2/batch_norm/beta", dbeta), ("CD1_encode_2/batch_norm/gamma", dgamma)):
+        gr = gr.cpu().numpy()
+        e[name] = np.abs(grads[name] - gr).max() / np.abs(gr).max()
+        assert e[name] < 2e-3, (name, e[name])
+    del ref
+    torch.cuda.empty_cache()
+    with capsys.disabled():
+        print("\n[config 5 full size, CD1_encode_2] d beta %.1e, d gamma %.1e of their max" % (
+            e["CD1_encode_2/batch_norm/beta"], e["CD1_encode_2/batch_norm/gamma"]))
