@@ -207,12 +207,17 @@ __device__ __forceinline__ void layer_end_sync() {
 // XMT >= 0: the extra slot only computes M-tile XMT (the tile's other M-tile belongs to another wave).
 // `pre` runs once the first operand reads are in flight: a layer's main pass issues the next packet's LDS-DMA there
 // (~30 mostly scalar instructions in the shadow of the reads' latency instead of between the barrier and the first read).
+// `each(s)` runs in front of b64 step s's MFMAs (s is a constant after unrolling): the training kernels issue the next
+// tile's global loads there, one 16-byte piece per step, instead of in a burst that stalls on the memory pipeline's queues.
 struct NoPre {
   __device__ __forceinline__ void operator()() const {}
 };
-template <int NR, int NX, int MT, int K, int STRIDE, int DEPTH, int XMT = -1, class Pre = NoPre>
+struct NoEach {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <int NR, int NX, int MT, int K, int STRIDE, int DEPTH, int XMT = -1, class Pre = NoPre, class Each = NoEach>
 __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, const float* w, int lane,
-                                          f32x4 (&acc)[NR + NX][MT], Pre pre = Pre()) {
+                                          f32x4 (&acc)[NR + NX][MT], Pre pre = Pre(), Each each = Each()) {
   constexpr int NT = NR + NX, RING = DEPTH + 1;
   constexpr int NB64 = K / 8, NTAIL = (K % 8 + 3) / 4;
   const int kq = lane >> 4;
@@ -255,6 +260,7 @@ __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, 
 #pragma unroll
   for (int s = 0; s < NB64; ++s) {
     if (s + DEPTH < NB64) load(s + DEPTH, a[(s + DEPTH) % RING], b[(s + DEPTH) % RING]);
+    each(s);
     pin();
 #pragma unroll
     for (int e = 0; e < 2; ++e)

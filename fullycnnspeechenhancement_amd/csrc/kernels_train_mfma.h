@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <type_traits>
 
 #include "kernels_fused_chain.h"
 
@@ -18,6 +19,7 @@ namespace tmm {
 
 using chain::f32x2;
 using chain::f32x4;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at a dword-aligned address
 using chain::mfma;
 using chain::pin;
 
@@ -206,6 +208,88 @@ __device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int f
     pre[i] = v;
   }
 }
+// One 16-byte piece of a WHOLE tile (wave-uniform precondition: frames - frame0 >= kTF): what tile_fetch's full-tile branch
+// does for piece I.  The kernels issue the next tile's pieces one at a time between the MFMAs of the current tile
+// (gemm_pass's `each`, the wgrad loops): issued in one burst right behind the barrier they took 3-4 k cycles per tile in
+// which nothing else ran (s_memtime stamps of bwd_fused_mfma: the memory pipeline's queues fill and vector-memory issue
+// blocks), 14 % of the fused backward kernel.
+template <int C, int NTHR, int I>
+__device__ __forceinline__ void tile_fetch_piece(const float* __restrict__ base, int frame0, int tid,
+                                                 f32x4 (&pre)[Stage<C, NTHR>::kPer]) {
+  using St = Stage<C, NTHR>;
+  static_assert(I < St::kPer, "piece index");
+  // wave-uniform base (SGPR pair) + ONE unsigned 32-bit lane offset shared by every piece: the saddr form of
+  // global_load_dwordx4 -- per-piece 64-bit lane addresses stayed live across the MFMA pass and spilled
+  const char* sb = reinterpret_cast<const char*>(base + (size_t)frame0 * St::kFrame + (size_t)I * St::kStride * 4);
+  const unsigned voff = (unsigned)tid * 16u;
+  const bool active = (St::kStride == NTHR || tid < St::kStride) &&
+                      ((I + 1) * St::kStride <= St::kVec || tid + I * St::kStride < St::kVec);
+  if (active) pre[I] = *reinterpret_cast<const f32x4*>(sb + voff);   // idle lanes: the commit never looks at theirs
+}
+// The same piece by LDS-DMA into a raw copy of the tile in LDS (`stg`, float4 q of the tile at stg + 4 q): no VGPR holds
+// the next tile while the current one is computed.  A wave's 64 lanes are 64 consecutive float4, i.e. one contiguous
+// 1-KiB transfer (global_load_lds_dwordx4: lane i writes M0 + 16 i); wave-uniform source base + one lane offset.
+// `tid` is the thread of the NTHR-thread mapping whose piece this is, not necessarily the issuing thread: the transfer
+// touches no register, so any wave can issue any wave's share (bwd_fused_mfma: the wgrad half issues the whole tile).
+template <int C, int NTHR, int I>
+__device__ __forceinline__ void tile_dma_piece(const float* __restrict__ base, int frame0, int tid, float* stg) {
+  using St = Stage<C, NTHR>;
+  static_assert(I < St::kPer, "piece index");
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool active = (St::kStride == NTHR || tid < St::kStride) &&
+                      ((I + 1) * St::kStride <= St::kVec || tid + I * St::kStride < St::kVec);
+  // (the source base is wave-uniform by construction; taken through readfirstlane because hipcc otherwise hands the "s"
+  // operand of the inline asm a VGPR pair in some instantiations -- an assembler error, not a silent one)
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base + (size_t)frame0 * St::kFrame + (size_t)(I * St::kStride + 64 * wave) * 4);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const float* src = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+  if (active) lds_dma16s(src, (unsigned)(tid & 63) * 16u, stg + (I * St::kStride + 64 * wave) * 4);
+}
+// staging copy -> the registers tile_commit* take (transient: only while a tile is committed)
+template <int C, int NTHR>
+__device__ __forceinline__ void stage_load(const float* stg, int tid, f32x4 (&pre)[Stage<C, NTHR>::kPer]) {
+  using St = Stage<C, NTHR>;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(stg) + tid;
+#pragma unroll
+  for (int i = 0; i < St::kPer; ++i)
+    if ((St::kStride == NTHR || tid < St::kStride) && ((i + 1) * St::kStride <= St::kVec || tid + i * St::kStride < St::kVec))
+      pre[i] = s4[i * St::kStride];
+}
+// a tile cut short by the end of the batch: tile_fetch's bounds-checked loads, then into the staging copy
+template <int C, int NTHR>
+__device__ __forceinline__ void stage_store(float* stg, int tid, const f32x4 (&pre)[Stage<C, NTHR>::kPer]) {
+  using St = Stage<C, NTHR>;
+  f32x4* s4 = reinterpret_cast<f32x4*>(stg) + tid;
+#pragma unroll
+  for (int i = 0; i < St::kPer; ++i)
+    if ((St::kStride == NTHR || tid < St::kStride) && tid + i * St::kStride < St::kVec) s4[i * St::kStride] = pre[i];
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void tm_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    tm_static_for<I + 1, N>(f);
+  }
+}
+#ifndef RCED_TM_BWD_DMA
+#define RCED_TM_BWD_DMA 0     // 1: bwd_fused_mfma stages the next tile by LDS-DMA into a raw LDS copy, issued by the wgrad half
+                              // (no VGPR holds the next tile: no scratch).  Measured slower than VGPR staging in every form
+                              // (all waves in a burst 2.99 / 2.05 ms, spread over the MFMA phase 3.29 / 2.13, wgrad half alone
+                              // 2.99 / 2.24, against 2.86 / 1.94 ms for the two CR-CED shapes): kept as a switch for the record
+#endif
+#ifndef RCED_TM_BWD_STAGGER
+#define RCED_TM_BWD_STAGGER 1 // VGPR staging: the wgrad half issues its share of the next tile's loads at the start of the MFMA
+                              // phase, the dgrad half its share BEHIND its MFMA pass (in front of its epilogue): two half-size
+                              // bursts, each beside the other half's MFMAs, instead of one that stalls all eight waves
+#endif
+#ifndef RCED_TM_BWD_DEPTH
+#define RCED_TM_BWD_DEPTH (RCED_TM_BWD_DMA ? 2 : 1)   // operand prefetch depth of the fused backward kernel's dgrad pass
+#endif
+#ifndef RCED_TM_SPREAD
+#define RCED_TM_SPREAD 0   // 1: the next tile's loads are issued piece by piece inside the MFMA phase; 0: in one burst.
+                           // Measured (round 3, CR-CED step): spread 55.1 ms, burst 51.5 ms -- a load that finds the memory
+                           // pipeline's queues full blocks its wave, and with it that wave's MFMAs, piece after piece
+#endif
 // dst index of element (frame fr, offset r inside the frame) = base_row(fr) * ROWSTRIDE-style mapping given by MAP
 // Input transform applied while committing a tile: the producer layer's BatchNorm + ReLU (module.py:28-33),
 //   act = relu(a * z + b),   a = gamma * rstd,  b = beta - a * mu   (per channel; bn_act_fwd2 / bwd_route2 use the
@@ -376,18 +460,23 @@ struct SumArgs {
 // SUMX (with SUMS, the fused backward kernel): the masked sums are formed from the TRANSFORMED tile x = relu(a z + b) the
 // same workgroup has staged for its wgrad half (zt = that tile, pixel p at row kG + p): x > 0 is the mask and the second
 // sum is sum d_u * x (sums_fix_x turns it into S2); no z tile, no extra barrier.
-template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false, bool OPQ = false, bool SUMX = false>
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false, bool OPQ = false, bool SUMX = false,
+          class Each = chain::NoEach, bool EXTACC = false, int DEPTH = 2>
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
                                           int frames, int wave, int lane,
-                                          double* red_wave, const float* zt = nullptr, const float* stab = nullptr) {
+                                          double* red_wave, const float* zt = nullptr, const float* stab = nullptr,
+                                          Each each = Each(), f32x4* acc_store = nullptr) {
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(!(SUMS && (STATS || ACCUM || G::kPH != 1 || (COUT & 1))), "SUMS: overwrite-mode dgrads with an even, unpaired cout");
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMT, PH = G::kPH;
   const float* in = lds_in + G::kG * G::kCinP;
   const int xtile = NR * kWaves + wave;
-  f32x4 acc[NT][MT];
+  // acc_store: the caller's registers for the tile's accumulators (bwd_fused_mfma shares them with its wgrad half's
+  // kernel-lifetime accumulators: a wave has one role, but two arrays are both live in every wave for the allocator)
+  f32x4 acc_local[EXTACC ? 1 : NT][EXTACC ? 1 : MT];
+  f32x4 (&acc)[NT][MT] = *reinterpret_cast<f32x4 (*)[NT][MT]>(EXTACC ? acc_store : &acc_local[0][0]);
 #if RCED_TM_STAMPS
-  const bool st_on = SUMS && CIN == 30 && blockIdx.x == 0;
+  const bool st_on = SUMS && (CIN == 30 || SUMX) && blockIdx.x == 0;
   unsigned long long c0 = 0;
 #endif
   {
@@ -403,8 +492,9 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
     c0 = st_on ? tm_stamp() : 0;
 #endif
     if (!(RCED_TM_EXP & 4))
-      chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, 2>(in, (PH * px0 - G::kG) * G::kCinP + 2 * kq,
-                                                                  (PH * pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc);
+      chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, DEPTH, -1, chain::NoPre, Each>(
+          in, (PH * px0 - G::kG) * G::kCinP + 2 * kq, (PH * pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc, chain::NoPre(), each);
+    each(-1);   // behind the pass, in front of the epilogue (bwd_fused_mfma's dgrad half issues its loads here)
   }
   // The epilogue's lane coordinates are re-derived behind an opaque barrier: left visible, hipcc hoists every per-lane
   // address of the epilogue (pixel -> frame / bin splits, LDS offsets of the z tile, 64-bit row offsets) out of the tile
@@ -457,8 +547,81 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #else
 #define TM_E(i)
 #endif
+  // Slot t of this wave is column tile k = wave + 4 t (the extra slot is t = NR): pixels [16 PH k, 16 PH (k + 1)), a
+  // wave-uniform range.  15 of a tile's 17 column tiles lie inside ONE frame (no gap pixel, nothing past the tile): for those
+  // the frame index is a scalar, every lane is valid, and a lane's global / LDS addresses are one per-lane offset (the
+  // same for every slot) plus wave-uniform terms -- no per-lane pixel -> (frame, bin) split, no validity masks, no 64-bit
+  // lane arithmetic (what used to be hoisted out of the tile loop for every slot and spilled).  The two mixed tiles keep
+  // the per-lane path below.
+#ifndef RCED_TM_CLEAN
+#define RCED_TM_CLEAN 1
+#endif
+  constexpr bool kCleanPath = RCED_TM_CLEAN && (COUT % 2 == 0) && !(SUMS && !SUMX) && !(RCED_TM_EXP & 2);
+  const int px_lane0 = PH == 2 ? 2 * px0 + (kq >> 1) : px0;                      // this lane's pixel in slot 0
+  const unsigned lane_b = (unsigned)(px_lane0 * COUT + (PH == 2 ? 4 * (kq & 1) : 4 * kq)) * 4u;   // bytes
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    if constexpr (kCleanPath) {
+      const int k = wave + kWaves * t, pbeg = 16 * PH * k, pend = pbeg + 16 * PH - 1;
+      const bool in0 = pend < kF, in1 = pbeg >= G::kS && pend < G::kS + kF;
+      if (in0 || in1) {
+        const int fr = in1 ? 1 : 0;
+        if (frame0 + fr >= frames) continue;
+        if constexpr (STATS) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float v = acc[t][mt][j];
+              p1[mt][j] += v;
+              p2[mt][j] = fmaf(v, v, p2[mt][j]);
+            }
+        }
+        if constexpr (SUMS && SUMX) {
+          const char* zb = reinterpret_cast<const char*>(zt) + lane_b;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            constexpr int dummy = 0; (void)dummy;
+            const int imm = ((G::kG + 64 * t) * COUT + 16 * mt) * 4;
+            const int co0 = 16 * mt + 4 * kq;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (16 * mt + 16 <= COUT || co0 + 1 < COUT) { const f32x2 q = *reinterpret_cast<const f32x2*>(zb + imm); xv.x = q.x; xv.y = q.y; }
+            if (16 * mt + 16 <= COUT || co0 + 3 < COUT) { const f32x2 q = *reinterpret_cast<const f32x2*>(zb + imm + 8); xv.z = q.x; xv.w = q.y; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (16 * mt + 16 > COUT && co0 + (j | 1) >= COUT) continue;
+              const float du = xv[j] > 0.f ? acc[t][mt][j] : 0.f;
+              p1[mt][j] += du;
+              p2[mt][j] = fmaf(du, xv[j], p2[mt][j]);
+            }
+          }
+        }
+        // wave-uniform base of this slot (scalar registers) + the lane offset: the saddr form of the global accesses
+        char* ob = reinterpret_cast<char*>(out + (size_t)(frame0 + fr) * (kF * COUT)) + ((64 * PH * t) * COUT - (in1 ? G::kS * COUT : 0)) * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 v = acc[t][mt];
+          char* p = ob + 16 * mt * 4 + lane_b;
+          if (PH == 2 || 16 * mt + 16 <= COUT) {
+            f32x4 r = v;
+            if (ACCUM) r += *reinterpret_cast<const f32x4u*>(p);
+            *reinterpret_cast<f32x4u*>(p) = r;
+          } else {
+            const int co0 = 16 * mt + 4 * kq;
+            if (co0 + 3 < COUT) {
+              f32x4 r = v;
+              if (ACCUM) r += *reinterpret_cast<const f32x4u*>(p);
+              *reinterpret_cast<f32x4u*>(p) = r;
+            } else if (co0 + 1 < COUT) {
+              f32x2 r = {v.x, v.y};
+              if (ACCUM) { const f32x2 o = *reinterpret_cast<const f32x2*>(p); r.x += o.x; r.y += o.y; }
+              *reinterpret_cast<f32x2*>(p) = r;
+            }
+          }
+        }
+        continue;
+      }
+    }
     const int col = t < NR ? px0 + 64 * t : pxx;
     const int px = PH == 2 ? 2 * col + (kq >> 1) : col;   // PH = 2: lane rows 4kq.. = parity kq >> 1, couts 4 (kq & 1)..
     const int fr = px >= G::kS ? 1 : 0, f = px - (fr ? G::kS : 0);   // kTF = 2 (px < 2 kS + 16 is checked below)
@@ -516,17 +679,18 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
       const int co0 = PH == 2 ? 4 * (kq & 1) : 16 * mt + 4 * kq;
       f32x4 v = acc[t][mt];
       if (co0 + 1 < COUT || (co0 < COUT && (COUT & 1))) {
-        // 8-byte pieces where the row stride allows it (COUT even), else scalars
+        // the lane's four channels are 16 contiguous bytes of the pixel's row: ONE 16-byte store (dword-aligned: the row
+        // stride is a multiple of 8 bytes only; global_store_dwordx4 takes that) instead of two 8-byte ones -- half the
+        // vector-memory instructions of the epilogue, which queue behind the next tile's loads; a last pair: 8 bytes
         if constexpr ((COUT & 1) == 0) {
-          if (co0 + 1 < COUT) {
+          if (co0 + 3 < COUT) {
+            f32x4u* p = reinterpret_cast<f32x4u*>(op + co0);
+            f32x4 r = v;
+            if (ACCUM) { const f32x4 o = *p; r += o; }
+            *p = r;
+          } else if (co0 + 1 < COUT) {
             f32x2* p = reinterpret_cast<f32x2*>(op + co0);
             f32x2 r = {v.x, v.y};
-            if (ACCUM) { const f32x2 o = *p; r.x += o.x; r.y += o.y; }
-            *p = r;
-          }
-          if (co0 + 3 < COUT) {
-            f32x2* p = reinterpret_cast<f32x2*>(op + co0 + 2);
-            f32x2 r = {v.z, v.w};
             if (ACCUM) { const f32x2 o = *p; r.x += o.x; r.y += o.y; }
             *p = r;
           }
@@ -673,15 +837,35 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
       TM_ST(2);   // barrier 1
       if constexpr (SUMS)
         if (!(RCED_TM_EXP & 1) || tile == (int)blockIdx.x) ztile_fetch<COUT>(sa.z, zt, frame0, frames, tid);   // the previous tile's epilogue is behind a barrier
-      if (tile + (int)gridDim.x < ntiles && !(RCED_TM_EXP & 1)) {
-        tile_fetch<CIN>(in, (tile + gridDim.x) * kTF, frames, tid, pre);
-        if constexpr (XF == kXfBnBwd) tile_fetch<CIN>(ba.z, (tile + gridDim.x) * kTF, frames, tid, pre2);
+      // The next tile's loads: piece by piece between this tile's MFMAs (RCED_TM_SPREAD; not where the epilogue waits on
+      // vmcnt(0) for its z tile (SUMS), which would wait for them too), or all at once here -- a tile cut short by the
+      // end of the batch always takes the latter, with tile_fetch's per-element bounds.
+      constexpr bool kSpread = RCED_TM_SPREAD && !SUMS;
+      const int nframe0 = (tile + (int)gridDim.x) * kTF;
+      const bool more = tile + (int)gridDim.x < ntiles && !(RCED_TM_EXP & 1);
+      const bool spread = kSpread && more && frames - nframe0 >= kTF;
+      if (more && !spread) {
+        tile_fetch<CIN>(in, nframe0, frames, tid, pre);
+        if constexpr (XF == kXfBnBwd) tile_fetch<CIN>(ba.z, nframe0, frames, tid, pre2);
       }
       pin();
       TM_ST(3);   // fetch issue
+      constexpr int kP1 = Stage<CIN>::kPer, kNP = (XF == kXfBnBwd ? 2 : 1) * kP1, kNS = G::kKP / 8;
+      auto each = [&](int s) {
+        if constexpr (kSpread) {
+          if (spread)
+            tm_static_for<0, kNP>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              if (s == i * kNS / kNP) {
+                if constexpr (i < kP1) tile_fetch_piece<CIN, kThreads, i>(in, nframe0, tid, pre);
+                else if constexpr (XF == kXfBnBwd) tile_fetch_piece<CIN, kThreads, i - kP1>(ba.z, nframe0, tid, pre2);
+              }
+            });
+        }
+      };
       constexpr bool kOpq = (XF == kXfBnBwd ? 2 : 1) * Stage<CIN>::kPer * 4 >= RCED_TM_OPQ_MIN;   // VGPRs holding the next tile
-      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab);
-      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab);
+      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each);
+      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each);
       TM_ST(4);   // conv_tile
       __syncthreads();
       TM_ST(5);   // barrier 3
@@ -786,13 +970,28 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const flo
     if constexpr (DZF) tile_commit_bnbwd<COUT>(ldz, tid, prez, prez2, where_dz, dt, tile * kTF, frames, ba.beta != nullptr);
     else tile_commit<COUT>(ldz, tid, prez, where_dz);
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) {
-      tile_fetch<CIN>(x, (tile + gridDim.x) * kTF, frames, tid, prex);
-      tile_fetch<COUT>(dz, (tile + gridDim.x) * kTF, frames, tid, prez);
-      if constexpr (DZF) tile_fetch<COUT>(ba.z, (tile + gridDim.x) * kTF, frames, tid, prez2);
+    const int nframe0 = (tile + (int)gridDim.x) * kTF;
+    const bool more = tile + (int)gridDim.x < ntiles;
+    const bool spread = RCED_TM_SPREAD && more && frames - nframe0 >= kTF;
+    if (more && !spread) {
+      tile_fetch<CIN>(x, nframe0, frames, tid, prex);
+      tile_fetch<COUT>(dz, nframe0, frames, tid, prez);
+      if constexpr (DZF) tile_fetch<COUT>(ba.z, nframe0, frames, tid, prez2);
     }
     pin();
-    for (int g = wave; g < kGroups; g += kWaves) {
+    constexpr int kPX = Stage<CIN>::kPer, kPZ = Stage<COUT>::kPer, kNP = kPX + (DZF ? 2 : 1) * kPZ;
+    constexpr int kIters = kGroups / kWaves;     // iterations every wave runs: the pieces are spread over them
+    int it = 0;
+    for (int g = wave; g < kGroups; g += kWaves, ++it) {
+      if (spread)
+        tm_static_for<0, kNP>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if (it == i * kIters / kNP) {
+            if constexpr (i < kPX) tile_fetch_piece<CIN, kThreads, i>(x, nframe0, tid, prex);
+            else if constexpr (i < kPX + kPZ) tile_fetch_piece<COUT, kThreads, i - kPX>(dz, nframe0, tid, prez);
+            else if constexpr (DZF) tile_fetch_piece<COUT, kThreads, i - kPX - kPZ>(ba.z, nframe0, tid, prez2);
+          }
+        });
       const int px0 = 4 * PH * g;
       float a[KT], b[NTo];
 #pragma unroll
@@ -850,8 +1049,53 @@ struct BwdGeo {
   static constexpr int kXOff = r4(kPkOff + GD::kPacket);             // [GW::kInRows][CIN] (+ slack)
   static constexpr int kTabOff = r4(kXOff + GW::kInFloats + 64);     // [2][CIN] BatchNorm + ReLU of x, then [4][COUT] BatchNorm backward
   static constexpr int kRedOff = r4(kTabOff + 2 * CIN + 4 * COUT);   // [4 waves][32][2] doubles
-  static constexpr int kLdsFloats = kRedOff + kConvRedFloats;
+  // raw copies of the NEXT tile (LDS-DMA targets, RCED_TM_BWD_DMA): x [2][129][CIN], d_u / g [2][129][COUT], z [2][129][COUT]
+  static constexpr int kStgX = r4(kRedOff + kConvRedFloats);
+  static constexpr int kStgD = kStgX + r4(kTF * kF * CIN);
+  static constexpr int kStgZ = kStgD + r4(kTF * kF * COUT);
+  static constexpr int kLdsFloats = RCED_TM_BWD_DMA ? kStgZ + r4(kTF * kF * COUT) : kRedOff + kConvRedFloats;
+  static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
   static_assert(GD::kG == GW::kG && GD::kS == GW::kS, "one pixel space");
+};
+
+// Split of the wgrad pixel groups over the four wgrad waves (see the tile loop).  d[w] = MFMAs of dgrad wave w per tile,
+// g = MFMAs per wgrad group; wave w gets round((T - d[w]) / g) groups, T = the per-SIMD mean, the last wave the rest.
+template <int CIN, int TAPS, int COUT>
+struct BwdBalance {
+  using GD = Geo<COUT, TAPS, CIN>;
+  using GW = Geo<CIN, TAPS, COUT>;
+  static constexpr int PH = COUT == 8 ? 2 : 1;
+  static constexpr int kRowsK = (TAPS + PH - 1) * GW::kCinP;
+  static constexpr int KT = (kRowsK + 1 + 15) / 16, NTo = PH == 2 ? 1 : GW::kMT;
+  static constexpr int kGroups = PH == 2 ? (GW::kNPX / 2 + 3) / 4 : GW::kNPX / 4 + 1;
+  static constexpr int kPerTile = (GD::kKP / 8 * 2 + (GD::kKP % 8 + 3) / 4) * GD::kMT;   // MFMAs of one dgrad column tile
+  static constexpr int kPerGroup = KT * NTo;
+  static constexpr int dgrad(int w) { return (GD::kRegular + (w < GD::kExtra ? 1 : 0)) * kPerTile; }
+  static constexpr int kTotal = GD::kCTiles * kPerTile + kGroups * kPerGroup;
+  static constexpr int count(int w) {       // groups of wgrad wave w (0..3)
+    int used = 0;
+    for (int v = 0; v < 4; ++v) {
+      int n = (kTotal / 4 - dgrad(v) + kPerGroup / 2) / kPerGroup;
+      if (n < 1) n = 1;
+      if (v == 3 || used + n > kGroups - (3 - v)) n = v == 3 ? kGroups - used : kGroups - (3 - v) - used;
+      if (v == w) return n;
+      used += n;
+    }
+    return 0;
+  }
+  __host__ __device__ static constexpr int begin_c(int w) {
+    int b = 0;
+    for (int v = 0; v < w; ++v) b += count(v);
+    return b;
+  }
+  __device__ __forceinline__ static int begin(int w) {      // w wave-uniform, 0..4
+    return w == 0 ? 0 : w == 1 ? begin_c(1) : w == 2 ? begin_c(2) : w == 3 ? begin_c(3) : kGroups;
+  }
+  static constexpr int kMinIters = count(0) < count(1) ? (count(0) < count(2) ? (count(0) < count(3) ? count(0) : count(3))
+                                                                               : (count(2) < count(3) ? count(2) : count(3)))
+                                                        : (count(1) < count(2) ? (count(1) < count(3) ? count(1) : count(3))
+                                                                               : (count(2) < count(3) ? count(2) : count(3)));
+  static_assert(begin_c(4) == kGroups && count(0) > 0 && count(1) > 0 && count(2) > 0 && count(3) > 0, "every group has one owner");
 };
 
 // Measured alternatives: tile i+1 committed into a second pair of LDS buffers by the wgrad half alone while
@@ -891,41 +1135,144 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
   __syncthreads();
   if constexpr (XF) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
   bnbwd_table_fill<COUT>(dt, ba, tid);
-  f32x4 acc[KT][NTo];
+  // ONE register array for both roles: the wgrad half's [KT][NTo] accumulators live for the whole kernel, the dgrad
+  // half's [column tiles][M-tiles] per tile -- a wave has one role, but as two arrays both are live in every wave as far
+  // as the register allocator can tell (the kernel sat at 256 VGPRs + scratch)
+  constexpr int kDgAcc = (GD::kRegular + 1) * GD::kMT, kAccN = KT * NTo > kDgAcc ? KT * NTo : kDgAcc;
+  f32x4 accs[kAccN];
+  f32x4 (&acc)[KT][NTo] = *reinterpret_cast<f32x4 (*)[KT][NTo]>(&accs[0]);
 #pragma unroll
-  for (int a = 0; a < KT; ++a)
-#pragma unroll
-    for (int b = 0; b < NTo; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < kAccN; ++a) accs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (frames + kTF - 1) / kTF;
-  f32x4 prex[Stage<CIN, NTH>::kPer], pred[Stage<COUT, NTH>::kPer], prez[Stage<COUT, NTH>::kPer];
+  constexpr bool DMA = RCED_TM_BWD_DMA != 0;
+  constexpr int kPX = Stage<CIN, NTH>::kPer, kPZ = Stage<COUT, NTH>::kPer, kNP = kPX + 2 * kPZ;
+  float* sx = lds + B::kStgX;
+  float* sd = lds + B::kStgD;
+  float* sz = lds + B::kStgZ;
+  f32x4 prex[kPX], pred[kPZ], prez[kPZ];     // DMA: transient (stage_load -> commit); else the next tile for a whole tile time
+  // the next tile into the staging copies: by LDS-DMA piece i (whole tiles), or all of a ragged last tile with bounds checks
+  auto dma_piece = [&](auto ic, int f0, int vt) {     // vt: the thread of the piece map whose share is issued
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < kPX) tile_dma_piece<CIN, NTH, i>(x, f0, vt, sx);
+    else if constexpr (i < kPX + kPZ) tile_dma_piece<COUT, NTH, i - kPX>(du, f0, vt, sd);
+    else tile_dma_piece<COUT, NTH, i - kPX - kPZ>(ba.z, f0, vt, sz);
+  };
+  auto stage_ragged = [&](int f0) {
+    tile_fetch<CIN, NTH>(x, f0, frames, tid, prex);
+    tile_fetch<COUT, NTH>(du, f0, frames, tid, pred);
+    tile_fetch<COUT, NTH>(ba.z, f0, frames, tid, prez);
+    stage_store<CIN, NTH>(sx, tid, prex);
+    stage_store<COUT, NTH>(sd, tid, pred);
+    stage_store<COUT, NTH>(sz, tid, prez);
+  };
+  __syncthreads();                            // the LDS image is zeroed / the packet is in place before anything lands in it
   if ((int)blockIdx.x < ntiles) {
-    tile_fetch<CIN, NTH>(x, blockIdx.x * kTF, frames, tid, prex);
-    tile_fetch<COUT, NTH>(du, blockIdx.x * kTF, frames, tid, pred);
-    tile_fetch<COUT, NTH>(ba.z, blockIdx.x * kTF, frames, tid, prez);
+    const int f0 = blockIdx.x * kTF;
+    if constexpr (DMA) {
+      if (frames - f0 >= kTF) tm_static_for<0, kNP>([&](auto ic) { dma_piece(ic, f0, tid); });
+      else stage_ragged(f0);
+    } else {
+      tile_fetch<CIN, NTH>(x, f0, frames, tid, prex);
+      tile_fetch<COUT, NTH>(du, f0, frames, tid, pred);
+      tile_fetch<COUT, NTH>(ba.z, f0, frames, tid, prez);
+    }
   }
   __syncthreads();
   const float* ain = lx + PH * kq * GW::kCinP + i;
   const float* ldzp = ldz + GD::kG * COUT;
   const float* bin = PH == 2 ? ldzp + (2 * kq + (i >> 3)) * COUT + (i & 7) : ldzp + kq * COUT + i;
+#if RCED_TM_STAMPS
+  const bool stamps_on = SUMS && blockIdx.x == 0;
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamps_on ? tm_stamp() : 0;
+  if (stamps_on && lane == 0 && role == 0) for (int q = 0; q < 4; ++q) g_tm[wave][q] = g_tm2[wave][q] = 0;
+#endif
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int frame0 = tile * kTF;
     auto where_x = [](int fr, int r) { return (GW::kG + fr * GW::kS) * CIN + r; };
     auto where_dz = [](int fr, int r) { return (GD::kG + fr * GD::kS) * COUT + r; };
+    if constexpr (DMA) {
+      // this wave's transfers of the tile have landed ... and everybody's (this is also the barrier behind the previous
+      // tile's MFMA reads of the operand tiles the commit below overwrites)
+      // (the dgrad half issued none -- except in the prologue -- and must not wait here: vmcnt(0) would also wait for
+      // its epilogue's global stores, which are free to stay in flight across the barrier)
+      if (role == 1 || tile == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TM_ST(0);   // wait for the staged tile
+      __syncthreads();
+      stage_load<CIN, NTH>(sx, tid, prex);
+    } else {
+#if RCED_TM_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TM_ST(0);   // wait for the prefetched tile
+#endif
+    }
     if constexpr (XF) tile_commit_bnrelu<CIN, NTH>(lx, tid, prex, where_x, xt, frame0, frames);
     else tile_commit<CIN, NTH>(lx, tid, prex, where_x);
+    if constexpr (DMA) {      // the x pieces are dead before the (d_u, z) pieces are read: 12-16 fewer registers at the peak
+      pin();
+      stage_load<COUT, NTH>(sd, tid, pred);
+      stage_load<COUT, NTH>(sz, tid, prez);
+    }
     tile_commit_bnbwd<COUT, NTH>(ldz, tid, pred, prez, where_dz, dt, frame0, frames, ba.beta != nullptr);
+    TM_ST(1);   // commit
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) {
-      tile_fetch<CIN, NTH>(x, (tile + gridDim.x) * kTF, frames, tid, prex);
-      tile_fetch<COUT, NTH>(du, (tile + gridDim.x) * kTF, frames, tid, pred);
-      tile_fetch<COUT, NTH>(ba.z, (tile + gridDim.x) * kTF, frames, tid, prez);
+    TM_ST(2);   // barrier 1
+    const int nframe0 = (tile + (int)gridDim.x) * kTF;
+    const bool more = tile + (int)gridDim.x < ntiles;
+    const bool spread = RCED_TM_SPREAD && !DMA && more && frames - nframe0 >= kTF;
+    if (more && !spread) {
+      if constexpr (DMA) {
+        // Issued by the WGRAD half alone, each of its threads for two threads of the 512-thread piece map: the burst
+        // finds the memory pipeline's queues full and blocks the issuing waves for 3-4 k cycles (stamps) -- now only the
+        // wgrad wave of every SIMD, while its dgrad wave runs the MFMA pass; the wgrad wave's own MFMAs then run beside
+        // the dgrad wave's epilogue.  (All eight waves issuing their own pieces stalled the whole CU: 14 % of the kernel.)
+        if (frames - nframe0 >= kTF) {
+          if (role == 1)
+            tm_static_for<0, kNP>([&](auto ic) {
+              dma_piece(ic, nframe0, tid - 256);
+              dma_piece(ic, nframe0, tid);
+            });
+        } else {
+          stage_ragged(nframe0);
+        }
+      } else if (!RCED_TM_BWD_STAGGER || role == 1) {
+        tile_fetch<CIN, NTH>(x, nframe0, frames, tid, prex);
+        tile_fetch<COUT, NTH>(du, nframe0, frames, tid, pred);
+        tile_fetch<COUT, NTH>(ba.z, nframe0, frames, tid, prez);
+      }
     }
     pin();
+    TM_ST(3);   // fetch issue
+    auto piece = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (DMA) dma_piece(ic, nframe0, tid);
+      else if constexpr (i < kPX) tile_fetch_piece<CIN, NTH, i>(x, nframe0, tid, prex);
+      else if constexpr (i < kPX + kPZ) tile_fetch_piece<COUT, NTH, i - kPX>(du, nframe0, tid, pred);
+      else tile_fetch_piece<COUT, NTH, i - kPX - kPZ>(ba.z, nframe0, tid, prez);
+    };
     if (role == 0) {
-      if (wave < GD::kExtra) conv_tile<COUT, TAPS, CIN, false, false, 1, SUMS, false, true>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx);
-      else conv_tile<COUT, TAPS, CIN, false, false, 0, SUMS, false, true>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx);
+      constexpr int kNS = GD::kKP / 8;
+      auto each = [&](int s) {
+        if (spread)
+          tm_static_for<0, kNP>([&](auto ic) { if (s == decltype(ic)::value * kNS / kNP) piece(ic); });
+        if (RCED_TM_BWD_STAGGER && !DMA && s == -1 && more && !spread) {
+          tile_fetch<CIN, NTH>(x, nframe0, frames, tid, prex);
+          tile_fetch<COUT, NTH>(du, nframe0, frames, tid, pred);
+          tile_fetch<COUT, NTH>(ba.z, nframe0, frames, tid, prez);
+          pin();
+        }
+      };
+      if (wave < GD::kExtra) conv_tile<COUT, TAPS, CIN, false, false, 1, SUMS, false, true, decltype(each), true, RCED_TM_BWD_DEPTH>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx, nullptr, each, accs);
+      else conv_tile<COUT, TAPS, CIN, false, false, 0, SUMS, false, true, decltype(each), true, RCED_TM_BWD_DEPTH>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx, nullptr, each, accs);
     } else {
-      for (int g = wave; g < kGroups; g += kWaves) {
+      // Groups of this wgrad wave: a contiguous range sized so that every SIMD (dgrad wave w + wgrad wave w) issues the
+      // same number of MFMAs per tile -- the dgrad wave that carries the odd column tile gets fewer groups beside it
+      // (the barrier that ends a tile waits for the fullest SIMD: 573 / 498 / 498 / 498 MFMAs before, for the 18 -> 30 layer).
+      const int gbeg = BwdBalance<CIN, TAPS, COUT>::begin(wave), gend = BwdBalance<CIN, TAPS, COUT>::begin(wave + 1);
+      constexpr int kIters = BwdBalance<CIN, TAPS, COUT>::kMinIters;
+      int it = 0;
+      for (int g = gbeg; g < gend; ++g, ++it) {
+        if (spread)
+          tm_static_for<0, kNP>([&](auto ic) { if (it == decltype(ic)::value * kIters / kNP) piece(ic); });
         const int px0 = 4 * PH * g;
         float a[KT], b[NTo];
 #pragma unroll
@@ -939,8 +1286,18 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
           for (int nt = 0; nt < NTo; ++nt) acc[kt][nt] = mfma(a[kt], b[nt], acc[kt][nt]);
       }
     }
-    __syncthreads();
+    TM_ST(4);   // role work
+    if constexpr (!DMA) __syncthreads();   // (DMA: the barrier at the top of the next tile, behind its vmcnt wait)
+    TM_ST(5);   // barrier 2
   }
+  if constexpr (DMA) __syncthreads();      // the dgrad half's LDS records are complete before they are summed below
+#if RCED_TM_STAMPS
+  if (stamps_on && lane == 0)
+    printf("BWST<%d,%d,%d> wave8 %d: loadwait %llu commit %llu bar1 %llu fetch %llu work %llu bar2 %llu | gemm %llu epi %llu (coords %llu sums %llu stores %llu)\n",
+           CIN, TAPS, COUT, wave8, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], role == 0 ? g_tm[wave][0] : 0ull,
+           role == 0 ? g_tm[wave][2] : 0ull, role == 0 ? g_tm2[wave][0] : 0ull, role == 0 ? g_tm2[wave][1] : 0ull,
+           role == 0 ? g_tm2[wave][2] : 0ull);
+#endif
   if (role == 1) {
     // D row = k = 16*kt + 4*kq + r, column = co = 16*nt + i   (PH = 2: column = (parity i >> 3, co = i & 7), tap = k' - parity)
 #pragma unroll

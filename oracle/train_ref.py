@@ -32,6 +32,47 @@ def trainable_names(net_work):
     return [n for n, _ in L.variable_shapes(L.layers_for(net_work)) if "moving_" not in n]
 
 
+class _TapsConv(torch.autograd.Function):
+    """y[n,t,f,:] = sum_{i,j} xp[n,t+i,f+j,:] @ k[i,j] on NHWC tensors (xp = the SAME-padded input), tap by tap with plain
+    matmuls.  A custom Function because autograd through the plain loop keeps one contiguous copy of the shifted input PER
+    TAP for the backward (129 copies for the 1x129 output layer: 139 GB at BASELINE config 5's size); this one keeps x
+    and k only and walks the taps again in backward."""
+
+    @staticmethod
+    def forward(ctx, x, k, pads):
+        pt, pb, pl, pr = pads
+        kh, kw = k.shape[0], k.shape[1]
+        n, t, f, _ = x.shape
+        xp = Fn.pad(x, (0, 0, pl, pr, pt, pb))
+        y = None
+        for i in range(kh):
+            for j in range(kw):
+                term = xp[:, i:i + t, j:j + f, :] @ k[i, j]
+                y = term if y is None else y.add_(term)
+        ctx.save_for_backward(x, k)
+        ctx.pads = pads
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, k = ctx.saved_tensors
+        pt, pb, pl, pr = ctx.pads
+        kh, kw, cin, cout = k.shape
+        n, t, f, _ = x.shape
+        xp = Fn.pad(x, (0, 0, pl, pr, pt, pb))
+        g2 = g.reshape(-1, cout)
+        dk = torch.empty_like(k)
+        dxp = torch.zeros_like(xp) if ctx.needs_input_grad[0] else None
+        for i in range(kh):
+            for j in range(kw):
+                if ctx.needs_input_grad[1]:
+                    dk[i, j] = xp[:, i:i + t, j:j + f, :].reshape(-1, cin).t() @ g2
+                if dxp is not None:
+                    dxp[:, i:i + t, j:j + f, :] += g @ k[i, j].t()
+        dx = dxp[:, pt:pt + t, pl:pl + f, :] if dxp is not None else None
+        return dx, (dk if ctx.needs_input_grad[1] else None), None
+
+
 class TrainRef:
     def __init__(self, net_work, weights, batch_size, dtype=torch.float64, device="cpu", conv="conv2d"):
         """device / conv: the default is F.conv2d on the CPU.  conv="taps" computes every convolution as a sum over
@@ -68,13 +109,7 @@ class TrainRef:
                 pl, pr = (l.kw - 1) // 2, (l.kw - 1) - (l.kw - 1) // 2
                 src = tens[l.src]
                 n, t, f, _ = src.shape
-                xp = Fn.pad(src, (0, 0, pl, pr, pt, pb))
-                y = None
-                for i in range(l.kh):
-                    for j in range(l.kw):
-                        term = xp[:, i:i + t, j:j + f, :] @ k[i, j]
-                        y = term if y is None else y.add_(term)
-                del xp
+                y = _TapsConv.apply(src, k, (pt, pb, pl, pr))
                 y = y + self.vars[l.scope + "/bias"]
                 zhat = None
                 if l.use_norm:
