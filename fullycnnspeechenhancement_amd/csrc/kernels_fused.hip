@@ -299,13 +299,14 @@ void pack_chain16(const rced_model* m, std::vector<float>* wpack) {
     } else {
       const int cpi = G::cp(l - 1), K = G::K(l);
       unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+      constexpr int KS = G::kKStep, PL = KS / 4;     // k per MFMA (16 or 32) and per lane (4 or 8): k = KS s + PL kq + e
       for (int s = 0; s < G::steps(l); ++s)
         for (int mt = 0; mt < MT; ++mt)
           for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < 4; ++e) {
-              const int k = 16 * s + 4 * (lane >> 4) + e, co = 16 * mt + (lane & 15), tap = k / cpi, ci = k % cpi;
+            for (int e = 0; e < PL; ++e) {
+              const int k = KS * s + PL * (lane >> 4) + e, co = 16 * mt + (lane & 15), tap = k / cpi, ci = k % cpi;
               const float v = (k < K && co < d.cout && ci < d.cin) ? wq(L, tap, ci, co, d.cin) : 0.f;
-              d16[((size_t)(s * MT + mt) * 64 + lane) * 4 + e] = bf16_rne(v);
+              d16[((size_t)(s * MT + mt) * 64 + lane) * PL + e] = bf16_rne(v);
             }
     }
     for (int c = 0; c < d.cout; ++c) dst[G::data(l) + c] = L.host_shift[c];

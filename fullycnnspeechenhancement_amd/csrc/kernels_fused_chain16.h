@@ -26,6 +26,14 @@
 #define RCED_C16_LDS_KB 160
 #define RCED_C16_ATTR
 #endif
+#ifndef RCED_C16_K32
+#define RCED_C16_K32 0     // 1: inner layers on v_mfma_f32_16x16x32_bf16 (K = 32 per instruction in 16 cycles: the full bf16
+                           // rate, half the matrix-pipe time); 0: v_mfma_f32_16x16x16_bf16 (K = 16 in the same 16 cycles).
+                           // Measured, round 3 (A/B on one box, bench.py --dtype bf16): R-CED V2 batch 64 (BASELINE config 2)
+                           // fused kernel 0.890 vs 0.897 ms, batch 256 3.60 vs 3.67 ms; R-CED V1 batch 64 0.805 vs 0.700 ms
+                           // (K rounds up to 32 per layer).  Halving the MFMA cycles buys < 1 %: this kernel is not bound by
+                           // the matrix pipe -- so the default stays the K = 16 form
+#endif
 #ifndef RCED_C16_DEPTH
 #define RCED_C16_DEPTH 1   // operand prefetch depth of the bf16 pass (steps)
 #endif
@@ -70,14 +78,16 @@ struct Geo {
   }
   static constexpr int kChX = chmax(0), kChY = chmax(1);                      // X holds outputs of even layers
   // LDS map in floats (4-byte units); bf16 buffers take rows * ch / 2 floats
-  static constexpr int kXFloats = ((kRows * kChX / 2 + 8 + 3) / 4) * 4;       // + slack for the K-padding reads
-  static constexpr int kYFloats = ((kRows * kChY / 2 + 8 + 3) / 4) * 4;
+  static constexpr int kSlack = RCED_C16_K32 ? 16 : 8;                        // floats: reads of the zero-weight K padding
+  static constexpr int kXFloats = ((kRows * kChX / 2 + kSlack + 3) / 4) * 4;
+  static constexpr int kYFloats = ((kRows * kChY / 2 + kSlack + 3) / 4) * 4;
   static constexpr int kXOff = 0, kYOff = kXOff + kXFloats, kWOff = kYOff + kYFloats;
   // packets: layer 0 as in the fp32 kernel (b32 steps); layers >= 1: [step][mt][lane] x 4 bf16, then 32 shifts
   static constexpr int K(int l) { return N::layer[l].taps * cp(l - 1); }
-  static constexpr int steps(int l) { return (K(l) + 15) / 16; }
+  static constexpr int kKStep = RCED_C16_K32 ? 32 : 16;                       // K per MFMA
+  static constexpr int steps(int l) { return (K(l) + kKStep - 1) / kKStep; }
   static constexpr int MT(int l) { return (N::layer[l].cout + 15) / 16; }
-  static constexpr int data(int l) { return l == 0 ? G32::data(0) : steps(l) * MT(l) * 128; }
+  static constexpr int data(int l) { return l == 0 ? G32::data(0) : steps(l) * MT(l) * 64 * (kKStep / 8); }   // 2 bytes per k and lane
   static constexpr int packet(int l) { return data(l) + 32; }
   static constexpr int packet_off(int l) {
     int o = 0;
@@ -119,6 +129,53 @@ __device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
 __device__ __forceinline__ f32x4 from_bf16x4(s16x4 s) {
   const bf16x4 h = __builtin_bit_cast(bf16x4, s);
   return f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+}
+
+// K = 32 per instruction: lane kq supplies k = 32 s + 8 kq .. + 7 -- eight consecutive bf16 of the pixel's im2col window,
+// which starts 8-byte aligned (channel strides are multiples of 4), so the B operand is two 8-byte halves (hipcc fuses them
+// into one ds_read_b128 at an 8-byte-aligned address; the LDS takes that) and the A fragment one 16-byte read of the packet.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma32(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int NR, int NX, int MT, int STEPS, int STRIDE, int DEPTH, class Pre>
+__device__ __forceinline__ void pass32(const __bf16* act, int off0, int offx, const float* w, int lane,
+                                       f32x4 (&acc)[NR + NX][MT], Pre pre) {
+  constexpr int NT = NR + NX, RING = DEPTH + 1;
+  const s16x8* wp = reinterpret_cast<const s16x8*>(w) + lane;
+  s16x8 a[RING][MT], b[RING][NT];
+  int offs[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    offs[t] = t < NR ? off0 + t * STRIDE : offx;
+    asm volatile("" : "+v"(offs[t]));
+  }
+  auto load = [&](int s, int buf) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[buf][mt] = wp[(s * MT + mt) * 64];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const s16x4 lo = *reinterpret_cast<const s16x4*>(act + offs[t] + 32 * s);
+      const s16x4 hi = *reinterpret_cast<const s16x4*>(act + offs[t] + 32 * s + 4);
+      b[buf][t] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < DEPTH && s < STEPS; ++s) load(s, s % RING);
+  pin();
+  pre();
+  pin();
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    if (s + DEPTH < STEPS) load(s + DEPTH, (s + DEPTH) % RING);
+    pin();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma32(a[s % RING][mt], b[s % RING][t], acc[t][mt]);
+    pin();
+  }
 }
 
 // Implicit-GEMM pass on bf16: STEPS steps of K = 16 (lane kq supplies k = 16 s + 4 kq .. +3), NT = NR + NX slots.
@@ -186,7 +243,10 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     chain::first_pass<NR, NX, D.taps, G::kS, 2>(lds + G::kX0Off, px0 + kq * G::kS, pxx + kq * G::kS, w, lane, acc, dma);
   } else {
     constexpr int padl = (D.taps - 1) / 2, cpi = G::cp(L - 1);
-    pass16<NR, NX, MT, G::steps(L), 128 * cpi, RCED_C16_DEPTH>(in, (px0 - padl) * cpi + 4 * kq, (pxx - padl) * cpi + 4 * kq, w, lane, acc, dma);
+    if constexpr (RCED_C16_K32)
+      pass32<NR, NX, MT, G::steps(L), 128 * cpi, RCED_C16_DEPTH>(in, (px0 - padl) * cpi + 8 * kq, (pxx - padl) * cpi + 8 * kq, w, lane, acc, dma);
+    else
+      pass16<NR, NX, MT, G::steps(L), 128 * cpi, RCED_C16_DEPTH>(in, (px0 - padl) * cpi + 4 * kq, (pxx - padl) * cpi + 4 * kq, w, lane, acc, dma);
   }
   // skip fragments of the matching encoder layer (own stores of an earlier layer; L2-resident).  Loaded here, not
   // before the pass: 32 fewer live VGPRs during the pass keep the kernel at 128 and two workgroups on a CU, whose

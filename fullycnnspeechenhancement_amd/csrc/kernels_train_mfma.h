@@ -31,21 +31,24 @@ __device__ __forceinline__ void wg_put(float* base, unsigned pstride, int slice,
   if (pstride) base[(size_t)slice * pstride + idx] = v;
   else atomicAdd(base + idx, v);
 }
-// out[e] = sum over slices, in slice order: 16 slice-lanes per element (thread (e, p) adds slices p, p+16, ...), then
-// the 16 partial sums in order.  n = nW + nB elements per slice (dbias behind dW).
+// out[e] = sum over slices, in a fixed order: a workgroup owns 16 elements x 64 slice-lanes (thread (e, p) adds slices
+// p, p+64, ...), then the 64 partial sums in order.  n = nW + nB elements per slice (dbias behind dW).
+// (Round 2 had 64 elements x 16 slice-lanes: 43 workgroups for the largest layer, 35 us per call on a 256-CU part, sixteen
+// calls per step; with four times the workgroups and a quarter of the serial chain per thread ...)
+constexpr int kWgrElems = 16;
 static __global__ __launch_bounds__(1024) void wg_reduce(const float* __restrict__ part, int nslices, unsigned pstride, int nW,
                                                         int nB, float* __restrict__ dW, float* __restrict__ dbias) {
-  __shared__ float red[16][64];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6, n = nW + nB;
+  __shared__ float red[64][kWgrElems];
+  const int le = threadIdx.x & (kWgrElems - 1), p = threadIdx.x >> 4, e = blockIdx.x * kWgrElems + le, n = nW + nB;
   float s = 0.f;
   if (e < n)
-    for (int sl = p; sl < nslices; sl += 16) s += part[(size_t)sl * pstride + e];
-  red[p][threadIdx.x & 63] = s;
+    for (int sl = p; sl < nslices; sl += 64) s += part[(size_t)sl * pstride + e];
+  red[p][le] = s;
   __syncthreads();
   if (p == 0 && e < n) {
-    float t = red[0][threadIdx.x];
+    float t = red[0][le];
 #pragma unroll
-    for (int q = 1; q < 16; ++q) t += red[q][threadIdx.x];
+    for (int q = 1; q < 64; ++q) t += red[q][le];
     if (e < nW) dW[e] = t;
     else if (dbias) dbias[e - nW] = t;
   }
@@ -461,11 +464,12 @@ struct SumArgs {
 // same workgroup has staged for its wgrad half (zt = that tile, pixel p at row kG + p): x > 0 is the mask and the second
 // sum is sum d_u * x (sums_fix_x turns it into S2); no z tile, no extra barrier.
 template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false, bool OPQ = false, bool SUMX = false,
-          class Each = chain::NoEach, bool EXTACC = false, int DEPTH = 2>
+          class Each = chain::NoEach, bool EXTACC = false, int DEPTH = 2, bool KS = false>
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
                                           int frames, int wave, int lane,
                                           double* red_wave, const float* zt = nullptr, const float* stab = nullptr,
-                                          Each each = Each(), f32x4* acc_store = nullptr) {
+                                          Each each = Each(), f32x4* acc_store = nullptr, const f32x4* ks_own = nullptr,
+                                          const float* ks_lds = nullptr) {
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(!(SUMS && (STATS || ACCUM || G::kPH != 1 || (COUT & 1))), "SUMS: overwrite-mode dgrads with an even, unpaired cout");
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMT, PH = G::kPH;
@@ -491,9 +495,27 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #if RCED_TM_STAMPS
     c0 = st_on ? tm_stamp() : 0;
 #endif
+    if constexpr (KS) {
+      // K-split odd tile (conv_ks_partial): this pass covers the regular slots only; the four waves' shares of the odd
+      // tile meet in LDS behind a barrier every wave passes here, and wave 0 (NX = 1) takes the tile through the epilogue
+      if (!(RCED_TM_EXP & 4))
+        chain::gemm_pass<NR, 0, MT, G::kKP, PH * 64 * G::kCinP, DEPTH, -1, chain::NoPre, Each>(
+            in, (PH * px0 - G::kG) * G::kCinP + 2 * kq, 0, lds_w, lane, *reinterpret_cast<f32x4 (*)[NR][MT]>(&acc[0][0]), chain::NoPre(), each);
+      __syncthreads();
+      if constexpr (NX == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 v = ks_own[mt];
+#pragma unroll
+          for (int w = 0; w < kWaves - 1; ++w) v += *reinterpret_cast<const f32x4*>(ks_lds + ((w * MT + mt) * 64 + lane) * 4);
+          acc[NR][mt] = v;
+        }
+      }
+    } else {
     if (!(RCED_TM_EXP & 4))
       chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, DEPTH, -1, chain::NoPre, Each>(
           in, (PH * px0 - G::kG) * G::kCinP + 2 * kq, (PH * pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc, chain::NoPre(), each);
+    }
     each(-1);   // behind the pass, in front of the epilogue (bwd_fused_mfma's dgrad half issues its loads here)
   }
   // The epilogue's lane coordinates are re-derived behind an opaque barrier: left visible, hipcc hoists every per-lane
@@ -784,6 +806,59 @@ constexpr int conv_red_off() {   // even float offset: the records are doubles
   return conv_sums_off<CIN, TAPS, COUT, XF>() + (SUMS ? kTF * kF * COUT + ((2 * COUT + 3) & ~3) : 0);
 }
 constexpr int kConvRedFloats = kWaves * 64 * 2;
+// K-split of the odd column tile (RCED_TM_KSPLIT).  A tile of two frames is 17 column tiles (9 with pixel-pair columns)
+// for four waves: 5 / 4 / 4 / 4 (3 / 2 / 2 / 2), and with two workgroups per CU both heavy waves sit on SIMD 0 -- the
+// end-of-tile barrier waited for 25 % (50 %) more MFMAs than the mean.  Now every wave runs a QUARTER of the odd tile's K
+// steps FIRST (its own small pass; wave 0 starts from the shift, wave 3 also takes the b32 tail), waves 1..3 park their
+// partial sums in LDS, and behind the barrier that follows the regular pass wave 0 adds them up (in wave order: the same
+// bits every run) and takes the tile through the epilogue: 4.25 (2.25) tiles of MFMAs everywhere.
+// Measured (round 3, CR-CED step, A/B on one box): the 9-tile kernels' forward (30 -> 8: 3 / 2 / 2 / 2) 1.012 -> 0.898 ms; the
+// 17-tile shapes do not gain (18 -> 30 forward 1.049 -> 1.111 ms: 25 more VGPRs and the odd tile's A fragments read four
+// times cost more than 5 / 4 / 4 / 4 does), so the split is used where a wave would otherwise carry >= 1.5 x the mean.
+#ifndef RCED_TM_KSPLIT
+#define RCED_TM_KSPLIT 1
+#endif
+template <int CIN, int TAPS, int COUT>
+constexpr bool conv_ks_on() {
+  using G = Geo<CIN, TAPS, COUT>;
+  return RCED_TM_KSPLIT && G::kExtra == 1 && G::kRegular <= 2 && CIN % 2 == 0;
+}
+template <int CIN, int TAPS, int COUT, int XF, bool STATS, bool SUMS>
+constexpr int conv_ks_off() {
+  return ((conv_red_off<CIN, TAPS, COUT, XF, SUMS>() + ((STATS || SUMS) ? kConvRedFloats : 0)) + 3) & ~3;
+}
+template <int CIN, int TAPS, int COUT>
+constexpr int conv_ks_floats() { return (kWaves - 1) * Geo<CIN, TAPS, COUT>::kMT * 64 * 4; }
+template <int CIN, int TAPS, int COUT, int W>
+__device__ __forceinline__ void conv_ks_part(const float* lds_in, const float* lds_w, int lane, f32x4 (&xacc)[Geo<CIN, TAPS, COUT>::kMT]) {
+  using G = Geo<CIN, TAPS, COUT>;
+  constexpr int MT = G::kMT, PH = G::kPH, NB = G::kKP / 8;
+  constexpr int s0 = NB * W / kWaves, s1 = NB * (W + 1) / kWaves;
+  constexpr int Kpart = W == kWaves - 1 ? G::kKP - 8 * s0 : 8 * (s1 - s0);   // the last share runs to the end of K, tail included
+  const int n = lane & 15, kq = lane >> 4;
+  const int pxx = 16 * (G::kRegular * kWaves) + n;                             // the odd tile's columns
+  const float* in = lds_in + G::kG * G::kCinP;
+  f32x4 a[1][MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+    a[0][mt] = W == 0 ? *reinterpret_cast<const f32x4*>(lds_w + G::kData + 16 * mt + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  chain::gemm_pass<1, 0, MT, Kpart, 0, 1>(in, (PH * pxx - G::kG) * G::kCinP + 2 * kq + 8 * s0, 0, lds_w + s0 * MT * 128, lane, a);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) xacc[mt] = a[0][mt];
+}
+template <int CIN, int TAPS, int COUT>
+__device__ __forceinline__ void conv_ks_partial(const float* lds_in, const float* lds_w, float* ks_lds, int wave, int lane,
+                                                f32x4 (&xacc)[Geo<CIN, TAPS, COUT>::kMT]) {
+  constexpr int MT = Geo<CIN, TAPS, COUT>::kMT;
+  if (wave == 0) conv_ks_part<CIN, TAPS, COUT, 0>(lds_in, lds_w, lane, xacc);
+  else if (wave == 1) conv_ks_part<CIN, TAPS, COUT, 1>(lds_in, lds_w, lane, xacc);
+  else if (wave == 2) conv_ks_part<CIN, TAPS, COUT, 2>(lds_in, lds_w, lane, xacc);
+  else conv_ks_part<CIN, TAPS, COUT, 3>(lds_in, lds_w, lane, xacc);
+  if (wave != 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(ks_lds + (((wave - 1) * MT + mt) * 64 + lane) * 4) = xacc[mt];
+  }
+}
 template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF, bool SUMS = false>
 __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const float* __restrict__ in, const float* __restrict__ packet,
                                                           float* __restrict__ out, int frames, double* __restrict__ part,
@@ -864,8 +939,17 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
         }
       };
       constexpr bool kOpq = (XF == kXfBnBwd ? 2 : 1) * Stage<CIN>::kPer * 4 >= RCED_TM_OPQ_MIN;   // VGPRs holding the next tile
+      constexpr bool kKs = conv_ks_on<CIN, TAPS, COUT>() && !SUMS;
+      if constexpr (kKs) {
+        float* ks = lds + conv_ks_off<CIN, TAPS, COUT, XF, STATS, SUMS>();
+        f32x4 xacc[G::kMT];
+        conv_ks_partial<CIN, TAPS, COUT>(lin, lw, ks, wave, lane, xacc);
+        if (wave == 0) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, true>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, xacc, ks);
+        else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false, decltype(each), false, 2, true>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, xacc, ks);
+      } else {
       if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each);
       else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each);
+      }
       TM_ST(4);   // conv_tile
       __syncthreads();
       TM_ST(5);   // barrier 3

@@ -50,7 +50,7 @@ inline int wg_launch(F&& launch, int slices, int nW, int nB, float* dW, float* d
     *d.cap_floats = want;
   }
   launch(*d.part, *d.part + nW, pstride);
-  hipLaunchKernelGGL(tmm::wg_reduce, dim3((nW + nB + 63) / 64), dim3(1024), 0, st, (const float*)*d.part, slices, pstride, nW, nB,
+  hipLaunchKernelGGL(tmm::wg_reduce, dim3((nW + nB + tmm::kWgrElems - 1) / tmm::kWgrElems), dim3(1024), 0, st, (const float*)*d.part, slices, pstride, nW, nB,
                      dW, dbias);
   return 1;
 }
@@ -99,6 +99,8 @@ int tm_conv_launch1(const float* in, const float* packet, float* out, int frames
   size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 4 * CIN : 0)) * sizeof(float);
   if constexpr (STATS || SUMS)   // (SUMS: + the z tile being written and the producer's folded BatchNorm) + the running sums
     lds = (size_t)(tmm::conv_red_off<CIN, TAPS, COUT, XF, SUMS>() + tmm::kConvRedFloats) * sizeof(float);
+  if constexpr (tmm::conv_ks_on<CIN, TAPS, COUT>() && !SUMS)   // + the three parked partial sums of the K-split odd tile
+    lds = (size_t)(tmm::conv_ks_off<CIN, TAPS, COUT, XF, STATS, SUMS>() + tmm::conv_ks_floats<CIN, TAPS, COUT>()) * sizeof(float);
   static unsigned long long attr = 0;
   static int occ = 0;
   const void* kfn = reinterpret_cast<const void*>(tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF, SUMS>);
