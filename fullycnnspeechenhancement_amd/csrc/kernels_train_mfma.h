@@ -93,6 +93,17 @@ __device__ unsigned long long g_tm[4][4];   // [wave][gemm, barrier 2, epilogue,
                         // largest, 3 spills hundreds of bytes and is slower (64.8 / 60.9 / 77.8 ms per CR-CED step)
 #endif
 
+// Remainder pass (RCED_TM_REM): a conv with 18 output channels fills two 16-row M-tiles 56 %.  As in the inference kernels
+// (kernels_fused_v3.h's ->18 layers, kernels_fused_chain.h's 17..24-channel layers) channels 0..15 run as ONE M-tile (the
+// main pass) and channels 16, 17 in a remainder pass whose 16 rows are (pixel phase p < 8, channel 16 + c): a column is a
+// group of 8 adjacent pixels, K = (TAPS + 7) * cin (row (p, c) holds the kernel shifted by p taps), a remainder tile = 128
+// pixels.  Per two-frame tile: 17 x K/4 + 3 x (K + 7 cin)/4 MFMAs instead of 34 x K/4 (-29 % for the 30 -> 18 dgrad, -36 %
+// for the 8 -> 18 forward).  tm_rem(cout) = channels of the remainder pass (0: none); only the 18-channel form is built.
+#ifndef RCED_TM_REM
+#define RCED_TM_REM 1
+#endif
+__host__ __device__ constexpr int tm_rem(int cout) { return (RCED_TM_REM && cout == 18) ? 2 : 0; }
+
 template <int CIN, int TAPS, int COUT>
 struct Geo {
   static constexpr int kCinP = (CIN + 1) & ~1;
@@ -111,8 +122,16 @@ struct Geo {
   static constexpr int kRegular = kCTiles / kWaves, kExtra = kCTiles - kRegular * kWaves;
   static constexpr int kKP = (TAPS + kPH - 1) * kCinP;   // K of the conv packet
   static constexpr int kNB64 = kKP / 8, kNTail = (kKP % 8 + 3) / 4;
-  static constexpr int kData = kNB64 * kMT * 128 + kNTail * kMT * 64;
-  static constexpr int kPacket = kData + 32;             // + shift[32]
+  // remainder pass: R channels past the first M-tile, P pixel phases per column, its K and its tiles per two-frame tile
+  static constexpr int kR = tm_rem(COUT), kP = kR ? 16 / kR : 0;
+  static constexpr int kKR = kR ? (TAPS + kP - 1) * kCinP : 0;
+  static constexpr int kNRT = kR ? (kNPX + 16 * kP - 1) / (16 * kP) : 0;
+  static constexpr int kMTm = kR ? 1 : kMT;              // M-tiles of the MAIN pass
+  static constexpr int kDataMain = kNB64 * kMTm * 128 + kNTail * kMTm * 64;
+  static constexpr int kDataRem = kR ? (kKR / 8) * 128 + ((kKR % 8 + 3) / 4) * 64 : 0;
+  static constexpr int kData = kDataMain + kDataRem;
+  static constexpr int kPacket = kData + 32;             // + shift[32]: channels 0..15 (0..31 without a remainder pass), then the 16 remainder rows'
+  static_assert(!kR || kPH == 1, "remainder pass and pixel-pair columns do not combine");
   static constexpr int kInRows = kG + (kPH == 2 ? 32 * kCTiles + 1 : 16 * kTiles) + kG;
   static constexpr int kInFloats = ((kInRows * kCinP + 3) / 4) * 4;
   static constexpr int kLdsFloats = kInFloats + kPacket;
@@ -127,33 +146,57 @@ struct Geo {
 // kernel of output co shifted by p taps; shift[8 p + co] = shift[co].
 static __global__ void pack_packet(const float* __restrict__ w, const float* __restrict__ shift, int taps, int cin, int cout,
                             int transpose, int ph, float* __restrict__ packet) {
-  const int cinp = (cin + 1) & ~1, K = (taps + ph - 1) * cinp, MT = (cout + 15) / 16;
-  const int NB = K / 8, NTL = (K % 8 + 3) / 4, data = NB * MT * 128 + NTL * MT * 64;
+  const int R = ph == 1 ? tm_rem(cout) : 0, P = R ? 16 / R : 0;
+  const int cinp = (cin + 1) & ~1, K = (taps + ph - 1) * cinp, MT = R ? 1 : (cout + 15) / 16;
+  const int NB = K / 8, NTL = (K % 8 + 3) / 4, dmain = NB * MT * 128 + NTL * MT * 64;
+  const int KR = R ? (taps + P - 1) * cinp : 0, NBR = KR / 8, NTR = (KR % 8 + 3) / 4, drem = R ? NBR * 128 + NTR * 64 : 0;
+  const int data = dmain + drem;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= data + 32) return;
   if (e >= data) {
     const int c = e - data;
-    packet[e] = (shift && c < ph * cout) ? shift[ph == 2 ? (c & 7) : c] : 0.f;
+    if (R) packet[e] = !shift ? 0.f : (c < 16 ? shift[c] : shift[16 + (c - 16) % R]);   // 16 main channels, 16 remainder rows
+    else packet[e] = (shift && c < ph * cout) ? shift[ph == 2 ? (c & 7) : c] : 0.f;
     return;
   }
-  int k, co;
-  if (e < NB * MT * 128) {
-    const int s = e / (MT * 128), r = e - s * MT * 128, mt = r / 128, q = r - mt * 128, lane = q >> 1, ee = q & 1;
-    k = 8 * s + 2 * (lane >> 4) + ee;
-    co = 16 * mt + (lane & 15);
-  } else {
-    const int r = e - NB * MT * 128, j = r / (MT * 64), q = r - j * MT * 64, mt = q / 64, lane = q - mt * 64;
-    k = 8 * NB + 4 * j + (lane >> 4);
-    co = 16 * mt + (lane & 15);
+  int k, co, tap_shift = 0, klim = K;
+  if (e < dmain) {
+    if (e < NB * MT * 128) {
+      const int s = e / (MT * 128), r = e - s * MT * 128, mt = r / 128, q = r - mt * 128, lane = q >> 1, ee = q & 1;
+      k = 8 * s + 2 * (lane >> 4) + ee;
+      co = 16 * mt + (lane & 15);
+    } else {
+      const int r = e - NB * MT * 128, j = r / (MT * 64), q = r - j * MT * 64, mt = q / 64, lane = q - mt * 64;
+      k = 8 * NB + 4 * j + (lane >> 4);
+      co = 16 * mt + (lane & 15);
+    }
+    if (R && co >= 16) co = cout;    // (never: MT = 1)
+  } else {       // remainder pass: row i = (phase i / R, channel 16 + i % R) over K = (taps + P - 1) * cinp
+    const int r = e - dmain;
+    int lane;
+    if (r < NBR * 128) {
+      const int s = r / 128, q = r - s * 128;
+      lane = q >> 1;
+      k = 8 * s + 2 * (lane >> 4) + (q & 1);
+    } else {
+      const int q = r - NBR * 128, j = q / 64;
+      lane = q - j * 64;
+      k = 8 * NBR + 4 * j + (lane >> 4);
+    }
+    const int i = lane & 15;
+    tap_shift = i / R;
+    co = 16 + i % R;
+    klim = KR;
   }
   float v = 0.f;
   int tap = k / cinp;
   const int ci = k - tap * cinp;
+  tap -= tap_shift;
   if (ph == 2) {            // row = (parity, co): the parity-1 rows see the window one tap later
     tap -= co >> 3;
     co &= 7;
   }
-  if (k < K && co < cout && ci < cin && tap >= 0 && tap < taps)
+  if (k < klim && co < cout && ci < cin && tap >= 0 && tap < taps)
     v = transpose ? w[((taps - 1 - tap) * cout + co) * cin + ci]    // w[tap_l][ci_l = co][co_l = ci], layer dims (cout, cin)
                   : w[(tap * cin + ci) * cout + co];
   packet[e] = v;
@@ -472,7 +515,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
                                           const float* ks_lds = nullptr) {
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(!(SUMS && (STATS || ACCUM || G::kPH != 1 || (COUT & 1))), "SUMS: overwrite-mode dgrads with an even, unpaired cout");
-  constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMT, PH = G::kPH;
+  constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMTm, PH = G::kPH;   // MT: M-tiles of the MAIN pass
   const float* in = lds_in + G::kG * G::kCinP;
   const int xtile = NR * kWaves + wave;
   // acc_store: the caller's registers for the tile's accumulators (bwd_fused_mfma shares them with its wgrad half's
@@ -726,6 +769,51 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
     }
     TM_E(2);
   }
+  // ---- remainder pass (Geo::kR = 2): channels 16, 17 of 8 adjacent pixels per column.  Remainder tile rt goes to wave
+  // 3 - rt % 4 (wave 0 carries the odd main tile).  Lane (column n, kq) ends up with rows 4 kq + j = (phase 2 kq + j / 2,
+  // channel 16 + j % 2): two pixels x two channels.  Three tiles per two-frame tile, so everything here is per lane.
+  float pr1[2] = {0.f, 0.f}, pr2[2] = {0.f, 0.f};    // this tile's share of the two channels' sums
+  if constexpr (G::kR > 0) {
+    static_assert(G::kR == 2 && (COUT & 1) == 0 && !KS, "the 18-channel form");
+    constexpr int P = G::kP, KR = G::kKR;
+    const float* wr = lds_w + G::kDataMain;
+    const f32x4 rsh = *reinterpret_cast<const f32x4*>(lds_w + G::kData + 16 + 4 * kq);
+#pragma unroll 1
+    for (int rt = 3 - wave; rt < G::kNRT; rt += kWaves) {
+      const int pb = P * (16 * rt + n);                    // first pixel of this lane's column
+      f32x4 racc[1][1] = {{rsh}};
+      chain::gemm_pass<1, 0, 1, KR, 0, 1>(in, (pb - G::kG) * G::kCinP + 2 * kq, 0, wr, lane, racc);
+      const float vv[4] = {racc[0][0].x, racc[0][0].y, racc[0][0].z, racc[0][0].w};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                         // the lane's two pixels
+        const int px = pb + 2 * kq + h;
+        const int fr = px >= G::kS ? 1 : 0, f = px - (fr ? G::kS : 0);
+        if (px >= G::kNPX || f >= kF || frame0 + fr >= frames) continue;
+        const f32x2 v = {vv[2 * h], vv[2 * h + 1]};
+        if constexpr (STATS) {
+          pr1[0] += v.x; pr2[0] = fmaf(v.x, v.x, pr2[0]);
+          pr1[1] += v.y; pr2[1] = fmaf(v.y, v.y, pr2[1]);
+        }
+        if constexpr (SUMS && SUMX) {
+          const f32x2 xv = *reinterpret_cast<const f32x2*>(zt + (G::kG + px) * COUT + 16);
+          const float d0 = xv.x > 0.f ? v.x : 0.f, d1 = xv.y > 0.f ? v.y : 0.f;
+          pr1[0] += d0; pr2[0] = fmaf(d0, xv.x, pr2[0]);
+          pr1[1] += d1; pr2[1] = fmaf(d1, xv.y, pr2[1]);
+        }
+        if constexpr (SUMS && !SUMX) {
+          const f32x2 zv = *reinterpret_cast<const f32x2*>(zt + (fr * kF + f) * COUT + 16);
+          const f32x2 a2 = *reinterpret_cast<const f32x2*>(stab + 16), b2 = *reinterpret_cast<const f32x2*>(stab + COUT + 16);
+          const float d0 = fmaf(a2.x, zv.x, b2.x) > 0.f ? v.x : 0.f, d1 = fmaf(a2.y, zv.y, b2.y) > 0.f ? v.y : 0.f;
+          pr1[0] += d0; pr2[0] = fmaf(d0, zv.x, pr2[0]);
+          pr1[1] += d1; pr2[1] = fmaf(d1, zv.y, pr2[1]);
+        }
+        f32x2* op2 = reinterpret_cast<f32x2*>(out + ((size_t)(frame0 + fr) * kF + f) * COUT + 16);
+        f32x2 r = v;
+        if (ACCUM) { const f32x2 o = *op2; r.x += o.x; r.y += o.y; }
+        *op2 = r;
+      }
+    }
+  }
 #if RCED_TM_STAMPS
   if (st_on && lane == 0) for (int i = 0; i < 3; ++i) g_tm2[wave][i] += ea[i];
 #endif
@@ -750,6 +838,20 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #if RCED_TM_STAMPS
     if (st_on) { const unsigned long long n = tm_stamp(); if (lane == 0) g_tm[wave][2] += n - c0; c0 = n; }
 #endif
+    if constexpr (G::kR > 0) {   // channels 16, 17: every lane holds a share -- sum over the whole wave; lane 63 adds it to the record
+      float q[4] = {row_sum16(pr1[0]), row_sum16(pr2[0]), row_sum16(pr1[1]), row_sum16(pr2[1])};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        q[u] += __shfl_xor(q[u], 16, 64);      // lanes 15 / 31 / 47 / 63 hold the row sums
+        q[u] += __shfl_xor(q[u], 32, 64);
+      }
+      if (lane == 63) {
+        typedef double f64x2r __attribute__((ext_vector_type(2)));
+        f64x2r c16 = *reinterpret_cast<const f64x2r*>(red_wave + 2 * 16), c17 = *reinterpret_cast<const f64x2r*>(red_wave + 2 * 17);
+        *reinterpret_cast<f64x2r*>(red_wave + 2 * 16) = f64x2r{c16.x + (double)q[0], c16.y + (double)q[1]};
+        *reinterpret_cast<f64x2r*>(red_wave + 2 * 17) = f64x2r{c17.x + (double)q[2], c17.y + (double)q[3]};
+      }
+    }
     if (writer) {   // all reads, then all writes: one LDS round trip instead of one per value
       typedef double f64x2 __attribute__((ext_vector_type(2)));
       f64x2 cur[MT][4];
@@ -1152,10 +1254,16 @@ struct BwdBalance {
   static constexpr int kRowsK = (TAPS + PH - 1) * GW::kCinP;
   static constexpr int KT = (kRowsK + 1 + 15) / 16, NTo = PH == 2 ? 1 : GW::kMT;
   static constexpr int kGroups = PH == 2 ? (GW::kNPX / 2 + 3) / 4 : GW::kNPX / 4 + 1;
-  static constexpr int kPerTile = (GD::kKP / 8 * 2 + (GD::kKP % 8 + 3) / 4) * GD::kMT;   // MFMAs of one dgrad column tile
+  static constexpr int kPerTile = (GD::kKP / 8 * 2 + (GD::kKP % 8 + 3) / 4) * GD::kMTm;   // MFMAs of one dgrad column tile (main pass)
+  static constexpr int kPerRem = GD::kR ? GD::kKR / 8 * 2 + (GD::kKR % 8 + 3) / 4 : 0;      // ... of one remainder tile
   static constexpr int kPerGroup = KT * NTo;
-  static constexpr int dgrad(int w) { return (GD::kRegular + (w < GD::kExtra ? 1 : 0)) * kPerTile; }
-  static constexpr int kTotal = GD::kCTiles * kPerTile + kGroups * kPerGroup;
+  static constexpr int rem_tiles(int w) {                  // remainder tiles 3 - w, 7 - w, ... < kNRT (conv_tile)
+    int c = 0;
+    for (int rt = 3 - w; rt < GD::kNRT; rt += 4) ++c;
+    return c;
+  }
+  static constexpr int dgrad(int w) { return (GD::kRegular + (w < GD::kExtra ? 1 : 0)) * kPerTile + rem_tiles(w) * kPerRem; }
+  static constexpr int kTotal = dgrad(0) + dgrad(1) + dgrad(2) + dgrad(3) + kGroups * kPerGroup;
   static constexpr int count(int w) {       // groups of wgrad wave w (0..3)
     int used = 0;
     for (int v = 0; v < 4; ++v) {
@@ -1222,7 +1330,7 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
   // ONE register array for both roles: the wgrad half's [KT][NTo] accumulators live for the whole kernel, the dgrad
   // half's [column tiles][M-tiles] per tile -- a wave has one role, but as two arrays both are live in every wave as far
   // as the register allocator can tell (the kernel sat at 256 VGPRs + scratch)
-  constexpr int kDgAcc = (GD::kRegular + 1) * GD::kMT, kAccN = KT * NTo > kDgAcc ? KT * NTo : kDgAcc;
+  constexpr int kDgAcc = (GD::kRegular + 1) * GD::kMTm, kAccN = KT * NTo > kDgAcc ? KT * NTo : kDgAcc;
   f32x4 accs[kAccN];
   f32x4 (&acc)[KT][NTo] = *reinterpret_cast<f32x4 (*)[KT][NTo]>(&accs[0]);
 #pragma unroll

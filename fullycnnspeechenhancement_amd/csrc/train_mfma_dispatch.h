@@ -85,9 +85,11 @@ inline int resident_grid(const void* kernel, size_t lds, int cus, int& occ_cache
 }
 
 inline int tm_packet_parities(int cout) { return cout == 8 ? 2 : 1; }   // Geo::kPH
-inline size_t tm_packet_floats(int cin, int taps, int cout) {
-  const int cinp = (cin + 1) & ~1, K = (taps + tm_packet_parities(cout) - 1) * cinp, MT = (cout + 15) / 16;
-  return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + 32;
+inline size_t tm_packet_floats(int cin, int taps, int cout) {     // Geo::kPacket
+  const int ph = tm_packet_parities(cout), R = ph == 1 ? tmm::tm_rem(cout) : 0, P = R ? 16 / R : 0;
+  const int cinp = (cin + 1) & ~1, K = (taps + ph - 1) * cinp, MT = R ? 1 : (cout + 15) / 16;
+  const int KR = R ? (taps + P - 1) * cinp : 0;
+  return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + (R ? (size_t)(KR / 8) * 128 + (size_t)((KR % 8 + 3) / 4) * 64 : 0) + 32;
 }
 
 constexpr tmm::SumArgs kNoSums{nullptr, nullptr, nullptr, nullptr, nullptr};
