@@ -506,18 +506,54 @@ struct SumArgs {
 // SUMX (with SUMS, the fused backward kernel): the masked sums are formed from the TRANSFORMED tile x = relu(a z + b) the
 // same workgroup has staged for its wgrad half (zt = that tile, pixel p at row kG + p): x > 0 is the mask and the second
 // sum is sum d_u * x (sums_fix_x turns it into S2); no z tile, no extra barrier.
+// A lane's fp32 shares of the per-channel sums (STATS: sum z, sum z^2; SUMS: sum d_u, sum d_u z), carried over a few tiles
+// in registers and only then reduced over the lanes and added to the wave's record of doubles: the reduction (64 DPP adds,
+// 16 conversions, 16 double adds per wave and two-M-tile tile) was a fifth of the forward convolutions' non-MFMA
+// instructions when done per tile.  kSumFlush tiles x <= 5 values per lane stay far inside fp32 (the round-2 form summed 5).
+#ifndef RCED_TM_SUMFLUSH
+#define RCED_TM_SUMFLUSH 4
+#endif
+constexpr int kSumFlush = RCED_TM_SUMFLUSH;
+#ifndef RCED_TM_BWD_CARRY
+#define RCED_TM_BWD_CARRY 0     // 1: the fused backward kernel carries its masked sums too -- it sits at 256 VGPRs (10-12 dwords of
+                                // scratch with them) and gains nothing (2.407 / 1.895 vs 2.405 / 1.889 ms): off
+#endif
+template <int MT>
+struct SumState {
+  float p1[MT][4], p2[MT][4], pr1[2], pr2[2];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p1[mt][j] = p2[mt][j] = 0.f;
+    pr1[0] = pr1[1] = pr2[0] = pr2[1] = 0.f;
+  }
+};
 template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false, bool OPQ = false, bool SUMX = false,
-          class Each = chain::NoEach, bool EXTACC = false, int DEPTH = 2, bool KS = false>
+          class Each = chain::NoEach, bool EXTACC = false, int DEPTH = 2, bool KS = false, int XMT = -1>
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
                                           int frames, int wave, int lane,
                                           double* red_wave, const float* zt = nullptr, const float* stab = nullptr,
                                           Each each = Each(), f32x4* acc_store = nullptr, const f32x4* ks_own = nullptr,
                                           const float* ks_lds = nullptr) {
+  SumState<Geo<CIN, TAPS, COUT>::kMTm> local_sums;
+  conv_tile<CIN, TAPS, COUT, ACCUM, STATS, NX, SUMS, OPQ, SUMX, Each, EXTACC, DEPTH, KS, XMT>(
+      lds_in, lds_w, out, frame0, frames, wave, lane, red_wave, zt, stab, each, acc_store, ks_own, ks_lds, local_sums, false, true);
+}
+template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false, bool OPQ = false, bool SUMX = false,
+          class Each = chain::NoEach, bool EXTACC = false, int DEPTH = 2, bool KS = false, int XMT = -1>
+__device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
+                                          int frames, int wave, int lane, double* red_wave, const float* zt, const float* stab,
+                                          Each each, f32x4* acc_store, const f32x4* ks_own, const float* ks_lds,
+                                          SumState<Geo<CIN, TAPS, COUT>::kMTm>& S, bool carried, bool flush) {
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(!(SUMS && (STATS || ACCUM || G::kPH != 1 || (COUT & 1))), "SUMS: overwrite-mode dgrads with an even, unpaired cout");
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMTm, PH = G::kPH;   // MT: M-tiles of the MAIN pass
   const float* in = lds_in + G::kG * G::kCinP;
-  const int xtile = NR * kWaves + wave;
+  // XMT >= 0 (two-M-tile shapes, RCED_TM_MSPLIT): the odd column tile is cut by M-tile -- this wave's extra slot computes
+  // and stores only M-tile XMT of column tile 4 NR; another wave has the other half
+  const int xwave = XMT >= 0 ? 0 : wave;
+  const int xtile = NR * kWaves + xwave;
   // acc_store: the caller's registers for the tile's accumulators (bwd_fused_mfma shares them with its wgrad half's
   // kernel-lifetime accumulators: a wave has one role, but two arrays are both live in every wave for the allocator)
   f32x4 acc_local[EXTACC ? 1 : NT][EXTACC ? 1 : MT];
@@ -556,7 +592,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
       }
     } else {
     if (!(RCED_TM_EXP & 4))
-      chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, DEPTH, -1, chain::NoPre, Each>(
+      chain::gemm_pass<NR, NX, MT, G::kKP, PH * 64 * G::kCinP, DEPTH, XMT, chain::NoPre, Each>(
           in, (PH * px0 - G::kG) * G::kCinP + 2 * kq, (PH * pxx - G::kG) * G::kCinP + 2 * kq, lds_w, lane, acc, chain::NoPre(), each);
     }
     each(-1);   // behind the pass, in front of the epilogue (bwd_fused_mfma's dgrad half issues its loads here)
@@ -572,7 +608,12 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
   if constexpr (OPQ) asm volatile("" : "+v"(le));
   const int n = le & 15, kq = le >> 4;
   const int px0 = 16 * wave + n, pxx = 16 * xtile + n;
-  float p1[MT][4], p2[MT][4];   // this tile's share of sum z, sum z^2 (<= NT values each, fp32); SUMS: sum d_u, sum d_u z
+  // the lane's shares of sum z, sum z^2 (SUMS: sum d_u, sum d_u z), fp32: the caller's (carried over kSumFlush tiles) or local
+  // S: the caller's (carried over kSumFlush tiles) or the wrapper's local one -- by reference, never through a pointer select
+  float (&p1)[MT][4] = S.p1;
+  float (&p2)[MT][4] = S.p2;
+  float (&pr1)[2] = S.pr1;
+  float (&pr2)[2] = S.pr2;
   f32x4 sa4[MT], sb4[MT];       // SUMS: folded BatchNorm a, b of this lane's four channels per M-tile
 #if RCED_TM_STAMPS
   if (st_on) { const unsigned long long n = tm_stamp(); if (lane == 0) g_tm[wave][0] += n - c0; c0 = n; }
@@ -600,12 +641,8 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
       }
     }
   }
-  if constexpr (STATS || SUMS) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) p1[mt][j] = p2[mt][j] = 0.f;
-  }
+  if constexpr (STATS || SUMS)
+    if (!carried) S.zero();
 #if RCED_TM_STAMPS
   unsigned long long e0 = st_on ? tm_stamp() : 0, ea[4] = {0, 0, 0, 0};
 #define TM_E(i) do { if (st_on) { const unsigned long long n_ = tm_stamp(); ea[i] += n_ - e0; e0 = n_; } } while (0)
@@ -627,7 +664,8 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if constexpr (kCleanPath) {
-      const int k = wave + kWaves * t, pbeg = 16 * PH * k, pend = pbeg + 16 * PH - 1;
+      const bool xslot = XMT >= 0 && t == NR;                        // the M-split odd tile: column tile 4 NR for every wave
+      const int k = (xslot ? 0 : wave) + kWaves * t, pbeg = 16 * PH * k, pend = pbeg + 16 * PH - 1;
       const bool in0 = pend < kF, in1 = pbeg >= G::kS && pend < G::kS + kF;
       if (in0 || in1) {
         const int fr = in1 ? 1 : 0;
@@ -637,11 +675,13 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+              if (XMT >= 0 && t == NR && mt != XMT) continue;
               const float v = acc[t][mt][j];
               p1[mt][j] += v;
               p2[mt][j] = fmaf(v, v, p2[mt][j]);
             }
         }
+        static_assert(XMT < 0 || !SUMS, "M-split odd tiles: forward shapes only");
         if constexpr (SUMS && SUMX) {
           const char* zb = reinterpret_cast<const char*>(zt) + lane_b;
 #pragma unroll
@@ -662,9 +702,11 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
           }
         }
         // wave-uniform base of this slot (scalar registers) + the lane offset: the saddr form of the global accesses
-        char* ob = reinterpret_cast<char*>(out + (size_t)(frame0 + fr) * (kF * COUT)) + ((64 * PH * t) * COUT - (in1 ? G::kS * COUT : 0)) * 4;
+        char* ob = reinterpret_cast<char*>(out + (size_t)(frame0 + fr) * (kF * COUT)) +
+                   ((64 * PH * t - (xslot ? 16 * PH * wave : 0)) * COUT - (in1 ? G::kS * COUT : 0)) * 4;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+          if (XMT >= 0 && t == NR && mt != XMT) continue;
           const f32x4 v = acc[t][mt];
           char* p = ob + 16 * mt * 4 + lane_b;
           if (PH == 2 || 16 * mt + 16 <= COUT) {
@@ -697,6 +739,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+          if (XMT >= 0 && t == NR && mt != XMT) continue;
           const float v = acc[t][mt][j];
           p1[mt][j] += v;
           p2[mt][j] = fmaf(v, v, p2[mt][j]);
@@ -741,6 +784,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
     if ((RCED_TM_EXP & 2) && acc[t][0][0] != 12345.678f) continue;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      if (XMT >= 0 && t == NR && mt != XMT) continue;
       const int co0 = PH == 2 ? 4 * (kq & 1) : 16 * mt + 4 * kq;
       f32x4 v = acc[t][mt];
       if (co0 + 1 < COUT || (co0 < COUT && (COUT & 1))) {
@@ -772,7 +816,6 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
   // ---- remainder pass (Geo::kR = 2): channels 16, 17 of 8 adjacent pixels per column.  Remainder tile rt goes to wave
   // 3 - rt % 4 (wave 0 carries the odd main tile).  Lane (column n, kq) ends up with rows 4 kq + j = (phase 2 kq + j / 2,
   // channel 16 + j % 2): two pixels x two channels.  Three tiles per two-frame tile, so everything here is per lane.
-  float pr1[2] = {0.f, 0.f}, pr2[2] = {0.f, 0.f};    // this tile's share of the two channels' sums
   if constexpr (G::kR > 0) {
     static_assert(G::kR == 2 && (COUT & 1) == 0 && !KS, "the 18-channel form");
     constexpr int P = G::kP, KR = G::kKR;
@@ -817,7 +860,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #if RCED_TM_STAMPS
   if (st_on && lane == 0) for (int i = 0; i < 3; ++i) g_tm2[wave][i] += ea[i];
 #endif
-  if constexpr (STATS || SUMS) {
+  if constexpr (STATS || SUMS) if (flush) {
     // Running per-channel sums live in this wave's LDS record as doubles (in registers they cost 32 VGPRs for the whole
     // kernel, which is what decided the occupancy): add the tile's fp32 shares over the 16 pixel lanes of a row with
     // DPP shifts (lane 15 of the row ends up with the sum), then that lane adds them to red_wave[channel][2].
@@ -867,6 +910,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
           *reinterpret_cast<f64x2*>(red_wave + 2 * ((PH == 2 ? 0 : 16 * mt) + 4 * kq + j)) =
               f64x2{cur[mt][j].x + (double)ra[mt][j], cur[mt][j].y + (double)rb[mt][j]};
     }
+    if (carried) S.zero();
   }
 }
 
@@ -919,6 +963,10 @@ constexpr int kConvRedFloats = kWaves * 64 * 2;
 // times cost more than 5 / 4 / 4 / 4 does), so the split is used where a wave would otherwise carry >= 1.5 x the mean.
 #ifndef RCED_TM_KSPLIT
 #define RCED_TM_KSPLIT 1
+#endif
+#ifndef RCED_TM_MSPLIT
+#define RCED_TM_MSPLIT 0     // 1: two-M-tile shapes cut the odd column tile by M-tile over two waves (see conv1xk_mfma).  Measured:
+                             // 18 -> 30 forward 1.077 -> 1.10 ms -- the kernel is not bound by its fullest SIMD; off
 #endif
 template <int CIN, int TAPS, int COUT>
 constexpr bool conv_ks_on() {
@@ -997,8 +1045,13 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamps_on ? tm_stamp() : 0;
     if (stamps_on && lane == 0) for (int i = 0; i < 4; ++i) g_tm[wave][i] = g_tm2[wave][i] = 0;
 #endif
+    SumState<G::kMTm> sums;       // carried over kSumFlush tiles (conv_tile)
+    sums.zero();
+    int tile_no = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int frame0 = tile * kTF;
+      const bool flush = (++tile_no % kSumFlush) == 0 || tile + (int)gridDim.x >= ntiles;
+      constexpr bool carried = (STATS || SUMS) && kSumFlush > 1;
       auto where = [](int fr, int r) { return (G::kG + fr * G::kS) * CIN + r; };
 #if RCED_TM_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1046,11 +1099,19 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
         float* ks = lds + conv_ks_off<CIN, TAPS, COUT, XF, STATS, SUMS>();
         f32x4 xacc[G::kMT];
         conv_ks_partial<CIN, TAPS, COUT>(lin, lw, ks, wave, lane, xacc);
-        if (wave == 0) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, true>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, xacc, ks);
-        else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false, decltype(each), false, 2, true>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, xacc, ks);
+        if (wave == 0) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, true>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, xacc, ks, sums, carried, flush);
+        else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false, decltype(each), false, 2, true>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, xacc, ks, sums, carried, flush);
+      } else if constexpr (RCED_TM_MSPLIT && G::kExtra == 1 && G::kMTm == 2 && !SUMS && !ACCUM) {
+        // The odd column tile by M-tile: two waves carry half of it each (4.5 / 4.5 / 4 / 4 tiles of MFMAs instead of
+        // 5 / 4 / 4 / 4), and the second half of the grid -- with a resident grid of two workgroups per CU the likely partner
+        // on the same CU -- gives its halves to waves 2, 3: 8.5 on every SIMD.
+        const int xw = (int)blockIdx.x >= ((int)gridDim.x + 1) / 2 ? 2 : 0;
+        if (wave == xw) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, false, 0>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush);
+        else if (wave == xw + 1) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, false, 1>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush);
+        else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush);
       } else {
-      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each);
-      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each);
+      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush);
+      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush);
       }
       TM_ST(4);   // conv_tile
       __syncthreads();
@@ -1378,8 +1439,13 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamps_on ? tm_stamp() : 0;
   if (stamps_on && lane == 0 && role == 0) for (int q = 0; q < 4; ++q) g_tm[wave][q] = g_tm2[wave][q] = 0;
 #endif
+  SumState<GD::kMTm> sums;        // the dgrad half's masked sums, carried over kSumFlush tiles (conv_tile)
+  sums.zero();
+  int tile_no = 0;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int frame0 = tile * kTF;
+    const bool flush = (++tile_no % kSumFlush) == 0 || tile + (int)gridDim.x >= ntiles;
+    constexpr bool carried = SUMS && kSumFlush > 1 && RCED_TM_BWD_CARRY;
     auto where_x = [](int fr, int r) { return (GW::kG + fr * GW::kS) * CIN + r; };
     auto where_dz = [](int fr, int r) { return (GD::kG + fr * GD::kS) * COUT + r; };
     if constexpr (DMA) {
@@ -1453,8 +1519,8 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
           pin();
         }
       };
-      if (wave < GD::kExtra) conv_tile<COUT, TAPS, CIN, false, false, 1, SUMS, false, true, decltype(each), true, RCED_TM_BWD_DEPTH>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx, nullptr, each, accs);
-      else conv_tile<COUT, TAPS, CIN, false, false, 0, SUMS, false, true, decltype(each), true, RCED_TM_BWD_DEPTH>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx, nullptr, each, accs);
+      if (wave < GD::kExtra) conv_tile<COUT, TAPS, CIN, false, false, 1, SUMS, false, true, decltype(each), true, RCED_TM_BWD_DEPTH>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx, nullptr, each, accs, nullptr, nullptr, sums, carried, flush);
+      else conv_tile<COUT, TAPS, CIN, false, false, 0, SUMS, false, true, decltype(each), true, RCED_TM_BWD_DEPTH>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx, nullptr, each, accs, nullptr, nullptr, sums, carried, flush);
     } else {
       // Groups of this wgrad wave: a contiguous range sized so that every SIMD (dgrad wave w + wgrad wave w) issues the
       // same number of MFMAs per tile -- the dgrad wave that carries the odd column tile gets fewer groups beside it
