@@ -860,7 +860,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #if RCED_TM_STAMPS
   if (st_on && lane == 0) for (int i = 0; i < 3; ++i) g_tm2[wave][i] += ea[i];
 #endif
-  if constexpr (STATS || SUMS) if (flush) {
+  if constexpr (STATS || SUMS) if (flush || !carried) {      // (sums that are not carried leave with every tile)
     // Running per-channel sums live in this wave's LDS record as doubles (in registers they cost 32 VGPRs for the whole
     // kernel, which is what decided the occupancy): add the tile's fp32 shares over the 16 pixel lanes of a row with
     // DPP shifts (lane 15 of the row ends up with the sum), then that lane adds them to red_wave[channel][2].

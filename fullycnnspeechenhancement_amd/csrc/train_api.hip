@@ -350,6 +350,75 @@ __global__ void sums_to_float(const double* __restrict__ sums, int C, int which,
   if (c < C) dst[c] = (float)sums[2 * c + which];
 }
 
+// ONE launch for what used to be three to five (reduce_finish over 2 C workgroups, then sums_fix / sums_fix_x or
+// bn_stats_finish, then two sums_to_float): a CR-CED step issued ~150 of these 5-us kernels, all on the critical path.
+// One workgroup of 1024 threads: thread (i, p) adds records p, p + 16, ... of value i < 2 C, the 16 partial sums are added
+// in order (the same bits every run), then threads c < C finish the layer:
+//   kFinPlain  sums = (S1, S2) as they are                      (bwd_route2's records)
+//   kFinZ      S2 = rstd (sum d_u z - mu S1)                    (a SUMS dgrad's records: sums_fix)
+//   kFinX      S2 from sum d_u x, *redo on tiny gamma           (the fused backward kernel's records: sums_fix_x)
+//   kFinStats  (sum z, sum z^2) -> mu, rstd, moving statistics  (forward: bn_stats_finish)
+// kFinPlain / Z / X also write d beta = S1 and d gamma = S2 (g_beta / g_gamma).  only_if: a device flag, no-op when zero.
+enum { kFinPlain = 0, kFinZ = 1, kFinX = 2, kFinStats = 3 };
+struct FinishArgs {
+  const float *mu, *rstd, *gamma, *beta;      // kFinZ / kFinX
+  float *g_beta, *g_gamma;                    // backward modes (may be null)
+  int* redo;                                  // kFinX
+  double P; float eps, momentum;              // kFinStats
+  float *mu_out, *rstd_out, *moving_mean, *moving_var;
+};
+__global__ __launch_bounds__(1024) void bn_finish(const double* __restrict__ part, int nparts, int C, double* __restrict__ sums,
+                                                  int mode, FinishArgs a, const int* __restrict__ only_if) {
+  if (only_if && *only_if == 0) return;
+  __shared__ double red[16][64];
+  const int i = threadIdx.x & 63, p = threadIdx.x >> 6, n = 2 * C;
+  double t = 0.0;
+  if (i < n)
+    for (int k = p; k < nparts; k += 16) t += part[(size_t)k * n + i];
+  red[p][i] = t;
+  __syncthreads();
+  if (p == 0 && i < n) {
+    double v = red[0][i];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v += red[q][i];
+    red[0][i] = v;
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  bool tiny = false;
+  if (c < C) {
+    const double s1 = red[0][2 * c];
+    double s2 = red[0][2 * c + 1];
+    if (mode == kFinStats) {
+      const double m = s1 / a.P;
+      double var = s2 / a.P - m * m;
+      if (var < 0.0) var = 0.0;
+      a.mu_out[c] = (float)m;
+      a.rstd_out[c] = (float)(1.0 / sqrt(var + (double)a.eps));
+      const double unbiased = a.P > 1.0 ? var * a.P / (a.P - 1.0) : var;
+      a.moving_mean[c] = (float)((double)a.momentum * (double)a.moving_mean[c] + (1.0 - (double)a.momentum) * m);
+      a.moving_var[c] = (float)((double)a.momentum * (double)a.moving_var[c] + (1.0 - (double)a.momentum) * unbiased);
+    } else {
+      if (mode == kFinZ) {
+        s2 = (double)a.rstd[c] * (s2 - (double)a.mu[c] * s1);
+      } else if (mode == kFinX) {
+        const float ga = a.gamma[c] * a.rstd[c];                 // the folded forward, exactly as xform_table_fill forms it
+        const float gb = a.beta[c] - ga * a.mu[c];
+        tiny = !(fabsf(a.gamma[c]) >= kTinyGamma);
+        s2 = ga != 0.f ? (double)a.rstd[c] * ((s2 - (double)gb * s1) / (double)ga - (double)a.mu[c] * s1) : 0.0;
+      }
+      if (a.g_beta) a.g_beta[c] = (float)s1;
+      if (a.g_gamma) a.g_gamma[c] = (float)s2;
+    }
+    sums[2 * c] = s1;
+    sums[2 * c + 1] = s2;
+  }
+  if (mode == kFinX) {
+    const int any = __syncthreads_or(tiny);
+    if (threadIdx.x == 0) *a.redo = any;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -670,14 +739,18 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     }
     const size_t n = P * s.cout;
     if (s.use_norm) {
-      if (stat_parts > 0)
-        hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part, stat_parts,
-                           s.cout, t->sums);
-      else if (int rc = reduce_channels(t, t->z[l], t->z[l], nullptr, nullptr, P, s.cout, st))
-        return rc;
-      hipLaunchKernelGGL(train::bn_stats_finish, dim3(1), dim3(64), 0, st, (const double*)t->sums, (double)P, s.cout,
-                         kBnEps, forward_only ? 1.f : kBnMomentum, t->mu[l], t->rstd[l], t->params + f.mmean,
-                         t->params + f.mvar);   // momentum 1: the moving statistics stay as they are
+      if (stat_parts > 0) {
+        FinishArgs fa{};
+        fa.P = (double)P; fa.eps = kBnEps; fa.momentum = forward_only ? 1.f : kBnMomentum;   // momentum 1: the moving statistics stay as they are
+        fa.mu_out = t->mu[l]; fa.rstd_out = t->rstd[l]; fa.moving_mean = t->params + f.mmean; fa.moving_var = t->params + f.mvar;
+        hipLaunchKernelGGL(bn_finish, dim3(1), dim3(1024), 0, st, (const double*)t->part, stat_parts, s.cout, t->sums, (int)kFinStats, fa,
+                           (const int*)nullptr);
+      } else {
+        if (int rc = reduce_channels(t, t->z[l], t->z[l], nullptr, nullptr, P, s.cout, st)) return rc;
+        hipLaunchKernelGGL(train::bn_stats_finish, dim3(1), dim3(64), 0, st, (const double*)t->sums, (double)P, s.cout,
+                           kBnEps, forward_only ? 1.f : kBnMomentum, t->mu[l], t->rstd[l], t->params + f.mmean,
+                           t->params + f.mvar);
+      }
     }
     if (t->out[l + 1] != t->z[l] && !t->virt[l + 1]) {
       if (s.cout % 2 == 0)
@@ -749,22 +822,24 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     const bool fuse_dz = fuse_dz_of(l);
     const bool lazy_mask = lazy_mask_of(l);
     const float* dsrc = lazy_mask ? t->G[l + 1] : t->D;      // what wgrad / dgrad read as their "dz" input
+    bool grads_out = false;      // d beta / d gamma already written by bn_finish
+    FinishArgs fb{};
+    fb.mu = mu; fb.rstd = t->rstd[l]; fb.gamma = t->params + f.gamma; fb.beta = t->params + f.beta;
+    fb.g_beta = t->grads + f.beta; fb.g_gamma = t->grads + f.gamma; fb.redo = t->redo;
     if (lazy_mask && fused_sums[l] > 0) {
-      hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part,
-                         fused_sums[l], s.cout, t->sums);
+      hipLaunchKernelGGL(bn_finish, dim3(1), dim3(1024), 0, st, (const double*)t->part, fused_sums[l], s.cout, t->sums,
+                         (int)(sums_from_x[l] ? kFinX : kFinZ), fb, (const int*)nullptr);
+      grads_out = true;
       if (sums_from_x[l]) {
-        hipLaunchKernelGGL(sums_fix_x, dim3(1), dim3(64), 0, st, t->sums, (const float*)mu, (const float*)t->rstd[l],
-                           (const float*)(t->params + f.gamma), (const float*)(t->params + f.beta), s.cout, t->redo);
         // |gamma| tiny somewhere in this layer: the sums again, exactly, from (g, z) (no-ops otherwise; see sums_fix_x)
         const dim3 grid = pair_grid(s.cout);
         hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
                            (const float2*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
                            (const float*)(t->params + f.beta), (const float2*)nullptr, s.use_act, P, s.cout, (float2*)nullptr,
                            (float2*)nullptr, (float2*)nullptr, t->part, (const int*)t->redo);
-        hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part,
-                           (int)grid.x, s.cout, t->sums, (const int*)t->redo);
-      } else
-        hipLaunchKernelGGL(sums_fix, dim3(1), dim3(64), 0, st, t->sums, (const float*)mu, (const float*)t->rstd[l], s.cout);
+        hipLaunchKernelGGL(bn_finish, dim3(1), dim3(1024), 0, st, (const double*)t->part, (int)grid.x, s.cout, t->sums,
+                           (int)kFinPlain, fb, (const int*)t->redo);
+      }
     } else if (pairs) {
       const dim3 grid = pair_grid(s.cout);
       hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
@@ -773,9 +848,11 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
                          (float2*)(s.skip_pre > 0 ? t->G[s.skip_pre] : nullptr),
                          (float2*)(s.skip_post > 0 ? t->G[s.skip_post] : nullptr), (float2*)(lazy_mask ? nullptr : t->D),
                          s.use_norm ? t->part : (double*)nullptr);
-      if (s.use_norm)
-        hipLaunchKernelGGL(train::reduce_finish, dim3(2 * s.cout), dim3(train::kThreads), 0, st, (const double*)t->part, (int)grid.x,
-                           s.cout, t->sums);
+      if (s.use_norm) {
+        hipLaunchKernelGGL(bn_finish, dim3(1), dim3(1024), 0, st, (const double*)t->part, (int)grid.x, s.cout, t->sums,
+                           (int)kFinPlain, fb, (const int*)nullptr);
+        grads_out = true;
+      }
     } else {
       hipLaunchKernelGGL(train::bwd_route, blocks(n), dim3(train::kThreads), 0, st, (const float*)t->G[l + 1],
                          (const float*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
@@ -788,8 +865,10 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
                               lazy_mask ? t->params + f.beta : nullptr};
     const tmm::BnBwdArgs* ba = fuse_dz ? &ba_l : nullptr;
     if (s.use_norm) {
-      hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.beta);
-      hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 1, t->grads + f.gamma);
+      if (!grads_out) {
+        hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 0, t->grads + f.beta);
+        hipLaunchKernelGGL(sums_to_float, dim3(1), dim3(64), 0, st, (const double*)t->sums, s.cout, 1, t->grads + f.gamma);
+      }
       if (fuse_dz) {
         // nothing: wgrad and dgrad below rebuild dz from D = d_u and z
       } else if (pairs)
