@@ -1172,9 +1172,21 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const flo
   static_assert(PH == 1 || (PH == 2 && COUT == 8 && G::kNPX % 2 == 0), "two pixel parities x 8 channels = 16 columns");
   // one spare k row carries a constant 1, so its output row is sum_px dz = dbias
   constexpr int kRowsK = (TAPS + PH - 1) * G::kCinP;   // window rows (PH = 1: the layer's K)
-  constexpr int KT = (kRowsK + 1 + 15) / 16, NTo = PH == 2 ? 1 : G::kMT;
+  // NREM (18 output channels, tm_rem): the second N-tile would carry 2 channels in 16 columns.  Channels 16, 17 get a pass
+  // of their own whose 16 columns are (pixel phase ph < 8, channel 16 + c) and whose K axis walks GROUPS of 8 pixels:
+  //   D[k'][(ph, c)] = sum_q xwin[8 q][k'] * dz[8 q + ph][16 + c],   k' = (tap + ph) * cin + ci  in [0, (TAPS + 7) * cin),
+  // (TAPS + 7) cin / 16 M-tiles per 32 pixels instead of the second N-tile's KT per 4 pixels: 330 + 72 MFMAs per two-frame
+  // tile instead of 660 for the 8 -> 18 layers.  dW[tap][ci][16 + c] = sum_ph D[(tap + ph, ci)][(ph, c)] is gathered through
+  // LDS at the end of the kernel; d bias of the two channels is the lanes' running sum of the B values they fed.
+  constexpr bool NREM = PH == 1 && tm_rem(COUT) == 2;
+  constexpr int KT = (kRowsK + 1 + 15) / 16, NTo = PH == 2 || NREM ? 1 : G::kMT;
   constexpr int kOneTile = kRowsK / 16, kOneRow = kRowsK % 16;
-  constexpr int kDzRows = 16 * G::kTiles + 4;
+  constexpr int kRemRows = (TAPS + 7) * G::kCinP, KT8 = NREM ? kRemRows / 16 : 1;
+  constexpr int kSteps8 = (G::kNPX + 31) / 32;                     // K steps of the remainder pass: 4 groups of 8 pixels each
+  static_assert(!NREM || kRemRows % 16 == 0, "whole M-tiles");
+  constexpr int kDzRows = NREM && 32 * kSteps8 + 8 > 16 * G::kTiles + 4 ? 32 * kSteps8 + 8 : 16 * G::kTiles + 4;
+  static_assert(!NREM || (kDzRows * COUT <= (16 * G::kTiles + 4) * 32 && kWaves * kRemRows * 16 <= G::kInFloats + 64 + (16 * G::kTiles + 4) * 32),
+                "the launcher's LDS (32 floats per dz row) holds the longer dz tile and the final gather's scratch");
   constexpr int kDzStride = COUT;                      // floats per pixel row of the dz tile = the tensor's own row: staging needs no
                                                        // per-piece division (columns co >= COUT of the second N-tile read the next
                                                        // pixel's first channels and are never written out); the launcher allocates 32
@@ -1198,6 +1210,10 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const flo
   for (int a = 0; a < KT; ++a)
 #pragma unroll
     for (int b = 0; b < NTo; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 racc[KT8];               // NREM: the remainder pass's accumulators, rows 16 kt + 4 kq + r, column i = (ph, c)
+#pragma unroll
+  for (int a = 0; a < KT8; ++a) racc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
   const int ntiles = (frames + kTF - 1) / kTF;
   f32x4 prex[Stage<CIN>::kPer], prez[Stage<COUT>::kPer], prez2[DZF ? Stage<COUT>::kPer : 1];
   if ((int)blockIdx.x < ntiles) {
@@ -1251,6 +1267,20 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const flo
 #pragma unroll
         for (int nt = 0; nt < NTo; ++nt) acc[kt][nt] = mfma(a[kt], b[nt], acc[kt][nt]);
     }
+    if constexpr (NREM) {
+      // lane (i, kq): A = row 16 kt + i of the window that starts at pixel 8 (q0 + kq); B = dz[8 (q0 + kq) + i / 2][16 + i % 2]
+      // (rows past the tile's pixels are zero: never written)
+      for (int s8 = kWaves - 1 - wave; s8 < kSteps8; s8 += kWaves) {   // from the other end: the waves with fewer main groups first
+        const int p8 = 8 * (4 * s8 + kq);
+        float a8[KT8];
+#pragma unroll
+        for (int kt = 0; kt < KT8; ++kt) a8[kt] = lin[p8 * G::kCinP + 16 * kt + i];
+        const float b8 = ldz[(p8 + (i >> 1)) * kDzStride + 16 + (i & 1)];
+        bsum += b8;
+#pragma unroll
+        for (int kt = 0; kt < KT8; ++kt) racc[kt] = mfma(a8[kt], b8, racc[kt]);
+      }
+    }
     __syncthreads();
   }
   // D row = k = 16*kt + 4*kq + r, column = co = 16*nt + i   (PH = 2: column = (parity i >> 3, co = i & 7), tap = k' - parity)
@@ -1270,6 +1300,35 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const flo
         if (k == kRowsK && co < COUT && dbias) wg_put(dbias, pstride, slice, co, vv[r]);
       }
     }
+  if constexpr (NREM) {
+    // gather: this wave's D[k'][(ph, c)] through LDS (the tiles are dead: the loop ended on a barrier), then
+    // dW[tap][ci][16 + c] = sum over ph of D[(tap + ph) cin + ci][(ph, c)], added in phase order
+    float* sc = lds + wave * (kRemRows * 16);
+#pragma unroll
+    for (int kt = 0; kt < KT8; ++kt) {
+      const float vv[4] = {racc[kt].x, racc[kt].y, racc[kt].z, racc[kt].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[(16 * kt + 4 * kq + r) * 16 + i] = vv[r];
+    }
+    __syncthreads();
+    const int slice = (int)blockIdx.x * kWaves + wave;
+    for (int e = lane; e < TAPS * CIN * 2; e += 64) {
+      const int c = e & 1, ci = (e >> 1) % CIN, tap = (e >> 1) / CIN;
+      float t = 0.f;
+#pragma unroll
+      for (int ph = 0; ph < 8; ++ph) t += sc[((tap + ph) * G::kCinP + ci) * 16 + 2 * ph + c];
+      wg_put(dW, pstride, slice, (tap * CIN + ci) * COUT + 16 + c, t);
+    }
+    if (dbias) {      // lanes (i, kq) with the same c = i & 1 hold shares of sum dz[.][16 + c]
+      float v = bsum;
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 2) wg_put(dbias, pstride, slice, 16 + lane, v);
+    }
+  }
 }
 
 
