@@ -806,7 +806,9 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
   };
   auto lazy_mask_of = [&](int l) {
     const LayerSpec& s = net.layer[l];
-    return fuse_dz_of(l) && s.use_act && s.skip_pre < 0 && s.skip_post < 0;
+    // (a skip added AFTER the ReLU -- CR-CED's block outputs, model.py:75-76 -- does not enter the mask: d_u = g [bn(z) > 0]
+    // there too, so those layers' d_u need not be written either; bwd_route2 still routes g to the skip's source)
+    return fuse_dz_of(l) && s.use_act && s.skip_pre < 0;
   };
   for (int l = L - 1; l >= 0; --l) {
     const LayerSpec& s = net.layer[l];
