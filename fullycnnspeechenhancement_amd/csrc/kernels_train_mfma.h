@@ -230,10 +230,15 @@ __device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int f
   if (left >= kTF) {   // whole tile (wave-uniform): straight-line 16-byte loads, no per-piece bounds logic
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + tid;
     const bool active = St::kStride == NTHR || tid < St::kStride;
+#if RCED_TM_NT
+#define RCED_TM_LD(p) __builtin_nontemporal_load(p)
+#else
+#define RCED_TM_LD(p) (*(p))
+#endif
 #pragma unroll
     for (int i = 0; i < St::kPer; ++i) {
-      if ((i + 1) * St::kStride <= St::kVec) pre[i] = active ? s4[i * St::kStride] : f32x4{0.f, 0.f, 0.f, 0.f};
-      else pre[i] = (active && tid + i * St::kStride < St::kVec) ? s4[i * St::kStride] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((i + 1) * St::kStride <= St::kVec) pre[i] = active ? RCED_TM_LD(s4 + i * St::kStride) : f32x4{0.f, 0.f, 0.f, 0.f};
+      else pre[i] = (active && tid + i * St::kStride < St::kVec) ? RCED_TM_LD(s4 + i * St::kStride) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     return;
   }
@@ -322,6 +327,9 @@ __device__ __forceinline__ void tm_static_for(F&& f) {
                               // (no VGPR holds the next tile: no scratch).  Measured slower than VGPR staging in every form
                               // (all waves in a burst 2.99 / 2.05 ms, spread over the MFMA phase 3.29 / 2.13, wgrad half alone
                               // 2.99 / 2.24, against 2.86 / 1.94 ms for the two CR-CED shapes): kept as a switch for the record
+#endif
+#ifndef RCED_TM_NT
+#define RCED_TM_NT 1          // the tile fetches are nontemporal loads (every staged byte is used once): -0.6 ... -1 % per kernel (A/B, round 3)
 #endif
 #ifndef RCED_TM_BWD_STAGGER
 #define RCED_TM_BWD_STAGGER 1 // VGPR staging: the wgrad half issues its share of the next tile's loads at the start of the MFMA
