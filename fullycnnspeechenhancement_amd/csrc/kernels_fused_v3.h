@@ -1117,7 +1117,14 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   packet_dma<kW1>(P.wpack, WREG(0), wave, lane);
   int wcur = 0;
   unsigned epoch = 0;   // layer-3 instances so far (tags the split-tile hand-offs)
-  XStage xst = xstage_load(P, blockIdx.x, tid);
+  // This workgroup's tiles: a CONTIGUOUS range (balanced: the first total % grid workgroups take one more).  Consecutive
+  // tiles of an utterance share 7 of their 11 input rows; walked in order by one workgroup those re-reads hit the L2 (the
+  // round-2 stride of gridDim.x sent 2.75 x the input to the memory fabric: FETCH_SIZE 187 MB for a 67.6 MB input once the
+  // counter is calibrated -- tools/micro/fetch_cal.hip: it reports half the bytes for every access width on gfx950).
+  const int tiles_base = P.total_tiles / (int)gridDim.x, tiles_rem = P.total_tiles % (int)gridDim.x;
+  const int tile_begin = (int)blockIdx.x * tiles_base + ((int)blockIdx.x < tiles_rem ? (int)blockIdx.x : tiles_rem);
+  const int tile_end = tile_begin + tiles_base + ((int)blockIdx.x < tiles_rem ? 1 : 0);
+  XStage xst = xstage_load(P, tile_begin < tile_end ? tile_begin : P.total_tiles, tid);
 #if RCED_STAMPS
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tfin = 0, tdet[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1133,7 +1140,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   xstage_store(xst, lds + kX0Off, tid);   // the first tile's input rows; every later tile's are stored by final_phase
   __syncthreads();
 
-  for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int utt = tile / P.tiles_per_utt;
     const int t0 = (tile - utt * P.tiles_per_utt) * kTF;   // first frame of the tile
     f32x4 skip_ce1[3], skip_ce2[3];
@@ -1178,7 +1185,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         ++epoch;
         const unsigned tag = 0x80000000u | epoch;   // sign bit set: never the bits of a ReLU output
         if (blk == 4) {   // once per tile: stays in front of the layer
-          xst = xstage_load(P, tile + gridDim.x, tid);   // next tile's input rows
+          xst = xstage_load(P, tile + 1 < tile_end ? tile + 1 : P.total_tiles, tid);   // next tile's input rows (none: no loads)
           packet_dma<kFin128>(P.fin + kFinA, WREG(wcur ^ 1) + kW1, wave, lane);   // decode_final's bin-128 weights ride along
           fin_prefetch(P, wave, lane, finA);   // decode_final's A fragments: in flight during this layer
           fin_zero_pads(lds0, tid);            // B18 is dead from here on (layer 3's own scratch sits below the H image)
