@@ -538,11 +538,22 @@ def load_training_state(path, variant):
     # from the step counter, so the two must agree (they do for every checkpoint the reference trainer writes:
     # train_op bumps global_step once per update, trainer.py:178).  A checkpoint without global_step resumes at
     # the t that beta1_power implies.
+    # beta1_power is a float32: 0.9^(t+1) leaves the normal range near t = 830 and underflows to 0 near t = 980, so it is
+    # trusted only while it is comfortably normal; past that beta2_power (0.999^(t+1): normal for ~87 k updates) gives the
+    # count, and a checkpoint from which it cannot be recovered says so instead of silently resuming at step 0.
     t_adam = None
     if "beta1_power" in allv:
         b1p = float(np.asarray(allv["beta1_power"]).reshape(-1)[0])
-        if 0.0 < b1p < 1.0:
+        if 1e-30 < b1p < 1.0:
             t_adam = int(round(np.log(b1p) / np.log(0.9))) - 1
+    if t_adam is None and "beta2_power" in allv:
+        b2p = float(np.asarray(allv["beta2_power"]).reshape(-1)[0])
+        if 1e-30 < b2p < 1.0:
+            t_adam = int(round(np.log(b2p) / np.log(0.999))) - 1
+    if t_adam is None and ("beta1_power" in allv or "beta2_power" in allv) and "global_step" not in allv:
+        import warnings
+        warnings.warn("%s: the Adam update count cannot be recovered (beta1_power / beta2_power have underflowed and there is "
+                      "no global_step); resuming at step 0 resets Adam's bias correction and the Noam learning rate" % path)
     if step is None:
         step = max(t_adam, 0) if t_adam is not None else 0
     elif t_adam is not None and t_adam != step:

@@ -126,3 +126,29 @@ def test_engine_restores_from_checkpoint_prefix(tmp_path, monkeypatch):
     eng = engine.FullyCNNTester(net_work="FullyCNNV3", checkpoint_file=prefix)
     assert eng.checkpoint_file == prefix and set(seen) == set(w)
     assert all(np.array_equal(seen[k], w[k]) for k in w)
+
+
+def test_adam_step_is_recovered_past_the_underflow_of_beta1_power(tmp_path):
+    """tf.train.AdamOptimizer keeps beta1^(t+1) in a float32: denormal near t = 830, zero near t = 980.  A checkpoint
+    without global_step resumes at the count beta2_power (0.999^(t+1)) still gives; with neither, a warning says that
+    the step is lost instead of silently restarting Adam's bias correction and the Noam schedule at 0."""
+    import warnings
+    w = rced_np.make_weights("FullyCNNV3", seed=2)
+    for t, expect in ((10, 10), (500, 500), (900, 900), (2000, 2000)):
+        extra = dict(w)
+        extra["beta1_power"] = np.asarray(np.float32(0.9) ** np.float32(t + 1), np.float32)      # what TF holds (underflows)
+        extra["beta2_power"] = np.asarray(0.999 ** (t + 1), np.float32)
+        prefix = str(tmp_path / ("late_%d" % t))
+        tfc.write_checkpoint(prefix, extra)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            _, _, _, step = tfc.load_training_state(prefix, spec.V3)
+        assert step == expect, (t, step, float(extra["beta1_power"]))
+    extra = dict(w)
+    extra["beta1_power"] = np.asarray(0.0, np.float32)
+    extra["beta2_power"] = np.asarray(0.0, np.float32)
+    prefix = str(tmp_path / "lost")
+    tfc.write_checkpoint(prefix, extra)
+    with pytest.warns(UserWarning, match="cannot be recovered"):
+        _, _, _, step = tfc.load_training_state(prefix, spec.V3)
+    assert step == 0
