@@ -1858,14 +1858,21 @@ __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict_
   const int ntiles = (frames + kTF - 1) / kTF;
   float prex[kPerX];
   f32x4 prez[Stage<COUT>::kPer], prez2[DZF ? Stage<COUT>::kPer : 1];
+  // (utterance, time) of the tile's two frames from ONE wave-uniform division per tile: per element and tile the
+  // runtime division frame / T was ~40 VALU instructions, 9 elements per thread -- three non-MFMA VALU per MFMA in the
+  // first-layer kernels (rocprofv3, round 3); what depends on the element alone (fl, ih, f) is loop-invariant
   auto fetch_rows = [&](int tile) {
+    static_assert(kTF == 2, "two frames per tile: the second is the first's successor");
+    const int frame0 = tile * kTF;
+    const int un0 = frame0 / T, ut0 = frame0 - un0 * T;
+    const bool wrap = ut0 + 1 == T;
+    const int un1 = wrap ? un0 + 1 : un0, ut1 = wrap ? 0 : ut0 + 1;
 #pragma unroll
     for (int u = 0; u < kPerX; ++u) {
       const int e = tid + u * kThreads;
       const int fl = e / (KH * kF), r = e - fl * (KH * kF), ih = r / kF, f = r - ih * kF;
-      const int frame = tile * kTF + fl;
-      const int n = frame / T, tt = frame - n * T + ih - PT;
-      prex[u] = (e < kXElems && frame < frames && tt >= 0 && tt < T) ? x[((size_t)n * T + tt) * kF + f] : 0.f;
+      const int un = fl ? un1 : un0, tt = (fl ? ut1 : ut0) + ih - PT;
+      prex[u] = (e < kXElems && frame0 + fl < frames && tt >= 0 && tt < T) ? x[((size_t)un * T + tt) * kF + f] : 0.f;
     }
   };
   if ((int)blockIdx.x < ntiles) {
@@ -1976,14 +1983,21 @@ __global__ __launch_bounds__(kThreads) void first_fwd(const float* __restrict__ 
     for (int j = 0; j < 4; ++j) st1[mt][j] = st2[mt][j] = 0.0;
   const int ntiles = (frames + kTF - 1) / kTF;
   float prex[kPerX];
+  // (utterance, time) of the tile's two frames from ONE wave-uniform division per tile: per element and tile the
+  // runtime division frame / T was ~40 VALU instructions, 9 elements per thread -- three non-MFMA VALU per MFMA in the
+  // first-layer kernels (rocprofv3, round 3); what depends on the element alone (fl, ih, f) is loop-invariant
   auto fetch_rows = [&](int tile) {
+    static_assert(kTF == 2, "two frames per tile: the second is the first's successor");
+    const int frame0 = tile * kTF;
+    const int un0 = frame0 / T, ut0 = frame0 - un0 * T;
+    const bool wrap = ut0 + 1 == T;
+    const int un1 = wrap ? un0 + 1 : un0, ut1 = wrap ? 0 : ut0 + 1;
 #pragma unroll
     for (int u = 0; u < kPerX; ++u) {
       const int e = tid + u * kThreads;
       const int fl = e / (KH * kF), r = e - fl * (KH * kF), ih = r / kF, f = r - ih * kF;
-      const int frame = tile * kTF + fl;
-      const int nn = frame / T, tt = frame - nn * T + ih - PT;
-      prex[u] = (e < kXElems && frame < frames && tt >= 0 && tt < T) ? x[((size_t)nn * T + tt) * kF + f] : 0.f;
+      const int un = fl ? un1 : un0, tt = (fl ? ut1 : ut0) + ih - PT;
+      prex[u] = (e < kXElems && frame0 + fl < frames && tt >= 0 && tt < T) ? x[((size_t)un * T + tt) * kF + f] : 0.f;
     }
   };
   if ((int)blockIdx.x < ntiles) fetch_rows(blockIdx.x);
