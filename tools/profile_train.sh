@@ -21,7 +21,7 @@ import csv, glob, os, sys
 from collections import defaultdict
 out = sys.argv[1]
 def find(d, pat): return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
-def short(n): return n.split('(')[0].replace('void ', '').replace('rced::', '')[:62]
+def short(n): return n.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('rced::', '')[:62]
 print("# rocprofv3, tools/bench_train.py (CR-CED V3 train step, batch 256 x 512, 4 steps)")
 for f in find(os.path.join(out, "trace"), "*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
@@ -49,7 +49,7 @@ for (k, c), (v, n) in acc.items():
     if c in tot: tot[c] += v
 gb = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / 4 / 1e9
 json.dump({"_comment": "CR-CED V3 train step, batch 256 x 512: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) summed over "
-                       "all kernels of a step; FETCH_SIZE doubled per the guide's gfx950 correction for 16 B/lane streams",
+                       "all kernels of a step; FETCH_SIZE doubled: on gfx950 the counter reports half the bytes of a streaming read for every access width (profiles/r03_fetch_calibration.txt)",
            "kernel_hash": ge.train_kernel_hash(), "fetch_kib_raw_per_step": tot["FETCH_SIZE"] / 4, "write_kib_per_step": tot["WRITE_SIZE"] / 4,
            "hbm_gb_per_step": gb}, open(os.path.join(out, "pmc_train.json"), "w"), indent=1)
 print("HBM per step: %.1f GB (fetch x2 + write)" % gb)
