@@ -1756,24 +1756,32 @@ __global__ __launch_bounds__(kFinThreads) void final_fwd(const float* __restrict
 // K = q (4 bins per MFMA, 33 steps per frame).  A[i][kq] = dzpad[q0 + kq + 64 - (16 mt + i)] from a zero-padded
 // per-wave LDS copy of the frame's dz row; B[kq][j] = x[frame, q0 + kq, j] straight from global (the 4 bins of a
 // step are 4*CH contiguous floats).  A wave owns frames; the workgroup's waves add up through LDS, then atomics.
-constexpr int kFwPad = 80, kFwRow = 288;   // dzpad index = 80 + bin, reads span [-79, 195] around it
+constexpr int kFwPad = 96, kFwRow = 304;   // dzpad index = 96 + bin; reads span [-79, 195] around it ([-94, 195] in the tap-pair form)
+// CH = 8 (CR-CED), tap-pair form: eight input channels would fill half of the 16 columns.  A column is (shift s in {0, 1},
+// ci) with B = x[q - s][ci] (the K axis q runs to 131, so q - 1 covers every bin), and the rows are the EVEN taps only:
+// D[r][(s, ci)] = sum_q x[q - s][ci] dz[q + 64 - 2 r] = dW[2 r - s][ci] -- 5 M-tiles (65 rows) instead of 9 per K step,
+// 165 instead of 297 MFMAs per frame.  The ones column
+// that carried d bias is gone: the lanes add up the dz values they stage instead.
 template <int CH>
 __global__ __launch_bounds__(kThreads) void final_wgrad(const float* __restrict__ x, const float* __restrict__ dz,
                                                          float* __restrict__ dW, float* __restrict__ dbias, int frames,
                                                          unsigned pstride) {
+  constexpr bool PAIR = CH == 8;
+  constexpr int MTW = PAIR ? 5 : 9, kRedTaps = PAIR ? 160 : 144;
   __shared__ float rows[kWaves][kFwRow];
-  __shared__ float red[kWaves][9 * 16 * 16];   // one copy per wave, added in wave order (no LDS atomics: deterministic)
+  __shared__ float red[kWaves][kRedTaps * 16];   // one copy per wave, added in wave order (no LDS atomics: deterministic)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
   float* row = rows[wave];
   for (int e = lane; e < kFwRow; e += 64) row[e] = 0.f;
   __syncthreads();
-  f32x4 acc[9];
+  f32x4 acc[MTW];
 #pragma unroll
-  for (int m = 0; m < 9; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MTW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dsum = 0.f;                      // PAIR: this lane's share of sum dz = d bias
   constexpr int kSteps = (kF + 3) / 4;   // 33
-  const float* ap = row + kFwPad + 64 + kq - i;
+  const float* ap = row + kFwPad + 64 + kq - (PAIR ? 2 * i : i);
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
   for (int fr = gw; fr < frames; fr += nw) {
     const float* xr = x + (size_t)fr * kF * CH;
@@ -1782,35 +1790,49 @@ __global__ __launch_bounds__(kThreads) void final_wgrad(const float* __restrict_
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) {
       const int q = 4 * s + kq;
-      b[s] = (i < CH && q < kF) ? xr[q * CH + i] : (i == CH && q < kF ? 1.f : 0.f);
+      if constexpr (PAIR) b[s] = (q - (i >> 3) >= 0 && q - (i >> 3) < kF) ? xr[(q - (i >> 3)) * CH + (i & 7)] : 0.f;
+      else b[s] = (i < CH && q < kF) ? xr[q * CH + i] : (i == CH && q < kF ? 1.f : 0.f);
     }
     // the previous frame's MFMA reads of `row` are complete (same wave, in order): overwrite it
     const float d0 = dr[lane], d1 = dr[64 + lane], d2 = lane == 0 ? dr[128] : 0.f;
     row[kFwPad + lane] = d0;
     row[kFwPad + 64 + lane] = d1;
     if (lane == 0) row[kFwPad + 128] = d2;
+    if constexpr (PAIR) dsum += (d0 + d1) + d2;
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) {
-      float a[9];
+      float a[MTW];
 #pragma unroll
-      for (int m = 0; m < 9; ++m) a[m] = ap[4 * s - 16 * m];
+      for (int m = 0; m < MTW; ++m) a[m] = ap[4 * s - (PAIR ? 32 : 16) * m];
 #pragma unroll
-      for (int m = 0; m < 9; ++m) acc[m] = mfma(a[m], b[s], acc[m]);
+      for (int m = 0; m < MTW; ++m) acc[m] = mfma(a[m], b[s], acc[m]);
     }
   }
-  // D row = tap = 16*m + 4*kq + r, column = i (ci, or the ones column)
+  // D row = tap = 16*m + 4*kq + r, column = i (ci, or the ones column); PAIR: row = tap / 2, column = (tap % 2, ci)
 #pragma unroll
-  for (int m = 0; m < 9; ++m) {
+  for (int m = 0; m < MTW; ++m) {
     const float vv[4] = {acc[m].x, acc[m].y, acc[m].z, acc[m].w};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][(16 * m + 4 * kq + r) * 16 + i] = vv[r];
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (PAIR) {
+        const int tap = 2 * (16 * m + 4 * kq + r) - (i >> 3);
+        if (tap >= 0) red[wave][tap * 16 + (i & 7)] = vv[r];
+      }
+      else red[wave][(16 * m + 4 * kq + r) * 16 + i] = vv[r];
+    }
+  }
+  if constexpr (PAIR) {   // d bias: whole-wave sum of the lanes' shares, parked in a column no tap uses
+    float v = row_sum16(dsum);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane == 63) red[wave][15] = v;
   }
   __syncthreads();
-  for (int e = tid; e < 9 * 256; e += kThreads) {
+  for (int e = tid; e < kRedTaps * 16; e += kThreads) {
     const int tap = e >> 4, c = e & 15;
     const float v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
     if (tap < kF && c < CH) wg_put(dW, pstride, blockIdx.x, tap * CH + c, v);
-    if (tap == 64 && c == CH && dbias) wg_put(dbias, pstride, blockIdx.x, 0, v);
+    if (PAIR ? (e == 15 && dbias != nullptr) : (tap == 64 && c == CH && dbias != nullptr)) wg_put(dbias, pstride, blockIdx.x, 0, v);
   }
 }
 
