@@ -1845,14 +1845,22 @@ __global__ __launch_bounds__(kThreads) void final_wgrad(const float* __restrict_
 // SAME padding 3/4) are staged with their column halo, so A[k][pixel] = rows[(fl*8 + i)*RS + f + j]; dz as in
 // wgrad1xk_mfma (optionally rebuilt from (d_u, z): DZF).
 // ---------------------------------------------------------------------------------------------
+// dz rows per frame of first_wgrad's LDS tile (shared with its launcher), and whether the 18-channel N-remainder form runs
+constexpr bool first_wgrad_nrem(int kw, int cout) { return kw == 9 && tm_rem(cout) == 2; }
+constexpr int first_wgrad_fs(int kw, int cout) { return first_wgrad_nrem(kw, cout) ? 160 : 132; }
 template <int KW, int COUT, bool DZF>
 __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict__ x, const float* __restrict__ dz,
                                                          float* __restrict__ dW, float* __restrict__ dbias, int frames,
                                                          int T, BnBwdArgs ba, unsigned pstride) {
   constexpr int KH = 8, PT = 3, PL = (KW - 1) / 2, RS = kF + KW - 1, K1 = KH * KW;
-  constexpr int KT = (K1 + 1 + 15) / 16, NTo = (COUT + 15) / 16;
+  // NREM (18 channels; see wgrad1xk_mfma): channels 16, 17 as columns (bin phase ph < 8, c) over groups of 8 bins; the rows
+  // are k' = ih * 16 + (j + ph) -- for KW = 9 exactly 16 shifted taps per time tap, 8 M-tiles -- and
+  // dW[ih][j][16 + c] = sum_ph D[ih * 16 + j + ph][(ph, c)]
+  constexpr bool NREM = first_wgrad_nrem(KW, COUT);
+  constexpr int KT = (K1 + 1 + 15) / 16, NTo = NREM ? 1 : (COUT + 15) / 16;
   constexpr int kOneTile = K1 / 16, kOneRow = K1 % 16;
-  constexpr int kFS = 132;                              // dz rows per frame: 33 groups of 4 bins
+  constexpr int kFS = first_wgrad_fs(KW, COUT);         // dz rows per frame: 33 groups of 4 bins (NREM: 5 steps of 32 bins, zero past 129)
+  constexpr int KT8 = NREM ? KH : 1, kSteps8 = NREM ? 5 : 0;
   constexpr int kDzStride = 32, kDzRows = kTF * kFS + 4;
   constexpr int kRowsFloats = ((kTF * KH * RS + 32 + 3) / 4) * 4;
   constexpr int kXElems = kTF * KH * kF, kPerX = (kXElems + kThreads - 1) / kThreads;
@@ -1877,6 +1885,10 @@ __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict_
   for (int a = 0; a < KT; ++a)
 #pragma unroll
     for (int b = 0; b < NTo; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 racc[KT8];
+#pragma unroll
+  for (int a = 0; a < KT8; ++a) racc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
   const int ntiles = (frames + kTF - 1) / kTF;
   float prex[kPerX];
   f32x4 prez[Stage<COUT>::kPer], prez2[DZF ? Stage<COUT>::kPer : 1];
@@ -1940,6 +1952,18 @@ __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict_
 #pragma unroll
         for (int nt = 0; nt < NTo; ++nt) acc[kt][nt] = mfma(a[kt], b[nt], acc[kt][nt]);
     }
+    if constexpr (NREM) {
+      for (int g8 = kWaves - 1 - wave; g8 < kTF * kSteps8; g8 += kWaves) {
+        const int fl = g8 / kSteps8, b8 = 8 * (4 * (g8 - fl * kSteps8) + kq);      // this lane's group starts at bin b8
+        float a8[KT8];
+#pragma unroll
+        for (int kt = 0; kt < KT8; ++kt) a8[kt] = rows[(fl * KH + kt) * RS + b8 + i];
+        const float v8 = ldz[(fl * kFS + b8 + (i >> 1)) * kDzStride + 16 + (i & 1)];
+        bsum += v8;
+#pragma unroll
+        for (int kt = 0; kt < KT8; ++kt) racc[kt] = mfma(a8[kt], v8, racc[kt]);
+      }
+    }
     __syncthreads();
   }
   // D row = k = 16*kt + 4*kq + r (TF layout [8][KW][1][COUT] = k*COUT + co), column = co = 16*nt + i
@@ -1956,6 +1980,33 @@ __global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict_
         if (k == K1 && co < COUT && dbias) wg_put(dbias, pstride, (int)blockIdx.x * kWaves + wave, co, vv[r]);
       }
     }
+  if constexpr (NREM) {
+    float* sc = lds + wave * (KH * 16 * 16);      // the tiles are dead: the loop ended on a barrier
+#pragma unroll
+    for (int kt = 0; kt < KT8; ++kt) {
+      const float vv[4] = {racc[kt].x, racc[kt].y, racc[kt].z, racc[kt].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[(16 * kt + 4 * kq + r) * 16 + i] = vv[r];
+    }
+    __syncthreads();
+    const int slice = (int)blockIdx.x * kWaves + wave;
+    for (int e = lane; e < K1 * 2; e += 64) {
+      const int c = e & 1, k = e >> 1, ih = k / KW, j = k - ih * KW;
+      float t = 0.f;
+#pragma unroll
+      for (int ph = 0; ph < 8; ++ph) t += sc[(ih * 16 + j + ph) * 16 + 2 * ph + c];
+      wg_put(dW, pstride, slice, k * COUT + 16 + c, t);
+    }
+    if (dbias) {
+      float v = bsum;
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 2) wg_put(dbias, pstride, slice, 16 + lane, v);
+    }
+  }
 }
 
 

@@ -223,7 +223,7 @@ template <int KW, int COUT>
 int first_wgrad_launch(const float* x, const float* dz, float* dW, float* dbias, int frames, int T, int cus,
                        const tmm::BnBwdArgs* ba, hipStream_t st) {
   constexpr int RS = 129 + KW - 1;
-  const size_t lds = (((size_t)(tmm::kTF * 8 * RS + 32 + 3) / 4) * 4 + (size_t)(tmm::kTF * 132 + 4) * 32 + 4 * COUT) * sizeof(float);
+  const size_t lds = (((size_t)(tmm::kTF * 8 * RS + 32 + 3) / 4) * 4 + (size_t)(tmm::kTF * tmm::first_wgrad_fs(KW, COUT) + 4) * 32 + 4 * COUT) * sizeof(float);
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
   static unsigned long long attr_t = 0, attr_f = 0;
