@@ -1849,7 +1849,7 @@ __global__ __launch_bounds__(kThreads) void final_wgrad(const float* __restrict_
 constexpr bool first_wgrad_nrem(int kw, int cout) { return kw == 9 && tm_rem(cout) == 2; }
 constexpr int first_wgrad_fs(int kw, int cout) { return first_wgrad_nrem(kw, cout) ? 160 : 132; }
 template <int KW, int COUT, bool DZF>
-__global__ __launch_bounds__(kThreads) void first_wgrad(const float* __restrict__ x, const float* __restrict__ dz,
+__global__ __launch_bounds__(kThreads, 2) void first_wgrad(const float* __restrict__ x, const float* __restrict__ dz,
                                                          float* __restrict__ dW, float* __restrict__ dbias, int frames,
                                                          int T, BnBwdArgs ba, unsigned pstride) {
   constexpr int KH = 8, PT = 3, PL = (KW - 1) / 2, RS = kF + KW - 1, K1 = KH * KW;
