@@ -2033,7 +2033,7 @@ static __global__ void pack_first(const float* __restrict__ w, const float* __re
 }
 
 template <int KW, int COUT, bool STATS>
-__global__ __launch_bounds__(kThreads) void first_fwd(const float* __restrict__ x, const float* __restrict__ packet,
+__global__ __launch_bounds__(kThreads, 2) void first_fwd(const float* __restrict__ x, const float* __restrict__ packet,
                                                        float* __restrict__ z, int frames, int T, double* __restrict__ part) {
   constexpr int KH = 8, PT = 3, PL = (KW - 1) / 2, RS = kF + KW - 1, STEPS = 2 * KW;
   constexpr int MT = (COUT + 15) / 16, kData = STEPS * MT * 64;
@@ -2097,7 +2097,7 @@ __global__ __launch_bounds__(kThreads) void first_fwd(const float* __restrict__ 
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[t][mt] = *reinterpret_cast<const f32x4*>(lw + kData + 16 * mt + 4 * kq);
     }
-#pragma unroll 2
+#pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       const int ih = s / KW, j = s - ih * KW;
       float a[MT], b[NTW];
