@@ -588,10 +588,10 @@ template <int CH>
 struct FinalGeo {
   static constexpr int kK = kF * CH;
   static constexpr int kNB64 = kK / 8;
-  static constexpr int kTailValid = kK - 8 * kNB64;   // 4 (CH = 12) or 2 (CH = 10)
-  static_assert(kTailValid > 0 && kTailValid <= 4, "one b32 tail step");
+  static constexpr int kTailValid = kK - 8 * kNB64;   // 4 (CH = 12), 2 (CH = 10) or 0 (CH = 8: the training step's CR-CED output layer)
+  static_assert(kTailValid >= 0 && kTailValid <= 4, "at most one b32 tail step");
   static constexpr int kMT = 9;
-  static constexpr int kPack = kNB64 * kMT * 128 + kMT * 64;
+  static constexpr int kPack = kNB64 * kMT * 128 + (kTailValid ? kMT * 64 : 0);
 };
 constexpr int kFinFrames = 64;
 constexpr int kFinThreads = 192;
@@ -679,9 +679,11 @@ struct FinalLds {
 template <int CH>
 __global__ __launch_bounds__(kFinThreads) void final_gemm_lds_kernel(const float* __restrict__ h,
                                                                       const float* __restrict__ apack, float bias,
-                                                                      float* __restrict__ y, int frames) {
+                                                                      float* __restrict__ y, int frames,
+                                                                      const float* __restrict__ bias_dev = nullptr) {
   using FG = FinalGeo<CH>;
   using G = FinalLds<CH>;
+  if (bias_dev) bias = *bias_dev;      // the training step's bias is a device variable (it moves every step)
   __shared__ __attribute__((aligned(16))) float bs[2][kFinFrames * G::kRow];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(kFinThreads) void final_gemm_lds_kernel(const float
         }
       }
     }
-    if (c == G::kTailChunk) {   // b32 step: lane kq <-> k = 8*NB64 + kq (zero past K)
+    if (FG::kTailValid > 0 && c == G::kTailChunk) {   // b32 step: lane kq <-> k = 8*NB64 + kq (zero past K)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float b = bb[16 * t * G::kRow + G::kTailOff + kq];

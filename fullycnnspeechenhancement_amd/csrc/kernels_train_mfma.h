@@ -1688,68 +1688,8 @@ static __global__ void pack_final_fwd(const float* __restrict__ w, int CH, float
   pack[e] = (k < K && f < kF && tap >= 0 && tap < kF) ? w[tap * CH + ci] : 0.f;
 }
 
-template <int CH>
-__global__ __launch_bounds__(kFinThreads) void final_fwd(const float* __restrict__ h, const float* __restrict__ apack,
-                                                          const float* __restrict__ bias, float* __restrict__ y, int frames) {
-  using FG = FinGeo<CH>;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, kq = lane >> 4;
-  const int f0 = blockIdx.x * kFinFrames;
-  const f32x2* ap = reinterpret_cast<const f32x2*>(apack) + (wave * 3) * 64 + lane;
-  const float* bp[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    int fr = f0 + 16 * t + n;
-    if (fr >= frames) fr = frames - 1;   // clamp: computed, never stored
-    bp[t] = h + (size_t)fr * FG::kK;
-  }
-  const float b0 = bias[0];
-  f32x4 acc[4][3];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int m = 0; m < 3; ++m) acc[t][m] = f32x4{b0, b0, b0, b0};
-#pragma unroll 4
-  for (int s = 0; s < FG::kNB64; ++s) {
-    f32x2 a[3], b[4];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) a[m] = ap[(s * FG::kMT + m) * 64];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const f32x2*>(bp[t] + 8 * s + 2 * kq);
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < 3; ++m) acc[t][m] = mfma(a[m][e], b[t][e], acc[t][m]);
-  }
-  if constexpr (FG::kTail > 0) {
-    const float* at = apack + FG::kMain + (wave * 3) * 64 + lane;
-    const int kqe = kq < FG::kTail ? kq : FG::kTail - 1;      // rows past K carry zero weights
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float b = bp[t][8 * FG::kNB64 + kqe];
-#pragma unroll
-      for (int m = 0; m < 3; ++m) acc[t][m] = mfma(at[m * 64], b, acc[t][m]);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int fr = f0 + 16 * t + n;
-    if (fr >= frames) continue;
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int f = 16 * (3 * wave + m) + 4 * kq;
-      float* yp = y + (size_t)fr * kF + f;
-      const f32x4 v = acc[t][m];
-      if (f + 0 < kF) yp[0] = v.x;
-      if (f + 1 < kF) yp[1] = v.y;
-      if (f + 2 < kF) yp[2] = v.z;
-      if (f + 3 < kF) yp[3] = v.w;
-    }
-  }
-}
+// (The GEMM itself is chain::final_gemm_lds_kernel<CH>, the inference path's kernel with its B operand staged through LDS:
+// train_api.hip fin_forward.  Round 2's tmm::final_fwd read the h rows with strided global loads: 0.54 vs 0.41 ms.)
 
 // Output-layer wgrad: dW[tap, ci] = sum_{frame, q} x[frame, q, ci] * dz[frame, q + 64 - tap]  (q = f + tap - 64).
 // MFMA roles: M = tap (9 tiles), N = ci (one tile; column CH carries ones, so D[64][CH] = sum dz = dbias),

@@ -81,6 +81,8 @@ struct rced_trainer {
   float* zero32 = nullptr;
   double *part = nullptr, *sums = nullptr;
   int* redo = nullptr;         // device flag behind `sums` (same allocation): sums_fix_x asks for the exact recomputation
+  int* tiny_host = nullptr;    // [layers] pinned, host-mapped: 1 = some |gamma| of the layer is below kTinyGamma (written by
+  int* tiny_dev = nullptr;     // tiny_gamma_scan behind every Adam step, read by the host at the start of the next step)
   // activations for P pixels
   size_t cap_px = 0;
   std::vector<float*> out, z, G;   // out/G indexed by tensor id (0 unused), z by layer
@@ -90,6 +92,7 @@ struct rced_trainer {
     DeviceGuard g(device);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(params); fr(grads); fr(m); fr(v); fr(trainable); fr(zero32); fr(part); fr(sums); fr(D); fr(wpart);
+    if (tiny_host) (void)hipHostFree(tiny_host);
     for (auto* p : wf) fr(p);
     for (auto* p : wt) fr(p);
     for (auto* p : bias4) fr(p);
@@ -288,8 +291,14 @@ int fin_forward(int ch, const float* h, const float* w, const float* bias, float
   const int total = (int)fin_pack_floats(ch);
   hipLaunchKernelGGL(tmm::pack_final_fwd, dim3((total + 255) / 256), dim3(256), 0, st, w, ch, pack);
   const dim3 grid((frames + tmm::kFinFrames - 1) / tmm::kFinFrames);
-#define X(CH) \
-  if (ch == CH) hipLaunchKernelGGL((tmm::final_fwd<CH>), grid, dim3(tmm::kFinThreads), 0, st, h, (const float*)pack, bias, y, frames);
+  // the inference path's output-layer GEMM with its B operand staged through LDS (kernels_fused_chain.h: 0.54 -> 0.41 ms at
+  // config 5's size against tmm::final_fwd's strided global reads); same packed A fragments, the bias read on the device
+#define X(CH)                                                                                                               \
+  if (ch == CH) {                                                                                                           \
+    static_assert(tmm::FinGeo<CH>::kPack == chain::FinalGeo<CH>::kPack && tmm::kFinFrames == chain::kFinFrames, "one pack");   \
+    hipLaunchKernelGGL((chain::final_gemm_lds_kernel<CH>), grid, dim3(chain::kFinThreads), 0, st, h, (const float*)pack, 0.f,  \
+                       y, frames, bias);                                                                                    \
+  }
   RCED_FIN_CH(X)
 #undef X
   return 1;
@@ -430,6 +439,17 @@ __global__ __launch_bounds__(1024) void bn_finish(const double* __restrict__ par
   }
 }
 
+// One workgroup per layer: does any channel of the layer have |gamma| < kTinyGamma?  (the fused backward kernel's sums
+// cannot be trusted there: see sums_fix_x.)  Launched behind every Adam step into host-mapped memory, so that the NEXT
+// step knows on the host which layers need the exact recomputation -- instead of launching a conditional bwd_route2 +
+// finish pair for every plain layer in every step (20 no-op launches per CR-CED step).
+struct TinyScanArgs { int gamma_off[kMaxLayers]; int cout[kMaxLayers]; };
+__global__ void tiny_gamma_scan(const float* __restrict__ params, TinyScanArgs a, int* __restrict__ flags) {
+  const int l = blockIdx.x, c = threadIdx.x;
+  const bool tiny = a.gamma_off[l] >= 0 && c < a.cout[l] && !(fabsf(params[a.gamma_off[l] + c]) >= kTinyGamma);
+  const int any = __syncthreads_or(tiny);
+  if (c == 0) flags[l] = any;
+}
 }  // namespace
 
 extern "C" {
@@ -541,6 +561,14 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
   TRY_OR_FREE(hipMalloc(&t->sums, (train::kMaxC * 2 + 2) * sizeof(double)));
   t->redo = reinterpret_cast<int*>(t->sums + train::kMaxC * 2);
   TRY_OR_FREE(hipMemset(t->redo, 0, 2 * sizeof(double)));
+  TRY_OR_FREE(hipHostMalloc(reinterpret_cast<void**>(&t->tiny_host), kMaxLayers * sizeof(int), hipHostMallocMapped));
+  TRY_OR_FREE(hipHostGetDevicePointer(reinterpret_cast<void**>(&t->tiny_dev), t->tiny_host, 0));
+  for (int l = 0; l < kMaxLayers; ++l) {
+    t->tiny_host[l] = 0;
+    if (l < L && net->layer[l].use_norm)
+      for (int c = 0; c < net->layer[l].cout; ++c)
+        if (!(std::fabs(blob[t->off[l].gamma + c]) >= kTinyGamma)) t->tiny_host[l] = 1;    // (phantom channels: gamma 0)
+  }
   t->wf.assign(L, nullptr); t->wt.assign(L, nullptr); t->bias4.assign(L, nullptr);
   t->mu.assign(L, nullptr); t->rstd.assign(L, nullptr);
   t->pk_fwd.assign(L, nullptr); t->pk_bwd.assign(L, nullptr);
@@ -805,6 +833,8 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
   }
   // fused_sums[l] > 0: the dgrad that wrote G[l + 1] (layer l's only consumer) has left that many (sum d_u, sum d_u z)
   // records of layer l's BatchNorm backward in t->part (tmm::SumArgs): no bwd_route2 pass for layer l.
+  int tiny[kMaxLayers];
+  for (int l = 0; l < kMaxLayers; ++l) tiny[l] = t->tiny_host[l];     // as of the end of the previous step (it synchronised)
   std::vector<int> fused_sums(L, 0);
   std::vector<char> sums_from_x(L, 0);   // those records hold (sum d_u, sum d_u * x) (fused backward kernel) rather than (.., sum d_u * z)
   const bool fuse_sums_on = t->fuse_sums;
@@ -843,15 +873,16 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       hipLaunchKernelGGL(bn_finish, dim3(1), dim3(1024), 0, st, (const double*)t->part, fused_sums[l], s.cout, t->sums,
                          (int)(sums_from_x[l] ? kFinX : kFinZ), fb, (const int*)nullptr);
       grads_out = true;
-      if (sums_from_x[l]) {
-        // |gamma| tiny somewhere in this layer: the sums again, exactly, from (g, z) (no-ops otherwise; see sums_fix_x)
+      if (sums_from_x[l] && tiny[l]) {
+        // |gamma| tiny somewhere in this layer (known on the host since the previous step's tiny_gamma_scan): the sums
+        // again, exactly, from (g, z); see sums_fix_x.  Never taken in a real training run.
         const dim3 grid = pair_grid(s.cout);
         hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
                            (const float2*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
                            (const float*)(t->params + f.beta), (const float2*)nullptr, s.use_act, P, s.cout, (float2*)nullptr,
-                           (float2*)nullptr, (float2*)nullptr, t->part, (const int*)t->redo);
+                           (float2*)nullptr, (float2*)nullptr, t->part, (const int*)nullptr);
         hipLaunchKernelGGL(bn_finish, dim3(1), dim3(1024), 0, st, (const double*)t->part, (int)grid.x, s.cout, t->sums,
-                           (int)kFinPlain, fb, (const int*)t->redo);
+                           (int)kFinPlain, fb, (const int*)nullptr);
       }
     } else if (pairs) {
       const dim3 grid = pair_grid(s.cout);
@@ -967,6 +998,14 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
   hipLaunchKernelGGL(train::adam_step, dim3((unsigned)((t->nvars + train::kThreads - 1) / train::kThreads)),
                      dim3(train::kThreads), 0, st, t->params, (const float*)t->grads, t->m, t->v,
                      (const unsigned char*)t->trainable, t->nvars, lr_t, kAdamB1, kAdamB2, kAdamEps);
+  {
+    TinyScanArgs ta;
+    for (int l = 0; l < kMaxLayers; ++l) {
+      ta.gamma_off[l] = l < L && net.layer[l].use_norm ? (int)t->off[l].gamma : -1;
+      ta.cout[l] = l < L ? net.layer[l].cout : 0;
+    }
+    hipLaunchKernelGGL(tiny_gamma_scan, dim3(kMaxLayers), dim3(64), 0, st, (const float*)t->params, ta, t->tiny_dev);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));
   double loss = 0.0;
