@@ -239,7 +239,9 @@ __global__ __launch_bounds__(kThreads) void bwd_route2(const float2* __restrict_
                                                         const float2* __restrict__ skip_pre, int use_act, size_t P, int C,
                                                         float2* __restrict__ g_skip_pre, float2* __restrict__ g_skip_post,
                                                         float2* __restrict__ d, double* __restrict__ part,
-                                                        const int* __restrict__ only_if = nullptr) {
+                                                        const int* __restrict__ only_if = nullptr, int skip_first = 0) {
+  // skip_first: this launch is the FIRST writer of the skip source's gradient tensor -- it stores instead of adding, so
+  // the tensor needs neither a memset nor this kernel's read of it
   if (only_if && *only_if == 0) return;   // wave-uniform: see reduce_finish
   __shared__ double red[kThreads * 4];
   const PairLane L(C, threadIdx.x);
@@ -262,8 +264,8 @@ __global__ __launch_bounds__(kThreads) void bwd_route2(const float2* __restrict_
         gv[u] = ok ? g_out[q] : float2{0.f, 0.f};
         zv[u] = ok ? z[q] : float2{0.f, 0.f};
         sp[u] = (ok && skip_pre) ? skip_pre[q] : float2{0.f, 0.f};
-        gp[u] = (ok && g_skip_pre) ? g_skip_pre[q] : float2{0.f, 0.f};
-        gq[u] = (ok && g_skip_post) ? g_skip_post[q] : float2{0.f, 0.f};
+        gp[u] = (ok && g_skip_pre && !skip_first) ? g_skip_pre[q] : float2{0.f, 0.f};
+        gq[u] = (ok && g_skip_post && !skip_first) ? g_skip_post[q] : float2{0.f, 0.f};
       }
 #pragma unroll
       for (int u = 0; u < kPairUnroll; ++u) {

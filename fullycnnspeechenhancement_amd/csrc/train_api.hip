@@ -825,12 +825,33 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     const bool mfma_dgrad = t->pk_bwd[l] != nullptr || (t->pk_fin_bwd != nullptr && is_output_layer(s, t->off[l].cin));
     return t->use_mfma && mfma_dgrad && s.src > 0 && consumers[s.src] == 1;
   };
+  std::vector<char> lazy_zero(L + 1, 0), written(L + 1, 0);
   {
     std::vector<char> plain(L + 1, 0);
     for (int l = 0; l < L; ++l) if (overwrite(l)) plain[net.layer[l].src] = 1;
-    for (int id = 1; id < L; ++id)
-      if (!plain[id]) HIP_TRY(hipMemsetAsync(t->G[id], 0, P * net.layer[id - 1].cout * sizeof(float), st));
+    // A tensor that some layer adds as a skip gets its first gradient contribution from that layer's bwd_route2 (the skip
+    // consumer comes later in the net than the convolution that reads the tensor, so earlier in this loop), which can
+    // STORE it: no memset, no read-modify-write there.  written[id] tracks it; whoever must add to a tensor nobody has
+    // written yet zeroes it first (ensure_zero: not reached in the three nets).
+    for (int l = 0; l < L; ++l) {
+      const LayerSpec& s = net.layer[l];
+      if (t->use_mfma && s.cout % 2 == 0) {
+        if (s.skip_pre > 0) lazy_zero[s.skip_pre] = 1;
+        if (s.skip_post > 0) lazy_zero[s.skip_post] = 1;
+      }
+    }
+    for (int id = 1; id < L; ++id) {
+      if (plain[id] || !lazy_zero[id]) written[id] = 1;
+      if (!plain[id] && !lazy_zero[id]) HIP_TRY(hipMemsetAsync(t->G[id], 0, P * net.layer[id - 1].cout * sizeof(float), st));
+    }
   }
+  auto ensure_zero = [&](int id) -> int {
+    if (id > 0 && !written[id]) {
+      HIP_TRY(hipMemsetAsync(t->G[id], 0, P * net.layer[id - 1].cout * sizeof(float), st));
+      written[id] = 1;
+    }
+    return RCED_OK;
+  };
   // fused_sums[l] > 0: the dgrad that wrote G[l + 1] (layer l's only consumer) has left that many (sum d_u, sum d_u z)
   // records of layer l's BatchNorm backward in t->part (tmm::SumArgs): no bwd_route2 pass for layer l.
   int tiny[kMaxLayers];
@@ -851,6 +872,9 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     // there too, so those layers' d_u need not be written either; bwd_route2 still routes g to the skip's source)
     return fuse_dz_of(l) && s.use_act && s.skip_pre < 0;
   };
+  // a producer whose BatchNorm-backward sums may come out of its consumer's dgrad: masked lazily AND without a skip to
+  // route (a layer that adds a skip after its ReLU still needs its bwd_route2 pass for that)
+  auto sums_in_dgrad_ok = [&](int pl) { return lazy_mask_of(pl) && net.layer[pl].skip_post < 0; };
   for (int l = L - 1; l >= 0; --l) {
     const LayerSpec& s = net.layer[l];
     const LayerOff& f = t->off[l];
@@ -886,18 +910,24 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       }
     } else if (pairs) {
       const dim3 grid = pair_grid(s.cout);
+      // (a layer has at most one skip; first writer of its gradient tensor: store, see `written`)
+      const int skip_id = s.skip_pre > 0 ? s.skip_pre : s.skip_post;
+      const int skip_first = skip_id > 0 && !written[skip_id] ? 1 : 0;
+      if (skip_id > 0) written[skip_id] = 1;
       hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
                          (const float2*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
                          (const float*)(t->params + f.beta), (const float2*)tensor(s.skip_pre), s.use_act, P, s.cout,
                          (float2*)(s.skip_pre > 0 ? t->G[s.skip_pre] : nullptr),
                          (float2*)(s.skip_post > 0 ? t->G[s.skip_post] : nullptr), (float2*)(lazy_mask ? nullptr : t->D),
-                         s.use_norm ? t->part : (double*)nullptr);
+                         s.use_norm ? t->part : (double*)nullptr, (const int*)nullptr, skip_first);
       if (s.use_norm) {
         hipLaunchKernelGGL(bn_finish, dim3(1), dim3(1024), 0, st, (const double*)t->part, (int)grid.x, s.cout, t->sums,
                            (int)kFinPlain, fb, (const int*)nullptr);
         grads_out = true;
       }
     } else {
+      if (int rc = ensure_zero(s.skip_pre)) return rc;
+      if (int rc = ensure_zero(s.skip_post)) return rc;
       hipLaunchKernelGGL(train::bwd_route, blocks(n), dim3(train::kThreads), 0, st, (const float*)t->G[l + 1],
                          (const float*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
                          (const float*)(t->params + f.beta), tensor(s.skip_pre), s.use_act, n, s.cout,
@@ -928,7 +958,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     bool fused_done = false;
     if (t->fuse_bwd && t->use_mfma && s.kh == 1 && s.src > 0 && fuse_dz && t->pk_bwd[l] && overwrite(l)) {
       const int pl = s.src - 1;
-      const bool xvirt = t->virt[s.src] != 0, want_sums = fuse_sums_on && lazy_mask_of(pl);
+      const bool xvirt = t->virt[s.src] != 0, want_sums = fuse_sums_on && sums_in_dgrad_ok(pl);
       if (xvirt == want_sums) {
         const int g = tm_bwd_fused(f.cin, s.kw, s.cout, xvirt, conv_in(s.src), dsrc, t->pk_bwd[l], t->G[s.src], t->grads + f.kernel,
                                    t->grads + f.bias, frames, t->num_cus, t->part, xform_of(s.src, &xa_tmp), ba, st);
@@ -965,7 +995,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       if (t->use_mfma && t->pk_fin_bwd && is_output_layer(s, f.cin) && consumers[s.src] == 1) {
         fin_dgrad(f.cin, t->D, t->params + f.kernel, t->pk_fin_bwd, t->G[s.src], frames, st);   // overwrites G[src]
       } else if (const int pl = s.src - 1;   // the layer that produced this dgrad's output tensor
-                 fuse_sums_on && t->use_mfma && t->pk_bwd[l] && overwrite(l) && lazy_mask_of(pl) && [&] {
+                 fuse_sums_on && t->use_mfma && t->pk_bwd[l] && overwrite(l) && sums_in_dgrad_ok(pl) && [&] {
                    const LayerOff& pf = t->off[pl];
                    const tmm::SumArgs sa{t->z[pl], t->mu[pl], t->rstd[pl], t->params + pf.gamma, t->params + pf.beta};
                    fused_sums[pl] = tm_conv(false, s.cout, s.kw, f.cin, false, false, dsrc, t->pk_bwd[l], t->G[s.src], frames,
@@ -973,12 +1003,14 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
                    return fused_sums[pl] > 0;
                  }()) {
         // MFMA path; layer pl's BatchNorm-backward sums come out of the same kernel
-      } else if (t->use_mfma && t->pk_bwd[l] &&
+      } else if (t->use_mfma && t->pk_bwd[l] && (overwrite(l) || ensure_zero(s.src) == RCED_OK) &&
           tm_conv(false, s.cout, s.kw, f.cin, !overwrite(l), false, dsrc, t->pk_bwd[l], t->G[s.src], frames, t->num_cus,
                   nullptr, nullptr, ba, st)) {
         // MFMA path
       } else if (fuse_dz) {
         return rced_fail(RCED_ERR_STATE, "layer %d: no MFMA dgrad kernel for a layer with fused dz", l);
+      } else if (int rc0 = ensure_zero(s.src)) {
+        return rc0;
       } else if (int rc = launch_conv(t->D, t->G[s.src], t->wt[l], t->zero32, t->G[s.src], frames, T, F, s.cout, f.cin,
                                       f.cin4, s.kh, s.kw, (s.kh - 1) - (s.kh - 1) / 2, (s.kw - 1) - (s.kw - 1) / 2, st)) {
         return rc;
