@@ -888,12 +888,17 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     const bool first_mfma = t->use_mfma && first_has(s, f.cin);
     const bool fuse_dz = fuse_dz_of(l);
     const bool lazy_mask = lazy_mask_of(l);
-    const float* dsrc = lazy_mask ? t->G[l + 1] : t->D;      // what wgrad / dgrad read as their "dz" input
+    // a linear layer without BatchNorm or skips (decode_final): d_u IS the incoming gradient -- no routing pass, no copy
+    const bool passthrough = t->use_mfma && !s.use_act && !s.use_norm && s.skip_pre < 0 && s.skip_post < 0 && is_output_layer(s, f.cin) && t->pk_fin &&
+                             t->pk_fin_bwd && s.src > 0 && consumers[s.src] == 1;   // (both of its consumers below take dsrc)
+    const float* dsrc = lazy_mask || passthrough ? t->G[l + 1] : t->D;      // what wgrad / dgrad read as their "dz" input
     bool grads_out = false;      // d beta / d gamma already written by bn_finish
     FinishArgs fb{};
     fb.mu = mu; fb.rstd = t->rstd[l]; fb.gamma = t->params + f.gamma; fb.beta = t->params + f.beta;
     fb.g_beta = t->grads + f.beta; fb.g_gamma = t->grads + f.gamma; fb.redo = t->redo;
-    if (lazy_mask && fused_sums[l] > 0) {
+    if (passthrough) {
+      // nothing to route
+    } else if (lazy_mask && fused_sums[l] > 0) {
       hipLaunchKernelGGL(bn_finish, dim3(1), dim3(1024), 0, st, (const double*)t->part, fused_sums[l], s.cout, t->sums,
                          (int)(sums_from_x[l] ? kFinX : kFinZ), fb, (const int*)nullptr);
       grads_out = true;
@@ -977,7 +982,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     } else if (first_mfma && first_wgrad(s, x_dev, dsrc, t->grads + f.kernel, t->grads + f.bias, frames, T, t->num_cus, ba, st)) {
       // MFMA path, first layer
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
-      fin_wgrad(f.cin, tensor(s.src), t->D, t->grads + f.kernel, t->grads + f.bias, frames, t->num_cus, st);
+      fin_wgrad(f.cin, tensor(s.src), dsrc, t->grads + f.kernel, t->grads + f.bias, frames, t->num_cus, st);
     } else {
       if ((s.src > 0 && t->virt[s.src]) || fuse_dz)   // the direct kernel needs the activation and dz in HBM
         return rced_fail(RCED_ERR_STATE, "layer %d: no MFMA wgrad kernel for a layer with fused activation / dz", l);
@@ -993,7 +998,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
     if (s.src > 0 && !fused_done) {
       if (t->use_mfma && t->pk_fin_bwd && is_output_layer(s, f.cin) && consumers[s.src] == 1) {
-        fin_dgrad(f.cin, t->D, t->params + f.kernel, t->pk_fin_bwd, t->G[s.src], frames, st);   // overwrites G[src]
+        fin_dgrad(f.cin, dsrc, t->params + f.kernel, t->pk_fin_bwd, t->G[s.src], frames, st);   // overwrites G[src]
       } else if (const int pl = s.src - 1;   // the layer that produced this dgrad's output tensor
                  fuse_sums_on && t->use_mfma && t->pk_bwd[l] && overwrite(l) && sums_in_dgrad_ok(pl) && [&] {
                    const LayerOff& pf = t->off[pl];
