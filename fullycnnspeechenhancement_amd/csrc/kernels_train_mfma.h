@@ -553,7 +553,11 @@ template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
                                           int frames, int wave, int lane, double* red_wave, const float* zt, const float* stab,
                                           Each each, f32x4* acc_store, const f32x4* ks_own, const float* ks_lds,
-                                          SumState<Geo<CIN, TAPS, COUT>::kMTm>& S, bool carried, bool flush) {
+                                          SumState<Geo<CIN, TAPS, COUT>::kMTm>& S, bool carried, bool flush,
+                                          long acc_delta = 0) {
+  // acc_delta (ACCUM): the tensor the result is added to sits acc_delta floats from `out` -- out = acc_from + conv instead of
+  // out += conv: a gradient tensor whose other contribution is a plain copy (a post-ReLU skip) is never copied, the dgrad
+  // that completes it reads the copy's source instead (train_api.hip, skip_alias)
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(!(SUMS && (STATS || ACCUM || G::kPH != 1 || (COUT & 1))), "SUMS: overwrite-mode dgrads with an even, unpaired cout");
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMTm, PH = G::kPH;   // MT: M-tiles of the MAIN pass
@@ -719,17 +723,17 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
           char* p = ob + 16 * mt * 4 + lane_b;
           if (PH == 2 || 16 * mt + 16 <= COUT) {
             f32x4 r = v;
-            if (ACCUM) r += *reinterpret_cast<const f32x4u*>(p);
+            if (ACCUM) r += *reinterpret_cast<const f32x4u*>(p + 4 * acc_delta);
             *reinterpret_cast<f32x4u*>(p) = r;
           } else {
             const int co0 = 16 * mt + 4 * kq;
             if (co0 + 3 < COUT) {
               f32x4 r = v;
-              if (ACCUM) r += *reinterpret_cast<const f32x4u*>(p);
+              if (ACCUM) r += *reinterpret_cast<const f32x4u*>(p + 4 * acc_delta);
               *reinterpret_cast<f32x4u*>(p) = r;
             } else if (co0 + 1 < COUT) {
               f32x2 r = {v.x, v.y};
-              if (ACCUM) { const f32x2 o = *reinterpret_cast<const f32x2*>(p); r.x += o.x; r.y += o.y; }
+              if (ACCUM) { const f32x2 o = *reinterpret_cast<const f32x2*>(p + 4 * acc_delta); r.x += o.x; r.y += o.y; }
               *reinterpret_cast<f32x2*>(p) = r;
             }
           }
@@ -803,19 +807,19 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
           if (co0 + 3 < COUT) {
             f32x4u* p = reinterpret_cast<f32x4u*>(op + co0);
             f32x4 r = v;
-            if (ACCUM) { const f32x4 o = *p; r += o; }
+            if (ACCUM) { const f32x4 o = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const float*>(p) + acc_delta); r += o; }
             *p = r;
           } else if (co0 + 1 < COUT) {
             f32x2* p = reinterpret_cast<f32x2*>(op + co0);
             f32x2 r = {v.x, v.y};
-            if (ACCUM) { const f32x2 o = *p; r.x += o.x; r.y += o.y; }
+            if (ACCUM) { const f32x2 o = *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(p) + acc_delta); r.x += o.x; r.y += o.y; }
             *p = r;
           }
         } else {
           const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (co0 + j < COUT) op[co0 + j] = (ACCUM ? op[co0 + j] : 0.f) + vv[j];
+            if (co0 + j < COUT) op[co0 + j] = (ACCUM ? op[co0 + j + acc_delta] : 0.f) + vv[j];
         }
       }
     }
@@ -860,7 +864,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
         }
         f32x2* op2 = reinterpret_cast<f32x2*>(out + ((size_t)(frame0 + fr) * kF + f) * COUT + 16);
         f32x2 r = v;
-        if (ACCUM) { const f32x2 o = *op2; r.x += o.x; r.y += o.y; }
+        if (ACCUM) { const f32x2 o = *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(op2) + acc_delta); r.x += o.x; r.y += o.y; }
         *op2 = r;
       }
     }
@@ -1020,9 +1024,10 @@ __device__ __forceinline__ void conv_ks_partial(const float* lds_in, const float
 template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF, bool SUMS = false>
 __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const float* __restrict__ in, const float* __restrict__ packet,
                                                           float* __restrict__ out, int frames, double* __restrict__ part,
-                                                          XformArgs xa, BnBwdArgs ba, SumArgs sa) {
+                                                          XformArgs xa, BnBwdArgs ba, SumArgs sa, const float* acc_from) {
   using G = Geo<CIN, TAPS, COUT>;
   static_assert(!SUMS || CIN % 2 == 0, "SUMS lives in the wide-staging tile loop");
+  const long acc_delta = ACCUM && acc_from ? (long)(acc_from - out) : 0;   // ACCUM: out = acc_from + conv (null: out += conv)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lin = lds;
   float* lw = lds + G::kInFloats;
@@ -1107,19 +1112,19 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
         float* ks = lds + conv_ks_off<CIN, TAPS, COUT, XF, STATS, SUMS>();
         f32x4 xacc[G::kMT];
         conv_ks_partial<CIN, TAPS, COUT>(lin, lw, ks, wave, lane, xacc);
-        if (wave == 0) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, true>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, xacc, ks, sums, carried, flush);
-        else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false, decltype(each), false, 2, true>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, xacc, ks, sums, carried, flush);
+        if (wave == 0) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, true>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, xacc, ks, sums, carried, flush, acc_delta);
+        else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false, decltype(each), false, 2, true>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, xacc, ks, sums, carried, flush, acc_delta);
       } else if constexpr (RCED_TM_MSPLIT && G::kExtra == 1 && G::kMTm == 2 && !SUMS && !ACCUM) {
         // The odd column tile by M-tile: two waves carry half of it each (4.5 / 4.5 / 4 / 4 tiles of MFMAs instead of
         // 5 / 4 / 4 / 4), and the second half of the grid -- with a resident grid of two workgroups per CU the likely partner
         // on the same CU -- gives its halves to waves 2, 3: 8.5 on every SIMD.
         const int xw = (int)blockIdx.x >= ((int)gridDim.x + 1) / 2 ? 2 : 0;
-        if (wave == xw) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, false, 0>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush);
-        else if (wave == xw + 1) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, false, 1>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush);
-        else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush);
+        if (wave == xw) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, false, 0>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush, acc_delta);
+        else if (wave == xw + 1) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false, decltype(each), false, 2, false, 1>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush, acc_delta);
+        else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush, acc_delta);
       } else {
-      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush);
-      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush);
+      if (wave < G::kExtra) conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 1, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush, acc_delta);
+      else conv_tile<CIN, TAPS, COUT, ACCUM, STATS, 0, SUMS, kOpq, false>(lin, lw, out, frame0, frames, wave, lane, red_wave, zt, stab, each, nullptr, nullptr, nullptr, sums, carried, flush, acc_delta);
       }
       TM_ST(4);   // conv_tile
       __syncthreads();

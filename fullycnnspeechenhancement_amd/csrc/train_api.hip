@@ -178,7 +178,7 @@ RCED_TM_DEFINE_DISPATCH(_main, RCED_TM_FWD, RCED_TM_BWD)
 // train_mfma_v2.hip
 int rced_tm_conv_v2(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet,
                     float* out, int frames, int cus, double* part, const rced::tmm::XformArgs* xa,
-                    const rced::tmm::BnBwdArgs* ba, hipStream_t st, const rced::tmm::SumArgs* sa);
+                    const rced::tmm::BnBwdArgs* ba, hipStream_t st, const rced::tmm::SumArgs* sa, const float* acc_from);
 bool rced_tm_has_v2(bool fwd, int cin, int taps, int cout);
 int rced_tm_wgrad_v2(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
                      const rced::tmm::XformArgs* xa, const rced::tmm::BnBwdArgs* ba, hipStream_t st);
@@ -186,9 +186,10 @@ namespace {
 // Returns the grid size (= number of partial-sum records when stats), 0 if no kernel was built for the request.
 int tm_conv(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet, float* out,
             int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st,
-            const tmm::SumArgs* sa = nullptr) {
-  if (tm_has_main(fwd, cin, taps, cout)) return tm_conv_main(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa);
-  return rced_tm_conv_v2(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa);
+            const tmm::SumArgs* sa = nullptr, const float* acc_from = nullptr) {
+  if (tm_has_main(fwd, cin, taps, cout))
+    return tm_conv_main(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa, acc_from);
+  return rced_tm_conv_v2(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa, acc_from);
 }
 bool tm_has(bool fwd, int cin, int taps, int cout) { return tm_has_main(fwd, cin, taps, cout) || rced_tm_has_v2(fwd, cin, taps, cout); }
 int tm_wgrad(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
@@ -875,6 +876,25 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
   // a producer whose BatchNorm-backward sums may come out of its consumer's dgrad: masked lazily AND without a skip to
   // route (a layer that adds a skip after its ReLU still needs its bwd_route2 pass for that)
   auto sums_in_dgrad_ok = [&](int pl) { return lazy_mask_of(pl) && net.layer[pl].skip_post < 0; };
+  // alias_src[id]: G[id]'s first contribution would be a plain copy of another gradient tensor (layer ls adds tensor id
+  // AFTER its ReLU: d tensor id += G[ls + 1] unchanged).  The copy is not made: the one dgrad that completes G[id] reads
+  // its accumulate operand from G[ls + 1] instead (out = acc_from + conv).  G[ls + 1] is final by then -- its writers are
+  // the consumers of tensor ls + 1, all later layers -- and every G tensor is its own allocation.
+  std::vector<const float*> alias_src(L + 1, nullptr);
+  auto conv_consumer_of = [&](int id) {   // the layer reading tensor id as its convolution input, when there is exactly one
+    int lc = -1;
+    for (int k = 0; k < L; ++k)
+      if (net.layer[k].src == id) lc = lc < 0 ? k : -2;
+    return lc;
+  };
+  auto alias_ok = [&](int l) {
+    const LayerSpec& s = net.layer[l];
+    if (!t->use_mfma || !t->fuse_dz || s.skip_post <= 0 || s.skip_pre > 0 || written[s.skip_post] || consumers[s.skip_post] != 2) return false;
+    const int lc = conv_consumer_of(s.skip_post);
+    if (lc < 0 || lc >= l || !t->pk_bwd[lc]) return false;
+    const LayerSpec& c = net.layer[lc];
+    return c.kh == 1 && c.cout % 2 == 0 && tm_has(false, c.cout, c.kw, t->off[lc].cin);
+  };
   for (int l = L - 1; l >= 0; --l) {
     const LayerSpec& s = net.layer[l];
     const LayerOff& f = t->off[l];
@@ -917,13 +937,15 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       const dim3 grid = pair_grid(s.cout);
       // (a layer has at most one skip; first writer of its gradient tensor: store, see `written`)
       const int skip_id = s.skip_pre > 0 ? s.skip_pre : s.skip_post;
+      const bool alias = alias_ok(l);
+      if (alias) alias_src[skip_id] = t->G[l + 1];
       const int skip_first = skip_id > 0 && !written[skip_id] ? 1 : 0;
       if (skip_id > 0) written[skip_id] = 1;
       hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
                          (const float2*)t->z[l], mu, (const float*)t->rstd[l], (const float*)(t->params + f.gamma),
                          (const float*)(t->params + f.beta), (const float2*)tensor(s.skip_pre), s.use_act, P, s.cout,
                          (float2*)(s.skip_pre > 0 ? t->G[s.skip_pre] : nullptr),
-                         (float2*)(s.skip_post > 0 ? t->G[s.skip_post] : nullptr), (float2*)(lazy_mask ? nullptr : t->D),
+                         (float2*)(s.skip_post > 0 && !alias ? t->G[s.skip_post] : nullptr), (float2*)(lazy_mask ? nullptr : t->D),
                          s.use_norm ? t->part : (double*)nullptr, (const int*)nullptr, skip_first);
       if (s.use_norm) {
         hipLaunchKernelGGL(bn_finish, dim3(1), dim3(1024), 0, st, (const double*)t->part, (int)grid.x, s.cout, t->sums,
@@ -1010,8 +1032,10 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
         // MFMA path; layer pl's BatchNorm-backward sums come out of the same kernel
       } else if (t->use_mfma && t->pk_bwd[l] && (overwrite(l) || ensure_zero(s.src) == RCED_OK) &&
           tm_conv(false, s.cout, s.kw, f.cin, !overwrite(l), false, dsrc, t->pk_bwd[l], t->G[s.src], frames, t->num_cus,
-                  nullptr, nullptr, ba, st)) {
+                  nullptr, nullptr, ba, st, nullptr, overwrite(l) ? nullptr : alias_src[s.src])) {
         // MFMA path
+      } else if (alias_src[s.src]) {
+        return rced_fail(RCED_ERR_STATE, "layer %d: no accumulating MFMA dgrad kernel for an aliased skip gradient", l);
       } else if (fuse_dz) {
         return rced_fail(RCED_ERR_STATE, "layer %d: no MFMA dgrad kernel for a layer with fused dz", l);
       } else if (int rc0 = ensure_zero(s.src)) {

@@ -95,7 +95,8 @@ inline size_t tm_packet_floats(int cin, int taps, int cout) {     // Geo::kPacke
 constexpr tmm::SumArgs kNoSums{nullptr, nullptr, nullptr, nullptr, nullptr};
 template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF, bool SUMS = false>
 int tm_conv_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part,
-                    tmm::XformArgs xa, tmm::BnBwdArgs ba, hipStream_t st, tmm::SumArgs sa = kNoSums) {
+                    tmm::XformArgs xa, tmm::BnBwdArgs ba, hipStream_t st, tmm::SumArgs sa = kNoSums,
+                    const float* acc_from = nullptr) {
   using G = tmm::Geo<CIN, TAPS, COUT>;
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
   size_t lds = (G::kLdsFloats + (XF == tmm::kXfBnRelu ? 2 * CIN : XF == tmm::kXfBnBwd ? 4 * CIN : 0)) * sizeof(float);
@@ -109,7 +110,7 @@ int tm_conv_launch1(const float* in, const float* packet, float* out, int frames
   allow_lds(kfn, lds, attr);
   const int grid = std::min(ntiles, std::min(resident_grid(kfn, lds, cus, occ), kPairGrid));
   hipLaunchKernelGGL((tmm::conv1xk_mfma<CIN, TAPS, COUT, ACCUM, STATS, XF, SUMS>), dim3(grid), dim3(tmm::kThreads), lds, st, in,
-                     packet, out, frames, part, xa, ba, sa);
+                     packet, out, frames, part, xa, ba, sa, acc_from);
   return grid;
 }
 // One 1xk convolution on the MFMA kernels.  The shape decides the role: a layer's forward shape gets
@@ -119,10 +120,11 @@ int tm_conv_launch1(const float* in, const float* packet, float* out, int frames
 // Returns the grid size (= number of partial-sum records when stats), 0 if no kernel was built for the request.
 // sa (dgrad shapes, overwrite mode only): also leave the producer's BatchNorm-backward records in `part` (tmm::SumArgs);
 // 0 is returned when no such kernel exists for the shape and the caller launches again without sa.
+// acc_from (accum only): the tensor the result is added to, when that is not `out` itself (out = acc_from + conv).
 template <int CIN, int TAPS, int COUT, bool FWD>
 int tm_conv_launch(bool accum, bool stats, const float* in, const float* packet, float* out, int frames, int cus,
                    double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba, hipStream_t st,
-                   const tmm::SumArgs* sa = nullptr) {
+                   const tmm::SumArgs* sa = nullptr, const float* acc_from = nullptr) {
   const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
   const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
   if (sa) {
@@ -148,12 +150,12 @@ int tm_conv_launch(bool accum, bool stats, const float* in, const float* packet,
     if (stats || xa) return 0;
     if (ba) {
       if constexpr (CIN % 2 == 0) {
-        if (accum) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfBnBwd>(in, packet, out, frames, cus, nullptr, nx, *ba, st);
+        if (accum) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfBnBwd>(in, packet, out, frames, cus, nullptr, nx, *ba, st, kNoSums, acc_from);
         return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfBnBwd>(in, packet, out, frames, cus, nullptr, nx, *ba, st);
       }
       return 0;
     }
-    if (accum) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
+    if (accum) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st, kNoSums, acc_from);
     return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, nb, st);
   }
 }
@@ -213,7 +215,7 @@ int tm_bwd_fused_launch(const float* x, const float* du, const float* packet, fl
 #define RCED_TM_DEFINE_DISPATCH(SUFFIX, TM_FWD, TM_BWD)                                                                   \
   int tm_conv##SUFFIX(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet, \
                       float* out, int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba,    \
-                      hipStream_t st, const tmm::SumArgs* sa = nullptr) {                                                   \
+                      hipStream_t st, const tmm::SumArgs* sa = nullptr, const float* acc_from = nullptr) {                  \
     TM_FWD(RCED_TM_CONV_FWD_CASE)                                                                                           \
     TM_BWD(RCED_TM_CONV_BWD_CASE)                                                                                           \
     return 0;                                                                                                               \
@@ -229,10 +231,10 @@ int tm_bwd_fused_launch(const float* x, const float* du, const float* packet, fl
   }
 #define RCED_TM_CONV_FWD_CASE(CI, TP, CO)                \
   if (fwd && cin == CI && taps == TP && cout == CO)      \
-    return rced::tmd::tm_conv_launch<CI, TP, CO, true>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa);
+    return rced::tmd::tm_conv_launch<CI, TP, CO, true>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa, acc_from);
 #define RCED_TM_CONV_BWD_CASE(CI, TP, CO)                \
   if (!fwd && cin == CI && taps == TP && cout == CO)     \
-    return rced::tmd::tm_conv_launch<CI, TP, CO, false>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa);
+    return rced::tmd::tm_conv_launch<CI, TP, CO, false>(accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa, acc_from);
 #define RCED_TM_HAS_CASE(CI, TP, CO) \
   if (cin == CI && taps == TP && cout == CO) return true;
 #define RCED_TM_WGRAD_CASE(CI, TP, CO)              \

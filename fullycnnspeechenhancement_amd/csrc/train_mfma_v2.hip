@@ -20,8 +20,8 @@ RCED_TM_DEFINE_DISPATCH(_v2, RCED_TM_FWD_V2, RCED_TM_BWD_V2)
 
 int rced_tm_conv_v2(bool fwd, int cin, int taps, int cout, bool accum, bool stats, const float* in, const float* packet,
                     float* out, int frames, int cus, double* part, const tmm::XformArgs* xa, const tmm::BnBwdArgs* ba,
-                    hipStream_t st, const tmm::SumArgs* sa) {
-  return tm_conv_v2(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa);
+                    hipStream_t st, const tmm::SumArgs* sa, const float* acc_from) {
+  return tm_conv_v2(fwd, cin, taps, cout, accum, stats, in, packet, out, frames, cus, part, xa, ba, st, sa, acc_from);
 }
 bool rced_tm_has_v2(bool fwd, int cin, int taps, int cout) { return tm_has_v2(fwd, cin, taps, cout); }
 int rced_tm_wgrad_v2(int cin, int taps, int cout, const float* x, const float* dz, float* dW, float* dbias, int frames, int cus,
