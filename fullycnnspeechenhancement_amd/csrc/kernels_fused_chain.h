@@ -22,6 +22,9 @@
 
 #include "lds_dma.h"
 
+#ifndef RCED_CHAIN_EXP
+#define RCED_CHAIN_EXP 0     // timing experiments only (wrong results): 1 = no skip-fragment stores, 2 = no skip-fragment loads
+#endif
 #ifndef RCED_CHAIN_DEPTH
 #define RCED_CHAIN_DEPTH 1   // operand prefetch depth (b64 steps) of the fp32 R-CED passes
 #endif
@@ -414,7 +417,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         if (t < NR || XMT < 0 || mt == XMT)
-        skip[t][mt] = __builtin_bit_cast(
+        skip[t][mt] = (RCED_CHAIN_EXP & 2) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                        scratch, tid * 16, (G::skip_unit(D.skip_from) + t * MT + mt) * kThreads * 16, 0));
   }
@@ -446,7 +449,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     if constexpr (D.skip_from >= 0) v += skip[t][mt];   // module.py:30-31: before the ReLU
     v = relu4(v);
     if (masked && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (D.saves_skip)
+    if constexpr (D.saves_skip && !(RCED_CHAIN_EXP & 1))
     {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), scratch, tid * 16,
                                              (G::skip_unit(L) + t * MT + mt) * kThreads * 16, 0);
@@ -493,7 +496,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
       if (rt >= NRT) break;
       const int pb = PHS * (16 * rt + n);           // first pixel of this lane's column
       f32x4 sk = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (D.skip_from >= 0)
+      if constexpr (D.skip_from >= 0 && !(RCED_CHAIN_EXP & 2))
         sk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                            scratch, tid * 16, (G::skip_unit_rem(D.skip_from) + jj) * kThreads * 16, 0));
       f32x4 racc[1][1] = {{rsh}};
@@ -511,7 +514,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
           if (!px_valid<N>(px)) vv[j] = 0.f;   // gap pixels hold zeros (the next layer's SAME padding)
         }
       }
-      if constexpr (D.saves_skip)
+      if constexpr (D.saves_skip && !(RCED_CHAIN_EXP & 1))
       {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{vv[0], vv[1], vv[2], vv[3]}), scratch, tid * 16,
                                                (G::skip_unit_rem(L) + jj) * kThreads * 16, 0);

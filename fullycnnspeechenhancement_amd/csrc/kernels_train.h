@@ -198,12 +198,20 @@ __global__ __launch_bounds__(kThreads) void bn_act_fwd2(const float2* __restrict
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float2* __restrict__ skip_pre,
                                                          const float2* __restrict__ skip_post, int use_act, size_t P, int C,
-                                                         float2* __restrict__ out) {
+                                                         float2* __restrict__ out, const float* __restrict__ smu = nullptr,
+                                                         const float* __restrict__ srstd = nullptr,
+                                                         const float* __restrict__ sgamma = nullptr,
+                                                         const float* __restrict__ sbeta = nullptr) {
+  // smu: skip_post holds the PRE-BatchNorm output of the skip's producer (a plain conv+BN+ReLU layer whose output tensor
+  // was never written, train_api.hip `virt`); the skip value is relu(a z + b) with that layer's statistics
   const PairLane L(C, threadIdx.x);
   if (!L.active) return;
   float fa[2] = {1.f, 1.f}, fb[2] = {0.f, 0.f};   // folded BatchNorm: a*z + b (the form every consumer of z uses)
+  float ga[2] = {1.f, 1.f}, gb[2] = {0.f, 0.f};
   if (mu)
     for (int k = 0; k < 2; ++k) { const int c = 2 * L.c2 + k; fa[k] = gamma[c] * rstd[c]; fb[k] = beta[c] - fa[k] * mu[c]; }
+  if (smu)
+    for (int k = 0; k < 2; ++k) { const int c = 2 * L.c2 + k; ga[k] = sgamma[c] * srstd[c]; gb[k] = sbeta[c] - ga[k] * smu[c]; }
   const size_t stride = (size_t)gridDim.x * L.rows;
   for (size_t p = (size_t)blockIdx.x * L.rows + L.row; p < P; p += kPairUnroll * stride) {
     float2 zv[kPairUnroll], s1[kPairUnroll], s2[kPairUnroll];
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void bn_act_fwd2(const float2* __restrict
         if (mu) v[k] = fmaf(fa[k], v[k], fb[k]);
         if (skip_pre) v[k] += a1[k];
         if (use_act) v[k] = fmaxf(v[k], 0.f);
-        if (skip_post) v[k] += a2[k];
+        if (skip_post) v[k] += smu ? fmaxf(fmaf(ga[k], a2[k], gb[k]), 0.f) : a2[k];
       }
       out[(p + u * stride) * L.C2 + L.c2] = float2{v[0], v[1]};
     }

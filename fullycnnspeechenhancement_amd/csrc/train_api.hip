@@ -593,17 +593,19 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
   {
     const char* e = getenv("RCED_TRAIN_FUSE_ACT");
     const bool fuse = t->use_mfma && !(e && atoi(e) == 0);
-    std::vector<int> uses(L + 1, 0), conv_user(L + 1, -1);
+    std::vector<int> uses(L + 1, 0), conv_user(L + 1, -1), post_uses(L + 1, 0);
     for (int l = 0; l < L; ++l) {
       const LayerSpec& s = t->net->layer[l];
       if (s.src > 0) { ++uses[s.src]; conv_user[s.src] = l; }
-      if (s.skip_pre > 0) uses[s.skip_pre] += 2;     // a skip use disqualifies
-      if (s.skip_post > 0) uses[s.skip_post] += 2;
+      if (s.skip_pre > 0) uses[s.skip_pre] += 2;     // a skip added before the ReLU disqualifies (its backward reads the tensor)
+      // a skip added AFTER a ReLU (CR-CED's block skips) is read once, by bn_act_fwd2, which rebuilds it from the
+      // producer's z just as well (same bytes, same arithmetic); its backward needs no values
+      if (s.skip_post > 0) { if (s.cout % 2 == 0 && s.skip_pre < 0) ++post_uses[s.skip_post]; else uses[s.skip_post] += 2; }
     }
     for (int id = 1; fuse && id < L; ++id) {
       const LayerSpec& p = t->net->layer[id - 1];
       const int c = conv_user[id];
-      if (uses[id] != 1 || c < 0) continue;
+      if (uses[id] != 1 || c < 0 || post_uses[id] > 1) continue;
       const LayerSpec& q = t->net->layer[c];
       t->virt[id] = p.use_norm && p.use_act && p.skip_pre < 0 && p.skip_post < 0 && p.cout % 2 == 0 && q.kh == 1 &&
                     q.cout % 2 == 0 && t->pk_fwd[c] != nullptr && tm_has(true, p.cout, q.kw, q.cout);
@@ -793,12 +795,17 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       }
     }
     if (t->out[l + 1] != t->z[l] && !t->virt[l + 1]) {
+      // a virtual post-ReLU skip source: rebuilt from its producer's z inside bn_act_fwd2
+      const bool vskip = s.skip_post > 0 && t->virt[s.skip_post] != 0;
+      tmm::XformArgs vs{nullptr, nullptr, nullptr, nullptr};
+      if (vskip) xform_of(s.skip_post, &vs);
+      if (vskip && s.cout % 2 != 0) return rced_fail(RCED_ERR_STATE, "layer %d: a virtual skip source needs the pair kernel", l);
       if (s.cout % 2 == 0)
         hipLaunchKernelGGL(train::bn_act_fwd2, pair_grid(s.cout), dim3(train::kThreads), 0, st, (const float2*)t->z[l],
                            s.use_norm ? (const float*)t->mu[l] : nullptr, (const float*)t->rstd[l],
                            (const float*)(t->params + f.gamma), (const float*)(t->params + f.beta),
-                           (const float2*)tensor(s.skip_pre), (const float2*)tensor(s.skip_post), s.use_act, P, s.cout,
-                           (float2*)t->out[l + 1]);
+                           (const float2*)tensor(s.skip_pre), (const float2*)(vskip ? t->z[s.skip_post - 1] : tensor(s.skip_post)),
+                           s.use_act, P, s.cout, (float2*)t->out[l + 1], vskip ? vs.mu : nullptr, vs.rstd, vs.gamma, vs.beta);
       else
         hipLaunchKernelGGL(train::bn_act_fwd, blocks(n), dim3(train::kThreads), 0, st, (const float*)t->z[l],
                            s.use_norm ? (const float*)t->mu[l] : nullptr, (const float*)t->rstd[l],
