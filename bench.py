@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 2 / config 5 entries (N = 1 only)")
     ap.add_argument("--from-root-steps", type=int, default=5, help="timed forward_from_root calls at N > 1 (0 = skip)")
     ap.add_argument("--from-root-chunks", type=int, default=8, help="pipeline depth of forward_from_root")
+    ap.add_argument("--from-root-timeout", type=int, default=150,
+                    help="seconds after which a stalled forward_from_root is abandoned and the line printed without it")
     return ap.parse_args()
 
 
@@ -161,7 +163,7 @@ def synthetic_magnitudes(shape, seed):
     return np.abs(x, out=x)
 
 
-def forward_line(args, torch, model, spec, _lib, variant, dtype, B, T, steps, warmup, world, rank, profile):
+def forward_line(args, torch, model, spec, _lib, variant, dtype, B, T, steps, warmup, world, rank, profile, ctl="cuda"):
     """Time `steps` forwards of one resident batch; returns (elapsed_s, per-kind HIP-event times or None)."""
     import torch.distributed as dist
     x = torch.from_numpy(synthetic_magnitudes((B, T, spec.FEATURE_DIM, 1), 1234 + rank)).cuda()   # resident before the clock starts
@@ -190,7 +192,7 @@ def forward_line(args, torch, model, spec, _lib, variant, dtype, B, T, steps, wa
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=ctl, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     times = None
@@ -506,12 +508,21 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d "
                          "(or bare `python bench.py --gpus %d`, which starts the ranks itself)"
                          % (args.gpus, world, args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # RCED_BENCH_REHEARSE=1 (tests only, labelled in the line): the N > 1 control flow on a box with fewer GPUs than ranks --
+    # ranks share the GPUs round-robin and the control plane is gloo (RCCL refuses two ranks on one device).  What it
+    # exercises is this file's N > 1 branch (launch, barriers, max over ranks, the line); it measures nothing.
+    rehearse = world > 1 and os.environ.get("RCED_BENCH_REHEARSE", "0") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if rehearse else local_rank
+    ctl = "cpu" if rehearse else "cuda"
+    torch.cuda.set_device(dev_index)
     rccl_world = 1
     if world > 1:
         import datetime
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=4))
-        ones = torch.ones(1, device="cuda")
+        if rehearse:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=4))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=4))
+        ones = torch.ones(1, device=ctl)
         dist.all_reduce(ones)                      # the rank count RCCL itself sees
         rccl_world = int(ones.item())
 
@@ -520,20 +531,12 @@ def main():
 
     variant = args.variant
     weights = _weights.synthetic_weights(variant, seed=42)                # random-init, SURVEY 8(d2)
-    model = build_model(NET_WORK[variant], False, weights=weights, device=local_rank,
+    model = build_model(NET_WORK[variant], False, weights=weights, device=dev_index,
                         dtype="bfloat16" if args.dtype == "bf16" else "float32")
     model.set_path(args.path)
     B, T = args.batch, args.frames
     elapsed, times, (x, y) = forward_line(args, torch, model, spec, _lib, variant, args.dtype, B, T, args.steps,
-                                          args.warmup, world, rank, not args.no_profile)
-
-    # ---- the reference's single-host-process convention over RCCL: scatter from rank 0, compute, gather -------
-    from_root = None
-    if world > 1 and args.from_root_steps > 0:
-        try:
-            from_root = from_root_line(args, torch, dist, model, spec, world, rank, local_rank, B, T)
-        except Exception as e:      # the headline line must survive a failure of the secondary figure
-            from_root = {"error": "%s: %s" % (type(e).__name__, e)}
+                                          args.warmup, world, rank, not args.no_profile, ctl)
 
     frames_total = world * B * T * args.steps
     flops_frame = spec.flops_per_frame(variant)
@@ -552,8 +555,11 @@ def main():
                    "rccl_world_size": rccl_world, "weights": "random-init (glorot, seed 42)",
                    "input": "|N(0,1)| float32, numpy default_rng(1234 + rank), resident in HBM before the timed region",
                    "library": _lib.version()},
-        "from_root": from_root,
+        "from_root": None,
     }
+    if rehearse:
+        out["config"]["rehearsal"] = ("RCED_BENCH_REHEARSE=1: %d ranks on %d GPU(s), gloo control plane -- a test of the N > 1 "
+                                      "control flow, NOT a measurement" % (world, torch.cuda.device_count()))
     if rank == 0:
         roof = None
         if times is not None:
@@ -582,6 +588,39 @@ def main():
                         "note": "compute-bound path (7950 FLOP/B): peak = dense fp32 157.3 TFLOP/s, not HBM; "
                                 "algorithmic HBM bytes are 1032 B/frame"}
         out["roofline"] = roof
+    # ---- the reference's single-host-process convention over RCCL: scatter from rank 0, compute, gather -------
+    # The headline figures above are complete at this point.  from_root is the first code of a run that sends utterances
+    # between GPUs; if it stalls (a link, a communicator that never forms), the collective would sit until the process
+    # group's own watchdog ABORTS every rank -- and the line with it.  So a timer stands beside it: on expiry rank 0 prints
+    # the line as it is (from_root = the timeout) and every rank leaves with status 0.
+    if world > 1 and args.from_root_steps > 0:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["from_root"] = {"error": "timeout: forward_from_root did not finish within %d s; the headline figures "
+                                             "were complete before it started" % args.from_root_timeout}
+                out.setdefault("host_buffers", None)
+                out.setdefault("cpu_baseline", None)
+                print(json.dumps(out), flush=True)
+            sys.stderr.write("[bench] rank %d: from_root timed out after %d s, leaving\n" % (rank, args.from_root_timeout))
+            sys.stderr.flush()
+            os._exit(0)
+
+        timer = threading.Timer(args.from_root_timeout, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            if rehearse:
+                if os.environ.get("RCED_BENCH_REHEARSE_HANG", "0") == "1":     # tests: a from_root that never returns
+                    while True:
+                        time.sleep(1.0)
+                out["from_root"] = {"skipped": "rehearsal: gloo does not move device tensors between ranks"}
+            else:
+                out["from_root"] = from_root_line(args, torch, dist, model, spec, world, rank, local_rank, B, T)
+        except Exception as e:      # the headline line must survive a failure of the secondary figure
+            out["from_root"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        timer.cancel()
     host_line = None
     if rank == 0 and world == 1 and not args.no_secondary:
         try:
@@ -612,8 +651,14 @@ def main():
             out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
+        # the line is out; a peer that is gone must not turn the run into a watchdog abort while everybody says goodbye
+        import threading
+        bye = threading.Timer(60.0, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
 
 
 if __name__ == "__main__":

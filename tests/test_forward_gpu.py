@@ -3,6 +3,7 @@ against the fp64 oracle and the committed golden vectors.  Tolerance: BASELINE.j
 "masks within 1e-4 rel fp32" -> max|y - ref| <= 1e-4 * max|ref|  (conftest.RTOL)."""
 
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -497,3 +498,42 @@ def test_single_op_conv_bn_relu_training_mode(shape, use_act, with_skip, built):
     y = conv_bn_relu(torch.from_numpy(x).cuda(), cout, (kh, kw), is_training=True, use_act=use_act, scope="c",
                      skip_input=torch.from_numpy(skip).cuda() if with_skip else None, params=params)
     check_parity(y.cpu().numpy(), ref, what="conv_bn_relu(is_training=True) %s" % (shape,))
+
+
+def _run_bench_rehearsal(extra_env, timeout_s, *args):
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update({"RCED_BENCH_REHEARSE": "1"}, **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--cpu-seconds", "0", "--no-secondary", "--batch", "8", "--frames", "64"] + list(args),
+                       env=env, capture_output=True, text=True, timeout=timeout_s)
+    lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_control_flow_rehearsal():
+    """bench.py's N > 1 branch (self-launch through torch.distributed.run, barriers around the timed region, the max over
+    ranks, one JSON line from rank 0) with two ranks sharing this box's GPU and gloo as the control plane: RCCL itself
+    cannot be rehearsed on one GPU, everything around it can."""
+    r, d = _run_bench_rehearsal({}, 600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert d is not None and d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 16 and d["config"]["rccl_world_size"] == 2 and "rehearsal" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 64 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["kernel"] == "rced_fused" and d["roofline"]["launches"] == 3
+    assert d["from_root"] == {"skipped": "rehearsal: gloo does not move device tensors between ranks"}
+    assert "of WORLD_SIZE=2 started" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_line_survives_a_from_root_that_never_returns():
+    """The first exchange of utterances between GPUs must not be able to take the headline line down: with a from_root
+    that hangs, rank 0 prints the line (from_root = the timeout) and every rank leaves with status 0."""
+    r, d = _run_bench_rehearsal({"RCED_BENCH_REHEARSE_HANG": "1"}, 600, "--from-root-timeout", "5")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert d is not None and d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"] is not None
+    assert "timeout" in d["from_root"]["error"]
