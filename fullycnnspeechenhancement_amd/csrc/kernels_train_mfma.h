@@ -1964,12 +1964,22 @@ __global__ __launch_bounds__(kThreads, 2) void first_wgrad(const float* __restri
 // ---------------------------------------------------------------------------------------------
 static __global__ void pack_first(const float* __restrict__ w, const float* __restrict__ bias, int kw, int cout,
                            float* __restrict__ packet) {
-  const int MT = (cout + 15) / 16, steps = 2 * kw, data = steps * MT * 64;
+  // 18 channels (tm_rem): the main section holds ONE M-tile (channels 0..15); a second section holds the remainder pass's
+  // A fragments -- rows (bin phase ph < 8, channel 16 + c), K = 8 time rows x 16 window columns in b32 steps
+  // s' = ih*16 + j' with lane kq <-> time tap 4 ih + kq:  A[(ph, c)][(i, j')] = W[i][j' - ph][16 + c]  (0 outside the kw taps)
+  const int rem = tm_rem(cout);
+  const int MT = rem ? 1 : (cout + 15) / 16, steps = 2 * kw, data = steps * MT * 64, rdata = rem ? 32 * 64 : 0;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= data + 32) return;
-  if (e >= data) {
-    const int c = e - data;
+  if (e >= data + rdata + 32) return;
+  if (e >= data + rdata) {
+    const int c = e - data - rdata;
     packet[e] = c < cout ? bias[c] : 0.f;
+    return;
+  }
+  if (e >= data) {
+    const int q = e - data, sr = q / 64, lane = q - sr * 64;
+    const int ih = sr / 16, jw = sr - ih * 16, i = 4 * ih + (lane >> 4), ph = (lane & 15) >> 1, c = lane & 1, j = jw - ph;
+    packet[e] = (j >= 0 && j < kw) ? w[(i * kw + j) * cout + 16 + c] : 0.f;
     return;
   }
   const int s = e / (MT * 64), r = e - s * MT * 64, mt = r / 64, lane = r - mt * 64;
@@ -1981,12 +1991,21 @@ template <int KW, int COUT, bool STATS>
 __global__ __launch_bounds__(kThreads, 2) void first_fwd(const float* __restrict__ x, const float* __restrict__ packet,
                                                        float* __restrict__ z, int frames, int T, double* __restrict__ part) {
   constexpr int KH = 8, PT = 3, PL = (KW - 1) / 2, RS = kF + KW - 1, STEPS = 2 * KW;
-  constexpr int MT = (COUT + 15) / 16, kData = STEPS * MT * 64;
+  // NREM (18 channels, tm_rem; the other kernels' remainder form): channels 0..15 are ONE M-tile; channels 16, 17 run as rows
+  // (bin phase ph < 8, channel) over a window of 16 columns x 8 time rows (32 b32 steps), one column per group of 8 bins:
+  // 17 columns per frame = 3 remainder tiles per two-frame tile.  324 + 96 MFMAs per tile instead of 720, shared as
+  // 4 main tiles + 1 remainder tile (104) on waves 0..2 and 6 main tiles (108) on wave 3 -- before: 5 slots x 2 M-tiles = 180
+  // on every wave (two of them idle slots).
+  constexpr bool NREM = tm_rem(COUT) == 2;
+  constexpr int MT = NREM ? 1 : (COUT + 15) / 16, kMain = STEPS * MT * 64, kData = kMain + (NREM ? 32 * 64 : 0);
   constexpr int kRowsFloats = ((kTF * KH * RS + 32 + 3) / 4) * 4;
   constexpr int kXElems = kTF * KH * kF, kPerX = (kXElems + kThreads - 1) / kThreads;
   constexpr int kTilesPerFrame = (kF + 15) / 16, kTiles = kTF * kTilesPerFrame;       // 9 per frame
-  constexpr int NTW = (kTiles + kWaves - 1) / kWaves;                                  // tiles per wave (some idle slots)
+  constexpr int NTW = NREM ? kTiles / kWaves : (kTiles + kWaves - 1) / kWaves;         // slots every wave runs
+  constexpr int NXT = NREM ? kTiles - NTW * kWaves : 0;                                 // NREM: the tiles left over, all on the last wave
+  constexpr int kRemCols = (kF + 7) / 8;                                                // 17 groups of 8 bins per frame
   static_assert(COUT % 2 == 0, "z is stored in float2 pieces");
+  static_assert(!NREM || (NXT == 2 && kTF * kRemCols <= 16 * (kWaves - 1) && KW + 7 <= 16), "the 18-channel split of the work");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* rows = lds;                       // [kTF*8][RS] + slack
   float* lw = lds + kRowsFloats;           // packet
@@ -1994,7 +2013,7 @@ __global__ __launch_bounds__(kThreads, 2) void first_fwd(const float* __restrict
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, kq = lane >> 4;
   for (int e = tid; e < kRowsFloats + kData + 32; e += kThreads) lds[e] = e < kRowsFloats ? 0.f : packet[e - kRowsFloats];
-  double st1[MT][4], st2[MT][4];
+  double st1[MT][4], st2[MT][4], sr1[2] = {0.0, 0.0}, sr2[2] = {0.0, 0.0};
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -2032,53 +2051,93 @@ __global__ __launch_bounds__(kThreads, 2) void first_fwd(const float* __restrict
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) fetch_rows(tile + gridDim.x);
     pin();
-    // tile index q = wave + 4*slot: frame fl = q / 9, bins 16*(q % 9) .. +15
-    f32x4 acc[NTW][MT];
-    int boff[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int q = wave + kWaves * t, fl = q / kTilesPerFrame, f0 = 16 * (q - fl * kTilesPerFrame);
-      boff[t] = q < kTiles ? (fl * KH + kq) * RS + f0 + n : kq * RS + n;     // idle slots re-read tile 0 (not stored)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = *reinterpret_cast<const f32x4*>(lw + kData + 16 * mt + 4 * kq);
-    }
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      const int ih = s / KW, j = s - ih * KW;
-      float a[MT], b[NTW];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = lw[(s * MT + mt) * 64 + lane];
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) b[t] = rows[boff[t] + 4 * ih * RS + j];
-#pragma unroll
-      for (int t = 0; t < NTW; ++t)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(a[mt], b[t], acc[t][mt]);
-    }
-    // D row = co = 16*mt + 4*kq + r, column = bin f0 + n
     float p1[MT][4], p2[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) p1[mt][j] = p2[mt][j] = 0.f;
+    // one pass over NS column tiles q(t): MFMAs, then the stores and the lanes' shares of the sums
+    auto main_pass = [&](auto ns_tag, auto qof) {
+      constexpr int NS = decltype(ns_tag)::value;
+      f32x4 acc[NS][MT];
+      int boff[NS];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int q = wave + kWaves * t, fl = q / kTilesPerFrame, f = 16 * (q - fl * kTilesPerFrame) + n;
-      const int frame = tile * kTF + fl;
-      if (q >= kTiles || f >= kF || frame >= frames) continue;
-      float* op = z + ((size_t)frame * kF + f) * COUT;
+      for (int t = 0; t < NS; ++t) {
+        const int q = qof(t), fl = q / kTilesPerFrame, f0 = 16 * (q - fl * kTilesPerFrame);
+        boff[t] = q < kTiles ? (fl * KH + kq) * RS + f0 + n : kq * RS + n;     // idle slots re-read tile 0 (not stored)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int co0 = 16 * mt + 4 * kq;
-        const f32x4 v = acc[t][mt];
-        if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(op + co0) = f32x2{v.x, v.y};
-        if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(op + co0 + 2) = f32x2{v.z, v.w};
-        if constexpr (STATS) {
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = *reinterpret_cast<const f32x4*>(lw + kData + 16 * mt + 4 * kq);
+      }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            p1[mt][j] += v[j];
-            p2[mt][j] = fmaf(v[j], v[j], p2[mt][j]);
+      for (int s = 0; s < STEPS; ++s) {
+        const int ih = s / KW, j = s - ih * KW;
+        float a[MT], b[NS];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = lw[(s * MT + mt) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) b[t] = rows[boff[t] + 4 * ih * RS + j];
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma(a[mt], b[t], acc[t][mt]);
+      }
+      // D row = co = 16*mt + 4*kq + r, column = bin f0 + n
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        const int q = qof(t), fl = q / kTilesPerFrame, f = 16 * (q - fl * kTilesPerFrame) + n;
+        const int frame = tile * kTF + fl;
+        if (q >= kTiles || f >= kF || frame >= frames) continue;
+        float* op = z + ((size_t)frame * kF + f) * COUT;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int co0 = 16 * mt + 4 * kq;
+          const f32x4 v = acc[t][mt];
+          if (co0 + 1 < COUT) *reinterpret_cast<f32x2*>(op + co0) = f32x2{v.x, v.y};
+          if (co0 + 3 < COUT) *reinterpret_cast<f32x2*>(op + co0 + 2) = f32x2{v.z, v.w};
+          if constexpr (STATS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              p1[mt][j] += v[j];
+              p2[mt][j] = fmaf(v[j], v[j], p2[mt][j]);
+            }
           }
+        }
+      }
+    };
+    // tile index q = wave + 4*slot: frame fl = q / 9, bins 16*(q % 9) .. +15
+    main_pass(std::integral_constant<int, NTW>{}, [&](int t) { return wave + kWaves * t; });
+    if constexpr (NREM) {
+      if (wave == kWaves - 1) {
+        main_pass(std::integral_constant<int, NXT>{}, [&](int t) { return NTW * kWaves + t; });
+      } else {
+        // remainder tile rt = wave: column n is group b8 of 8 bins of frame fl; rows 4 kq + r = (ph 2 kq + r / 2, channel 16 + r % 2)
+        const int col = 16 * wave + n, fl = col >= kRemCols ? 1 : 0, b8 = col - fl * kRemCols;
+        const bool live = col < kTF * kRemCols;
+        const int boffr = live ? (fl * KH + kq) * RS + 8 * b8 : kq * RS;
+        const f32x2 rb = *reinterpret_cast<const f32x2*>(lw + kData + 16);
+        f32x4 racc = {rb.x, rb.y, rb.x, rb.y};
+        const float* wr = lw + kMain;
+#pragma unroll
+        for (int sr = 0; sr < 32; ++sr) {
+          const int ih = sr / 16, jw = sr - ih * 16;
+          racc = mfma(wr[sr * 64 + lane], rows[boffr + 4 * ih * RS + jw], racc);
+        }
+        const int frame = tile * kTF + fl;
+        float q1[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int f = 8 * b8 + 2 * kq + h;
+          if (!live || f >= kF || frame >= frames) continue;
+          const f32x2 v = {racc[2 * h], racc[2 * h + 1]};
+          *reinterpret_cast<f32x2*>(z + ((size_t)frame * kF + f) * COUT + 16) = v;
+          if constexpr (STATS) {
+            q1[0] += v.x; q2[0] = fmaf(v.x, v.x, q2[0]);
+            q1[1] += v.y; q2[1] = fmaf(v.y, v.y, q2[1]);
+          }
+        }
+        if constexpr (STATS) {
+          sr1[0] += (double)q1[0]; sr2[0] += (double)q2[0];
+          sr1[1] += (double)q1[1]; sr2[1] += (double)q2[1];
         }
       }
     }
@@ -2111,6 +2170,21 @@ __global__ __launch_bounds__(kThreads, 2) void first_fwd(const float* __restrict
           red[(wave * 32 + c) * 2 + 1] = b;
         }
       }
+    if constexpr (NREM) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        double a = sr1[c], b = sr2[c];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        if (lane == 0) {
+          red[(wave * 32 + 16 + c) * 2 + 0] = a;
+          red[(wave * 32 + 16 + c) * 2 + 1] = b;
+        }
+      }
+    }
     __syncthreads();
     if (tid < 2 * COUT) {
       const int c = tid >> 1, k = tid & 1;

@@ -254,7 +254,7 @@ int first_wgrad(const LayerSpec& s, const float* x, const float* dz, float* dW, 
 template <int KW, int COUT>
 int first_fwd_launch(const float* x, const float* w, const float* bias, float* packet, float* z, int frames, int T, int cus,
                      bool stats, double* part, hipStream_t st) {
-  constexpr int MT = (COUT + 15) / 16, data = 2 * KW * MT * 64, RS = 129 + KW - 1;
+  constexpr int MT = tmm::tm_rem(COUT) ? 1 : (COUT + 15) / 16, data = 2 * KW * MT * 64 + (tmm::tm_rem(COUT) ? 32 * 64 : 0), RS = 129 + KW - 1;
   hipLaunchKernelGGL(tmm::pack_first, dim3((data + 32 + 255) / 256), dim3(256), 0, st, w, bias, KW, COUT, packet);
   const size_t lds = (((size_t)(tmm::kTF * 8 * RS + 32 + 3) / 4) * 4 + data + 32) * sizeof(float);
   const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
@@ -274,7 +274,9 @@ int first_fwd(const LayerSpec& s, const float* x, const float* w, const float* b
 #undef X
   return 0;
 }
-size_t first_packet_floats(const LayerSpec& s) { return (size_t)2 * s.kw * ((s.cout + 15) / 16) * 64 + 32; }
+size_t first_packet_floats(const LayerSpec& s) {   // pack_first: main section, the 18-channel form's remainder section, 32 shifts
+  return (size_t)2 * s.kw * (tmm::tm_rem(s.cout) ? 1 : (s.cout + 15) / 16) * 64 + (tmm::tm_rem(s.cout) ? 32 * 64 : 0) + 32;
+}
 
 // ---- output layer (1x129, CH -> 1): Toeplitz forward + MFMA wgrad (kernels_train_mfma.h) ----
 #define RCED_FIN_CH(X) X(8) X(10) X(12)
