@@ -105,11 +105,10 @@ struct rced_trainer {
     fr(pk_first);
     free_acts();
   }
+  std::vector<void*> act_bases;   // the allocations behind out / z / G (those pointers may sit at a skew inside them)
   void free_acts() {
-    for (size_t i = 1; i < out.size(); ++i)
-      if (out[i] && out[i] != z[i - 1]) (void)hipFree(out[i]);   // a plain conv layer's output aliases its z
-    for (auto* p : z) if (p) (void)hipFree(p);
-    for (auto* p : G) if (p) (void)hipFree(p);
+    for (void* p : act_bases) (void)hipFree(p);
+    act_bases.clear();
     out.clear(); z.clear(); G.clear();
     cap_px = 0;
   }
@@ -128,17 +127,30 @@ int ensure_acts(rced_trainer* t, size_t P) {
   t->G.assign(L + 1, nullptr);
   t->z.assign(L, nullptr);
   int maxc = 1;
+  // RCED_TRAIN_SKEW (bytes, multiple of 256; experiment): every tensor starts at a different offset inside its allocation, so that
+  // the two to four tensors a kernel streams in lockstep do not walk the same HBM channel sequence
+  static const size_t skew = [] { const char* e = getenv("RCED_TRAIN_SKEW"); return e ? (size_t)atol(e) & ~(size_t)255 : (size_t)0; }();
+  int nalloc = 0;
+  auto alloc = [&](float** out_ptr, size_t bytes) -> int {
+    void* base = nullptr;
+    const size_t off = skew * (size_t)(nalloc % 61);
+    HIP_TRY(hipMalloc(&base, bytes + skew * 61));
+    t->act_bases.push_back(base);
+    *out_ptr = reinterpret_cast<float*>(static_cast<char*>(base) + off);
+    ++nalloc;
+    return RCED_OK;
+  };
   for (int l = 0; l < L; ++l) {
     const int c = net.layer[l].cout;
     maxc = std::max(maxc, c);
-    HIP_TRY(hipMalloc(&t->z[l], P * c * sizeof(float)));
+    if (int rc = alloc(&t->z[l], P * c * sizeof(float))) return rc;
     if (!t->virt.empty() && t->virt[l + 1])
       t->out[l + 1] = nullptr;   // rebuilt from z by its consumer (BnReluXform)
-    else if (net.layer[l].use_norm || net.layer[l].use_act || net.layer[l].skip_pre >= 0 || net.layer[l].skip_post >= 0)
-      HIP_TRY(hipMalloc(&t->out[l + 1], P * c * sizeof(float)));
-    else
+    else if (net.layer[l].use_norm || net.layer[l].use_act || net.layer[l].skip_pre >= 0 || net.layer[l].skip_post >= 0) {
+      if (int rc = alloc(&t->out[l + 1], P * c * sizeof(float))) return rc;
+    } else
       t->out[l + 1] = t->z[l];   // plain conv layer (decode_final): its output IS z
-    HIP_TRY(hipMalloc(&t->G[l + 1], P * c * sizeof(float)));
+    if (int rc = alloc(&t->G[l + 1], P * c * sizeof(float))) return rc;
   }
   HIP_TRY(hipMalloc(&t->D, P * maxc * sizeof(float)));
   t->cap_px = P;
