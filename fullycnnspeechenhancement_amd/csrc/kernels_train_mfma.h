@@ -1423,6 +1423,19 @@ struct BwdBalance {
   static_assert(begin_c(4) == kGroups && count(0) > 0 && count(1) > 0 && count(2) > 0 && count(3) > 0, "every group has one owner");
 };
 
+#ifndef RCED_TM_OWN_B
+#define RCED_TM_OWN_B 1     // bwd_fused_mfma<18,5,30>: tensors staged by the dgrad half alone (bit 0: x, bit 1: (d_u, z))
+#endif
+#ifndef RCED_TM_OWN_C
+#define RCED_TM_OWN_C 0     // bwd_fused_mfma<30,9,8>
+#endif
+#ifndef RCED_TM_OWN_OTHER
+#define RCED_TM_OWN_OTHER 0 // the R-CED shapes
+#endif
+template <int CIN, int TAPS, int COUT>
+constexpr int bwd_own() {
+  return (CIN == 18 && TAPS == 5 && COUT == 30) ? RCED_TM_OWN_B : (CIN == 30 && TAPS == 9 && COUT == 8) ? RCED_TM_OWN_C : RCED_TM_OWN_OTHER;
+}
 // Measured alternatives: tile i+1 committed into a second pair of LDS buffers by the wgrad half alone while
 // tile i is computed (one barrier per tile), with the staging behind or in front of that half's MFMAs, with s_setprio on
 // the staging half: 3.17 ms against 3.09 ms for this form -- the two waves of a SIMD do not overlap one's VALU / staging
@@ -1470,7 +1483,14 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
   for (int a = 0; a < kAccN; ++a) accs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (frames + kTF - 1) / kTF;
   constexpr bool DMA = RCED_TM_BWD_DMA != 0;
-  constexpr int kPX = Stage<CIN, NTH>::kPer, kPZ = Stage<COUT, NTH>::kPer, kNP = kPX + 2 * kPZ;
+  // OWN: which of the tile's tensors are fetched and committed by the DGRAD half alone (bit 0: x, bit 1: (d_u, z)) instead
+  // of by all 512 threads.  The wgrad half is the tile's critical path (stamps: commit, then ~7.5 k cycles blocked in the
+  // issue of its share of the next tile's loads, then its MFMAs), the dgrad half waits 3-6 k cycles at the tile's end:
+  // bytes moved from one half's burst to the other's shorten the first by what the second has to spare.
+  constexpr int OWN = bwd_own<CIN, TAPS, COUT>();
+  static_assert(OWN == 0 || (!DMA && !RCED_TM_SPREAD && RCED_TM_BWD_STAGGER), "ownership is built for the staggered VGPR staging");
+  constexpr int XN = (OWN & 1) ? NTH / 2 : NTH, ZN = (OWN & 2) ? NTH / 2 : NTH;
+  constexpr int kPX = Stage<CIN, XN>::kPer, kPZ = Stage<COUT, ZN>::kPer, kNP = kPX + 2 * kPZ;
   float* sx = lds + B::kStgX;
   float* sd = lds + B::kStgD;
   float* sz = lds + B::kStgZ;
@@ -1478,17 +1498,25 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
   // the next tile into the staging copies: by LDS-DMA piece i (whole tiles), or all of a ragged last tile with bounds checks
   auto dma_piece = [&](auto ic, int f0, int vt) {     // vt: the thread of the piece map whose share is issued
     constexpr int i = decltype(ic)::value;
-    if constexpr (i < kPX) tile_dma_piece<CIN, NTH, i>(x, f0, vt, sx);
-    else if constexpr (i < kPX + kPZ) tile_dma_piece<COUT, NTH, i - kPX>(du, f0, vt, sd);
-    else tile_dma_piece<COUT, NTH, i - kPX - kPZ>(ba.z, f0, vt, sz);
+    if constexpr (i < kPX) tile_dma_piece<CIN, XN, i>(x, f0, vt, sx);
+    else if constexpr (i < kPX + kPZ) tile_dma_piece<COUT, ZN, i - kPX>(du, f0, vt, sd);
+    else tile_dma_piece<COUT, ZN, i - kPX - kPZ>(ba.z, f0, vt, sz);
   };
   auto stage_ragged = [&](int f0) {
-    tile_fetch<CIN, NTH>(x, f0, frames, tid, prex);
-    tile_fetch<COUT, NTH>(du, f0, frames, tid, pred);
-    tile_fetch<COUT, NTH>(ba.z, f0, frames, tid, prez);
-    stage_store<CIN, NTH>(sx, tid, prex);
-    stage_store<COUT, NTH>(sd, tid, pred);
-    stage_store<COUT, NTH>(sz, tid, prez);
+    tile_fetch<CIN, XN>(x, f0, frames, tid, prex);
+    tile_fetch<COUT, ZN>(du, f0, frames, tid, pred);
+    tile_fetch<COUT, ZN>(ba.z, f0, frames, tid, prez);
+    stage_store<CIN, XN>(sx, tid, prex);
+    stage_store<COUT, ZN>(sd, tid, pred);
+    stage_store<COUT, ZN>(sz, tid, prez);
+  };
+  // this thread's pieces of the tile at frame f0 (VGPR staging): the tensors its half owns, or shares
+  auto fetch_mine = [&](int f0) {
+    if (!(OWN & 1) || role == 0) tile_fetch<CIN, XN>(x, f0, frames, tid, prex);
+    if (!(OWN & 2) || role == 0) {
+      tile_fetch<COUT, ZN>(du, f0, frames, tid, pred);
+      tile_fetch<COUT, ZN>(ba.z, f0, frames, tid, prez);
+    }
   };
   __syncthreads();                            // the LDS image is zeroed / the packet is in place before anything lands in it
   if ((int)blockIdx.x < ntiles) {
@@ -1497,9 +1525,7 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
       if (frames - f0 >= kTF) tm_static_for<0, kNP>([&](auto ic) { dma_piece(ic, f0, tid); });
       else stage_ragged(f0);
     } else {
-      tile_fetch<CIN, NTH>(x, f0, frames, tid, prex);
-      tile_fetch<COUT, NTH>(du, f0, frames, tid, pred);
-      tile_fetch<COUT, NTH>(ba.z, f0, frames, tid, prez);
+      fetch_mine(f0);
     }
   }
   __syncthreads();
@@ -1528,21 +1554,24 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
       if (role == 1 || tile == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       TM_ST(0);   // wait for the staged tile
       __syncthreads();
-      stage_load<CIN, NTH>(sx, tid, prex);
+      stage_load<CIN, XN>(sx, tid, prex);
     } else {
 #if RCED_TM_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       TM_ST(0);   // wait for the prefetched tile
 #endif
     }
-    if constexpr (XF) tile_commit_bnrelu<CIN, NTH>(lx, tid, prex, where_x, xt, frame0, frames);
-    else tile_commit<CIN, NTH>(lx, tid, prex, where_x);
+    if (!(OWN & 1) || role == 0) {
+      if constexpr (XF) tile_commit_bnrelu<CIN, XN>(lx, tid, prex, where_x, xt, frame0, frames);
+      else tile_commit<CIN, XN>(lx, tid, prex, where_x);
+    }
     if constexpr (DMA) {      // the x pieces are dead before the (d_u, z) pieces are read: 12-16 fewer registers at the peak
       pin();
-      stage_load<COUT, NTH>(sd, tid, pred);
-      stage_load<COUT, NTH>(sz, tid, prez);
+      stage_load<COUT, ZN>(sd, tid, pred);
+      stage_load<COUT, ZN>(sz, tid, prez);
     }
-    tile_commit_bnbwd<COUT, NTH>(ldz, tid, pred, prez, where_dz, dt, frame0, frames, ba.beta != nullptr);
+    if (!(OWN & 2) || role == 0)
+      tile_commit_bnbwd<COUT, ZN>(ldz, tid, pred, prez, where_dz, dt, frame0, frames, ba.beta != nullptr);
     TM_ST(1);   // commit
     __syncthreads();
     TM_ST(2);   // barrier 1
@@ -1565,9 +1594,7 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
           stage_ragged(nframe0);
         }
       } else if (!RCED_TM_BWD_STAGGER || role == 1) {
-        tile_fetch<CIN, NTH>(x, nframe0, frames, tid, prex);
-        tile_fetch<COUT, NTH>(du, nframe0, frames, tid, pred);
-        tile_fetch<COUT, NTH>(ba.z, nframe0, frames, tid, prez);
+        fetch_mine(nframe0);
       }
     }
     pin();
@@ -1575,9 +1602,9 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
     auto piece = [&](auto ic) {
       constexpr int i = decltype(ic)::value;
       if constexpr (DMA) dma_piece(ic, nframe0, tid);
-      else if constexpr (i < kPX) tile_fetch_piece<CIN, NTH, i>(x, nframe0, tid, prex);
-      else if constexpr (i < kPX + kPZ) tile_fetch_piece<COUT, NTH, i - kPX>(du, nframe0, tid, pred);
-      else tile_fetch_piece<COUT, NTH, i - kPX - kPZ>(ba.z, nframe0, tid, prez);
+      else if constexpr (i < kPX) tile_fetch_piece<CIN, XN, i>(x, nframe0, tid, prex);
+      else if constexpr (i < kPX + kPZ) tile_fetch_piece<COUT, ZN, i - kPX>(du, nframe0, tid, pred);
+      else tile_fetch_piece<COUT, ZN, i - kPX - kPZ>(ba.z, nframe0, tid, prez);
     };
     if (role == 0) {
       constexpr int kNS = GD::kKP / 8;
@@ -1585,9 +1612,7 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
         if (spread)
           tm_static_for<0, kNP>([&](auto ic) { if (s == decltype(ic)::value * kNS / kNP) piece(ic); });
         if (RCED_TM_BWD_STAGGER && !DMA && s == -1 && more && !spread) {
-          tile_fetch<CIN, NTH>(x, nframe0, frames, tid, prex);
-          tile_fetch<COUT, NTH>(du, nframe0, frames, tid, pred);
-          tile_fetch<COUT, NTH>(ba.z, nframe0, frames, tid, prez);
+          fetch_mine(nframe0);
           pin();
         }
       };
