@@ -559,7 +559,10 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
   // out += conv: a gradient tensor whose other contribution is a plain copy (a post-ReLU skip) is never copied, the dgrad
   // that completes it reads the copy's source instead (train_api.hip, skip_alias)
   using G = Geo<CIN, TAPS, COUT>;
-  static_assert(!(SUMS && (STATS || ACCUM || G::kPH != 1 || (COUT & 1))), "SUMS: overwrite-mode dgrads with an even, unpaired cout");
+  // SUMS reads the COMPLETE gradient out of the accumulators: an overwriting dgrad, or (z form) the accumulating dgrad that
+  // adds the last contribution (ACCUM: the operand is added in front of the sums; train_api.hip launches it only there)
+  static_assert(!(SUMS && (STATS || (COUT & 1))), "SUMS: dgrads with an even cout");
+  static_assert(!(SUMS && SUMX && (ACCUM || G::kPH != 1)), "SUMX: the fused backward kernel's overwriting, unpaired dgrad");
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMTm, PH = G::kPH;   // MT: M-tiles of the MAIN pass
   const float* in = lds_in + G::kG * G::kCinP;
   // XMT >= 0 (two-M-tile shapes, RCED_TM_MSPLIT): the odd column tile is cut by M-tile -- this wave's extra slot computes
@@ -641,7 +644,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
 #endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int co0 = 16 * mt + 4 * kq;
+      const int co0 = PH == 2 ? 4 * (kq & 1) : 16 * mt + 4 * kq;      // (PH = 2: lane rows 4 kq.. = parity kq >> 1, channels 4 (kq & 1)..)
       sa4[mt] = sb4[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (co0 + 1 < COUT) {
         const f32x2 a = *reinterpret_cast<const f32x2*>(stab + co0), b = *reinterpret_cast<const f32x2*>(stab + COUT + co0);
@@ -774,11 +777,20 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
         }
       }
     }
+    if constexpr (SUMS && ACCUM) {       // complete the gradient first: the sums are taken of what is stored
+      const float* ap = out + ((size_t)(frame0 + fr) * kF + f) * COUT + acc_delta;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co0 = PH == 2 ? 4 * (kq & 1) : 16 * mt + 4 * kq;
+        if (co0 + 3 < COUT) acc[t][mt] += *reinterpret_cast<const f32x4u*>(ap + co0);
+        else if (co0 + 1 < COUT) { const f32x2 o = *reinterpret_cast<const f32x2*>(ap + co0); acc[t][mt].x += o.x; acc[t][mt].y += o.y; }
+      }
+    }
     if constexpr (SUMS && !SUMX && !(RCED_TM_EXP & 16)) {
       const float* zp = zt + (fr * kF + f) * COUT;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int co0 = 16 * mt + 4 * kq;
+        const int co0 = PH == 2 ? 4 * (kq & 1) : 16 * mt + 4 * kq;
         f32x4 zv = {0.f, 0.f, 0.f, 0.f};
         if (co0 + 1 < COUT) { const f32x2 q = *reinterpret_cast<const f32x2*>(zp + co0); zv.x = q.x; zv.y = q.y; }
         if (co0 + 3 < COUT) { const f32x2 q = *reinterpret_cast<const f32x2*>(zp + co0 + 2); zv.z = q.x; zv.w = q.y; }
@@ -807,12 +819,12 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
           if (co0 + 3 < COUT) {
             f32x4u* p = reinterpret_cast<f32x4u*>(op + co0);
             f32x4 r = v;
-            if (ACCUM) { const f32x4 o = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const float*>(p) + acc_delta); r += o; }
+            if (ACCUM && !SUMS) { const f32x4 o = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const float*>(p) + acc_delta); r += o; }
             *p = r;
           } else if (co0 + 1 < COUT) {
             f32x2* p = reinterpret_cast<f32x2*>(op + co0);
             f32x2 r = {v.x, v.y};
-            if (ACCUM) { const f32x2 o = *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(p) + acc_delta); r.x += o.x; r.y += o.y; }
+            if (ACCUM && !SUMS) { const f32x2 o = *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(p) + acc_delta); r.x += o.x; r.y += o.y; }
             *p = r;
           }
         } else {

@@ -894,9 +894,6 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     // there too, so those layers' d_u need not be written either; bwd_route2 still routes g to the skip's source)
     return fuse_dz_of(l) && s.use_act && s.skip_pre < 0;
   };
-  // a producer whose BatchNorm-backward sums may come out of its consumer's dgrad: masked lazily AND without a skip to
-  // route (a layer that adds a skip after its ReLU still needs its bwd_route2 pass for that)
-  auto sums_in_dgrad_ok = [&](int pl) { return lazy_mask_of(pl) && net.layer[pl].skip_post < 0; };
   // alias_src[id]: G[id]'s first contribution would be a plain copy of another gradient tensor (layer ls adds tensor id
   // AFTER its ReLU: d tensor id += G[ls + 1] unchanged).  The copy is not made: the one dgrad that completes G[id] reads
   // its accumulate operand from G[ls + 1] instead (out = acc_from + conv).  G[ls + 1] is final by then -- its writers are
@@ -916,6 +913,10 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     const LayerSpec& c = net.layer[lc];
     return c.kh == 1 && c.cout % 2 == 0 && tm_has(false, c.cout, c.kw, t->off[lc].cin);
   };
+  // a producer whose BatchNorm-backward sums may come out of its consumer's dgrad: masked lazily, and nothing left to
+  // route -- no skip, or a post-ReLU skip whose gradient is not copied (alias_ok; evaluated here, at the consumer, and again at
+  // the producer itself, with nothing writing the skip's gradient tensor in between)
+  auto sums_in_dgrad_ok = [&](int pl) { return lazy_mask_of(pl) && (net.layer[pl].skip_post < 0 || alias_ok(pl)); };
   for (int l = L - 1; l >= 0; --l) {
     const LayerSpec& s = net.layer[l];
     const LayerOff& f = t->off[l];
@@ -937,9 +938,18 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     FinishArgs fb{};
     fb.mu = mu; fb.rstd = t->rstd[l]; fb.gamma = t->params + f.gamma; fb.beta = t->params + f.beta;
     fb.g_beta = t->grads + f.beta; fb.g_gamma = t->grads + f.gamma; fb.redo = t->redo;
+    // a post-ReLU skip whose gradient is not copied (alias_src above): recorded before the branches -- the layer's sums may
+    // already be there (fused_sums), in which case nothing of this layer is routed at all
+    const bool alias = alias_ok(l);
+    if (alias) {
+      alias_src[s.skip_post] = t->G[l + 1];
+      written[s.skip_post] = 1;
+    }
     if (passthrough) {
       // nothing to route
     } else if (lazy_mask && fused_sums[l] > 0) {
+      if (s.skip_post > 0 && !alias)
+        return rced_fail(RCED_ERR_STATE, "layer %d: sums came out of the dgrad but its skip gradient still needs routing", l);
       hipLaunchKernelGGL(bn_finish, dim3(1), dim3(1024), 0, st, (const double*)t->part, fused_sums[l], s.cout, t->sums,
                          (int)(sums_from_x[l] ? kFinX : kFinZ), fb, (const int*)nullptr);
       grads_out = true;
@@ -958,8 +968,6 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       const dim3 grid = pair_grid(s.cout);
       // (a layer has at most one skip; first writer of its gradient tensor: store, see `written`)
       const int skip_id = s.skip_pre > 0 ? s.skip_pre : s.skip_post;
-      const bool alias = alias_ok(l);
-      if (alias) alias_src[skip_id] = t->G[l + 1];
       const int skip_first = skip_id > 0 && !written[skip_id] ? 1 : 0;
       if (skip_id > 0) written[skip_id] = 1;
       hipLaunchKernelGGL(train::bwd_route2, grid, dim3(train::kThreads), 0, st, (const float2*)t->G[l + 1],
@@ -1051,6 +1059,18 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
                    return fused_sums[pl] > 0;
                  }()) {
         // MFMA path; layer pl's BatchNorm-backward sums come out of the same kernel
+      } else if (const int pl = s.src - 1;   // an accumulating dgrad that adds the LAST contribution to G[src] -- the conv
+                 // consumer of a tensor comes before its skip consumers in the net, so after them here -- sees the complete
+                 // gradient in its epilogue: layer pl's sums come out of it as well (8-channel tensors: CR-CED's skip sources)
+                 fuse_sums_on && t->use_mfma && t->pk_bwd[l] && !overwrite(l) && ba && written[s.src] &&
+                 conv_consumer_of(s.src) == l && sums_in_dgrad_ok(pl) && [&] {
+                   const LayerOff& pf = t->off[pl];
+                   const tmm::SumArgs sa{t->z[pl], t->mu[pl], t->rstd[pl], t->params + pf.gamma, t->params + pf.beta};
+                   fused_sums[pl] = tm_conv(false, s.cout, s.kw, f.cin, true, false, dsrc, t->pk_bwd[l], t->G[s.src], frames,
+                                            t->num_cus, t->part, nullptr, ba, st, &sa, alias_src[s.src]);
+                   return fused_sums[pl] > 0;
+                 }()) {
+        // MFMA path; sums of layer pl included
       } else if (t->use_mfma && t->pk_bwd[l] && (overwrite(l) || ensure_zero(s.src) == RCED_OK) &&
           tm_conv(false, s.cout, s.kw, f.cin, !overwrite(l), false, dsrc, t->pk_bwd[l], t->G[s.src], frames, t->num_cus,
                   nullptr, nullptr, ba, st, nullptr, overwrite(l) ? nullptr : alias_src[s.src])) {

@@ -118,7 +118,8 @@ int tm_conv_launch1(const float* in, const float* packet, float* out, int frames
 //   optionally with in = relu(bn(z)) rebuilt from the producer's z (xa);
 // a dgrad shape gets  out (=|+=) conv(in)  with in = dz, optionally rebuilt from (d_u, z) (ba).
 // Returns the grid size (= number of partial-sum records when stats), 0 if no kernel was built for the request.
-// sa (dgrad shapes, overwrite mode only): also leave the producer's BatchNorm-backward records in `part` (tmm::SumArgs);
+// sa (dgrad shapes; overwrite mode, or -- 8-channel outputs -- the accumulating dgrad that adds the LAST contribution): also
+// leave the producer's BatchNorm-backward records in `part` (tmm::SumArgs);
 // 0 is returned when no such kernel exists for the shape and the caller launches again without sa.
 // acc_from (accum only): the tensor the result is added to, when that is not `out` itself (out = acc_from + conv).
 template <int CIN, int TAPS, int COUT, bool FWD>
@@ -128,10 +129,18 @@ int tm_conv_launch(bool accum, bool stats, const float* in, const float* packet,
   const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
   const tmm::BnBwdArgs nb{nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr};
   if (sa) {
-    if constexpr (!FWD && CIN % 2 == 0 && COUT % 2 == 0 && COUT != 8) {
-      if (accum || stats || xa) return 0;
+    if constexpr (!FWD && CIN % 2 == 0 && COUT % 2 == 0) {
+      if (stats || xa) return 0;
+      if (accum) {
+        // the accumulating form exists for the 8-channel tensors (CR-CED's skip sources) with the rebuilt dz only
+        if constexpr (COUT == 8) {
+          if (ba) return tm_conv_launch1<CIN, TAPS, COUT, true, false, tmm::kXfBnBwd, true>(in, packet, out, frames, cus, part, nx, *ba, st, *sa, acc_from);
+        }
+        return 0;
+      }
       if (ba) return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfBnBwd, true>(in, packet, out, frames, cus, part, nx, *ba, st, *sa);
-      return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfNone, true>(in, packet, out, frames, cus, part, nx, nb, st, *sa);
+      if constexpr (COUT != 8)
+        return tm_conv_launch1<CIN, TAPS, COUT, false, false, tmm::kXfNone, true>(in, packet, out, frames, cus, part, nx, nb, st, *sa);
     }
     return 0;
   }
