@@ -11,6 +11,7 @@
 #include "kernels_fused_chain.h"
 #include "kernels_fused_v3.h"
 #include "kernels_fused_chain16.h"
+#include "kernels_final_x6.h"
 #include "rced_internal.h"
 
 using namespace rced;
@@ -27,6 +28,7 @@ struct rced_fused {
   int bf16 = 0;               // option "bf16" (V1/V2): bf16 activations + weights (kernels_fused_chain16.h)
   float* wpack16 = nullptr;   // its packet stream (built when the option is first set)
   unsigned short* fin_apack16 = nullptr;   // the output layer's Toeplitz A fragments in bf16 (chain16::final_gemm16_kernel)
+  unsigned short* fin_apack_x6 = nullptr;  // ... as three bf16 parts per value: fp32 quality on the bf16 pipe (x6::final_gemm_x6_kernel)
   float* scratch16 = nullptr; // skip fragments for 2 workgroups per CU
   int bf16_wgs_per_cu = 1;
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
@@ -219,10 +221,18 @@ inline bool final_lds_enabled() {
   static const bool on = !(getenv("RCED_FINAL_LDS") && atoi(getenv("RCED_FINAL_LDS")) == 0);
   return on;
 }
+// RCED_FINAL_X6=0: the output layer on the fp32 MFMA (chain::final_gemm_lds_kernel) instead of the three-part bf16 form
+inline bool final_x6_enabled() {
+  static const bool on = !(getenv("RCED_FINAL_X6") && atoi(getenv("RCED_FINAL_X6")) == 0);
+  return on;
+}
 template <int CH>
 void chain_final_layer(const rced_fused* f, float* y, int frames, hipStream_t st) {
   const dim3 grid((frames + chain::kFinFrames - 1) / chain::kFinFrames);
-  if (final_lds_enabled())
+  if (final_x6_enabled() && f->fin_apack_x6)
+    hipLaunchKernelGGL(x6::final_gemm_x6_kernel<CH>, grid, dim3(chain::kFinThreads), 0, st, (const float*)f->h,
+                       (const unsigned short*)f->fin_apack_x6, f->fin_bias, y, frames, (const float*)nullptr);
+  else if (final_lds_enabled())
     hipLaunchKernelGGL(chain::final_gemm_lds_kernel<CH>, grid, dim3(chain::kFinThreads), 0, st, (const float*)f->h,
                        (const float*)f->fin_apack, f->fin_bias, y, frames);
   else
@@ -256,6 +266,13 @@ int chain_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb
   return RCED_OK;
 }
 
+inline unsigned short bf16_rne(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
 template <class N>
 int chain_create(rced_model* m, rced_fused* f) {
   using G = chain::Geo<N>;
@@ -264,6 +281,30 @@ int chain_create(rced_model* m, rced_fused* f) {
   int rc = upload(&f->wpack, wpack);
   if (!rc) rc = upload(&f->fin_apack, fin);
   if (rc) return rc;
+  {  // the output layer's A[f, k] once more, every value as three bf16 parts in K-32 fragment order (kernels_final_x6.h)
+    constexpr int CH = N::kFinalCh;
+    using X = x6::FinalX6<CH>;
+    const rced_layer_dev& lf = m->layers[N::kLayers];
+    std::vector<unsigned short> p(X::kPackShorts, 0);
+    auto b2f = [](unsigned short b) { const unsigned u = (unsigned)b << 16; float v; memcpy(&v, &u, 4); return v; };
+    for (int S = 0; S < X::kSteps; ++S)
+      for (int mt = 0; mt < X::kMT; ++mt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int k = 32 * S + 8 * (lane >> 4) + e, fo = 16 * mt + (lane & 15), fp = k / CH, ci = k % CH, tap = fp - fo + 64;
+            const float v = (k < X::kK && fo < 129 && tap >= 0 && tap < 129) ? wq(lf, tap, ci, 0, CH) : 0.f;
+            const unsigned short h = bf16_rne(v);
+            const float r1 = v - b2f(h);
+            const unsigned short mm = bf16_rne(r1);
+            const unsigned short l = bf16_rne(r1 - b2f(mm));
+            const size_t base = ((size_t)(S * X::kMT + mt) * 3) * 512 + lane * 8 + e;
+            p[base] = h;
+            p[base + 512] = mm;
+            p[base + 1024] = l;
+          }
+    HIP_TRY(hipMalloc(&f->fin_apack_x6, p.size() * sizeof(unsigned short)));
+    HIP_TRY(hipMemcpy(f->fin_apack_x6, p.data(), p.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  }
   f->scratch_bytes = (size_t)m->num_cus * G::kScratchFloatsPerWg * sizeof(float);
   HIP_TRY(hipMalloc(&f->scratch, f->scratch_bytes));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain::fused_chain_kernel<N>),
@@ -272,13 +313,6 @@ int chain_create(rced_model* m, rced_fused* f) {
 }
 
 // ---- bf16 variant (kernels_fused_chain16.h) ----------------------------------------------------
-inline unsigned short bf16_rne(float f) {
-  unsigned u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;   // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
 template <class N>
 void pack_chain16(const rced_model* m, std::vector<float>* wpack) {
   using G = chain16::Geo<N>;
@@ -429,6 +463,7 @@ void fused_destroy(rced_model* m) {
   if (f->wpack) (void)hipFree(f->wpack);
   if (f->wpack16) (void)hipFree(f->wpack16);
   if (f->fin_apack16) (void)hipFree(f->fin_apack16);
+  if (f->fin_apack_x6) (void)hipFree(f->fin_apack_x6);
   if (f->scratch16) (void)hipFree(f->scratch16);
   if (f->fin_apack) (void)hipFree(f->fin_apack);
   if (f->h) (void)hipFree(f->h);

@@ -14,6 +14,7 @@
 #include "kernels_generic.h"
 #include "kernels_train.h"
 #include "kernels_train_mfma.h"
+#include "kernels_final_x6.h"
 #include "train_mfma_dispatch.h"
 #include "rced_internal.h"
 #include "rced_spec.h"
@@ -302,7 +303,26 @@ bool is_output_layer(const LayerSpec& s, int cin) {
   return s.kh == 1 && s.kw == kFeatureDim && s.cout == 1 && !s.use_norm && !s.use_act && s.skip_pre < 0 && s.skip_post < 0 &&
          fin_pack_floats(cin) > 0;
 }
+// floats of the buffer that holds the output layer's packed A: the fp32 form, or the three-part bf16 form (kernels_final_x6.h)
+size_t fin_pack_alloc_floats(int ch) {
+  const size_t x6 = ((size_t)((129 * ch + 31) / 32) * 9 * 3 * 64 * 8 * sizeof(unsigned short) + 3) / 4;
+  return std::max(fin_pack_floats(ch), x6);
+}
 int fin_forward(int ch, const float* h, const float* w, const float* bias, float* pack, float* y, int frames, hipStream_t st) {
+  static const bool use_x6 = !(getenv("RCED_FINAL_X6") && atoi(getenv("RCED_FINAL_X6")) == 0);
+  if (use_x6) {
+    // fp32 quality on the bf16 matrix pipe: every operand as three bf16 parts, six MFMAs of K = 32 per product
+    const int total6 = ((129 * ch + 31) / 32) * 9 * 64 * 8;
+    hipLaunchKernelGGL(x6::pack_final_x6_dev, dim3((total6 + 255) / 256), dim3(256), 0, st, w, ch, reinterpret_cast<unsigned short*>(pack));
+    const dim3 grid6((frames + chain::kFinFrames - 1) / chain::kFinFrames);
+#define X(CH)                                                                                                                      \
+  if (ch == CH)                                                                                                                    \
+    hipLaunchKernelGGL((x6::final_gemm_x6_kernel<CH>), grid6, dim3(chain::kFinThreads), 0, st, h,                                  \
+                       (const unsigned short*)reinterpret_cast<unsigned short*>(pack), 0.f, y, frames, bias);
+    RCED_FIN_CH(X)
+#undef X
+    return 1;
+  }
   const int total = (int)fin_pack_floats(ch);
   hipLaunchKernelGGL(tmm::pack_final_fwd, dim3((total + 255) / 256), dim3(256), 0, st, w, ch, pack);
   const dim3 grid((frames + tmm::kFinFrames - 1) / tmm::kFinFrames);
@@ -597,7 +617,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     TRY_OR_FREE(hipMalloc(&t->rstd[l], 64 * sizeof(float)));
     if (first_has(s, f.cin) && !t->pk_first) TRY_OR_FREE(hipMalloc(&t->pk_first, first_packet_floats(s) * sizeof(float)));
     if (is_output_layer(s, f.cin) && !t->pk_fin_bwd) TRY_OR_FREE(hipMalloc(&t->pk_fin_bwd, fin_dgrad_pack_floats(f.cin) * sizeof(float)));
-    if (is_output_layer(s, f.cin) && !t->pk_fin) TRY_OR_FREE(hipMalloc(&t->pk_fin, fin_pack_floats(f.cin) * sizeof(float)));
+    if (is_output_layer(s, f.cin) && !t->pk_fin) TRY_OR_FREE(hipMalloc(&t->pk_fin, fin_pack_alloc_floats(f.cin) * sizeof(float)));
     if (s.kh == 1 && tm_has(true, f.cin, s.kw, s.cout)) TRY_OR_FREE(hipMalloc(&t->pk_fwd[l], tm_packet_floats(f.cin, s.kw, s.cout) * sizeof(float)));
     if (s.kh == 1 && tm_has(false, s.cout, s.kw, f.cin)) TRY_OR_FREE(hipMalloc(&t->pk_bwd[l], tm_packet_floats(s.cout, s.kw, f.cin) * sizeof(float)));
   }
