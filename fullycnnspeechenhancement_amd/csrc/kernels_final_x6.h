@@ -222,5 +222,120 @@ __global__ __launch_bounds__(chain::kFinThreads, RCED_X6_OCC) void final_gemm_x6
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Output-layer dgrad (1x129, CH -> 1; tmm::final_dgrad's GEMM) in the same arithmetic:
+//     dx[frame, f', ci] = sum_f dz[frame, f] * W[f' - f + 64, ci]  =  D[m = f' CH + ci][frame] = sum_f A[m, f] dz[frame, f],
+// K = 129 padded to 160 (five K = 32 steps; the fp32 kernel runs 33 steps of K = 4).  A [M-tile][step][part][lane] x 8 bf16 is
+// rebuilt on the device every step (pack_dgrad_x6_dev) and streams from L2; B = the 64 frames' dz rows, split into three bf16
+// planes while they are staged.  One workgroup = 4 waves = 64 frames; wave w owns M-tiles w, w + 4, ... kMc at a time.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDgX6Steps = 5, kDgX6Frames = 64, kDgX6Threads = 256, kDgX6Mc = 2;
+constexpr int kDgX6Row = 32 * kDgX6Steps + 8;          // bf16 per staged row: 16-byte aligned, 16 B off a bank period
+static __global__ void pack_dgrad_x6_dev(const float* __restrict__ w, int CH, unsigned short* __restrict__ pack) {
+  const int M = kF * CH, MT = (M + 15) / 16, total = MT * kDgX6Steps * 64 * 8;      // one thread per (mt, S, lane, e)
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx & 7, lane = (idx >> 3) & 63, r = idx >> 9, S = r % kDgX6Steps, mt = r / kDgX6Steps;
+  const int m = 16 * mt + (lane & 15), f = 32 * S + 8 * (lane >> 4) + e;
+  const int fp = m / CH, ci = m - fp * CH, tap = fp - f + 64;
+  const float v = (m < M && f < kF && tap >= 0 && tap < kF) ? w[tap * CH + ci] : 0.f;
+  const __bf16 h = (__bf16)v;
+  const float r1 = v - (float)h;
+  const __bf16 mm = (__bf16)r1;
+  const __bf16 l = (__bf16)(r1 - (float)mm);
+  const size_t base = ((size_t)(mt * kDgX6Steps + S) * 3) * 512 + lane * 8 + e;
+  pack[base] = __builtin_bit_cast(unsigned short, h);
+  pack[base + 512] = __builtin_bit_cast(unsigned short, mm);
+  pack[base + 1024] = __builtin_bit_cast(unsigned short, l);
+}
+
+template <int CH>
+__global__ __launch_bounds__(kDgX6Threads, 2) void final_dgrad_x6_kernel(const float* __restrict__ dz,
+                                                                          const unsigned short* __restrict__ apack,
+                                                                          float* __restrict__ dx, int frames) {
+  constexpr int M = kF * CH, MT = (M + 15) / 16;            // 1032 rows -> 65 M-tiles (CH 8)
+  constexpr int kPlane = kDgX6Frames * kDgX6Row;
+  __shared__ __attribute__((aligned(16))) unsigned short rows[3 * kPlane];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kq = lane >> 4;
+  const int f0 = blockIdx.x * kDgX6Frames;
+  // stage: pieces of 4 consecutive f of one frame (rows of 129 floats are only 4-byte aligned: scalar loads)
+  for (int q = tid; q < kDgX6Frames * (kDgX6Row / 4); q += kDgX6Threads) {
+    const int fr = q / (kDgX6Row / 4), f = 4 * (q - fr * (kDgX6Row / 4));
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (f0 + fr < frames) {
+      const float* src = dz + (size_t)(f0 + fr) * kF + f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (f + j < kF) v[j] = src[j];
+    }
+    s16x4 ph, pm, pl;
+    split3(v, ph, pm, pl);
+    unsigned short* d = rows + fr * kDgX6Row + f;
+    *reinterpret_cast<s16x4*>(d) = ph;
+    *reinterpret_cast<s16x4*>(d + kPlane) = pm;
+    *reinterpret_cast<s16x4*>(d + 2 * kPlane) = pl;
+  }
+  __syncthreads();
+  // B fragment (step S, frame tile t, part p): eight consecutive f of frame 16 t + n
+  const unsigned short* bp = rows + n * kDgX6Row + 8 * kq;
+  for (int m0 = wave * kDgX6Mc; m0 < MT; m0 += 4 * kDgX6Mc) {
+    f32x4 acc[kDgX6Mc][4];
+#pragma unroll
+    for (int c = 0; c < kDgX6Mc; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const s16x8* ap = reinterpret_cast<const s16x8*>(apack) + (size_t)m0 * kDgX6Steps * 3 * 64 + lane;
+#pragma unroll 1     // (unrolled, hipcc hoists all five steps' operand loads: 256 VGPRs and scratch)
+    for (int S = 0; S < kDgX6Steps; ++S) {
+      s16x8 a[kDgX6Mc][3], b[4][3];
+#pragma unroll
+      for (int c = 0; c < kDgX6Mc; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[c][p] = (m0 + c < MT) ? ap[((c * kDgX6Steps + S) * 3 + p) * 64] : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[t][p] = *reinterpret_cast<const s16x8*>(bp + 16 * t * kDgX6Row + 32 * S + p * kPlane);
+#pragma unroll
+      for (int c = 0; c < kDgX6Mc; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x4 v = acc[c][t];
+          v = mfma32(a[c][1], b[t][1], v);
+          v = mfma32(a[c][2], b[t][0], v);
+          v = mfma32(a[c][0], b[t][2], v);
+          v = mfma32(a[c][1], b[t][0], v);
+          v = mfma32(a[c][0], b[t][1], v);
+          v = mfma32(a[c][0], b[t][0], v);
+          acc[c][t] = v;
+        }
+    }
+    // D row = m = 16 (m0 + c) + 4 kq + r (four consecutive floats of the frame's [129 CH] row), column = frame
+#pragma unroll
+    for (int c = 0; c < kDgX6Mc; ++c) {
+      const int mrow = 16 * (m0 + c) + 4 * kq;
+      if (m0 + c >= MT) continue;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int fr = f0 + 16 * t + n;
+        if (fr >= frames) continue;
+        float* op = dx + (size_t)fr * M + mrow;
+        const f32x4 v = acc[c][t];
+        if (mrow + 3 < M) {
+          *reinterpret_cast<f32x2*>(op) = f32x2{v.x, v.y};          // M even (CH even): 8-byte aligned
+          *reinterpret_cast<f32x2*>(op + 2) = f32x2{v.z, v.w};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (mrow + r < M) op[r] = v[r];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace x6
 }  // namespace rced

@@ -338,9 +338,23 @@ int fin_forward(int ch, const float* h, const float* w, const float* bias, float
 #undef X
   return 1;
 }
-size_t fin_dgrad_pack_floats(int ch) { return (size_t)((129 * ch + 15) / 16) * tmm::kDgSteps * 64; }
+size_t fin_dgrad_pack_floats(int ch) {   // the fp32 pack, or the three-part bf16 pack of x6::final_dgrad_x6_kernel
+  const size_t mt = (size_t)((129 * ch + 15) / 16);
+  return std::max(mt * tmm::kDgSteps * 64, (mt * x6::kDgX6Steps * 3 * 64 * 8 * sizeof(unsigned short) + 3) / 4);
+}
 int fin_dgrad(int ch, const float* dz, const float* w, float* pack, float* dx, int frames, hipStream_t st) {
-  const int total = (int)fin_dgrad_pack_floats(ch);
+  static const bool use_x6 = !(getenv("RCED_FINAL_X6") && atoi(getenv("RCED_FINAL_X6")) == 0);
+  if (use_x6) {
+    const int total6 = ((129 * ch + 15) / 16) * x6::kDgX6Steps * 64 * 8;
+    hipLaunchKernelGGL(x6::pack_dgrad_x6_dev, dim3((total6 + 255) / 256), dim3(256), 0, st, w, ch, reinterpret_cast<unsigned short*>(pack));
+    const dim3 grid6((frames + x6::kDgX6Frames - 1) / x6::kDgX6Frames);
+#define X(CH) \
+  if (ch == CH) hipLaunchKernelGGL((x6::final_dgrad_x6_kernel<CH>), grid6, dim3(x6::kDgX6Threads), 0, st, dz, (const unsigned short*)reinterpret_cast<unsigned short*>(pack), dx, frames);
+    RCED_FIN_CH(X)
+#undef X
+    return 1;
+  }
+  const int total = (int)(((129 * ch + 15) / 16) * tmm::kDgSteps * 64);
   hipLaunchKernelGGL(tmm::pack_final_dgrad, dim3((total + 255) / 256), dim3(256), 0, st, w, ch, pack);
   const dim3 grid((frames + tmm::kDgFrames - 1) / tmm::kDgFrames);
 #define X(CH) \
