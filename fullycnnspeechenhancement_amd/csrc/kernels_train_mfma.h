@@ -537,19 +537,186 @@ struct SumState {
     pr1[0] = pr1[1] = pr2[0] = pr2[1] = 0.f;
   }
 };
+// ---------------------------------------------------------------------------------------------
+// fp32 quality on the bf16 matrix pipe for the forward convolutions (kernels_final_x6.h): the input tile lives
+// in LDS as THREE bf16 planes [pixel][channel] (x = h + m + l, exact to 2^-24; channel stride rounded to 4 so that a lane's
+// eight consecutive k of a pixel's im2col window start 8-byte aligned), the packet holds the weights the same way
+// ([step][M-tile][part][lane] x 8 bf16, k = 32 S + 8 kq + e), and a product is six v_mfma_f32_16x16x32_bf16 (m m, l h, h l,
+// m h, h m, h h) into the fp32 accumulator: 6 x 16 cycles per K = 32 where the fp32 pipe takes 8 x 32.  The epilogue
+// (conv_tile) does not change: same accumulator layout.  Built for the shapes without a remainder pass.
+// ---------------------------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// channel stride of a plane (bf16 elements): the even-padded channel count rounded to 4 (8-byte aligned windows), plus 4 where a
+// column's stride (ph pixels) would be a multiple of 128 bytes -- all 16 columns of a B fragment on the same banks
+// (30 -> 32 channels with pixel-pair columns: measured 1.50 ms against 0.85 ms for the fp32 kernel)
+__host__ __device__ constexpr int x6_cs(int cin, int ph) {
+  const int cs = ((((cin + 1) & ~1) + 3) & ~3);
+  return (ph * cs * 2) % 128 == 0 ? cs + 4 : cs;
+}
+template <int CIN, int TAPS, int COUT>
+struct GeoX6 {
+  using G = Geo<CIN, TAPS, COUT>;
+  static constexpr int kCS = x6_cs(CIN, G::kPH);                         // channel stride of a plane, bf16 elements
+  static constexpr int kKX = (TAPS + G::kPH - 1) * kCS;                  // K of the packet (window of TAPS (+1) pixels)
+  static constexpr int kSteps = (kKX + 31) / 32;
+  static constexpr int kPlane = ((G::kInRows * kCS + 32 + 7) / 8) * 8;   // bf16 per part; + 32: the last step reads past its window
+  static constexpr int kInFloats = ((3 * kPlane / 2 + 3) / 4) * 4;       // the three parts, counted in floats
+  static constexpr int kDataFloats = kSteps * G::kMTm * 3 * 64 * 4;      // A fragments: 16 bytes per (step, M-tile, part, lane)
+  static constexpr int kPacket = kDataFloats + 32;                       // + shift[32]
+  static constexpr int kShiftOff = kDataFloats;
+  static constexpr int kLdsFloats = kInFloats + kPacket;
+  // Two workgroups per CU are what overlaps one's staging with the other's MFMAs.  The 30 -> 8 layer does not fit that way
+  // (three planes of a 30-channel tile + its packet = 102 KB): with one workgroup per CU it ran 1.44 ms, with its A fragments
+  // streamed from L2 instead (every wave re-reads 37 KB per two-frame tile: ~9 TB/s of L2 traffic over the chip) 1.07 ms,
+  // against 0.85 ms for the fp32 kernel -- so it stays on the fp32 MFMA, and this form is built where it fits.
+  static constexpr bool kFits = kLdsFloats * 4 <= 76 * 1024;
+  static_assert(G::kR == 0, "built for the shapes without a remainder pass (30 and 8 output channels)");
+};
+__device__ __forceinline__ f32x4 mfma32(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// two floats -> their three bf16 parts, each pair packed in 4 bytes
+__device__ __forceinline__ void split3_pair(f32x2 v, s16x2& h, s16x2& m, s16x2& l) {
+  const bf16x2 bh = {(__bf16)v.x, (__bf16)v.y};
+  const f32x2 r1 = {v.x - (float)bh.x, v.y - (float)bh.y};
+  const bf16x2 bm = {(__bf16)r1.x, (__bf16)r1.y};
+  const bf16x2 bl = {(__bf16)(r1.x - (float)bm.x), (__bf16)(r1.y - (float)bm.y)};
+  h = __builtin_bit_cast(s16x2, bh);
+  m = __builtin_bit_cast(s16x2, bm);
+  l = __builtin_bit_cast(s16x2, bl);
+}
+// in: part 0 of the tile at pixel 0 (bf16), the other parts PLANE elements further; off0 / offx: this lane's window start of
+// its first regular / its extra column tile; TSTRIDE: elements between a wave's consecutive column tiles
+template <int NR, int NX, int MT, int STEPS, int TSTRIDE, int PLANE>
+__device__ __forceinline__ void gemm_pass_x6(const unsigned short* in, int off0, int offx, const s16x8* wpk, int lane,
+                                             f32x4 (&acc)[NR + NX][MT]) {
+  constexpr int NT = NR + NX;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    s16x8 a[MT][3], b[NT][3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[mt][p] = wpk[((s * MT + mt) * 3 + p) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const unsigned short* q = in + (t < NR ? off0 + t * TSTRIDE : offx) + 32 * s + p * PLANE;
+        const s16x4 lo = *reinterpret_cast<const s16x4*>(q), hi = *reinterpret_cast<const s16x4*>(q + 4);   // 8-byte aligned
+        b[t][p] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 v = acc[t][mt];
+        v = mfma32(a[mt][1], b[t][1], v);
+        v = mfma32(a[mt][2], b[t][0], v);
+        v = mfma32(a[mt][0], b[t][2], v);
+        v = mfma32(a[mt][1], b[t][0], v);
+        v = mfma32(a[mt][0], b[t][1], v);
+        v = mfma32(a[mt][0], b[t][0], v);
+        acc[t][mt] = v;
+      }
+  }
+}
+// Commit a prefetched tile into the three planes.  XF: the producer's BatchNorm + ReLU first (tile_commit_bnrelu).
+// G0 = pixel row of bin 0 of frame 0, GAP = rows between the frames (the halo).  All of a thread's float4 start at the same
+// channel (Stage::kStride), so its pixel walks in constant steps: one division and one table read per commit, not per piece.
+template <int C, int CS, int PLANE, bool XF, int G0, int GAP>
+__device__ __forceinline__ void tile_commit_x6(unsigned short* planes, int tid, const f32x4 (&pre)[Stage<C>::kPer],
+                                               const float* table, int frame0, int frames) {
+  using St = Stage<C>;
+  static_assert(C % 2 == 0 && (4 * St::kStride) % C == 0 && St::kFrame % C == 0, "float2 pieces inside a pixel; constant pixel step");
+  constexpr int kPxStep = 4 * St::kStride / C;
+  const int gp0 = (4 * tid) / C, c0 = 4 * tid - gp0 * C;          // pixel (over both frames) and channel of the thread's pieces
+  const bool wrap = c0 + 2 >= C;                                     // the second pair lies in the next pixel
+  const int c1 = wrap ? c0 + 2 - C : c0 + 2;
+  f32x2 ta[2], tb[2];
+  if constexpr (XF) {
+    ta[0] = *reinterpret_cast<const f32x2*>(table + c0);
+    tb[0] = *reinterpret_cast<const f32x2*>(table + C + c0);
+    ta[1] = *reinterpret_cast<const f32x2*>(table + c1);
+    tb[1] = *reinterpret_cast<const f32x2*>(table + C + c1);
+  }
+#pragma unroll
+  for (int i = 0; i < St::kPer; ++i) {
+    const int q = tid + i * St::kStride;
+    if (q < St::kVec && tid < St::kStride) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gp = gp0 + i * kPxStep + (h && wrap ? 1 : 0);
+        const int fr = gp >= kF ? 1 : 0;
+        f32x2 v = {pre[i][2 * h], pre[i][2 * h + 1]};
+        if constexpr (XF) {
+          v = f32x2{fmaxf(fmaf(ta[h].x, v.x, tb[h].x), 0.f), fmaxf(fmaf(ta[h].y, v.y, tb[h].y), 0.f)};
+          if (frame0 + fr >= frames) v = f32x2{0.f, 0.f};      // frames past the batch stay zero
+        }
+        s16x2 ph, pm, pl;
+        split3_pair(v, ph, pm, pl);
+        unsigned short* d = planes + (G0 + gp + (fr ? GAP : 0)) * CS + (h ? c1 : c0);
+        *reinterpret_cast<s16x2*>(d) = ph;
+        *reinterpret_cast<s16x2*>(d + PLANE) = pm;
+        *reinterpret_cast<s16x2*>(d + 2 * PLANE) = pl;
+      }
+    }
+  }
+}
+// The weights (TF layout [TAPS][CIN][COUT]) as the three-part packet of a FORWARD convolution (pack_packet's transpose = 0).
+static __global__ void pack_packet_x6(const float* __restrict__ w, const float* __restrict__ shift, int taps, int cin, int cout,
+                                      int ph, float* __restrict__ packet) {
+  const int cs = x6_cs(cin, ph), K = (taps + ph - 1) * cs, steps = (K + 31) / 32, MT = (cout + 15) / 16;
+  const int ndata = steps * MT * 64 * 8;            // one thread per (S, mt, lane, e); the three parts by the same thread
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ndata + 32) return;
+  if (idx >= ndata) {
+    const int c = idx - ndata;
+    packet[steps * MT * 3 * 64 * 4 + c] = (shift && c < ph * cout) ? shift[ph == 2 ? (c & 7) : c] : 0.f;
+    return;
+  }
+  const int e = idx & 7, lane = (idx >> 3) & 63, r = idx >> 9, mt = r % MT, S = r / MT;
+  const int k = 32 * S + 8 * (lane >> 4) + e;
+  int co = 16 * mt + (lane & 15), tap = k / cs;
+  const int ci = k - tap * cs;
+  if (ph == 2) {            // row = (parity, co): the parity-1 rows see the window one tap later
+    tap -= co >> 3;
+    co &= 7;
+  }
+  const float v = (k < K && co < cout && ci < cin && tap >= 0 && tap < taps) ? w[(tap * cin + ci) * cout + co] : 0.f;
+  const __bf16 h = (__bf16)v;
+  const float r1 = v - (float)h;
+  const __bf16 m = (__bf16)r1;
+  const __bf16 l = (__bf16)(r1 - (float)m);
+  unsigned short* p16 = reinterpret_cast<unsigned short*>(packet);
+  const size_t base = ((size_t)(S * MT + mt) * 3) * 512 + lane * 8 + e;
+  p16[base] = __builtin_bit_cast(unsigned short, h);
+  p16[base + 512] = __builtin_bit_cast(unsigned short, m);
+  p16[base + 1024] = __builtin_bit_cast(unsigned short, l);
+}
+
+template <bool X6, int CIN, int TAPS, int COUT>
+constexpr int conv_shift_off() {      // floats in front of the packet's shift[32]
+  if constexpr (X6) return GeoX6<CIN, TAPS, COUT>::kShiftOff;
+  else return Geo<CIN, TAPS, COUT>::kData;
+}
 template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false, bool OPQ = false, bool SUMX = false,
-          class Each = chain::NoEach, bool EXTACC = false, int DEPTH = 2, bool KS = false, int XMT = -1>
+          class Each = chain::NoEach, bool EXTACC = false, int DEPTH = 2, bool KS = false, int XMT = -1, bool X6 = false>
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
                                           int frames, int wave, int lane,
                                           double* red_wave, const float* zt = nullptr, const float* stab = nullptr,
                                           Each each = Each(), f32x4* acc_store = nullptr, const f32x4* ks_own = nullptr,
                                           const float* ks_lds = nullptr) {
   SumState<Geo<CIN, TAPS, COUT>::kMTm> local_sums;
-  conv_tile<CIN, TAPS, COUT, ACCUM, STATS, NX, SUMS, OPQ, SUMX, Each, EXTACC, DEPTH, KS, XMT>(
+  conv_tile<CIN, TAPS, COUT, ACCUM, STATS, NX, SUMS, OPQ, SUMX, Each, EXTACC, DEPTH, KS, XMT, X6>(
       lds_in, lds_w, out, frame0, frames, wave, lane, red_wave, zt, stab, each, acc_store, ks_own, ks_lds, local_sums, false, true);
 }
 template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int NX, bool SUMS = false, bool OPQ = false, bool SUMX = false,
-          class Each = chain::NoEach, bool EXTACC = false, int DEPTH = 2, bool KS = false, int XMT = -1>
+          class Each = chain::NoEach, bool EXTACC = false, int DEPTH = 2, bool KS = false, int XMT = -1, bool X6 = false>
 __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_w, float* __restrict__ out, int frame0,
                                           int frames, int wave, int lane, double* red_wave, const float* zt, const float* stab,
                                           Each each, f32x4* acc_store, const f32x4* ks_own, const float* ks_lds,
@@ -564,6 +731,8 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
   static_assert(!(SUMS && (STATS || (COUT & 1))), "SUMS: dgrads with an even cout");
   static_assert(!(SUMS && SUMX && (ACCUM || G::kPH != 1)), "SUMX: the fused backward kernel's overwriting, unpaired dgrad");
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMTm, PH = G::kPH;   // MT: M-tiles of the MAIN pass
+  static_assert(!X6 || (!KS && XMT < 0 && !SUMS && !ACCUM && G::kR == 0), "the three-part bf16 form: plain forward convolutions");
+  constexpr int kShiftOff = conv_shift_off<X6, CIN, TAPS, COUT>();
   const float* in = lds_in + G::kG * G::kCinP;
   // XMT >= 0 (two-M-tile shapes, RCED_TM_MSPLIT): the odd column tile is cut by M-tile -- this wave's extra slot computes
   // and stores only M-tile XMT of column tile 4 NR; another wave has the other half
@@ -582,14 +751,21 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
     const int px0 = 16 * wave + n, pxx = 16 * xtile + n;     // column index: a pixel, or a pixel pair when PH = 2
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(lds_w + G::kData + 16 * mt + 4 * kq);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(lds_w + kShiftOff + 16 * mt + 4 * kq);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t][mt] = sh;
     }
 #if RCED_TM_STAMPS
     c0 = st_on ? tm_stamp() : 0;
 #endif
-    if constexpr (KS) {
+    if constexpr (X6) {
+      using GX = GeoX6<CIN, TAPS, COUT>;
+      const unsigned short* inx = reinterpret_cast<const unsigned short*>(lds_in) + G::kG * GX::kCS;
+      if (!(RCED_TM_EXP & 4))
+        gemm_pass_x6<NR, NX, MT, GX::kSteps, PH * 64 * GX::kCS, GX::kPlane>(inx, (PH * px0 - G::kG) * GX::kCS + 8 * kq,
+                                                                          (PH * pxx - G::kG) * GX::kCS + 8 * kq,
+                                                                          reinterpret_cast<const s16x8*>(lds_w), lane, acc);
+    } else if constexpr (KS) {
       // K-split odd tile (conv_ks_partial): this pass covers the regular slots only; the four waves' shares of the odd
       // tile meet in LDS behind a barrier every wave passes here, and wave 0 (NX = 1) takes the tile through the epilogue
       if (!(RCED_TM_EXP & 4))
@@ -1166,6 +1342,71 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv1xk_mfma(const floa
   }
   if constexpr (STATS || SUMS) {
     __syncthreads();   // every wave's record is complete (conv_tile adds to it tile by tile)
+    if (tid < 2 * COUT) {
+      const int c = tid >> 1, k = tid & 1;
+      double t = 0.0;
+      for (int w = 0; w < kWaves; ++w) t += red[(w * 32 + c) * 2 + k];
+      part[((size_t)blockIdx.x * COUT + c) * 2 + k] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward convolution in the three-part bf16 form (GeoX6): conv1xk_mfma's tile loop with the x6 commit and GEMM pass.
+// in [frames][129][CIN] (XF: the producer's z), packet from pack_packet_x6, out = z [frames][129][COUT];
+// STATS: per-workgroup (sum z, sum z^2) records in part, as conv1xk_mfma.
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int TAPS, int COUT, int XF>
+constexpr int conv_x6_red_off() {
+  return (GeoX6<CIN, TAPS, COUT>::kLdsFloats + (XF == kXfBnRelu ? 2 * CIN : 0) + 3) & ~3;
+}
+template <int CIN, int TAPS, int COUT, bool STATS, int XF>
+__global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv_x6_fwd(const float* __restrict__ in, const float* __restrict__ packet,
+                                                         float* __restrict__ out, int frames, double* __restrict__ part,
+                                                         XformArgs xa) {
+  using G = Geo<CIN, TAPS, COUT>;
+  using GX = GeoX6<CIN, TAPS, COUT>;
+  static_assert(CIN % 2 == 0 && (XF == kXfNone || XF == kXfBnRelu), "wide staging; plain or BatchNorm + ReLU input");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned short* planes = reinterpret_cast<unsigned short*>(lds);
+  float* lw = lds + GX::kInFloats;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  static_assert(GX::kFits, "two workgroups per CU");
+  for (int e = tid; e < GX::kLdsFloats; e += kThreads) lds[e] = e < GX::kInFloats ? 0.f : packet[e - GX::kInFloats];
+  float* xt = lds + GX::kLdsFloats;                      // [2][CIN], only with XF
+  if constexpr (XF == kXfBnRelu) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
+  double* red = reinterpret_cast<double*>(lds + conv_x6_red_off<CIN, TAPS, COUT, XF>());
+  if constexpr (STATS)
+    for (int e = tid; e < kWaves * 64; e += kThreads) red[e] = 0.0;
+  double* red_wave = red + wave * 64;
+  __syncthreads();
+  const int ntiles = (frames + kTF - 1) / kTF;
+  f32x4 pre[Stage<CIN>::kPer];
+  if ((int)blockIdx.x < ntiles) tile_fetch<CIN>(in, blockIdx.x * kTF, frames, tid, pre);
+  SumState<G::kMTm> sums;
+  sums.zero();
+  int tile_no = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int frame0 = tile * kTF;
+    const bool flush = (++tile_no % kSumFlush) == 0 || tile + (int)gridDim.x >= ntiles;
+    constexpr bool carried = STATS && kSumFlush > 1;
+    tile_commit_x6<CIN, GX::kCS, GX::kPlane, XF == kXfBnRelu, G::kG, G::kS - kF>(planes, tid, pre, xt, frame0, frames);
+    __syncthreads();
+    const int nframe0 = (tile + (int)gridDim.x) * kTF;
+    if (tile + (int)gridDim.x < ntiles) tile_fetch<CIN>(in, nframe0, frames, tid, pre);
+    pin();
+    constexpr bool kOpq = Stage<CIN>::kPer * 4 >= RCED_TM_OPQ_MIN;
+    if (wave < G::kExtra)
+      conv_tile<CIN, TAPS, COUT, false, STATS, 1, false, kOpq, false, chain::NoEach, false, 2, false, -1, true>(
+          lds, lw, out, frame0, frames, wave, lane, red_wave, nullptr, nullptr, chain::NoEach(), nullptr, nullptr, nullptr, sums, carried, flush);
+    else
+      conv_tile<CIN, TAPS, COUT, false, STATS, 0, false, kOpq, false, chain::NoEach, false, 2, false, -1, true>(
+          lds, lw, out, frame0, frames, wave, lane, red_wave, nullptr, nullptr, chain::NoEach(), nullptr, nullptr, nullptr, sums, carried, flush);
+    __syncthreads();
+  }
+  if constexpr (STATS) {
+    __syncthreads();
     if (tid < 2 * COUT) {
       const int c = tid >> 1, k = tid & 1;
       double t = 0.0;

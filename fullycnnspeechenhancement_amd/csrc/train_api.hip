@@ -78,6 +78,8 @@ struct rced_trainer {
   int wg_error = 0;            // tmd::wg_launch could not grow wpart: the step fails instead of using atomics
   std::vector<char> virt;      // virt[id]: tensor id (= relu(bn(z[id-1]))) is never materialised; its consumer rebuilds it
   float* pk_first = nullptr;   // A fragments of the 8xk first layer (rebuilt every step)
+  std::vector<float*> pk_fwd_x6;   // the forward packets of the layers that run in the three-part bf16 form (tmm::conv_x6_fwd)
+  bool use_x6 = true;          // RCED_TRAIN_X6=0: every convolution on the fp32 MFMA
   float* pk_fin = nullptr, *pk_fin_bwd = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
   float* zero32 = nullptr;
   double *part = nullptr, *sums = nullptr;
@@ -101,6 +103,7 @@ struct rced_trainer {
     for (auto* p : rstd) fr(p);
     for (auto* p : pk_fwd) fr(p);
     for (auto* p : pk_bwd) fr(p);
+    for (auto* p : pk_fwd_x6) fr(p);
     fr(pk_fin);
     fr(pk_fin_bwd);
     fr(pk_first);
@@ -529,6 +532,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     if (const char* e = getenv("RCED_TRAIN_FUSE_SUMS")) t->fuse_sums = atoi(e) != 0;
     if (const char* e = getenv("RCED_TRAIN_DET")) t->det = atoi(e) != 0;
     if (const char* e = getenv("RCED_TRAIN_FUSE_BWD")) t->fuse_bwd = atoi(e) != 0;
+    if (const char* e = getenv("RCED_TRAIN_X6")) t->use_x6 = atoi(e) != 0;
   }
   const NetSpec* xnet = net;     // the reference's layout (what crosses the ABI)
   t->inet = *xnet;
@@ -620,7 +624,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
   }
   t->wf.assign(L, nullptr); t->wt.assign(L, nullptr); t->bias4.assign(L, nullptr);
   t->mu.assign(L, nullptr); t->rstd.assign(L, nullptr);
-  t->pk_fwd.assign(L, nullptr); t->pk_bwd.assign(L, nullptr);
+  t->pk_fwd.assign(L, nullptr); t->pk_bwd.assign(L, nullptr); t->pk_fwd_x6.assign(L, nullptr);
   for (int l = 0; l < L; ++l) {
     const LayerSpec& s = net->layer[l];
     const LayerOff& f = t->off[l];
@@ -633,6 +637,8 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     if (is_output_layer(s, f.cin) && !t->pk_fin_bwd) TRY_OR_FREE(hipMalloc(&t->pk_fin_bwd, fin_dgrad_pack_floats(f.cin) * sizeof(float)));
     if (is_output_layer(s, f.cin) && !t->pk_fin) TRY_OR_FREE(hipMalloc(&t->pk_fin, fin_pack_alloc_floats(f.cin) * sizeof(float)));
     if (s.kh == 1 && tm_has(true, f.cin, s.kw, s.cout)) TRY_OR_FREE(hipMalloc(&t->pk_fwd[l], tm_packet_floats(f.cin, s.kw, s.cout) * sizeof(float)));
+    if (t->use_x6 && s.kh == 1 && t->pk_fwd[l] && rced::tmd::tm_x6_has(f.cin, s.kw, s.cout))
+      TRY_OR_FREE(hipMalloc(&t->pk_fwd_x6[l], rced::tmd::tm_packet_x6_floats(f.cin, s.kw, s.cout) * sizeof(float)));
     if (s.kh == 1 && tm_has(false, s.cout, s.kw, f.cin)) TRY_OR_FREE(hipMalloc(&t->pk_bwd[l], tm_packet_floats(s.cout, s.kw, f.cin) * sizeof(float)));
   }
   // Tensors that need not exist in HBM: output of a plain conv+BN+ReLU layer (no skip in or out) whose only
@@ -793,7 +799,12 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     for (int l = 0; l < L; ++l) {
       const LayerSpec& s = net.layer[l];
       const LayerOff& f = t->off[l];
-      if (t->pk_fwd[l]) {
+      if (t->pk_fwd_x6[l]) {
+        const int ph = rced::tmd::tm_packet_parities(s.cout), cs = tmm::x6_cs(f.cin, ph);
+        const int n = (((s.kw + ph - 1) * cs + 31) / 32) * ((s.cout + 15) / 16) * 64 * 8 + 32;
+        hipLaunchKernelGGL(tmm::pack_packet_x6, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
+                           (const float*)(t->params + f.bias), s.kw, f.cin, s.cout, ph, t->pk_fwd_x6[l]);
+      } else if (t->pk_fwd[l]) {
         const int n = (int)tm_packet_floats(f.cin, s.kw, s.cout);
         hipLaunchKernelGGL(tmm::pack_packet, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
                            (const float*)(t->params + f.bias), s.kw, f.cin, s.cout, 0, rced::tmd::tm_packet_parities(s.cout),
@@ -810,7 +821,11 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     const LayerSpec& s = net.layer[l];
     const LayerOff& f = t->off[l];
     int stat_parts = 0;   // > 0: the conv kernel already left that many (sum z, sum z^2) records in t->part
-    if (t->use_mfma && t->pk_fwd[l] &&
+    if (t->use_mfma && t->pk_fwd_x6[l] &&
+        (stat_parts = rced::tmd::tm_conv_x6(f.cin, s.kw, s.cout, s.use_norm != 0, conv_in(s.src), t->pk_fwd_x6[l], t->z[l], frames,
+                                            t->num_cus, t->part, xform_of(s.src, &xa_tmp), st)) > 0) {
+      if (!s.use_norm) stat_parts = 0;
+    } else if (t->use_mfma && t->pk_fwd[l] &&
         (stat_parts = tm_conv(true, f.cin, s.kw, s.cout, false, s.use_norm != 0, conv_in(s.src), t->pk_fwd[l], t->z[l],
                               frames, t->num_cus, t->part, xform_of(s.src, &xa_tmp), nullptr, st)) > 0) {
       if (!s.use_norm) stat_parts = 0;

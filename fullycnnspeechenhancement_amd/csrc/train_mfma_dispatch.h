@@ -92,6 +92,49 @@ inline size_t tm_packet_floats(int cin, int taps, int cout) {     // Geo::kPacke
   return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + (R ? (size_t)(KR / 8) * 128 + (size_t)((KR % 8 + 3) / 4) * 64 : 0) + 32;
 }
 
+// ---- the forward convolutions in the three-part bf16 form (tmm::conv_x6_fwd) ----
+inline size_t tm_packet_x6_floats(int cin, int taps, int cout) {   // tmm::GeoX6::kPacket
+  const int ph = tm_packet_parities(cout), cs = tmm::x6_cs(cin, ph), K = (taps + ph - 1) * cs;
+  return (size_t)((K + 31) / 32) * ((cout + 15) / 16) * 3 * 64 * 4 + 32;
+}
+template <int CIN, int TAPS, int COUT, bool STATS, int XF>
+int tm_conv_x6_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part, tmm::XformArgs xa,
+                       hipStream_t st) {
+  const int ntiles = (frames + tmm::kTF - 1) / tmm::kTF;
+  const size_t lds = (size_t)(tmm::conv_x6_red_off<CIN, TAPS, COUT, XF>() + (STATS ? tmm::kConvRedFloats : 0)) * sizeof(float);
+  static unsigned long long attr = 0;
+  static int occ = 0;
+  const void* kfn = reinterpret_cast<const void*>(tmm::conv_x6_fwd<CIN, TAPS, COUT, STATS, XF>);
+  allow_lds(kfn, lds, attr);
+  const int grid = std::min(ntiles, std::min(resident_grid(kfn, lds, cus, occ), kPairGrid));
+  hipLaunchKernelGGL((tmm::conv_x6_fwd<CIN, TAPS, COUT, STATS, XF>), dim3(grid), dim3(tmm::kThreads), lds, st, in, packet, out,
+                     frames, part, xa);
+  return grid;
+}
+// forward shapes built in this form: CR-CED's 18 -> 30 layers (no remainder pass; the 30 -> 8 layers' three planes + packet do not
+// leave room for two workgroups per CU: tmm::GeoX6::kFits).  Returns the grid, 0 if not built.
+#define RCED_TM_X6_FWD(X) X(18, 5, 30)
+inline bool tm_x6_has(int cin, int taps, int cout) {
+#define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return true;
+  RCED_TM_X6_FWD(X)
+#undef X
+  return false;
+}
+inline int tm_conv_x6(int cin, int taps, int cout, bool stats, const float* in, const float* packet, float* out, int frames, int cus,
+                      double* part, const tmm::XformArgs* xa, hipStream_t st) {
+  const tmm::XformArgs nx{nullptr, nullptr, nullptr, nullptr};
+#define X(CI, TP, CO)                                                                                                              \
+  if (cin == CI && taps == TP && cout == CO) {                                                                                     \
+    if (xa) return stats ? tm_conv_x6_launch1<CI, TP, CO, true, tmm::kXfBnRelu>(in, packet, out, frames, cus, part, *xa, st)       \
+                         : tm_conv_x6_launch1<CI, TP, CO, false, tmm::kXfBnRelu>(in, packet, out, frames, cus, nullptr, *xa, st);  \
+    return stats ? tm_conv_x6_launch1<CI, TP, CO, true, tmm::kXfNone>(in, packet, out, frames, cus, part, nx, st)                  \
+                 : tm_conv_x6_launch1<CI, TP, CO, false, tmm::kXfNone>(in, packet, out, frames, cus, nullptr, nx, st);             \
+  }
+  RCED_TM_X6_FWD(X)
+#undef X
+  return 0;
+}
+
 constexpr tmm::SumArgs kNoSums{nullptr, nullptr, nullptr, nullptr, nullptr};
 template <int CIN, int TAPS, int COUT, bool ACCUM, bool STATS, int XF, bool SUMS = false>
 int tm_conv_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part,
