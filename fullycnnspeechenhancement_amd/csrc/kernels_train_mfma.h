@@ -553,9 +553,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // channel stride of a plane (bf16 elements): the even-padded channel count rounded to 4 (8-byte aligned windows), plus 4 where a
 // column's stride (ph pixels) would be a multiple of 128 bytes -- all 16 columns of a B fragment on the same banks
 // (30 -> 32 channels with pixel-pair columns: measured 1.50 ms against 0.85 ms for the fp32 kernel)
+#ifndef RCED_X6_ALIGN
+#define RCED_X6_ALIGN 2      // channel stride granularity of the planes: 4 (8-byte aligned windows, two ds_read_b64 per fragment) or
+                             // 2 (the even-padded channel count itself: no K padding per tap, four ds_read_b32 per fragment).
+                             // Measured on the 18 -> 30 forward: K 100 -> 90 (four steps -> three): 0.85 -> 0.78 ms
+#endif
 __host__ __device__ constexpr int x6_cs(int cin, int ph) {
-  const int cs = ((((cin + 1) & ~1) + 3) & ~3);
-  return (ph * cs * 2) % 128 == 0 ? cs + 4 : cs;
+  const int cs = ((((cin + 1) & ~1) + RCED_X6_ALIGN - 1) / RCED_X6_ALIGN) * RCED_X6_ALIGN;
+  return (ph * cs * 2) % 128 == 0 ? cs + RCED_X6_ALIGN : cs;
 }
 template <int CIN, int TAPS, int COUT>
 struct GeoX6 {
@@ -607,8 +612,14 @@ __device__ __forceinline__ void gemm_pass_x6(const unsigned short* in, int off0,
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const unsigned short* q = in + (t < NR ? off0 + t * TSTRIDE : offx) + 32 * s + p * PLANE;
-        const s16x4 lo = *reinterpret_cast<const s16x4*>(q), hi = *reinterpret_cast<const s16x4*>(q + 4);   // 8-byte aligned
-        b[t][p] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if constexpr (RCED_X6_ALIGN == 4) {
+          const s16x4 lo = *reinterpret_cast<const s16x4*>(q), hi = *reinterpret_cast<const s16x4*>(q + 4);   // 8-byte aligned
+          b[t][p] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        } else {
+          const s16x2 q0 = *reinterpret_cast<const s16x2*>(q), q1 = *reinterpret_cast<const s16x2*>(q + 2),
+                      q2 = *reinterpret_cast<const s16x2*>(q + 4), q3 = *reinterpret_cast<const s16x2*>(q + 6);   // 4-byte aligned
+          b[t][p] = s16x8{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+        }
       }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
