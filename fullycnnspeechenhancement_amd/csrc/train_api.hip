@@ -79,7 +79,7 @@ struct rced_trainer {
   std::vector<char> virt;      // virt[id]: tensor id (= relu(bn(z[id-1]))) is never materialised; its consumer rebuilds it
   float* pk_first = nullptr;   // A fragments of the 8xk first layer (rebuilt every step)
   std::vector<float*> pk_fwd_x6;   // the forward packets of the layers that run in the three-part bf16 form (tmm::conv_x6_fwd)
-  bool use_x6 = true;          // RCED_TRAIN_X6=0: every convolution on the fp32 MFMA
+  bool use_x6 = true;          // RCED_TRAIN_X6=0: every convolution on the fp32 MFMA (forward 18 -> 30 layers, the output layer's forward and dgrad)
   float* pk_fin = nullptr, *pk_fin_bwd = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
   float* zero32 = nullptr;
   double *part = nullptr, *sums = nullptr;
@@ -311,8 +311,8 @@ size_t fin_pack_alloc_floats(int ch) {
   const size_t x6 = ((size_t)((129 * ch + 31) / 32) * 9 * 3 * 64 * 8 * sizeof(unsigned short) + 3) / 4;
   return std::max(fin_pack_floats(ch), x6);
 }
-int fin_forward(int ch, const float* h, const float* w, const float* bias, float* pack, float* y, int frames, hipStream_t st) {
-  static const bool use_x6 = !(getenv("RCED_FINAL_X6") && atoi(getenv("RCED_FINAL_X6")) == 0);
+int fin_forward(int ch, const float* h, const float* w, const float* bias, float* pack, float* y, int frames, hipStream_t st,
+                bool use_x6) {
   if (use_x6) {
     // fp32 quality on the bf16 matrix pipe: every operand as three bf16 parts, six MFMAs of K = 32 per product
     const int total6 = ((129 * ch + 31) / 32) * 9 * 64 * 8;
@@ -345,8 +345,7 @@ size_t fin_dgrad_pack_floats(int ch) {   // the fp32 pack, or the three-part bf1
   const size_t mt = (size_t)((129 * ch + 15) / 16);
   return std::max(mt * tmm::kDgSteps * 64, (mt * x6::kDgX6Steps * 3 * 64 * 8 * sizeof(unsigned short) + 3) / 4);
 }
-int fin_dgrad(int ch, const float* dz, const float* w, float* pack, float* dx, int frames, hipStream_t st) {
-  static const bool use_x6 = !(getenv("RCED_FINAL_X6") && atoi(getenv("RCED_FINAL_X6")) == 0);
+int fin_dgrad(int ch, const float* dz, const float* w, float* pack, float* dx, int frames, hipStream_t st, bool use_x6) {
   if (use_x6) {
     const int total6 = ((129 * ch + 15) / 16) * x6::kDgX6Steps * 64 * 8;
     hipLaunchKernelGGL(x6::pack_dgrad_x6_dev, dim3((total6 + 255) / 256), dim3(256), 0, st, w, ch, reinterpret_cast<unsigned short*>(pack));
@@ -834,7 +833,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
                                        t->num_cus, s.use_norm != 0, t->part, st)) > 0) {
       if (!s.use_norm) stat_parts = 0;
     } else if (t->use_mfma && t->pk_fin && is_output_layer(s, f.cin)) {
-      fin_forward(f.cin, tensor(s.src), t->params + f.kernel, t->params + f.bias, t->pk_fin, t->z[l], frames, st);
+      fin_forward(f.cin, tensor(s.src), t->params + f.kernel, t->params + f.bias, t->pk_fin, t->z[l], frames, st, t->use_x6);
     } else if (s.src > 0 && t->virt[s.src]) {
       // a virtual input exists only inside the MFMA kernels' staging: never hand its (null) pointer to the direct kernel
       return rced_fail(RCED_ERR_STATE, "layer %d: no MFMA forward kernel for a layer whose input is not materialised", l);
@@ -1098,7 +1097,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     // dx into G[src] (+=), as a forward conv of dz with the flipped / transposed kernel and the other SAME half
     if (s.src > 0 && !fused_done) {
       if (t->use_mfma && t->pk_fin_bwd && is_output_layer(s, f.cin) && consumers[s.src] == 1) {
-        fin_dgrad(f.cin, dsrc, t->params + f.kernel, t->pk_fin_bwd, t->G[s.src], frames, st);   // overwrites G[src]
+        fin_dgrad(f.cin, dsrc, t->params + f.kernel, t->pk_fin_bwd, t->G[s.src], frames, st, t->use_x6);   // overwrites G[src]
       } else if (const int pl = s.src - 1;   // the layer that produced this dgrad's output tensor
                  fuse_sums_on && t->use_mfma && t->pk_bwd[l] && overwrite(l) && sums_in_dgrad_ok(pl) && [&] {
                    const LayerOff& pf = t->off[pl];

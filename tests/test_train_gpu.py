@@ -226,6 +226,41 @@ def test_sums_from_the_dgrad_agree_with_the_separate_pass(switch, built, monkeyp
         assert cosine(out["1"][1][name], g0) > 1 - 1e-8, name
 
 
+def test_bf16_pipe_kernels_agree_with_the_fp32_mfma_kernels(built, monkeypatch):
+    """RCED_TRAIN_X6: the 18 -> 30 forward convolutions (tmm::conv_x6_fwd) and the output layer's forward and dgrad
+    (kernels_final_x6.h) compute fp32 products as six bf16 MFMAs over three-part operands; RCED_TRAIN_X6=0 keeps the fp32 MFMA
+    kernels.  Same ragged multi-tile batch as above.  The loss must agree to 1e-6.  The gradients are held to the bound the
+    fp64 comparison of this batch uses (5e-3 of the tensor's largest entry, cosine 1 - 2.5e-5): forward values that differ in
+    the last bits move a few of 625 k ReLU masks, and a deep layer's gradient changes by whole terms -- two fp32 arithmetics
+    differ from each other as much as each differs from fp64 (measured: 2.3e-3 on CE1_encode_1/kernel; against fp64 2.7e-3 /
+    4.0e-3).  That the three-part products themselves are exact to fp32 rounding is what the tight element-wise test (inputs
+    without ReLU ties, 5e-6) and tools/micro/f32_on_bf16.hip establish."""
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer
+    w = rced_np.make_weights("FullyCNNV3", seed=27)
+    x = rced_np.make_input(37, 131, seed=41)
+    y = rced_np.make_input(37, 131, seed=42)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RCED_TRAIN_X6", mode)
+        tr = FullyCNNTrainer("FullyCNNV3", batch_size=37, lr=1e-3, weights=w)
+        pred = np.array(tr.valid_step(x))           # the train-mode forward alone: every tile of both arithmetics, element-wise
+        loss, _, _ = tr.train_step(x, y)
+        out[mode] = (loss, tr.gradients(), pred)
+        tr.close()
+    assert abs(out["0"][0] - out["1"][0]) <= 1e-6 * abs(out["0"][0])
+    fwd = np.abs(out["0"][2] - out["1"][2]).max() / np.abs(out["0"][2]).max()
+    assert fwd < 2e-5, fwd                          # (measured ~1e-6: last-bit differences carried through sixteen layers)
+    worst = 0.0
+    for name, g0 in out["0"][1].items():
+        if "moving_" in name or (name.endswith("/bias") and not name.startswith("decode_final")):
+            continue                                        # a bias in front of BatchNorm has gradient 0: rounding noise only
+        worst = max(worst, rel(out["1"][1][name], g0))
+        assert rel(out["1"][1][name], g0) < 5e-3, name
+        assert cosine(out["1"][1][name], g0) > 1 - 2.5e-5, name
+    print("\n[bf16-pipe kernels vs fp32 MFMA kernels] loss %.3e apart, forward %.2e, worst gradient %.2e of its tensor's max"
+          % (abs(out["0"][0] - out["1"][0]) / abs(out["0"][0]), fwd, worst))
+
+
 def test_padded_layout_round_trips_variables_and_adam_state(built):
     """R-CED V2 trains in an even-padded internal layout; what crosses the ABI (variables, gradients, Adam slots) is the
     reference's unpadded layout: get -> set -> get is the identity and a resumed trainer continues like the original."""
