@@ -440,10 +440,15 @@ __device__ __forceinline__ void bnbwd_table_fill(float* table, const BnBwdArgs& 
     table[3 * C + tid] = a.beta ? a.beta[tid] - gr * a.mu[tid] : 0.f;   // b of the folded forward a*z + b (a = gr)
   }
 }
-template <int C, int NTHR = kThreads, class MAP>
+struct NoExtra {
+  __device__ __forceinline__ void operator()(int, int, f32x2) const {}
+};
+// extra(fr, r, v): called with every committed pair (frame of the tile, offset in the frame's [129][C] row, value) -- the fused
+// backward kernel keeps a second copy of dz as bf16 planes for its dgrad half through it
+template <int C, int NTHR = kThreads, class MAP, class EXTRA = NoExtra>
 __device__ __forceinline__ void tile_commit_bnbwd(float* lds, int tid, const f32x4 (&pd)[Stage<C, NTHR>::kPer],
                                                   const f32x4 (&pz)[Stage<C, NTHR>::kPer], MAP map, const float* table,
-                                                  int frame0, int frames, bool mask) {
+                                                  int frame0, int frames, bool mask, EXTRA extra = EXTRA()) {
   using St = Stage<C, NTHR>;
   static_assert(St::kFrame % C == 0 && C % 2 == 0, "frames start at channel 0; float2 pieces stay inside a pixel");
   constexpr int kStep = (4 * St::kStride) % C;   // 0 with RCED_TM_FIXCH: the tables are read once per commit
@@ -480,6 +485,7 @@ __device__ __forceinline__ void tile_commit_bnbwd(float* lds, int tid, const f32
         f32x2 v = {fmaf(A.x, d.x, fmaf(B.x, pz[i][2 * h], K.x)), fmaf(A.y, d.y, fmaf(B.y, pz[i][2 * h + 1], K.y))};
         if (frame0 + fr >= frames) v = f32x2{0.f, 0.f};      // frames past the batch stay zero
         *reinterpret_cast<f32x2*>(lds + map(fr, r)) = v;
+        extra(fr, r, v);
       }
     }
     c += kStep;
@@ -679,8 +685,9 @@ __device__ __forceinline__ void tile_commit_x6(unsigned short* planes, int tid, 
   }
 }
 // The weights (TF layout [TAPS][CIN][COUT]) as the three-part packet of a FORWARD convolution (pack_packet's transpose = 0).
+// transpose = 1: the dgrad's packet (pack_packet's convention: cin / cout are those of the conv being packed).
 static __global__ void pack_packet_x6(const float* __restrict__ w, const float* __restrict__ shift, int taps, int cin, int cout,
-                                      int ph, float* __restrict__ packet) {
+                                      int ph, float* __restrict__ packet, int transpose = 0) {
   const int cs = x6_cs(cin, ph), K = (taps + ph - 1) * cs, steps = (K + 31) / 32, MT = (cout + 15) / 16;
   const int ndata = steps * MT * 64 * 8;            // one thread per (S, mt, lane, e); the three parts by the same thread
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -698,7 +705,9 @@ static __global__ void pack_packet_x6(const float* __restrict__ w, const float* 
     tap -= co >> 3;
     co &= 7;
   }
-  const float v = (k < K && co < cout && ci < cin && tap >= 0 && tap < taps) ? w[(tap * cin + ci) * cout + co] : 0.f;
+  float v = 0.f;
+  if (k < K && co < cout && ci < cin && tap >= 0 && tap < taps)
+    v = transpose ? w[((taps - 1 - tap) * cout + co) * cin + ci] : w[(tap * cin + ci) * cout + co];
   const __bf16 h = (__bf16)v;
   const float r1 = v - (float)h;
   const __bf16 m = (__bf16)r1;
@@ -742,7 +751,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
   static_assert(!(SUMS && (STATS || (COUT & 1))), "SUMS: dgrads with an even cout");
   static_assert(!(SUMS && SUMX && (ACCUM || G::kPH != 1)), "SUMX: the fused backward kernel's overwriting, unpaired dgrad");
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMTm, PH = G::kPH;   // MT: M-tiles of the MAIN pass
-  static_assert(!X6 || (!KS && XMT < 0 && !SUMS && !ACCUM && G::kR == 0), "the three-part bf16 form: plain forward convolutions");
+  static_assert(!X6 || (!KS && XMT < 0 && (!SUMS || SUMX) && !ACCUM && G::kR == 0), "the three-part bf16 form: no remainder pass, no K split");
   constexpr int kShiftOff = conv_shift_off<X6, CIN, TAPS, COUT>();
   const float* in = lds_in + G::kG * G::kCinP;
   // XMT >= 0 (two-M-tile shapes, RCED_TM_MSPLIT): the odd column tile is cut by M-tile -- this wave's extra slot computes
@@ -1622,6 +1631,21 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void wgrad1xk_mfma(const flo
 // CIN / COUT are the LAYER's (x has CIN channels, dz COUT); the packet is the dgrad packet (pack_packet transpose = 1).
 // ---------------------------------------------------------------------------------------------
 constexpr int kBwdThreads = 512;
+#ifndef RCED_TM_BWD_X6_C
+#define RCED_TM_BWD_X6_C 1   // bwd_fused_mfma<30,9,8>: its dgrad half (8 -> 30, no remainder pass) in the three-part bf16 form (GeoX6)
+#endif
+// fused backward shapes whose dgrad half runs on the bf16 pipe: the host packs their dgrad packet with pack_packet_x6
+__host__ __device__ constexpr bool bwd_x6(int cin, int taps, int cout) { return RCED_TM_BWD_X6_C && cin == 30 && taps == 9 && cout == 8; }
+template <int CIN, int TAPS, int COUT, bool X6D>
+struct BwdX6Sizes {      // floats the dgrad's packet region and its planes take
+  static constexpr int kPacket = Geo<COUT, TAPS, CIN>::kPacket, kPlanes = 0;
+};
+template <int CIN, int TAPS, int COUT>
+struct BwdX6Sizes<CIN, TAPS, COUT, true> {
+  using GX = GeoX6<COUT, TAPS, CIN>;
+  static constexpr int kPacket = GX::kPacket > Geo<COUT, TAPS, CIN>::kPacket ? GX::kPacket : Geo<COUT, TAPS, CIN>::kPacket;
+  static constexpr int kPlanes = GX::kInFloats;
+};
 template <int CIN, int TAPS, int COUT>
 struct BwdGeo {
   using GD = Geo<COUT, TAPS, CIN>;     // the dgrad convolution: dz (COUT channels) -> dx (CIN channels)
@@ -1629,14 +1653,17 @@ struct BwdGeo {
   static constexpr int r4(int v) { return (v + 3) & ~3; }
   static constexpr int kDzOff = 0;                                   // [GD::kInRows][COUT] (+ slack for the last group's reads)
   static constexpr int kPkOff = r4(GD::kInFloats + 64);
-  static constexpr int kXOff = r4(kPkOff + GD::kPacket);             // [GW::kInRows][CIN] (+ slack)
+  static constexpr bool kX6D = bwd_x6(CIN, TAPS, COUT);
+  using XS = BwdX6Sizes<CIN, TAPS, COUT, kX6D>;
+  static constexpr int kXOff = r4(kPkOff + XS::kPacket);             // [GW::kInRows][CIN] (+ slack)
   static constexpr int kTabOff = r4(kXOff + GW::kInFloats + 64);     // [2][CIN] BatchNorm + ReLU of x, then [4][COUT] BatchNorm backward
   static constexpr int kRedOff = r4(kTabOff + 2 * CIN + 4 * COUT);   // [4 waves][32][2] doubles
   // raw copies of the NEXT tile (LDS-DMA targets, RCED_TM_BWD_DMA): x [2][129][CIN], d_u / g [2][129][COUT], z [2][129][COUT]
   static constexpr int kStgX = r4(kRedOff + kConvRedFloats);
   static constexpr int kStgD = kStgX + r4(kTF * kF * CIN);
   static constexpr int kStgZ = kStgD + r4(kTF * kF * COUT);
-  static constexpr int kLdsFloats = RCED_TM_BWD_DMA ? kStgZ + r4(kTF * kF * COUT) : kRedOff + kConvRedFloats;
+  static constexpr int kPlOff = r4(RCED_TM_BWD_DMA ? kStgZ + r4(kTF * kF * COUT) : kRedOff + kConvRedFloats);   // dz as three bf16 planes (kX6D)
+  static constexpr int kLdsFloats = kPlOff + XS::kPlanes;
   static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
   static_assert(GD::kG == GW::kG && GD::kS == GW::kS, "one pixel space");
 };
@@ -1714,6 +1741,10 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
   using GW = typename B::GW;
   static_assert(CIN % 2 == 0 && COUT % 2 == 0, "wide staging");
   constexpr int NTH = kBwdThreads;
+  // X6D: the dgrad half in the three-part bf16 form -- dz is committed a second time as bf16 planes (tile_commit_bnbwd's
+  // `extra`), the packet arrives from pack_packet_x6, conv_tile runs gemm_pass_x6; the wgrad half reads the fp32 dz tile as before
+  constexpr bool X6D = B::kX6D;
+  constexpr int kPkFloats = X6D ? BwdX6Sizes<CIN, TAPS, COUT, X6D>::kPacket : GD::kPacket;
   constexpr int PH = COUT == 8 ? 2 : 1;                       // wgrad column packing (see wgrad1xk_mfma)
   constexpr int kRowsK = (TAPS + PH - 1) * GW::kCinP;
   constexpr int KT = (kRowsK + 1 + 15) / 16, NTo = PH == 2 ? 1 : GW::kMT;
@@ -1733,7 +1764,7 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
   const int role = wave8 >> 2, wave = wave8 & 3;              // role 0: dgrad, 1: wgrad
   const int i = lane & 15, kq = lane >> 4;
   for (int e = tid; e < B::kLdsFloats; e += NTH)
-    lds[e] = (e >= B::kPkOff && e < B::kPkOff + GD::kPacket) ? packet[e - B::kPkOff] : 0.f;
+    lds[e] = (e >= B::kPkOff && e < B::kPkOff + kPkFloats) ? packet[e - B::kPkOff] : 0.f;
   __syncthreads();
   if constexpr (XF) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
   bnbwd_table_fill<COUT>(dt, ba, tid);
@@ -1834,8 +1865,24 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
       stage_load<COUT, ZN>(sd, tid, pred);
       stage_load<COUT, ZN>(sz, tid, prez);
     }
-    if (!(OWN & 2) || role == 0)
-      tile_commit_bnbwd<COUT, ZN>(ldz, tid, pred, prez, where_dz, dt, frame0, frames, ba.beta != nullptr);
+    if (!(OWN & 2) || role == 0) {
+      if constexpr (X6D) {
+        using GX = GeoX6<COUT, TAPS, CIN>;
+        unsigned short* planes = reinterpret_cast<unsigned short*>(lds + B::kPlOff);
+        auto to_planes = [&](int fr, int r, f32x2 v) {
+          const int px = r / COUT, c = r - px * COUT;
+          s16x2 ph, pm, pl;
+          split3_pair(v, ph, pm, pl);
+          unsigned short* d = planes + (GD::kG + fr * GD::kS + px) * GX::kCS + c;
+          *reinterpret_cast<s16x2*>(d) = ph;
+          *reinterpret_cast<s16x2*>(d + GX::kPlane) = pm;
+          *reinterpret_cast<s16x2*>(d + 2 * GX::kPlane) = pl;
+        };
+        tile_commit_bnbwd<COUT, ZN>(ldz, tid, pred, prez, where_dz, dt, frame0, frames, ba.beta != nullptr, to_planes);
+      } else {
+        tile_commit_bnbwd<COUT, ZN>(ldz, tid, pred, prez, where_dz, dt, frame0, frames, ba.beta != nullptr);
+      }
+    }
     TM_ST(1);   // commit
     __syncthreads();
     TM_ST(2);   // barrier 1
@@ -1880,8 +1927,9 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
           pin();
         }
       };
-      if (wave < GD::kExtra) conv_tile<COUT, TAPS, CIN, false, false, 1, SUMS, false, true, decltype(each), true, RCED_TM_BWD_DEPTH>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx, nullptr, each, accs, nullptr, nullptr, sums, carried, flush);
-      else conv_tile<COUT, TAPS, CIN, false, false, 0, SUMS, false, true, decltype(each), true, RCED_TM_BWD_DEPTH>(ldz, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx, nullptr, each, accs, nullptr, nullptr, sums, carried, flush);
+      const float* dgin = X6D ? lds + B::kPlOff : ldz;      // the dgrad's input tile: bf16 planes, or the fp32 dz tile
+      if (wave < GD::kExtra) conv_tile<COUT, TAPS, CIN, false, false, 1, SUMS, false, true, decltype(each), true, RCED_TM_BWD_DEPTH, false, -1, X6D>(dgin, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx, nullptr, each, accs, nullptr, nullptr, sums, carried, flush);
+      else conv_tile<COUT, TAPS, CIN, false, false, 0, SUMS, false, true, decltype(each), true, RCED_TM_BWD_DEPTH, false, -1, X6D>(dgin, lw, dx, frame0, frames, wave, lane, red + wave * 64, lx, nullptr, each, accs, nullptr, nullptr, sums, carried, flush);
     } else {
       // Groups of this wgrad wave: a contiguous range sized so that every SIMD (dgrad wave w + wgrad wave w) issues the
       // same number of MFMAs per tile -- the dgrad wave that carries the odd column tile gets fewer groups beside it

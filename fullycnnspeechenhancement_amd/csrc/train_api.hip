@@ -79,6 +79,7 @@ struct rced_trainer {
   std::vector<char> virt;      // virt[id]: tensor id (= relu(bn(z[id-1]))) is never materialised; its consumer rebuilds it
   float* pk_first = nullptr;   // A fragments of the 8xk first layer (rebuilt every step)
   std::vector<float*> pk_fwd_x6;   // the forward packets of the layers that run in the three-part bf16 form (tmm::conv_x6_fwd)
+  std::vector<float*> pk_bwd_x6;   // the dgrad packets of the fused backward kernels whose dgrad half runs in that form (tmm::bwd_x6)
   bool use_x6 = true;          // RCED_TRAIN_X6=0: every convolution on the fp32 MFMA (forward 18 -> 30 layers, the output layer's forward and dgrad)
   float* pk_fin = nullptr, *pk_fin_bwd = nullptr;     // Toeplitz A fragments of the 1x129 output layer (rebuilt every step)
   float* zero32 = nullptr;
@@ -104,6 +105,7 @@ struct rced_trainer {
     for (auto* p : pk_fwd) fr(p);
     for (auto* p : pk_bwd) fr(p);
     for (auto* p : pk_fwd_x6) fr(p);
+    for (auto* p : pk_bwd_x6) fr(p);
     fr(pk_fin);
     fr(pk_fin_bwd);
     fr(pk_first);
@@ -623,7 +625,7 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
   }
   t->wf.assign(L, nullptr); t->wt.assign(L, nullptr); t->bias4.assign(L, nullptr);
   t->mu.assign(L, nullptr); t->rstd.assign(L, nullptr);
-  t->pk_fwd.assign(L, nullptr); t->pk_bwd.assign(L, nullptr); t->pk_fwd_x6.assign(L, nullptr);
+  t->pk_fwd.assign(L, nullptr); t->pk_bwd.assign(L, nullptr); t->pk_fwd_x6.assign(L, nullptr); t->pk_bwd_x6.assign(L, nullptr);
   for (int l = 0; l < L; ++l) {
     const LayerSpec& s = net->layer[l];
     const LayerOff& f = t->off[l];
@@ -639,6 +641,8 @@ int rced_train_create(int variant, const float* blob, size_t n_floats, int batch
     if (t->use_x6 && s.kh == 1 && t->pk_fwd[l] && rced::tmd::tm_x6_has(f.cin, s.kw, s.cout))
       TRY_OR_FREE(hipMalloc(&t->pk_fwd_x6[l], rced::tmd::tm_packet_x6_floats(f.cin, s.kw, s.cout) * sizeof(float)));
     if (s.kh == 1 && tm_has(false, s.cout, s.kw, f.cin)) TRY_OR_FREE(hipMalloc(&t->pk_bwd[l], tm_packet_floats(s.cout, s.kw, f.cin) * sizeof(float)));
+    if (t->pk_bwd[l] && tmm::bwd_x6(f.cin, s.kw, s.cout))   // (compiled into the fused kernel of this shape: not a per-trainer switch)
+      TRY_OR_FREE(hipMalloc(&t->pk_bwd_x6[l], rced::tmd::tm_packet_x6_floats(s.cout, s.kw, f.cin) * sizeof(float)));
   }
   // Tensors that need not exist in HBM: output of a plain conv+BN+ReLU layer (no skip in or out) whose only
   // consumer is a 1xk layer with MFMA forward and wgrad kernels.  RCED_TRAIN_FUSE_ACT=0 turns this off.
@@ -808,6 +812,14 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
         hipLaunchKernelGGL(tmm::pack_packet, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
                            (const float*)(t->params + f.bias), s.kw, f.cin, s.cout, 0, rced::tmd::tm_packet_parities(s.cout),
                            t->pk_fwd[l]);
+      }
+      if (t->pk_bwd_x6[l]) {
+        // the fused backward kernel of this shape runs its dgrad half in the three-part bf16 form: its packet in that form too
+        // (the fp32 packet below stays: the separate dgrad kernel takes it when the fused one is not used)
+        const int ph = rced::tmd::tm_packet_parities(f.cin), cs = tmm::x6_cs(s.cout, ph);
+        const int n = (((s.kw + ph - 1) * cs + 31) / 32) * ((f.cin + 15) / 16) * 64 * 8 + 32;
+        hipLaunchKernelGGL(tmm::pack_packet_x6, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
+                           (const float*)nullptr, s.kw, s.cout, f.cin, ph, t->pk_bwd_x6[l], 1);
       }
       if (t->pk_bwd[l]) {
         const int n = (int)tm_packet_floats(s.cout, s.kw, f.cin);
@@ -1064,7 +1076,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       const int pl = s.src - 1;
       const bool xvirt = t->virt[s.src] != 0, want_sums = fuse_sums_on && sums_in_dgrad_ok(pl);
       if (xvirt == want_sums) {
-        const int g = tm_bwd_fused(f.cin, s.kw, s.cout, xvirt, conv_in(s.src), dsrc, t->pk_bwd[l], t->G[s.src], t->grads + f.kernel,
+        const int g = tm_bwd_fused(f.cin, s.kw, s.cout, xvirt, conv_in(s.src), dsrc, t->pk_bwd_x6[l] ? t->pk_bwd_x6[l] : t->pk_bwd[l], t->G[s.src], t->grads + f.kernel,
                                    t->grads + f.bias, frames, t->num_cus, t->part, xform_of(s.src, &xa_tmp), ba, st);
         if (g > 0) {
           fused_done = true;
