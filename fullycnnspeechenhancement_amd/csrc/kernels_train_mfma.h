@@ -576,7 +576,10 @@ struct GeoX6 {
   static constexpr int kSteps = (kKX + 31) / 32;
   static constexpr int kPlane = ((G::kInRows * kCS + 32 + 7) / 8) * 8;   // bf16 per part; + 32: the last step reads past its window
   static constexpr int kInFloats = ((3 * kPlane / 2 + 3) / 4) * 4;       // the three parts, counted in floats
-  static constexpr int kDataFloats = kSteps * G::kMTm * 3 * 64 * 4;      // A fragments: 16 bytes per (step, M-tile, part, lane)
+  // remainder pass (G::kR channels past the first M-tile; Geo): rows (pixel phase, channel) over K = (TAPS + P - 1) * kCS
+  static constexpr int kKXR = G::kR ? (TAPS + G::kP - 1) * kCS : 0, kStepsR = (kKXR + 31) / 32;
+  static constexpr int kDataMainFloats = kSteps * G::kMTm * 3 * 64 * 4;  // A fragments: 16 bytes per (step, M-tile, part, lane)
+  static constexpr int kDataFloats = kDataMainFloats + kStepsR * 3 * 64 * 4;
   static constexpr int kPacket = kDataFloats + 32;                       // + shift[32]
   static constexpr int kShiftOff = kDataFloats;
   static constexpr int kLdsFloats = kInFloats + kPacket;
@@ -585,7 +588,6 @@ struct GeoX6 {
   // streamed from L2 instead (every wave re-reads 37 KB per two-frame tile: ~9 TB/s of L2 traffic over the chip) 1.07 ms,
   // against 0.85 ms for the fp32 kernel -- so it stays on the fp32 MFMA, and this form is built where it fits.
   static constexpr bool kFits = kLdsFloats * 4 <= 76 * 1024;
-  static_assert(G::kR == 0, "built for the shapes without a remainder pass (30 and 8 output channels)");
 };
 __device__ __forceinline__ f32x4 mfma32(s16x8 a, s16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -688,32 +690,51 @@ __device__ __forceinline__ void tile_commit_x6(unsigned short* planes, int tid, 
 // transpose = 1: the dgrad's packet (pack_packet's convention: cin / cout are those of the conv being packed).
 static __global__ void pack_packet_x6(const float* __restrict__ w, const float* __restrict__ shift, int taps, int cin, int cout,
                                       int ph, float* __restrict__ packet, int transpose = 0) {
-  const int cs = x6_cs(cin, ph), K = (taps + ph - 1) * cs, steps = (K + 31) / 32, MT = (cout + 15) / 16;
-  const int ndata = steps * MT * 64 * 8;            // one thread per (S, mt, lane, e); the three parts by the same thread
+  const int R = ph == 1 ? tm_rem(cout) : 0, P = R ? 16 / R : 0;
+  const int cs = x6_cs(cin, ph), K = (taps + ph - 1) * cs, steps = (K + 31) / 32, MT = R ? 1 : (cout + 15) / 16;
+  const int KR = R ? (taps + P - 1) * cs : 0, stepsR = (KR + 31) / 32;
+  const int nmain = steps * MT * 64 * 8, nrem = stepsR * 64 * 8;   // one thread per (S, mt, lane, e); the three parts by the same thread
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ndata + 32) return;
-  if (idx >= ndata) {
-    const int c = idx - ndata;
-    packet[steps * MT * 3 * 64 * 4 + c] = (shift && c < ph * cout) ? shift[ph == 2 ? (c & 7) : c] : 0.f;
+  if (idx >= nmain + nrem + 32) return;
+  const int data_floats = (steps * MT + stepsR) * 3 * 64 * 4;
+  if (idx >= nmain + nrem) {
+    const int c = idx - nmain - nrem;
+    float v;
+    if (R) v = !shift ? 0.f : (c < 16 ? shift[c] : shift[16 + (c - 16) % R]);   // 16 main channels, 16 remainder rows
+    else v = (shift && c < ph * cout) ? shift[ph == 2 ? (c & 7) : c] : 0.f;
+    packet[data_floats + c] = v;
     return;
   }
-  const int e = idx & 7, lane = (idx >> 3) & 63, r = idx >> 9, mt = r % MT, S = r / MT;
-  const int k = 32 * S + 8 * (lane >> 4) + e;
-  int co = 16 * mt + (lane & 15), tap = k / cs;
+  int k, co, tap_shift = 0, klim = K;
+  size_t base;
+  if (idx < nmain) {
+    const int e = idx & 7, lane = (idx >> 3) & 63, r = idx >> 9, mt = r % MT, S = r / MT;
+    k = 32 * S + 8 * (lane >> 4) + e;
+    co = 16 * mt + (lane & 15);
+    base = ((size_t)(S * MT + mt) * 3) * 512 + lane * 8 + e;
+  } else {     // remainder pass: row i = (phase i / R, channel 16 + i % R) over K = (taps + P - 1) * cs
+    const int q = idx - nmain, e = q & 7, lane = (q >> 3) & 63, S = q >> 9, i = lane & 15;
+    k = 32 * S + 8 * (lane >> 4) + e;
+    tap_shift = i / R;
+    co = 16 + i % R;
+    klim = KR;
+    base = ((size_t)steps * MT * 3 + (size_t)S * 3) * 512 + lane * 8 + e;
+  }
+  int tap = k / cs;
   const int ci = k - tap * cs;
+  tap -= tap_shift;
   if (ph == 2) {            // row = (parity, co): the parity-1 rows see the window one tap later
     tap -= co >> 3;
     co &= 7;
   }
   float v = 0.f;
-  if (k < K && co < cout && ci < cin && tap >= 0 && tap < taps)
+  if (k < klim && co < cout && ci < cin && tap >= 0 && tap < taps)
     v = transpose ? w[((taps - 1 - tap) * cout + co) * cin + ci] : w[(tap * cin + ci) * cout + co];
   const __bf16 h = (__bf16)v;
   const float r1 = v - (float)h;
   const __bf16 m = (__bf16)r1;
   const __bf16 l = (__bf16)(r1 - (float)m);
   unsigned short* p16 = reinterpret_cast<unsigned short*>(packet);
-  const size_t base = ((size_t)(S * MT + mt) * 3) * 512 + lane * 8 + e;
   p16[base] = __builtin_bit_cast(unsigned short, h);
   p16[base + 512] = __builtin_bit_cast(unsigned short, m);
   p16[base + 1024] = __builtin_bit_cast(unsigned short, l);
@@ -751,7 +772,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
   static_assert(!(SUMS && (STATS || (COUT & 1))), "SUMS: dgrads with an even cout");
   static_assert(!(SUMS && SUMX && (ACCUM || G::kPH != 1)), "SUMX: the fused backward kernel's overwriting, unpaired dgrad");
   constexpr int NR = G::kRegular, NT = NR + NX, MT = G::kMTm, PH = G::kPH;   // MT: M-tiles of the MAIN pass
-  static_assert(!X6 || (!KS && XMT < 0 && (!SUMS || SUMX) && !ACCUM && G::kR == 0), "the three-part bf16 form: no remainder pass, no K split");
+  static_assert(!X6 || (!KS && XMT < 0 && (!SUMS || SUMX) && !ACCUM), "the three-part bf16 form: overwriting, no K split");
   constexpr int kShiftOff = conv_shift_off<X6, CIN, TAPS, COUT>();
   const float* in = lds_in + G::kG * G::kCinP;
   // XMT >= 0 (two-M-tile shapes, RCED_TM_MSPLIT): the odd column tile is cut by M-tile -- this wave's extra slot computes
@@ -1040,11 +1061,17 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
     static_assert(G::kR == 2 && (COUT & 1) == 0 && !KS, "the 18-channel form");
     constexpr int P = G::kP, KR = G::kKR;
     const float* wr = lds_w + G::kDataMain;
-    const f32x4 rsh = *reinterpret_cast<const f32x4*>(lds_w + G::kData + 16 + 4 * kq);
+    const f32x4 rsh = *reinterpret_cast<const f32x4*>(lds_w + kShiftOff + 16 + 4 * kq);
 #pragma unroll 1
     for (int rt = 3 - wave; rt < G::kNRT; rt += kWaves) {
       const int pb = P * (16 * rt + n);                    // first pixel of this lane's column
       f32x4 racc[1][1] = {{rsh}};
+      if constexpr (X6) {
+        using GX = GeoX6<CIN, TAPS, COUT>;
+        const unsigned short* inx = reinterpret_cast<const unsigned short*>(lds_in) + G::kG * GX::kCS;
+        gemm_pass_x6<1, 0, 1, GX::kStepsR, 0, GX::kPlane>(inx, (pb - G::kG) * GX::kCS + 8 * kq, 0,
+                                                          reinterpret_cast<const s16x8*>(lds_w) + GX::kSteps * MT * 3 * 64, lane, racc);
+      } else
       chain::gemm_pass<1, 0, 1, KR, 0, 1>(in, (pb - G::kG) * G::kCinP + 2 * kq, 0, wr, lane, racc);
       const float vv[4] = {racc[0][0].x, racc[0][0].y, racc[0][0].z, racc[0][0].w};
 #pragma unroll
@@ -1392,7 +1419,7 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv_x6_fwd(const float
   float* lw = lds + GX::kInFloats;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  static_assert(GX::kFits, "two workgroups per CU");
+  static_assert(GX::kFits && G::kR == 0, "two workgroups per CU; the forward form has no remainder pass");
   for (int e = tid; e < GX::kLdsFloats; e += kThreads) lds[e] = e < GX::kInFloats ? 0.f : packet[e - GX::kInFloats];
   float* xt = lds + GX::kLdsFloats;                      // [2][CIN], only with XF
   if constexpr (XF == kXfBnRelu) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);
@@ -1635,7 +1662,15 @@ constexpr int kBwdThreads = 512;
 #define RCED_TM_BWD_X6_C 1   // bwd_fused_mfma<30,9,8>: its dgrad half (8 -> 30, no remainder pass) in the three-part bf16 form (GeoX6)
 #endif
 // fused backward shapes whose dgrad half runs on the bf16 pipe: the host packs their dgrad packet with pack_packet_x6
-__host__ __device__ constexpr bool bwd_x6(int cin, int taps, int cout) { return RCED_TM_BWD_X6_C && cin == 30 && taps == 9 && cout == 8; }
+#ifndef RCED_TM_BWD_X6_B
+#define RCED_TM_BWD_X6_B 0   // bwd_fused_mfma<18,5,30>: its dgrad half (30 -> 18: main pass + remainder pass) likewise.  Measured
+                             // 3.2 ms against 2.35 ms: with ONE M-tile a B fragment (48 bytes per lane for the three parts) feeds only six
+                             // MFMAs (96 cycles) -- four dgrad waves saturate the LDS port (24 cycles per fragment each); the
+                             // two-M-tile shapes (8 -> 30 dgrad, 18 -> 30 forward) reuse every fragment twice and gain.  Off.
+#endif
+__host__ __device__ constexpr bool bwd_x6(int cin, int taps, int cout) {
+  return (RCED_TM_BWD_X6_C && cin == 30 && taps == 9 && cout == 8) || (RCED_TM_BWD_X6_B && cin == 18 && taps == 5 && cout == 30);
+}
 template <int CIN, int TAPS, int COUT, bool X6D>
 struct BwdX6Sizes {      // floats the dgrad's packet region and its planes take
   static constexpr int kPacket = Geo<COUT, TAPS, CIN>::kPacket, kPlanes = 0;

@@ -803,10 +803,9 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       const LayerSpec& s = net.layer[l];
       const LayerOff& f = t->off[l];
       if (t->pk_fwd_x6[l]) {
-        const int ph = rced::tmd::tm_packet_parities(s.cout), cs = tmm::x6_cs(f.cin, ph);
-        const int n = (((s.kw + ph - 1) * cs + 31) / 32) * ((s.cout + 15) / 16) * 64 * 8 + 32;
+        const int n = rced::tmd::tm_packet_x6_threads(f.cin, s.kw, s.cout);
         hipLaunchKernelGGL(tmm::pack_packet_x6, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
-                           (const float*)(t->params + f.bias), s.kw, f.cin, s.cout, ph, t->pk_fwd_x6[l]);
+                           (const float*)(t->params + f.bias), s.kw, f.cin, s.cout, rced::tmd::tm_packet_parities(s.cout), t->pk_fwd_x6[l]);
       } else if (t->pk_fwd[l]) {
         const int n = (int)tm_packet_floats(f.cin, s.kw, s.cout);
         hipLaunchKernelGGL(tmm::pack_packet, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
@@ -816,10 +815,9 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       if (t->pk_bwd_x6[l]) {
         // the fused backward kernel of this shape runs its dgrad half in the three-part bf16 form: its packet in that form too
         // (the fp32 packet below stays: the separate dgrad kernel takes it when the fused one is not used)
-        const int ph = rced::tmd::tm_packet_parities(f.cin), cs = tmm::x6_cs(s.cout, ph);
-        const int n = (((s.kw + ph - 1) * cs + 31) / 32) * ((f.cin + 15) / 16) * 64 * 8 + 32;
+        const int n = rced::tmd::tm_packet_x6_threads(s.cout, s.kw, f.cin);
         hipLaunchKernelGGL(tmm::pack_packet_x6, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)(t->params + f.kernel),
-                           (const float*)nullptr, s.kw, s.cout, f.cin, ph, t->pk_bwd_x6[l], 1);
+                           (const float*)nullptr, s.kw, s.cout, f.cin, rced::tmd::tm_packet_parities(f.cin), t->pk_bwd_x6[l], 1);
       }
       if (t->pk_bwd[l]) {
         const int n = (int)tm_packet_floats(s.cout, s.kw, f.cin);

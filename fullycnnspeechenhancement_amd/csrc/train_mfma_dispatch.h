@@ -95,7 +95,11 @@ inline size_t tm_packet_floats(int cin, int taps, int cout) {     // Geo::kPacke
 // ---- the forward convolutions in the three-part bf16 form (tmm::conv_x6_fwd) ----
 inline size_t tm_packet_x6_floats(int cin, int taps, int cout) {   // tmm::GeoX6::kPacket
   const int ph = tm_packet_parities(cout), cs = tmm::x6_cs(cin, ph), K = (taps + ph - 1) * cs;
-  return (size_t)((K + 31) / 32) * ((cout + 15) / 16) * 3 * 64 * 4 + 32;
+  const int R = ph == 1 ? tmm::tm_rem(cout) : 0, P = R ? 16 / R : 0, KR = R ? (taps + P - 1) * cs : 0;
+  return (size_t)(((K + 31) / 32) * (R ? 1 : (cout + 15) / 16) + (KR + 31) / 32) * 3 * 64 * 4 + 32;
+}
+inline int tm_packet_x6_threads(int cin, int taps, int cout) {     // pack_packet_x6: one thread per (step, M-tile, lane, element) + 32 shifts
+  return (int)((tm_packet_x6_floats(cin, taps, cout) - 32) / (3 * 4) * 8) + 32;
 }
 template <int CIN, int TAPS, int COUT, bool STATS, int XF>
 int tm_conv_x6_launch1(const float* in, const float* packet, float* out, int frames, int cus, double* part, tmm::XformArgs xa,
