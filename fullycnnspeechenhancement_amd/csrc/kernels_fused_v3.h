@@ -660,6 +660,10 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave, 
 // publishes it through LDS scratch + a tagged flag word before its regular tiles, and the reducer picks it up after
 // its last job, when it has long been there.  Scratch: in the B8 buffer, which is dead during layer 2 (layer 3
 // rewrites every real pixel of it).
+#ifndef RCED_V3_EXP_L2HALF
+#define RCED_V3_EXP_L2HALF 0   // timing experiment only (wrong results): layer 2's pair jobs issue half of their MFMAs -- what a form of
+                               // this layer with half the matrix-pipe cycles (the three-part bf16 form) could return at most
+#endif
 #ifndef RCED_L2_CUT
 #define RCED_L2_CUT 6
 #endif
@@ -762,7 +766,7 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
           acc[p][0][1] = mfma(a[r][1].x, b[r][0].x, acc[p][0][1]);
           acc[p][1][0] = mfma(a[r][0].x, b[r][1].x, acc[p][1][0]);
           acc[p][1][1] = mfma(a[r][1].x, b[r][1].x, acc[p][1][1]);
-          if constexpr (st < kL2Steps) {
+          if constexpr (st < kL2Steps && !RCED_V3_EXP_L2HALF) {
             acc[p][0][0] = mfma(a[r][0].y, b[r][0].y, acc[p][0][0]);
             acc[p][0][1] = mfma(a[r][1].y, b[r][0].y, acc[p][0][1]);
             acc[p][1][0] = mfma(a[r][0].y, b[r][1].y, acc[p][1][0]);
