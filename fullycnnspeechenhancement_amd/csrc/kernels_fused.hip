@@ -16,6 +16,14 @@
 
 using namespace rced;
 
+inline unsigned short bf16_rne(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
 struct rced_fused {
   float* scratch = nullptr;   // V1/V2: skip fragments, per workgroup
   size_t scratch_bytes = 0;
@@ -102,6 +110,25 @@ void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>*
         const int co = 16 * mt + i;
         return (k < 90 && co < 30) ? wq(l2, k / 18, k % 18, co, 18) : 0.f;
       };
+#if RCED_V3_L2X6
+      // x6 form: [chunk][M-tile][part][lane] x 8 bf16, k = 32 c + 8 kq + e; every weight as three bf16 parts
+      unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+      auto b2f = [](unsigned short b) { const unsigned u = (unsigned)b << 16; float v; memcpy(&v, &u, 4); return v; };
+      for (int c = 0; c < v3::kL2Chunks; ++c)
+        for (int mt = 0; mt < 2; ++mt)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+              const float v = w2(lane & 15, mt, 32 * c + 8 * (lane >> 4) + e);
+              const unsigned short h = bf16_rne(v);
+              const float r1 = v - b2f(h);
+              const unsigned short mm = bf16_rne(r1);
+              const unsigned short l = bf16_rne(r1 - b2f(mm));
+              const size_t base = ((size_t)(c * 2 + mt) * 3) * 512 + lane * 8 + e;
+              d16[base] = h;
+              d16[base + 512] = mm;
+              d16[base + 1024] = l;
+            }
+#else
       for (int s = 0; s < v3::kL2Steps; ++s)
         for (int mt = 0; mt < 2; ++mt)
           for (int lane = 0; lane < 64; ++lane)
@@ -110,6 +137,7 @@ void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>*
       for (int mt = 0; mt < 2; ++mt)
         for (int lane = 0; lane < 64; ++lane)
           dst[v3::kL2Steps * 2 * 128 + mt * 64 + lane] = w2(lane & 15, mt, 8 * v3::kL2Steps + (lane >> 4));
+#endif
     }
     put_shift(dst + v3::kW2Data, 3 * blk + 1);
     dst += v3::kW2;
@@ -266,13 +294,6 @@ int chain_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb
   return RCED_OK;
 }
 
-inline unsigned short bf16_rne(float f) {
-  unsigned u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;   // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
 template <class N>
 int chain_create(rced_model* m, rced_fused* f) {
   using G = chain::Geo<N>;

@@ -132,7 +132,17 @@ constexpr int kW1Main = 9 * 128;          // 1152 (= 18 * 64 for the first layer
 constexpr int kW1Rem = 16 * 128;          // 2048 (= 32 * 64 for the first layer)
 constexpr int kW1Data = kW1Main + kW1Rem; // 3200
 constexpr int kL2Steps = 11, kL3Steps = 37;                  // b64 steps; each pass ends with one b32 step
+#ifndef RCED_V3_L2X6
+#define RCED_V3_L2X6 1    // 1: layer 2 (18 -> 30, two M-tiles) at fp32 quality on the bf16 matrix pipe: the weights as
+                          // three bf16 parts in the packet, the B fragments split in registers out of the fp32 B18 buffer (there is no
+                          // LDS left for planes), six v_mfma_f32_16x16x32_bf16 per K = 32 chunk, M-tile and tile
+#endif
+constexpr int kL2Chunks = 3;                                  // K = 90 in three K = 32 chunks (x6 form)
+#if RCED_V3_L2X6
+constexpr int kW2Data = kL2Chunks * 2 * 3 * 64 * 4;    // 4608 floats: [chunk][M-tile][part][lane] x 8 bf16
+#else
 constexpr int kW2Data = kL2Steps * 2 * 128 + 2 * 64;   // 2944
+#endif
 constexpr int kW3Data = kL3Steps * 128 + 64;           // 4800
 constexpr int kW1 = kW1Data + kShiftPerLayer;
 constexpr int kW2 = kW2Data + kShiftPerLayer;
@@ -353,6 +363,7 @@ struct Lane {
   unsigned rd1, rd1b, wr1; // layer 1 main tile `wave` (/ the tile 8 further: a base of its own, see make_lane): B8 window start, B18 output
   unsigned rd1r, wr1r;     // layer 1 remainder tile xr0 (waves 4..7)
   unsigned rd2, rd2b, rd2t, rd2tb, wr2; // layer 2 tile `wave` (/ + 8): B18 window start (b64 steps / tail), B30 output
+  unsigned rd2x;           // layer 2 in the x6 form: B18 window start + 8 kq floats (a lane's eight consecutive k of a K = 32 chunk)
   unsigned rd3, rd3b, rd3t, rd3tb, wr3; // layer 3 pair tile `wave` (/ + 8): B30 window start (b64 steps / tail), B8 output
   unsigned wh0, wh1, whx;  // block 4's layer 3: where this lane's output pixel of pair tile 0 / 1 / 16 goes in the H image
   unsigned scr;            // lane*16: offset inside a hand-off scratch area
@@ -385,6 +396,7 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   L.wr1r = B18 + 4 * ((rpx + 2 * kq) * 18 + 16);            // channels 16,17 of pixels rpx+2kq, +1
   L.rd2 = B18 + 4 * ((px0 - 2) * 18 + 2 * kq);
   L.rd2t = L.rd2 + 4 * (8 * kL2Steps + (kq < 1 ? kq : 1) - 2 * kq);   // K = 90: tail k = 88 + kq is real for kq < 2
+  L.rd2x = B18 + 4 * ((px0 - 2) * 18 + 8 * kq);
   L.wr2 = B30 + 4 * (px0 * 30 + 4 * kq);
   L.rd3 = B30 + 4 * ((2 * px0 - 4) * 30 + 2 * kq);          // px0 doubles as the pixel-PAIR index of layer 3
   L.rd3t = L.rd3 + 4 * (8 * kL3Steps - kq);                 // K = 300: tail k = 296 + kq, all four real
@@ -673,6 +685,7 @@ constexpr int kFlag2Off = kScratch2Off + 2 * 256;
 static_assert((kScratch2Off * 4) % 16 == 0, "scratch is read/written with b128");
 static_assert(8 + (2 * 256 + 2 + kB8S - 1) / kB8S <= kF, "layer-2 scratch stays inside frame 0's real pixels");
 
+#if !RCED_V3_L2X6
 template <int XM, bool HELPER, class Pre>   // the share of tile 32: M-tile XM, slots [0, kL2Cut) (helper) or [kL2Cut, 11) + tail
 __device__ __forceinline__ f32x4 l2_share(unsigned wa, unsigned wt, unsigned rdx, unsigned rdxt, f32x4 init, Pre& pre) {
   constexpr int S0 = HELPER ? 0 : kL2Cut, NS = HELPER ? kL2Cut : kL2Steps + 1 - kL2Cut, D = RCED_D2, RING = D + 1;
@@ -698,6 +711,8 @@ __device__ __forceinline__ f32x4 l2_share(unsigned wa, unsigned wt, unsigned rdx
   return acc;
 }
 
+#endif
+
 // one M-tile of one tile: ReLU, [pixel][30] stores; lanes kq = 3 of M-tile 1 hold channels 28,29 and the padding 30,31
 template <int MT>
 __device__ __forceinline__ void l2_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
@@ -708,8 +723,155 @@ __device__ __forceinline__ void l2_store(const Lane& L, f32x4 acc4, unsigned wr,
   }
 }
 
+#if RCED_V3_L2X6
+// ---- layer 2 in the x6 form ---------------------------------------------------------------------------------
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma32(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+struct Parts {
+  s16x8 h, m, l;
+};
+// eight consecutive fp32 of a window -> their three bf16 parts (x = h + m + l to 2^-24)
+__device__ __forceinline__ Parts split8(const f32x2 (&q)[4]) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  s16x2 ph[4], pm[4], pl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bf16x2 bh = {(__bf16)q[j].x, (__bf16)q[j].y};
+    const f32x2 r1 = {q[j].x - (float)bh.x, q[j].y - (float)bh.y};
+    const bf16x2 bm = {(__bf16)r1.x, (__bf16)r1.y};
+    const bf16x2 bl = {(__bf16)(r1.x - (float)bm.x), (__bf16)(r1.y - (float)bm.y)};
+    ph[j] = __builtin_bit_cast(s16x2, bh);      // (whole-vector casts: element-wise bit_cast of a bf16 vector's members miscompiled)
+    pm[j] = __builtin_bit_cast(s16x2, bm);
+    pl[j] = __builtin_bit_cast(s16x2, bl);
+  }
+  Parts r;
+  r.h = s16x8{ph[0].x, ph[0].y, ph[1].x, ph[1].y, ph[2].x, ph[2].y, ph[3].x, ph[3].y};
+  r.m = s16x8{pm[0].x, pm[0].y, pm[1].x, pm[1].y, pm[2].x, pm[2].y, pm[3].x, pm[3].y};
+  r.l = s16x8{pl[0].x, pl[0].y, pl[1].x, pl[1].y, pl[2].x, pl[2].y, pl[3].x, pl[3].y};
+  return r;
+}
+// six products (smallest first) of one A fragment triple and one B fragment triple
+__device__ __forceinline__ f32x4 mma6(const s16x8 (&a)[3], const Parts& b, f32x4 acc) {
+  acc = mfma32(a[1], b.m, acc);
+  acc = mfma32(a[2], b.h, acc);
+  acc = mfma32(a[0], b.l, acc);
+  acc = mfma32(a[1], b.h, acc);
+  acc = mfma32(a[0], b.m, acc);
+  acc = mfma32(a[0], b.h, acc);
+  return acc;
+}
+// A fragment (chunk c, M-tile mt, part p) of this lane: wa16 = packet + lane * 16
+__device__ __forceinline__ s16x8 l2x_a(unsigned wa16, int c, int mt, int p) { return lds_ld<s16x8>(wa16, ((c * 2 + mt) * 3 + p) * 1024); }
+// the share of tile 32: M-tile XM, chunk 0 (helper) or chunks 1, 2 (reducer)
+template <int XM, bool HELPER, class Pre>
+__device__ __forceinline__ f32x4 l2_share(unsigned wa16, unsigned rdx, f32x4 init, Pre& pre) {
+  constexpr int C0 = HELPER ? 0 : 1, NC = HELPER ? 1 : 2;
+  s16x8 a[2][3];
+  f32x2 b[2][4];
+  f32x4 acc = init;
+  run_job<NC, 1>(
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value, r = i % 2, c = C0 + i;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[r][p] = l2x_a(wa16, c, XM, p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[r][j] = lds_ld<f32x2>(rdx, 128 * c + 8 * j);
+      },
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value, r = i % 2;
+        acc = mma6(a[r], split8(b[r]), acc);
+      },
+      pre);
+  return acc;
+}
+#endif
+
 template <class Dma>
 __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wbase, int wave, unsigned tag, unsigned* err, Dma dma DET_ARG) {
+#if RCED_V3_L2X6
+  DET_BEGIN();
+  const unsigned wa16 = wbase + L.scr;            // packet + lane * 16: the lane's A fragments
+  f32x4 sh[2];
+  sh[0] = lds_ld<f32x4>(wbase + L.kq16, kW2Data * 4);
+  sh[1] = lds_ld<f32x4>(wbase + L.kq16, (kW2Data + 16) * 4);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // ---- the share of tile 32 (waves 0..3), first: M-tile x K-part (chunk 0 | chunks 1, 2)
+  f32x4 accx = zero4, part = zero4;
+  unsigned pflag = 0u;
+  auto pre = once(dma);
+  if (wave < 4) {
+    const unsigned rdx = L.rd2x + (32 - wave) * (16 * 18 * 4);
+    if (wave == 0) accx = l2_share<0, true>(wa16, rdx, zero4, pre);
+    else if (wave == 1) accx = l2_share<1, true>(wa16, rdx, zero4, pre);
+    else if (wave == 2) accx = l2_share<0, false>(wa16, rdx, sh[0], pre);
+    else accx = l2_share<1, false>(wa16, rdx, sh[1], pre);
+    if (wave < 2) {   // publish (LDS operations of a wave execute in order: data, then flag)
+      lds_st<f32x4>(lds0 + L.scr + wave * 1024, kScratch2Off * 4, accx);
+      cbar();
+      if (L.a4 == 0) lds_poke_a(lds0 + (kFlag2Off + wave) * 4, tag);
+    }
+  }
+  DET(7);
+  // ---- two pair jobs, tiles (wave, wave+8) and (wave+16, wave+24), as ONE stream of six K = 32 chunks: pair 0's stores
+  //      ride between pair 1's MFMAs
+  {
+    constexpr int NS = kL2Chunks, NT = 2 * NS;
+    f32x2 b[2][2][4];     // [ring][tile][four pairs of consecutive k]: the fp32 B fragments, read one chunk ahead
+    f32x4 acc[2][2][2];   // [pair][tile][M-tile]
+    const bool g1 = tile_has_gap(wave + 8), g2 = tile_has_gap(wave + 16), g3 = tile_has_gap(wave + 24);
+    run_job<NT, 1>(
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, r = i % 2, p = i / NS, c = i % NS;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[r][t][j] = lds_ld<f32x2>(L.rd2x, (2 * p + t) * kT2R + 128 * c + 8 * j);
+        },
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, r = i % 2, p = i / NS, c = i % NS;
+          if constexpr (c == 0) {
+            acc[p][0][0] = acc[p][1][0] = sh[0];
+            acc[p][0][1] = acc[p][1][1] = sh[1];
+          }
+          // this chunk's A fragments: issued here, they land while the B fragments are split (no ring for them: 24 VGPRs)
+          s16x8 a[2][3];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[mt][q] = l2x_a(wa16, c, mt, q);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const Parts bp = split8(b[r][t]);
+            acc[p][t][0] = mma6(a[0], bp, acc[p][t][0]);
+            acc[p][t][1] = mma6(a[1], bp, acc[p][t][1]);
+          }
+          if constexpr (p == 1 && c == 0) {
+            l2_store<0>(L, acc[0][0][0], L.wr2, 0, false, kVMain);       // tile `wave`: no gap
+            l2_store<1>(L, acc[0][0][1], L.wr2, 0, false, kVMain);
+          }
+          if constexpr (p == 1 && c == 1) {
+            l2_store<0>(L, acc[0][1][0], L.wr2, kT2W, g1, kVMain + 1);
+            l2_store<1>(L, acc[0][1][1], L.wr2, kT2W, g1, kVMain + 1);
+          }
+          if constexpr (p == 1 && c == 2) {   // reducers: the helper's flag and partial sums, fetched inside the stream
+            if (wave == 2 || wave == 3) {
+              pflag = lds_peek_a(lds0 + (kFlag2Off + wave - 2) * 4);
+              cbar();
+              part = lds_ld<f32x4>(lds0 + L.scr + (wave - 2) * 1024, kScratch2Off * 4);
+            }
+          }
+        },
+        pre);
+    l2_store<0>(L, acc[1][0][0], L.wr2, 2 * kT2W, g2, kVMain + 2);
+    l2_store<1>(L, acc[1][0][1], L.wr2, 2 * kT2W, g2, kVMain + 2);
+    l2_store<0>(L, acc[1][1][0], L.wr2, 3 * kT2W, g3, kVMain + 3);
+    l2_store<1>(L, acc[1][1][1], L.wr2, 3 * kT2W, g3, kVMain + 3);
+  }
+#else
   constexpr int D = RCED_D2, RING = D + 1, NS = kL2Steps + 1;
   DET_BEGIN();
   const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
@@ -790,6 +952,7 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
     l2_store<0>(L, acc[1][1][0], L.wr2, 3 * kT2W, g3, kVMain + 3);
     l2_store<1>(L, acc[1][1][1], L.wr2, 3 * kT2W, g3, kVMain + 3);
   }
+#endif
   // ---- reducers: add the helper's share, store tile 32 (pixels 512..527: no gap inside)
   if (wave == 2 || wave == 3) {
     const int xm = wave - 2;
