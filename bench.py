@@ -585,7 +585,10 @@ def main():
                         "avg_launch_ms": ms / launches, "launches": launches,
                         "flop_per_frame": kflops, "frames_per_forward": B * T,
                         "other_kernels_ms_per_step": {k: v[0] / args.steps for k, v in times.items() if k != dom and v[1]},
-                        "note": "compute-bound path (7950 FLOP/B): peak = dense fp32 157.3 TFLOP/s, not HBM; "
+                        "note": "compute-bound path (7950 FLOP/B): peak = dense fp32 MFMA 157.3 TFLOP/s, not HBM "
+                                "(CR-CED: the 18->30 layers, 43 % of the FLOPs, are computed at fp32 quality as six bf16 "
+                                "MFMAs per product over three-part operands -- DESIGN 3.1 / 3.4a; the fraction stays "
+                                "quoted against the fp32 pipe's peak); "
                                 "algorithmic HBM bytes are 1032 B/frame"}
         out["roofline"] = roof
     # ---- the reference's single-host-process convention over RCCL: scatter from rank 0, compute, gather -------
