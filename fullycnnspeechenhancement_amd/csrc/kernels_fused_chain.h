@@ -23,7 +23,8 @@
 #include "lds_dma.h"
 
 #ifndef RCED_CHAIN_EXP
-#define RCED_CHAIN_EXP 0     // timing experiments only (wrong results): 1 = no skip-fragment stores, 2 = no skip-fragment loads
+#define RCED_CHAIN_EXP 0     // timing experiments only (wrong results): 1 = no skip-fragment stores, 2 = no skip-fragment loads,
+                             // 4 = the two-M-tile layers issue half of their MFMAs (the bound on a bf16-pipe form of those layers)
 #endif
 #ifndef RCED_CHAIN_DEPTH
 #define RCED_CHAIN_DEPTH 1   // operand prefetch depth (b64 steps) of the fp32 R-CED passes
@@ -266,7 +267,7 @@ __device__ __forceinline__ void gemm_pass(const float* act, int off0, int offx, 
     each(s);
     pin();
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < ((RCED_CHAIN_EXP & 4) && MT == 2 ? 1 : 2); ++e)      // (EXP 4: half of the two-M-tile layers' MFMAs)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
