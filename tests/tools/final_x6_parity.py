@@ -1,7 +1,7 @@
 """The output layer on the bf16 matrix pipe (kernels_final_x6.h) against the golden vectors: run with RCED_FINAL_X6=0 / 1 to compare
 the three-part form with the fp32 MFMA kernel (tests use the default, the three-part form)."""
 import sys, os, numpy as np
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))   # run from the repo root
 from conftest import NETS, load_golden
 from fullycnnspeechenhancement_amd import build_model
 for net_work, tag, variant in NETS:
