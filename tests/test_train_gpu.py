@@ -261,6 +261,40 @@ def test_bf16_pipe_kernels_agree_with_the_fp32_mfma_kernels(built, monkeypatch):
           % (abs(out["0"][0] - out["1"][0]) / abs(out["0"][0]), fwd, worst))
 
 
+@pytest.mark.parametrize("switch", ["RCED_TRAIN_FUSE_ACT", "RCED_TRAIN_FUSE_DZ"])
+def test_fused_staging_switches_agree_with_the_materialised_tensors(switch, built, monkeypatch):
+    """RCED_TRAIN_FUSE_ACT=0 materialises every activation tensor (relu(bn(z)) written by bn_act_fwd2 and read back) instead of
+    rebuilding it in the consumers' staging; RCED_TRAIN_FUSE_DZ=0 applies the BatchNorm backward in place instead of inside
+    the wgrad / dgrad staging.  Both are the fallbacks the fused forms replaced, and the only callers of the kernels' plain
+    variants (among them tmm::conv_x6_fwd without a transform): same ragged multi-tile batch, same step up to rounding -- the
+    loss to 1e-6, the train-mode forward element-wise (the arithmetic is the same: measured identical), every gradient to 1e-4
+    of its tensor's largest entry (summation order)."""
+    from fullycnnspeechenhancement_amd import FullyCNNTrainer
+    w = rced_np.make_weights("FullyCNNV3", seed=27)
+    x = rced_np.make_input(37, 131, seed=41)
+    y = rced_np.make_input(37, 131, seed=42)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv(switch, mode)
+        tr = FullyCNNTrainer("FullyCNNV3", batch_size=37, lr=1e-3, weights=w)
+        pred = np.array(tr.valid_step(x))
+        loss, _, _ = tr.train_step(x, y)
+        out[mode] = (loss, tr.gradients(), pred)
+        tr.close()
+    assert abs(out["0"][0] - out["1"][0]) <= 1e-6 * abs(out["0"][0])
+    fwd = np.abs(out["0"][2] - out["1"][2]).max() / np.abs(out["0"][2]).max()
+    assert fwd < 1e-6, fwd                          # (measured 0: the same arithmetic either way)
+    worst = 0.0
+    for name, g0 in out["0"][1].items():
+        if "moving_" in name or (name.endswith("/bias") and not name.startswith("decode_final")):
+            continue
+        worst = max(worst, rel(out["1"][1][name], g0))
+        assert rel(out["1"][1][name], g0) < 1e-4, name   # (measured 2.5e-6 / 2.8e-6: summation order only -- the forward is identical)
+        assert cosine(out["1"][1][name], g0) > 1 - 1e-8, name
+    print("\n[%s = 0 vs 1] loss %.3e apart, forward %.2e, worst gradient %.2e of its tensor's max"
+          % (switch, abs(out["0"][0] - out["1"][0]) / abs(out["0"][0]), fwd, worst))
+
+
 def test_padded_layout_round_trips_variables_and_adam_state(built):
     """R-CED V2 trains in an even-padded internal layout; what crosses the ABI (variables, gradients, Adam slots) is the
     reference's unpadded layout: get -> set -> get is the identity and a resumed trainer continues like the original."""
