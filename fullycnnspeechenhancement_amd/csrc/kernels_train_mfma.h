@@ -602,6 +602,27 @@ __device__ __forceinline__ void split3_pair(f32x2 v, s16x2& h, s16x2& m, s16x2& 
   m = __builtin_bit_cast(s16x2, bm);
   l = __builtin_bit_cast(s16x2, bl);
 }
+// eight floats (four pairs) -> their three bf16 parts as MFMA fragments, in registers (whole-vector casts only: bit-casting the
+// MEMBERS of a __bf16 vector miscompiles, tools/micro/split_test.hip)
+struct X6Parts {
+  s16x8 h, m, l;
+};
+__device__ __forceinline__ X6Parts x6_split8(const f32x2 (&q)[4]) {
+  s16x2 ph[4], pm[4], pl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split3_pair(q[j], ph[j], pm[j], pl[j]);
+  X6Parts r;
+  r.h = s16x8{ph[0].x, ph[0].y, ph[1].x, ph[1].y, ph[2].x, ph[2].y, ph[3].x, ph[3].y};
+  r.m = s16x8{pm[0].x, pm[0].y, pm[1].x, pm[1].y, pm[2].x, pm[2].y, pm[3].x, pm[3].y};
+  r.l = s16x8{pl[0].x, pl[0].y, pl[1].x, pl[1].y, pl[2].x, pl[2].y, pl[3].x, pl[3].y};
+  return r;
+}
+#ifndef RCED_TM_WG_X6_B
+#define RCED_TM_WG_X6_B 1    // bwd_fused_mfma<18,5,30>: whole runs of eight pixel groups of the wgrad half in the three-part bf16 form:
+                             // 2.38 -> 2.28 ms.  (The 30 -> 8 kernel's wgrad has ONE N-tile: its 19 A fragments per 32 pixel pairs would each be
+                             // split for six MFMAs -- 36 VALU for 96 cycles of MFMA: no gain, not built.)
+#endif
+__host__ __device__ constexpr bool bwd_wg_x6(int cin, int taps, int cout) { return RCED_TM_WG_X6_B && cin == 18 && taps == 5 && cout == 30; }
 // in: part 0 of the tile at pixel 0 (bf16), the other parts PLANE elements further; off0 / offx: this lane's window start of
 // its first regular / its extra column tile; TSTRIDE: elements between a wave's consecutive column tiles
 template <int NR, int NX, int MT, int STEPS, int TSTRIDE, int PLANE>
@@ -1972,7 +1993,49 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_fused_mfma(const float* __res
       const int gbeg = BwdBalance<CIN, TAPS, COUT>::begin(wave), gend = BwdBalance<CIN, TAPS, COUT>::begin(wave + 1);
       constexpr int kIters = BwdBalance<CIN, TAPS, COUT>::kMinIters;
       int it = 0;
-      for (int g = gbeg; g < gend; ++g, ++it) {
+      int g = gbeg;
+      if constexpr (bwd_wg_x6(CIN, TAPS, COUT) && PH == 1) {
+        // Whole runs of eight groups (32 pixels) in the three-part bf16 form: the operands run along PIXELS here, so a lane's
+        // fragment is eight strided scalars (as many LDS reads as the fp32 form issues for these pixels), split in registers
+        // (split8); an A fragment feeds the NTo N-tiles, a B fragment the KT M-tiles: KT * NTo * 6 MFMAs of 16 cycles per 32
+        // pixels where the fp32 form issues KT * NTo * 8 of 32.  The groups left over (< 8) take the fp32 loop below.
+        const float* ain8 = lx + 8 * kq * GW::kCinP + i;
+        const float* bin8 = ldzp + 8 * kq * COUT + i;
+        for (; g + 8 <= gend; g += 8, it += 8) {
+          const int pxc = 4 * g;
+          X6Parts bp[NTo];
+#pragma unroll
+          for (int nt = 0; nt < NTo; ++nt) {
+            f32x2 q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = f32x2{bin8[(pxc + 2 * e) * COUT + 16 * nt], bin8[(pxc + 2 * e + 1) * COUT + 16 * nt]};
+            bp[nt] = x6_split8(q);
+          }
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+            f32x2 q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = f32x2{ain8[(pxc + 2 * e) * GW::kCinP + 16 * kt], ain8[(pxc + 2 * e + 1) * GW::kCinP + 16 * kt]};
+            if (kt == kOneTile && i == kOneRow) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) q[e] = f32x2{1.f, 1.f};
+            }
+            const X6Parts ap = x6_split8(q);
+#pragma unroll
+            for (int nt = 0; nt < NTo; ++nt) {
+              f32x4 v = acc[kt][nt];
+              v = mfma32(ap.m, bp[nt].m, v);
+              v = mfma32(ap.l, bp[nt].h, v);
+              v = mfma32(ap.h, bp[nt].l, v);
+              v = mfma32(ap.m, bp[nt].h, v);
+              v = mfma32(ap.h, bp[nt].m, v);
+              v = mfma32(ap.h, bp[nt].h, v);
+              acc[kt][nt] = v;
+            }
+          }
+        }
+      }
+      for (; g < gend; ++g, ++it) {
         if (spread)
           tm_static_for<0, kNP>([&](auto ic) { if (it == decltype(ic)::value * kIters / kNP) piece(ic); });
         const int px0 = 4 * PH * g;
