@@ -27,7 +27,10 @@ inline unsigned short bf16_rne(float f) {
 struct rced_fused {
   float* scratch = nullptr;   // V1/V2: skip fragments, per workgroup
   size_t scratch_bytes = 0;
-  float* wpack = nullptr;     // packed A-fragment stream
+  float* wpack = nullptr;     // packed A-fragment stream (CR-CED: of the F32 form, built when that form is first selected)
+  float* wpack_x6 = nullptr;  // CR-CED, X6 form (v3::kGTotal floats)
+  int v3_l2x6 = 1;            // option "v3_l2x6": 1 = the 18 -> 30 layers at fp32 quality on the bf16 matrix pipe (the product), 0 = every
+                              // layer on the fp32 MFMA (the comparator): kernels_fused_v3.h
   float* fin_apack = nullptr; // v3::kFinPack
   float fin_bias = 0.f;
   float* h = nullptr;         // [frames, 129, 8] hand-off to the final layer
@@ -59,8 +62,19 @@ inline float wq(const rced_layer_dev& d, int tap, int ci, int co, int cin) {
   return d.host_w[((size_t)tap * cin + ci) * d.cout4 + co];
 }
 
-void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>* fin, float* fin_bias) {
-  wpack->assign(v3::kWTotal, 0.f);
+// three bf16 parts of a weight (round to nearest at every step): v = h + m + l to 2^-24
+inline void split3(float v, unsigned short* h, unsigned short* mm, unsigned short* l) {
+  auto b2f = [](unsigned short b) { const unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; };
+  *h = bf16_rne(v);
+  const float r1 = v - b2f(*h);
+  *mm = bf16_rne(r1);
+  *l = bf16_rne(r1 - b2f(*mm));
+}
+
+// CR-CED weight streams (kernels_fused_v3.h, "packed weight streams").  x6 = false: one LDS packet per layer (F32 form);
+// x6 = true: layer 1 / layer 2 as register images for 16-byte-per-lane global loads, layer 3's packet unchanged.
+void pack_v3(const rced_model* m, bool x6, std::vector<float>* wpack) {
+  wpack->assign(x6 ? v3::kGTotal : v3::kWTotal, 0.f);
   auto put_shift = [&](float* at, int layer) {  // the packet's last 32 floats: shift[co]
     const int cout = m->net->layer[layer].cout;
     for (int c = 0; c < cout; ++c) at[c] = m->layers[layer].host_shift[c];
@@ -71,64 +85,82 @@ void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>*
     const rced_layer_dev& l2 = m->layers[3 * blk + 1];
     const rced_layer_dev& l3 = m->layers[3 * blk + 2];
     // ---- layer 1 = main pass (channels 0..15) + remainder pass (channels 16,17 x 8 pixel phases)
-    if (blk == 0) {
-      // 8x9x1: main [s = ih*9 + j][lane]; lane = (row i = co, kq), time tap = 4*ih + kq
-      for (int s = 0; s < 18; ++s)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int i = lane & 15, kq = lane >> 4, ih = s / 9, j = s % 9, ti = 4 * ih + kq;
-          dst[s * 64 + lane] = wq(l1, ti * 9 + j, 0, i, 1);
-        }
-      // remainder [s = ih*16 + u][lane]; row i = (phase r = i>>1, channel 16 + (i&1)); freq tap = u - r
-      for (int s = 0; s < 32; ++s)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int i = lane & 15, kq = lane >> 4, ih = s / 16, u = s % 16, ti = 4 * ih + kq;
-          const int r = i >> 1, co = 16 + (i & 1), tap = u - r;
-          dst[v3::kW1Main + s * 64 + lane] = (tap >= 0 && tap < 9) ? wq(l1, ti * 9 + tap, 0, co, 1) : 0.f;
-        }
+    // A[row][K-step s][e]: block 0 (8x9x1): one k per lane and step: main s = ih*9 + j, remainder s = ih*16 + u, time tap
+    // 4*ih + kq; blocks 1..4 (1x9, 8 -> 18): two k per lane and step, k = 8s + 2kq + e = tap*8 + ci.
+    // Remainder rows i = (phase r = i>>1, channel 16 + (i&1)), frequency tap = u - r over a window of 16 taps.
+    auto w1main = [&](int lane, int s, int e) {
+      const int i = lane & 15, kq = lane >> 4;
+      if (blk == 0) return wq(l1, (4 * (s / 9) + kq) * 9 + s % 9, 0, i, 1);
+      const int k = 8 * s + 2 * kq + e;
+      return wq(l1, k / 8, k % 8, i, 8);
+    };
+    auto w1rem = [&](int lane, int s, int e) {
+      const int i = lane & 15, kq = lane >> 4, r = i >> 1, co = 16 + (i & 1);
+      if (blk == 0) {
+        const int tap = s % 16 - r;
+        return (tap >= 0 && tap < 9) ? wq(l1, (4 * (s / 16) + kq) * 9 + tap, 0, co, 1) : 0.f;
+      }
+      const int k = 8 * s + 2 * kq + e, tap = k / 8 - r;
+      return (tap >= 0 && tap < 9) ? wq(l1, tap, k % 8, co, 8) : 0.f;
+    };
+    if (x6) {
+      // register images [j][lane][4 floats]: float 4j + q of a lane = its fragment of K-step 4j + q (block 0) or element
+      // (4j + q) & 1 of K-step (4j + q) >> 1 (blocks 1..4)
+      for (int lane = 0; lane < 64; ++lane) {
+        for (int i = 0; i < 18; ++i)
+          dst[(i / 4) * 256 + lane * 4 + i % 4] = blk == 0 ? w1main(lane, i, 0) : w1main(lane, i / 2, i % 2);
+        for (int i = 0; i < 32; ++i)
+          dst[v3::kG1Main + (i / 4) * 256 + lane * 4 + i % 4] = blk == 0 ? w1rem(lane, i, 0) : w1rem(lane, i / 2, i % 2);
+      }
+      put_shift(dst + v3::kG1Main + v3::kG1Rem, 3 * blk + 0);
+      dst += v3::kG1;
     } else {
-      // 1x9, 8 -> 18: main [s][lane][e], k = 8s + 2kq + e = tap*8 + ci
-      for (int s = 0; s < 9; ++s)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int e = 0; e < 2; ++e) {
-            const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
-            dst[s * 128 + lane * 2 + e] = wq(l1, k / 8, k % 8, i, 8);
-          }
-      // remainder: k = u*8 + ci over 16 taps; row i = (phase r, channel 16 + (i&1)); tap = u - r
-      for (int s = 0; s < 16; ++s)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int e = 0; e < 2; ++e) {
-            const int i = lane & 15, kq = lane >> 4, k = 8 * s + 2 * kq + e;
-            const int r = i >> 1, co = 16 + (i & 1), u = k / 8, ci = k % 8, tap = u - r;
-            dst[v3::kW1Main + s * 128 + lane * 2 + e] = (tap >= 0 && tap < 9) ? wq(l1, tap, ci, co, 8) : 0.f;
-          }
+      if (blk == 0) {
+        for (int s = 0; s < 18; ++s)
+          for (int lane = 0; lane < 64; ++lane) dst[s * 64 + lane] = w1main(lane, s, 0);
+        for (int s = 0; s < 32; ++s)
+          for (int lane = 0; lane < 64; ++lane) dst[v3::kW1Main + s * 64 + lane] = w1rem(lane, s, 0);
+      } else {
+        for (int s = 0; s < 9; ++s)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 2; ++e) dst[s * 128 + lane * 2 + e] = w1main(lane, s, e);
+        for (int s = 0; s < 16; ++s)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 2; ++e) dst[v3::kW1Main + s * 128 + lane * 2 + e] = w1rem(lane, s, e);
+      }
+      put_shift(dst + v3::kW1Data, 3 * blk + 0);
+      dst += v3::kW1;
     }
-    put_shift(dst + v3::kW1Data, 3 * blk + 0);
-    dst += v3::kW1;
-    // ---- layer 2: 1x5, 18 -> 30, K = 90: 11 b64 steps (k = 8s + 2kq + e) + b32 tail (k = 88 + kq)
-    {
-      auto w2 = [&](int i, int mt, int k) {
+    // ---- layer 2: 1x5, 18 -> 30
+    if (x6) {
+      // [chunk][M-tile][part][lane] x 8 bf16; slot k = 32c + 8kq + e of the K axis (kernels_fused_v3.h, "X6 form"):
+      //   c < 2: tap 2c + (kq >> 1), channel 8 (kq & 1) + e;  c = 2: kq < 2: tap 4, channel 8kq + e; kq = 2: tap e >> 1,
+      //   channel 16 + (e & 1); kq = 3: tap 4, channel 16 + e (e < 2), else zero
+      auto w2x = [&](int i, int mt, int c, int kq, int e) {
         const int co = 16 * mt + i;
-        return (k < 90 && co < 30) ? wq(l2, k / 18, k % 18, co, 18) : 0.f;
+        int tap, ci;
+        if (c < 2) { tap = 2 * c + (kq >> 1); ci = 8 * (kq & 1) + e; }
+        else if (kq < 2) { tap = 4; ci = 8 * kq + e; }
+        else if (kq == 2) { tap = e >> 1; ci = 16 + (e & 1); }
+        else { tap = 4; ci = 16 + e; if (e >= 2) return 0.f; }
+        return co < 30 ? wq(l2, tap, ci, co, 18) : 0.f;
       };
-#if RCED_V3_L2X6
-      // x6 form: [chunk][M-tile][part][lane] x 8 bf16, k = 32 c + 8 kq + e; every weight as three bf16 parts
       unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
-      auto b2f = [](unsigned short b) { const unsigned u = (unsigned)b << 16; float v; memcpy(&v, &u, 4); return v; };
       for (int c = 0; c < v3::kL2Chunks; ++c)
         for (int mt = 0; mt < 2; ++mt)
           for (int lane = 0; lane < 64; ++lane)
             for (int e = 0; e < 8; ++e) {
-              const float v = w2(lane & 15, mt, 32 * c + 8 * (lane >> 4) + e);
-              const unsigned short h = bf16_rne(v);
-              const float r1 = v - b2f(h);
-              const unsigned short mm = bf16_rne(r1);
-              const unsigned short l = bf16_rne(r1 - b2f(mm));
               const size_t base = ((size_t)(c * 2 + mt) * 3) * 512 + lane * 8 + e;
-              d16[base] = h;
-              d16[base + 512] = mm;
-              d16[base + 1024] = l;
+              split3(w2x(lane & 15, mt, c, lane >> 4, e), &d16[base], &d16[base + 512], &d16[base + 1024]);
             }
-#else
+      put_shift(dst + v3::kG2Data, 3 * blk + 1);
+      dst += v3::kG2;
+    } else {
+      // K = 90: 11 b64 steps (k = 8s + 2kq + e = tap*18 + ci) + b32 tail (k = 88 + kq)
+      auto w2 = [&](int i, int mt, int k) {
+        const int co = 16 * mt + i;
+        return (k < 90 && co < 30) ? wq(l2, k / 18, k % 18, co, 18) : 0.f;
+      };
       for (int s = 0; s < v3::kL2Steps; ++s)
         for (int mt = 0; mt < 2; ++mt)
           for (int lane = 0; lane < 64; ++lane)
@@ -137,10 +169,9 @@ void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>*
       for (int mt = 0; mt < 2; ++mt)
         for (int lane = 0; lane < 64; ++lane)
           dst[v3::kL2Steps * 2 * 128 + mt * 64 + lane] = w2(lane & 15, mt, 8 * v3::kL2Steps + (lane >> 4));
-#endif
+      put_shift(dst + v3::kW2Data, 3 * blk + 1);
+      dst += v3::kW2;
     }
-    put_shift(dst + v3::kW2Data, 3 * blk + 1);
-    dst += v3::kW2;
     // ---- layer 3: 1x9, 30 -> 8 on pixel pairs: row i = (phase r, co), k = u*30 + ci, tap = u - r;
     //      37 b64 steps + b32 tail (k = 296 + kq)
     {
@@ -157,9 +188,12 @@ void pack_v3(const rced_model* m, std::vector<float>* wpack, std::vector<float>*
     put_shift(dst + v3::kW3Data, 3 * blk + 2);
     dst += v3::kW3;
   }
-  // ---- decode_final (1x129, 8 -> 1): A fragments of the in-kernel GEMM, [u][lane][e]: row r = lane & 15 (pixel phase),
-  //      k = (window tap u, channel 2*kq + e), value W[u - r][c] (zero outside taps 0..128); then the bin-128 weights
-  //      W[t][c], t = 0..64 (kernels_fused_v3.h, "decode_final inside the kernel")
+}
+
+// decode_final (1x129, 8 -> 1): A fragments of the in-kernel GEMM, [u][lane][e]: row r = lane & 15 (pixel phase),
+// k = (window tap u, channel 2*kq + e), value W[u - r][c] (zero outside taps 0..128); then the bin-128 weights
+// W[t][c], t = 0..64 (kernels_fused_v3.h, "decode_final inside the kernel")
+void pack_v3_final(const rced_model* m, std::vector<float>* fin, float* fin_bias) {
   const rced_layer_dev& lf = m->layers[15];
   fin->assign(v3::kFinPack, 0.f);
   for (int u = 0; u < v3::kFinU; ++u)
@@ -441,6 +475,22 @@ int upload(float** dev, const std::vector<float>& host) {
 
 }  // namespace
 
+template <class M>
+int v3_set_lds() {
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3::fused_v3_kernel<M>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, M::kLdsBytes);
+  if (e != hipSuccess) return rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(LDS %d): %s", M::kLdsBytes, hipGetErrorString(e));
+  return RCED_OK;
+}
+// option "v3_l2x6" = 0: the F32 form's packets are built when it is first selected
+int v3_enable_f32(rced_model* m, rced_fused* f) {
+  if (f->wpack) return RCED_OK;
+  std::vector<float> wpack;
+  pack_v3(m, false, &wpack);
+  if (int rc = upload(&f->wpack, wpack)) return rc;
+  return v3_set_lds<v3::MapF32>();
+}
+
 int fused_create(rced_model* m) {
   m->fused = nullptr;
   rced_fused* f = new rced_fused();
@@ -451,13 +501,17 @@ int fused_create(rced_model* m) {
     return rc;
   }
   std::vector<float> wpack, fin;
-  pack_v3(m, &wpack, &fin, &f->fin_bias);
-  int rc = upload(&f->wpack, wpack);
+  pack_v3(m, true, &wpack);
+  pack_v3_final(m, &fin, &f->fin_bias);
+  int rc = upload(&f->wpack_x6, wpack);
   if (!rc) rc = upload(&f->fin_apack, fin);
-  if (!rc) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3::fused_v3_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLdsBytes);
-    if (e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(LDS %d): %s", v3::kLdsBytes, hipGetErrorString(e));
+  if (!rc) rc = v3_set_lds<v3::MapX6>();
+  if (!rc) {   // the environment only supplies the DEFAULT of the per-handle option, read when the handle is created
+    const char* e = getenv("RCED_V3_L2X6");
+    if (e && atoi(e) == 0) {
+      rc = v3_enable_f32(m, f);
+      if (!rc) f->v3_l2x6 = 0;
+    }
   }
   if (!rc) {
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&f->err_host), 64, hipHostMallocMapped);
@@ -482,6 +536,7 @@ void fused_destroy(rced_model* m) {
   rced_fused* f = m->fused;
   if (!f) return;
   if (f->wpack) (void)hipFree(f->wpack);
+  if (f->wpack_x6) (void)hipFree(f->wpack_x6);
   if (f->wpack16) (void)hipFree(f->wpack16);
   if (f->fin_apack16) (void)hipFree(f->fin_apack16);
   if (f->fin_apack_x6) (void)hipFree(f->fin_apack_x6);
@@ -537,7 +592,7 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   P.err = f->err_dev;
   P.x = x;
   P.y = y;
-  P.wpack = f->wpack;
+  P.wpack = f->v3_l2x6 ? f->wpack_x6 : f->wpack;
   P.fin = f->fin_apack;
   P.fin_bias = f->fin_bias;
   P.N = N;
@@ -548,7 +603,8 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   const int cus = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
   const int grid = std::min(P.total_tiles, cus);
   m->prof_begin(RCED_K_FUSED, st);   // all 16 layers: decode_final is the kernel's last phase
-  hipLaunchKernelGGL(v3::fused_v3_kernel, dim3(grid), dim3(v3::kThreads), v3::kLdsBytes, st, P);
+  if (f->v3_l2x6) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapX6>, dim3(grid), dim3(v3::kThreads), v3::MapX6::kLdsBytes, st, P);
+  else hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapF32>, dim3(grid), dim3(v3::kThreads), v3::MapF32::kLdsBytes, st, P);
   m->prof_end(RCED_K_FUSED, st);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
@@ -559,6 +615,14 @@ int fused_set_option(rced_model* m, const char* key, int value) {
   if (!strcmp(key, "fused_grid")) {
     if (value < 0) return RCED_ERR_ARG;
     m->fused->grid_limit = value;
+    return RCED_OK;
+  }
+  if (!strcmp(key, "v3_l2x6")) {
+    if (m->variant != RCED_V3) return rced_fail(RCED_ERR_ARG, "v3_l2x6 selects the form of the CR-CED kernel only");
+    if (value != 0 && value != 1) return RCED_ERR_ARG;
+    if (!value)
+      if (int rc = v3_enable_f32(m, m->fused)) return rc;
+    m->fused->v3_l2x6 = value;
     return RCED_OK;
   }
   if (!strcmp(key, "bf16")) {
@@ -596,6 +660,10 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
   }
   if (!strcmp(key, "fused_final")) {   // 1: the 1x129 output layer runs inside the fused kernel (no hand-off tensor in HBM)
     *value = m->variant == RCED_V3;
+    return RCED_OK;
+  }
+  if (!strcmp(key, "v3_l2x6")) {
+    *value = m->variant == RCED_V3 ? m->fused->v3_l2x6 : 0;
     return RCED_OK;
   }
   if (!strcmp(key, "bf16")) {

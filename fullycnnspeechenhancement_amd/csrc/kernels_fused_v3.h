@@ -1,15 +1,12 @@
-// Fused CR-CED (V3) forward: layers 0..14 of model_utils/model.py:64-96 in ONE kernel, fp32 MFMA.
+// Fused CR-CED (V3) forward: all 16 layers of model_utils/model.py:64-96 in ONE kernel.
 //
 // Why this shape (DESIGN.md has the long form):
 //   * only the first conv (8x9) looks along time; everything after is 1xk along frequency, so a
-//     tile of frames runs through all 15 conv+BN+ReLU layers without leaving the CU;
+//     tile of frames runs through all 15 conv+BN+ReLU layers (and decode_final) without leaving the CU;
 //   * per layer the conv is an implicit GEMM  D[cout, pixel] = sum_k W[cout, k] * X[k, pixel]
 //     with k = (tap, cin).  Activations live in LDS as [pixel][channel] with the channel stride
-//     EXACTLY cin, so the im2col row of a pixel is one contiguous window of taps*cin floats:
-//     the B operand of v_mfma_f32_16x16x4_f32 is read straight out of LDS with ds_read_b64,
-//     no im2col copy, no shuffles;
-//   * weights are pre-packed on the host into MFMA A-fragment order, BN folded, and streamed
-//     L2 -> LDS by LDS-DMA one layer ahead (ping-pong), each packet carrying its 32 shift values;
+//     EXACTLY cin, so the im2col row of a pixel is one contiguous window of taps*cin values:
+//     the B operand of the MFMA is read straight out of LDS, no im2col copy, no shuffles;
 //   * cout sits on the MFMA M axis (16 rows).  30 pads to 2 M-tiles; the 30->8 layers use two
 //     pixel phases as rows (8 cout x 2 adjacent pixels = 16 rows, K = 10 taps instead of 9); the
 //     ->18 layers run channels 0..15 as one M-tile plus a remainder pass that computes channels
@@ -20,6 +17,20 @@
 //     each LDS read right before its use and the MFMA pipe starves;
 //   * a wave walks its tiles one after the other and stores tile j's results between the MFMAs of tile j+1
 //     ("slot streams", below): the epilogues' LDS stores no longer sit on every layer's tail.
+//
+// TWO FORMS of the kernel, one template (`Map<X6>`), both in the library (option "v3_l2x6"):
+//   X6 = true (the product): the 18 -> 30 layers -- 43 % of the net's multiply-adds and the only ones whose B fragment
+//     feeds two M-tiles -- run at fp32 quality on the bf16 matrix pipe: every operand as three bf16 parts (x = h + m + l,
+//     exact to 2^-24), every product as six v_mfma_f32_16x16x32_bf16 (m.m, l.h, h.l, m.h, h.m, h.h -- smallest first --
+//     into the fp32 accumulator).  The activation is split ONCE, where it is produced: layer 1's epilogue writes the
+//     18-channel tensor as bf16 planes (h, m, l) and layer 2 reads its fragments with ds_read_b128 and issues only
+//     MFMAs (round 3 split every fragment in the consumer, 36 VALU per 12 MFMAs, each element five times over).  The
+//     planes are 19 KB more than the fp32 buffer; the LDS for them comes from the weights: layer 1's and layer 2's
+//     A fragments (50 + 72 registers) are loaded from global memory into VGPRs one layer ahead and only layer 3's
+//     packet still goes through LDS (one region, no ping-pong).
+//   X6 = false: every layer on v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32 fmaf chain), all weight packets streamed
+//     L2 -> LDS by LDS-DMA one layer ahead (ping-pong).  Rounds 1 / 2's kernel; kept as the in-build comparator of the
+//     X6 arithmetic (tests/test_forward_gpu.py holds the two against each other and both against the oracle).
 //
 // Pixel space of a tile: kTF frames, frame i at flat pixels [i*kS, i*kS+129); the kS-129 = 4 gap
 // pixels between frames are always zero and serve as the SAME-padding halo of both neighbours.
@@ -35,6 +46,9 @@
 #endif
 #ifndef RCED_D2
 #define RCED_D2 2
+#endif
+#ifndef RCED_D2X
+#define RCED_D2X 2  // ... of layer 2 in the X6 form (a slot = one K = 32 chunk of one tile: 12 MFMAs)
 #endif
 #ifndef RCED_D3
 #define RCED_D3 2
@@ -83,6 +97,11 @@ __device__ __forceinline__ unsigned long long stamp() {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kF = 129;
 constexpr int kTF = 4;                       // frames per tile
@@ -91,7 +110,7 @@ constexpr int kNPX = kTF * kS;               // 532 pixels per tile
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 
-// ---- LDS map, in floats -----------------------------------------------------------------
+// ---- LDS map ----------------------------------------------------------------------------
 // B8 keeps its 8 channels at a pixel stride of 10 floats: with 8 channels one b64-step of the
 // 9-tap window is exactly one pixel, so the stride is free, and 10 turns the remainder pass's
 // 16-way bank conflict (column stride 8 pixels x 8 floats = 64 banks) into 4-way.
@@ -102,53 +121,115 @@ constexpr int kB8Pad = 4, kB18Pad = 2, kB30Pad = 4;       // leading zero rows (
 constexpr int kB8Rows = kB8Pad + kNPX + 4;                // pixels -4 .. 535
 constexpr int kB18Rows = kB18Pad + kNPX;                  // pixels -2 .. 531
 constexpr int kB30Rows = kB30Pad + kNPX;                  // pixels -4 .. 531
-constexpr int kB8Off = 0;
-constexpr int kB18Off = kB8Off + kB8Rows * kB8S;
-constexpr int kB30Off = kB18Off + kB18Rows * 18;
 constexpr int kWRegion = 37 * 128 + 64 + 32;              // largest packet: 30->8 (b64 steps + tail + shifts)
-constexpr int kWOff = kB30Off + kB30Rows * 30;
-constexpr int kLdsFloats = kWOff + 2 * kWRegion;
-constexpr int kLdsBytes = kLdsFloats * 4;
-static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
-static_assert((kWOff * 4) % 16 == 0 && (kWRegion * 4) % 16 == 0, "LDS-DMA destinations are 16-byte aligned");
-static_assert((kB18Off % 2) == 0 && (kB30Off % 2) == 0, "8-byte aligned buffers");
-// input rows of the 8x9 first layer alias the (not yet live) B30 buffer, from its pixel-0 row on
-constexpr int kX0Rows = kTF + 7;
+constexpr int kX0Rows = kTF + 7;                          // input rows of the 8x9 first layer (they alias B30)
 constexpr int kX0Floats = ((kX0Rows * kS + 24 + 3) / 4) * 4;   // 1488: max main-pass index 527 + 7*133 + 8
-constexpr int kX0Off = kB30Off + kB30Pad * 30;
-static_assert(kX0Floats <= 60 * 30, "X0 must sit inside rows that layer 2 rewrites");
+constexpr int kHS = 10;                                   // decode_final's H image: channel stride (floats): 8-byte aligned b64 reads
+constexpr int kHFrame = 193;                              // H pixels per frame: 64 zero + 129 bins
+constexpr int kHPix = kTF * kHFrame + 64;                 // 836
+constexpr int kFinU = 144, kFinRun = kFinU / kWaves;      // decode_final: window taps; K-steps per wave
+constexpr int kFinA = kFinU * 128;                        // floats of its A fragments: [u][lane][2]
+constexpr int kFin128 = 80 * 8;                           // bin 128: W[t][c] for taps t = 0..64 (window bins 64..128), zero for t = 65..79
+constexpr int kFinPack = kFinA + kFin128;
 
-// ---- packed weight stream (floats), per layer --------------------------------------------
+// The 18-channel tensor between layers 1 and 2 ("B18"):
+//   F32 form: fp32 [pixel][18].
+//   X6 form:  three bf16 planes (h, m, l) of channels 0..15, [pixel][16] = 32-byte rows -- a lane's fragment of a
+//             K = 32 chunk is ONE 16-byte-aligned ds_read_b128 (tap 2c + (kq >> 1), channels 8 (kq & 1)..+7), bank-conflict
+//             free in the instruction's lane groups -- and the two remainder channels 16, 17 beside them as rows of
+//             [h16 h17 m16 m17] (8 bytes) and [l16 l17] (4 bytes): their five taps ride in the last chunk's upper lanes.
+template <bool X6>
+struct Map {
+  static constexpr bool kX6 = X6;
+  static constexpr int kB8Off = 0;                                     // all offsets in floats unless named *Bytes
+  static constexpr int kB18Off = kB8Off + kB8Rows * kB8S;
+  static constexpr int kPlaneBytes = kB18Rows * 32;                    // one bf16 plane of 16 channels: 17,088
+  static constexpr int kRemRows = kB18Rows + 4;                        // the last chunk's zero-weight slots read 3 rows past a window
+  static constexpr int kRemHMBytes = 3 * kPlaneBytes;                  // byte offset of the [h16 h17 m16 m17] rows from the B18 base
+  static constexpr int kRemLBytes = kRemHMBytes + kRemRows * 8;        // ... of the [l16 l17] rows
+  static constexpr int kB18Bytes = X6 ? ((kRemLBytes + kRemRows * 4 + 15) / 16) * 16 : kB18Rows * 18 * 4;
+  static constexpr int kB30Off = kB18Off + kB18Bytes / 4;
+  static constexpr int kWRegions = X6 ? 1 : 2;                         // X6: only layer 3's packet goes through LDS
+  static constexpr int kWOff = kB30Off + kB30Rows * 30;
+  static constexpr int kLdsFloats = kWOff + kWRegions * kWRegion;
+  static constexpr int kLdsBytes = kLdsFloats * 4;
+  static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+  static_assert((kWOff * 4) % 16 == 0 && (kWRegion * 4) % 16 == 0, "LDS-DMA destinations are 16-byte aligned");
+  static_assert((kB18Off * 4) % 16 == 0 && (kB30Off % 2) == 0, "aligned buffers");
+  // input rows of the 8x9 first layer alias the (not yet live) B30 buffer, from its pixel-0 row on
+  static constexpr int kX0Off = kB30Off + kB30Pad * 30;
+  static_assert(kX0Floats <= 60 * 30, "X0 must sit inside rows that layer 2 rewrites");
+  // decode_final's H image aliases the (by then dead) B18 buffer, behind layer 3's hand-off scratch (B18 floats 180..951)
+  static constexpr int kHOff = kB18Off + 1200;
+  static_assert(kHOff + kHPix * kHS <= kB30Off && (kHOff % 2) == 0, "H fits inside B18");
+  // decode_final's bin-128 weights: F32 form: behind a layer-1 packet in its weight region; X6 form: behind the H image in
+  // rows of the l plane that belong to real pixels of frame 1 (rewritten by every layer 1, never a gap row)
+  static constexpr int kFin128Off = kB18Off + (2 * kPlaneBytes + (kS + kB18Pad) * 32) / 4;
+  static_assert(!X6 || (kFin128Off >= kHOff + kHPix * kHS && (kFin128Off * 4) % 16 == 0 &&
+                        (kFin128Off + kFin128) * 4 <= kB18Off * 4 + 2 * kPlaneBytes + (kS + kF + kB18Pad) * 32),
+                "bin-128 weights: behind H, 16-byte aligned, inside frame 1's real rows of the l plane");
+  // decode_final's partial sums: 8 waves x 256 floats per column tile, in two stretches of B30 (dead by then) that contain NO
+  // gap pixel (B30's gap rows sit at floats 3990.., 7980.., 11970.. and must stay zero) and are clear of X0
+  static constexpr int kFinScr0 = kB30Off + 4112, kFinScr1 = kB30Off + 8112;
+  static_assert(kFinScr0 >= kX0Off + kX0Floats && ((kFinScr0 * 4) % 16) == 0 && ((kFinScr1 * 4) % 16) == 0, "16-byte aligned, clear of X0");
+  static_assert(kFinScr0 >= kB30Off + (kB30Pad + kF + 4) * 30 && kFinScr0 + 2048 <= kB30Off + (kB30Pad + kS + kF) * 30, "no gap row");
+  static_assert(kFinScr1 >= kB30Off + (kB30Pad + kS + kF + 4) * 30 && kFinScr1 + 2048 <= kB30Off + (kB30Pad + 2 * kS + kF) * 30, "no gap row");
+  // layer 2's split-tile hand-off: in the B8 buffer, which is dead during layer 2 (layer 3 rewrites every real pixel of it)
+  static constexpr int kScr2Slots = X6 ? 4 : 2;                            // helpers of the split tile (1 KiB of partial sums each)
+  static constexpr int kScratch2Off = kB8Off + kB8Pad * kB8S + 8 * kB8S;   // B8 rows 8.. of frame 0 (slots x 256 floats + flags)
+  static constexpr int kFlag2Off = kScratch2Off + kScr2Slots * 256;
+  static_assert((kScratch2Off * 4) % 16 == 0, "scratch is read/written with b128");
+  static_assert(8 + (kScr2Slots * 257 + kB8S - 1) / kB8S <= kF, "layer-2 scratch stays inside frame 0's real pixels");
+  // layer 3's: in the B18 buffer (dead during layer 3), in rows of frame 0's real pixels: always rewritten by layer 1
+  static constexpr int kScratchOff = kB18Off + 180;
+  static constexpr int kFlagOff = kScratchOff + 3 * 256;
+  static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
+  static_assert(X6 ? (kScratchOff - kB18Off) * 4 >= (8 + kB18Pad) * 32 && (kFlagOff + 3 - kB18Off) * 4 <= (kF + kB18Pad) * 32
+                   : kScratchOff - kB18Off >= (8 + kB18Pad) * 18 && kFlagOff + 3 - kB18Off <= (kF + kB18Pad) * 18,
+                "scratch + flags stay inside frame 0's real pixels");
+  static_assert(kFlagOff + 3 <= kHOff, "layer 3's hand-off scratch and the H image do not overlap");
+  // byte strides between a wave's regular tiles (8 tiles = 128 pixels apart)
+  static constexpr int kT1R = 128 * kB8S * 4, kT1W = X6 ? 128 * 32 : 128 * 18 * 4;
+  static constexpr int kT2R = X6 ? 64 * 32 : 128 * 18 * 4, kT2W = X6 ? 64 * 30 * 4 : 128 * 30 * 4;   // X6: a wave's layer-2 tiles are 4 apart
+  static constexpr int kT3R = 128 * 60 * 4, kT3W = 256 * kB8S * 4;
+  static constexpr int kTileB18 = X6 ? 16 * 32 : 16 * 18 * 4;          // ... between adjacent 16-pixel tiles of B18
+};
+typedef Map<false> MapF32;
+typedef Map<true> MapX6;
+
+// ---- packed weight streams (floats), per block -----------------------------------------------
 //  first layer main (8x9x1 -> ch 0..15): 18 k-steps x 64 lanes (b32 steps, k = (time tap, freq tap))
 //  first layer rem  (ch 16,17 x 8 phases): 32 k-steps x 64 lanes (k = (time tap, 16 freq taps))
 //  L1 main (1x9, 8 -> ch 0..15):  9 b64-steps x 64 lanes x 2
 //  L1 rem  (ch 16,17 x 8 phases): 16 b64-steps x 64 x 2   (K = 16 taps x 8)
-//  L2 (1x5, 18->30): 11 b64-steps x 2 M-tiles x 64 x 2 + a b32 tail step (k = 88 + kq; K = 90)
+//  L2 (1x5, 18->30), F32 form: 11 b64-steps x 2 M-tiles x 64 x 2 + a b32 tail step (k = 88 + kq; K = 90)
+//  L2, X6 form: [chunk 3][M-tile 2][part 3][lane 64] x 8 bf16 (K = 96 slots: three K = 32 chunks, see pack_v3)
 //  L3 (1x9, 30->8):  37 b64-steps x 64 x 2 + a b32 tail step (k = 296 + kq; K = 300 = 10 taps x 30,
 //                    rows = 2 pixel phases x 8 channels)
-// Every packet ends with its 32 shift values (bias + folded BatchNorm).
+// F32 form: one packet per layer, each ending with its 32 shift values (bias + folded BatchNorm), streamed into LDS.
+// X6 form: layer 1's and layer 2's weights are laid out for 16-byte-per-lane global loads into registers
+// ([j][lane][4 floats]: main j < 5, remainder j < 8), each followed by its 32 shifts; layer 3's packet as in the F32 form.
 constexpr int kShiftPerLayer = 32;
 constexpr int kW1Main = 9 * 128;          // 1152 (= 18 * 64 for the first layer)
 constexpr int kW1Rem = 16 * 128;          // 2048 (= 32 * 64 for the first layer)
 constexpr int kW1Data = kW1Main + kW1Rem; // 3200
 constexpr int kL2Steps = 11, kL3Steps = 37;                  // b64 steps; each pass ends with one b32 step
-#ifndef RCED_V3_L2X6
-#define RCED_V3_L2X6 1    // 1: layer 2 (18 -> 30, two M-tiles) at fp32 quality on the bf16 matrix pipe: the weights as
-                          // three bf16 parts in the packet, the B fragments split in registers out of the fp32 B18 buffer (there is no
-                          // LDS left for planes), six v_mfma_f32_16x16x32_bf16 per K = 32 chunk, M-tile and tile
-#endif
-constexpr int kL2Chunks = 3;                                  // K = 90 in three K = 32 chunks (x6 form)
-#if RCED_V3_L2X6
-constexpr int kW2Data = kL2Chunks * 2 * 3 * 64 * 4;    // 4608 floats: [chunk][M-tile][part][lane] x 8 bf16
-#else
+constexpr int kL2Chunks = 3;                                  // X6 form: K = 90 in three K = 32 chunks
 constexpr int kW2Data = kL2Steps * 2 * 128 + 2 * 64;   // 2944
-#endif
 constexpr int kW3Data = kL3Steps * 128 + 64;           // 4800
 constexpr int kW1 = kW1Data + kShiftPerLayer;
 constexpr int kW2 = kW2Data + kShiftPerLayer;
 constexpr int kW3 = kW3Data + kShiftPerLayer;
 constexpr int kWBlock = kW1 + kW2 + kW3;
 constexpr int kWTotal = 5 * kWBlock;
+constexpr int kG1Main = 5 * 256, kG1Rem = 8 * 256;                        // X6 form: register images of layer 1's A fragments
+constexpr int kG1 = kG1Main + kG1Rem + kShiftPerLayer;                    // 3360
+constexpr int kG2Data = kL2Chunks * 2 * 3 * 64 * 4;                       // 4608 floats
+constexpr int kG2 = kG2Data + kShiftPerLayer;                             // 4640
+constexpr int kGBlock = kG1 + kG2 + kW3;
+constexpr int kGTotal = 5 * kGBlock;
+static_assert(kG1 % 4 == 0 && kG2 % 4 == 0 && kW3 % 4 == 0, "16-byte aligned pieces");
+static_assert(kW1 + kFin128 <= kWRegion && (kW1 % 4) == 0, "F32 form: the bin-128 weights fit behind a layer-1 packet in its LDS region");
 
 // ---- decode_final (1x129, 8 -> 1, no BN, no ReLU; model.py:89-90) inside the kernel ----------------------------
 // The CD2 output of a tile never leaves the CU: block 4's layer 3 stores it to H, an LDS image that aliases the (by then
@@ -161,23 +242,6 @@ constexpr int kWTotal = 5 * kWBlock;
 // wave); the eight partial sums meet in LDS scratch (B30 is dead) and waves 0 / 1 finish column tile 0 / 1 in a fixed
 // order (deterministic).  Bin 128 (one output per frame, 65 x 8 taps) is a dot product on the VALU of wave 2.
 // A fragments (73.7 KB) stream from L2 into registers, issued before block 4's layer 3 so that their latency hides.
-constexpr int kHS = 10;                                   // H channel stride (floats): 8-byte aligned b64 reads
-constexpr int kHFrame = 193;                              // H pixels per frame: 64 zero + 129 bins
-constexpr int kHPix = kTF * kHFrame + 64;                 // 836
-constexpr int kHOff = kB18Off + 1200;                     // behind layer 3's hand-off scratch (B18 floats 180..1134)
-static_assert(kHOff + kHPix * kHS <= kB30Off, "H fits inside B18");
-static_assert((kHOff % 2) == 0, "8-byte aligned");
-constexpr int kFinU = 144, kFinRun = kFinU / kWaves;      // window taps; K-steps per wave
-constexpr int kFinA = kFinU * 128;                        // floats of A fragments: [u][lane][2]
-constexpr int kFin128 = 80 * 8;                           // bin 128: W[t][c] for taps t = 0..64 (window bins 64..128), zero for t = 65..79
-constexpr int kFinPack = kFinA + kFin128;
-static_assert(kW1 + kFin128 <= kWRegion && (kW1 % 4) == 0, "the bin-128 weights fit behind a layer-1 packet in its LDS region");
-// partial sums: 8 waves x 256 floats per column tile, in two stretches of B30 (dead by then) that contain NO gap pixel
-// (B30's gap rows sit at floats 3990.., 7980.., 11970.. and must stay zero) and are clear of X0 (the next tile's input rows)
-constexpr int kFinScr0 = kB30Off + 4112, kFinScr1 = kB30Off + 8112;
-static_assert(kFinScr0 >= kX0Off + kX0Floats && (kFinScr0 % 4) == 0 && (kFinScr1 % 4) == 0, "16-byte aligned, clear of X0");
-static_assert(kFinScr0 >= kB30Off + (kB30Pad + kF + 4) * 30 && kFinScr0 + 2048 <= kB30Off + (kB30Pad + kS + kF) * 30, "no gap row");
-static_assert(kFinScr1 >= kB30Off + (kB30Pad + kS + kF + 4) * 30 && kFinScr1 + 2048 <= kB30Off + (kB30Pad + 2 * kS + kF) * 30, "no gap row");
 
 // ---- tile -> wave assignment ---------------------------------------------------------------
 // 16-pixel tiles 0..32 (pixels 0..527; 528..531 is gap): wave w owns tiles w + 8*slot, slot < 4
@@ -188,14 +252,14 @@ static_assert(kFinScr1 >= kB30Off + (kB30Pad + kS + kF + 4) * 30 && kFinScr1 + 2
 //   layer 1: remainder tiles (128 pixels) 0..4 go one each to waves 4,5,6 and two to wave 7, which gives up
 //            main tile 31 (to wave 1; tile 32 to wave 0): 194, 194, 176, 190 per SIMD (18 per main tile,
 //            32 per remainder tile).
-//   layer 2: tile 32 is cut in four, M-tile x K-half, one piece on each of waves 0..3: 379.5 everywhere.
+//   layer 2: tile 32 is cut in four, M-tile x K-part, one piece on each of waves 0..3.
 //   layer 3: pair tile 16 is cut in four along K on waves 0..3: 318.75 everywhere.
 // The cut tiles are put back together through LDS scratch + tagged flag words (pairwise, no extra barrier).
 
 struct Params {
   const float* x;       // [N, T, 129]
   float* y;             // [N, T, 129]    the mask (output of decode_final)
-  const float* wpack;   // kWTotal floats
+  const float* wpack;   // kWTotal (F32 form) / kGTotal (X6 form) floats
   const float* fin;     // kFinPack floats: decode_final's A fragments + its bin-128 weights (pack_v3)
   float fin_bias;
   int N, T;
@@ -207,6 +271,9 @@ struct Params {
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma32(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
 
@@ -223,6 +290,7 @@ __device__ __forceinline__ int opaque(int v) {
 // at the end of the layer during which it was issued.
 template <int NFLOATS>
 __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float* dst, int wave, int lane) {
+  lane = opaque(lane);   // (or hipcc keeps one 64-bit source address per call site alive across the tile loop)
   constexpr int n4 = NFLOATS / 4;
   constexpr int chunks = (n4 + 63) / 64;
 #pragma unroll
@@ -236,7 +304,12 @@ __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float*
   }
 }
 __device__ __forceinline__ void layer_end_sync() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
+  // This wave's LDS-DMA pieces (issued from asm: invisible to hipcc) and register-bound weight loads have landed.  The wait is
+  // stated twice: as asm (never dropped) and as the builtin, which hipcc's wait-count pass sees -- without it the pass believes
+  // the weight loads of the previous layer may still be in flight and puts s_waitcnt vmcnt(N) in front of their first uses,
+  // where N counts only the loads it knows: in hardware that waits for the prefetches just issued for the NEXT layer.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
   __syncthreads();
 }
 
@@ -246,6 +319,7 @@ __device__ __forceinline__ void layer_end_sync() {
 // v_max_f32 v,v,v in front (2 VALU per element); an inline-asm v_max_f32 is NOT an option: hipcc pads
 // no MFMA -> VALU wait states inside asm, and a ReLU issued right behind the last MFMA then reads the
 // accumulator before it lands (seen as rare wrong values in each wave's first tile).
+// (A NaN keeps its bits -- positive-signed NaNs, which is what the hardware generates, stay NaN.)
 __device__ __forceinline__ float relu1(float v) {
   const int b = __builtin_bit_cast(int, v);
   return __builtin_bit_cast(float, b > 0 ? b : 0);
@@ -281,6 +355,7 @@ __device__ __forceinline__ float xstage_one(const Params& P, bool live, const fl
   return v;
 }
 __device__ __forceinline__ XStage xstage_load(const Params& P, int tile, int tid) {
+  tid = opaque(tid);   // (once per tile: nothing of this is worth keeping in registers across the tile loop)
   const bool live = tile < P.total_tiles;
   const int utt = live ? tile / P.tiles_per_utt : 0;
   const int t0 = live ? (tile - utt * P.tiles_per_utt) * kTF : 0;
@@ -356,53 +431,71 @@ __device__ __forceinline__ void lds_poke_a(unsigned addr, unsigned v) {
 
 // Per-lane LDS byte addresses and masks, computed ONCE per kernel (they depend on the lane and the wave only).
 // Everything a layer touches is one of these plus a compile-time immediate (plus, for the odd tiles, a wave-uniform
-// delta: one v_add per layer).
+// delta: one v_add per layer).  Members a form does not use are never computed.
 struct Lane {
   unsigned a8, a4, kq16;   // lane*8, lane*4, (lane>>4)*16: offsets inside a weight packet (A fragments, tail, shifts)
   unsigned rd0, rd0b, rd0r;// block 0's layer 1: input-row window start of main tile `wave` (/ + 8) and of remainder tile xr0
   unsigned rd1, rd1b, wr1; // layer 1 main tile `wave` (/ the tile 8 further: a base of its own, see make_lane): B8 window start, B18 output
-  unsigned rd1r, wr1r;     // layer 1 remainder tile xr0 (waves 4..7)
-  unsigned rd2, rd2b, rd2t, rd2tb, wr2; // layer 2 tile `wave` (/ + 8): B18 window start (b64 steps / tail), B30 output
-  unsigned rd2x;           // layer 2 in the x6 form: B18 window start + 8 kq floats (a lane's eight consecutive k of a K = 32 chunk)
+  unsigned rd1r, wr1r;     // layer 1 remainder tile xr0 (waves 4..7); X6: wr1r = the [h m] rows, wr1rl = the [l] rows
+  unsigned wr1rl;
+  unsigned rd2, rd2b, rd2t, rd2tb, wr2; // layer 2 tile `wave` (/ + 8): B18 window start (b64 steps / tail), B30 output (F32 form)
+  unsigned rd2m, rd2r, rd2rl;           // X6 form: this lane's fragment of chunk 0 in the h plane; its remainder rows ([h m] / [l])
   unsigned rd3, rd3b, rd3t, rd3tb, wr3; // layer 3 pair tile `wave` (/ + 8): B30 window start (b64 steps / tail), B8 output
   unsigned wh0, wh1, whx;  // block 4's layer 3: where this lane's output pixel of pair tile 0 / 1 / 16 goes in the H image
   unsigned scr;            // lane*16: offset inside a hand-off scratch area
   unsigned vbits;          // validity bits, see kV*
 };
 // vbits: bit t (0..3) main tile wave+8t pixel is a real bin; 4,5 / 6,7: remainder tile 0 / 1, this lane's two pixels;
-// 8,9: layer-3 pair tiles 0,1; 10: pair tile 16 (the split one); 11: lane < 48 (kq != 3: channels 28,29 vs padding 30,31)
-constexpr int kVMain = 0, kVRem = 4, kVL3 = 8, kVL3X = 10, kVLt48 = 11;
-constexpr int kT1R = 128 * kB8S * 4, kT1W = 128 * 18 * 4;     // byte strides between a wave's regular tiles (8 tiles apart)
-constexpr int kT2R = 128 * 18 * 4, kT2W = 128 * 30 * 4;
-constexpr int kT3R = 128 * 60 * 4, kT3W = 256 * kB8S * 4;
+// 8,9: layer-3 pair tiles 0,1; 10: pair tile 16 (the split one); 11: lane < 48 (kq != 3: channels 28,29 vs padding 30,31);
+// 12: lane >= 32 (the lanes whose slots of layer 2's last chunk are the remainder channels); X6 form: 13: this lane's second
+// pair of layer-2 outputs is real (M-tile 0, or lane < 48); 16..23: pixel of layer-2 tile (wave & 3) + 4t is a real bin
+constexpr int kVMain = 0, kVRem = 4, kVL3 = 8, kVL3X = 10, kVLt48 = 11, kVUpper = 12, kVSt2 = 13, kVL2 = 16;
 
+template <class M>
 __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr0) {
   const int n = lane & 15, kq = lane >> 4;
-  const unsigned B8 = lds_addr(lds + kB8Off + kB8Pad * kB8S), B18 = lds_addr(lds + kB18Off + kB18Pad * 18),
-                 B30 = lds_addr(lds + kB30Off + kB30Pad * 30);
+  const unsigned B8 = lds_addr(lds + M::kB8Off + kB8Pad * kB8S), B30 = lds_addr(lds + M::kB30Off + kB30Pad * 30);
   const int px0 = 16 * wave + n;
   Lane L;
   L.a8 = lane * 8;
   L.a4 = lane * 4;
   L.kq16 = kq * 16;
   L.scr = lane * 16;
-  const unsigned X0 = lds_addr(lds + kX0Off);
+  const unsigned X0 = lds_addr(lds + M::kX0Off);
   L.rd0 = X0 + 4 * (px0 + kq * kS);                         // lane kq <-> time taps 4*ih + kq
   L.rd0r = X0 + 4 * (8 * (16 * xr0 + n) + kq * kS);
   L.rd1 = B8 + 4 * ((px0 - 4) * kB8S + 2 * kq);
-  L.wr1 = B18 + 4 * (px0 * 18 + 4 * kq);
   const int rpx = 8 * (16 * xr0 + n);                       // first pixel of this lane's octet in remainder tile xr0
   L.rd1r = B8 + 4 * ((rpx - 4) * kB8S + 2 * kq);
-  L.wr1r = B18 + 4 * ((rpx + 2 * kq) * 18 + 16);            // channels 16,17 of pixels rpx+2kq, +1
-  L.rd2 = B18 + 4 * ((px0 - 2) * 18 + 2 * kq);
-  L.rd2t = L.rd2 + 4 * (8 * kL2Steps + (kq < 1 ? kq : 1) - 2 * kq);   // K = 90: tail k = 88 + kq is real for kq < 2
-  L.rd2x = B18 + 4 * ((px0 - 2) * 18 + 8 * kq);
-  L.wr2 = B30 + 4 * (px0 * 30 + 4 * kq);
+  if constexpr (M::kX6) {
+    const unsigned PL = lds_addr(lds + M::kB18Off);         // the h plane; row r = pixel r - kB18Pad
+    L.wr1 = PL + (px0 + kB18Pad) * 32 + kq * 8;             // channels 4kq..4kq+3 of pixel px0
+    L.wr1r = PL + M::kRemHMBytes + (rpx + 2 * kq + kB18Pad) * 8;   // channels 16,17 of pixels rpx+2kq, +1
+    L.wr1rl = PL + M::kRemLBytes + (rpx + 2 * kq + kB18Pad) * 4;
+    // layer 2: wave (g = M-tile, j) walks tiles j + 4t; px2 = this lane's pixel of tile j
+    // chunk c: tap 2c + (kq >> 1) = pixel px2 - 2 + tap = row px2 + tap, channels 8 (kq & 1)..+7
+    const int px2 = 16 * (wave & 3) + n;
+    L.rd2m = PL + (px2 + (kq >> 1)) * 32 + (kq & 1) * 16;
+    // the remainder channels' window of pixel px2 = rows px2 .. px2+4; lanes kq = 2 take rows px2..+3, kq = 3 rows px2+4..+7
+    // (one real tap, three zero-weight slots); the lower lanes read their upper partners' rows (same addresses: broadcast)
+    L.rd2r = PL + M::kRemHMBytes + (px2 + 4 * (kq & 1)) * 8;
+    L.rd2rl = PL + M::kRemLBytes + (px2 + 4 * (kq & 1)) * 4;
+    L.rd2 = L.rd2b = L.rd2t = L.rd2tb = 0u;
+  } else {
+    const unsigned B18 = lds_addr(lds + M::kB18Off + kB18Pad * 18);
+    L.wr1 = B18 + 4 * (px0 * 18 + 4 * kq);
+    L.wr1r = B18 + 4 * ((rpx + 2 * kq) * 18 + 16);          // channels 16,17 of pixels rpx+2kq, +1
+    L.rd2 = B18 + 4 * ((px0 - 2) * 18 + 2 * kq);
+    L.rd2t = L.rd2 + 4 * (8 * kL2Steps + (kq < 1 ? kq : 1) - 2 * kq);   // K = 90: tail k = 88 + kq is real for kq < 2
+    L.wr1rl = L.rd2m = L.rd2r = L.rd2rl = 0u;
+  }
+  if constexpr (M::kX6) L.wr2 = B30 + 4 * ((16 * (wave & 3) + n) * 30 + 16 * (wave >> 2) + 4 * kq);   // channels 16 g + 4kq..
+  else L.wr2 = B30 + 4 * (px0 * 30 + 4 * kq);
   L.rd3 = B30 + 4 * ((2 * px0 - 4) * 30 + 2 * kq);          // px0 doubles as the pixel-PAIR index of layer 3
   L.rd3t = L.rd3 + 4 * (8 * kL3Steps - kq);                 // K = 300: tail k = 296 + kq, all four real
   L.wr3 = B8 + 4 * ((2 * px0 + (kq >> 1)) * kB8S + 4 * (kq & 1));
   {
-    const unsigned H = lds_addr(lds + kHOff);
+    const unsigned H = lds_addr(lds + M::kHOff);
     auto haddr = [&](int px) {   // px: tile-flat pixel of frame px / kS, bin px % kS
       const int fr = px / kS, f = px - fr * kS;
       return H + 4 * ((kHFrame * fr + 64 + f) * kHS + 4 * (kq & 1));
@@ -424,22 +517,31 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   for (int t = 0; t < 2; ++t) v |= (unsigned)px_valid(2 * (px0 + 128 * t) + (kq >> 1)) << (kVL3 + t);
   v |= (unsigned)px_valid(2 * (256 + n) + (kq >> 1)) << kVL3X;
   v |= (unsigned)(lane < 48) << kVLt48;
+  v |= (unsigned)(lane >= 32) << kVUpper;
+  if constexpr (M::kX6) {
+    v |= (unsigned)(wave < 4 || lane < 48) << kVSt2;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v |= (unsigned)px_valid(16 * (wave & 3) + n + 64 * t) << (kVL2 + t);
+  }
   L.vbits = v;
   // The second tile of a pair job gets a base register of its own, hidden from the optimiser: with one base and two
   // immediates hipcc fuses the two reads of a slot into one ds_read2[st64]_b64, which needs a per-slot v_add for its
   // re-based address (VALU beside MFMAs is not free) and takes twice the LDS cycles of two ds_read_b64.
   L.rd0b = L.rd0 + 128 * 4;
-  L.rd1b = L.rd1 + kT1R;
-  L.rd2b = L.rd2 + kT2R;
-  L.rd3b = L.rd3 + kT3R;
-  L.rd2tb = L.rd2t + kT2R;
-  L.rd3tb = L.rd3t + kT3R;
-  asm volatile("" : "+v"(L.rd0b), "+v"(L.rd1b), "+v"(L.rd2b), "+v"(L.rd3b), "+v"(L.rd2tb), "+v"(L.rd3tb));
+  L.rd1b = L.rd1 + M::kT1R;
+  L.rd2b = L.rd2 + M::kT2R;
+  L.rd3b = L.rd3 + M::kT3R;
+  L.rd2tb = L.rd2t + M::kT2R;
+  L.rd3tb = L.rd3t + M::kT3R;
+  asm volatile("" : "+v"(L.rd0b), "+v"(L.rd1b), "+v"(L.rd3b), "+v"(L.rd3tb));
+  if constexpr (!M::kX6) asm volatile("" : "+v"(L.rd2b), "+v"(L.rd2tb));
 #if RCED_LANE_OPAQUE
   // every other address too: left visible, hipcc keeps only the lane-dependent part in a VGPR and re-adds the (scalar)
   // buffer base at each use -- a v_add per job and per epilogue store
-  asm volatile("" : "+v"(L.rd0), "+v"(L.rd0r), "+v"(L.rd1), "+v"(L.wr1), "+v"(L.rd1r), "+v"(L.wr1r), "+v"(L.rd2), "+v"(L.rd2t));
+  asm volatile("" : "+v"(L.rd0), "+v"(L.rd0r), "+v"(L.rd1), "+v"(L.wr1), "+v"(L.rd1r), "+v"(L.wr1r));
   asm volatile("" : "+v"(L.wr2), "+v"(L.rd3), "+v"(L.rd3t), "+v"(L.wr3), "+v"(L.wh0), "+v"(L.wh1), "+v"(L.whx));
+  if constexpr (M::kX6) asm volatile("" : "+v"(L.wr1rl), "+v"(L.rd2m), "+v"(L.rd2r), "+v"(L.rd2rl));
+  else asm volatile("" : "+v"(L.rd2), "+v"(L.rd2t));
 #endif
   return L;
 }
@@ -471,8 +573,8 @@ __device__ __forceinline__ bool tile_has_gap(int T) { return span_has_gap(16 * T
 // tiles, the shares of the split tiles -- is base registers and wave-uniform branches around the shared code.  With
 // one unrolled stream per wave role (an earlier version) the kernel was 60 KB of code and ran 40 % slower than at
 // 52 KB: the instruction cache (64 KB for two CUs) no longer held what 16 waves were executing.
-// `pre` runs once the job's first operand reads are in flight: a layer's first job issues the next weight packet's
-// LDS-DMA there (Once, below) -- ~30 mostly scalar instructions that used to sit between the barrier and the first LDS
+// `pre` runs once the job's first operand reads are in flight: a layer's first job issues the next layer's weight
+// transfers there (Once, below) -- ~30 mostly scalar instructions that used to sit between the barrier and the first LDS
 // read of the layer, where nothing overlaps them; here they run in the shadow of the reads' latency.
 template <int NSLOT, int D, class LoadF, class MathF, class Pre>
 __device__ __forceinline__ void run_job(LoadF&& load, MathF&& math, Pre&& pre) {
@@ -503,26 +605,136 @@ struct Once {   // the wave's first job of a layer calls it; later jobs skip it 
 template <class F>
 __device__ __forceinline__ Once<F> once(F f) { return Once<F>{f}; }
 
+// ---- X6 form: weights that live in registers ------------------------------------------------------------
+// Layer 1's A fragments (main pass: 18 floats per lane; remainder pass: 32, waves 4..7) and layer 2's (three chunks x two
+// M-tiles x three bf16 parts x 16 bytes = 72 registers) come straight from global memory (the XCD's L2: 92 KB of packets
+// shared by every workgroup), 16 bytes per lane and load, one layer ahead of their use.
+// The main pass's fragments are fetched during the previous layer 3 (they are what layer 1 starts with); the remainder pass's,
+// used by a wave's LAST job of layer 1, at the start of layer 1 itself: they are not carried across the block loop.
+struct A1Regs {
+  f32x4 m[5];   // main pass: floats 0..17 = the K-steps' fragments in order (blocks 1..4: two floats per b64 step)
+  f32x4 sh;     // shift[4kq .. 4kq+3]
+  f32x2 s2;     // shift[16], shift[17]
+};
+struct A1Rem {
+  f32x4 r[8];   // remainder pass (waves 4..7)
+};
+// (Every loader re-derives its lane offset behind opaque(): otherwise hipcc hoists one 64-bit address per load out of the tile
+// loop and spills them.)
+__device__ __forceinline__ void a1_load(A1Regs& A, const float* __restrict__ g1, int lane) {
+  lane = opaque(lane);
+  const f32x4* p = reinterpret_cast<const f32x4*>(g1) + lane;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) A.m[j] = p[j * 64];
+  A.sh = reinterpret_cast<const f32x4*>(g1 + kG1Main + kG1Rem)[lane >> 4];
+  A.s2 = *reinterpret_cast<const f32x2*>(g1 + kG1Main + kG1Rem + 16);
+}
+// Layer 2: a wave computes ONE M-tile (waves 0..3: channels 0..15, waves 4..7: 16..29) -- 36 registers of A fragments.
+struct A2Regs {
+  s16x8 a[kL2Chunks][3];   // [chunk][part h, m, l] of this wave's M-tile
+  f32x4 sh;                // shift[16 mt + 4kq ..]
+};
+// All of these loads are written as (wave-uniform base) + (one 32-bit per-lane byte offset, computed once per layer behind
+// opaque()) + (constant): hipcc then issues them in the saddr form with the constant as the immediate -- no per-load address
+// arithmetic on the vector ALU, nothing for it to hoist out of the tile loop and spill.
+template <class T>
+__device__ __forceinline__ T gld(const float* __restrict__ base, unsigned voff, int off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)voff + off);
+}
+// piece I of the ten: 0..8 = (chunk I / 3, part I % 3), 9 = the shifts.  g2m = the block's layer-2 image + this wave's M-tile
+// offset (mt * 3 KiB); voff = lane * 16
+template <int I>
+__device__ __forceinline__ void a2_load_one(A2Regs& A, const float* __restrict__ g2, int mt, unsigned voff) {
+  if constexpr (I < 9) {
+    constexpr int c = I / 3, q = I % 3;
+    A.a[c][q] = gld<s16x8>(g2 + mt * (3 * 256), voff, ((c * 2) * 3 + q) * 1024);
+  } else {
+    A.sh = gld<f32x4>(g2 + kG2Data + 16 * mt, (voff >> 4) & 0x30u, 0);   // shift[16 mt + 4 kq ..]: (lane >> 4) * 16 bytes
+  }
+}
+template <int I>
+__device__ __forceinline__ void a1_load_rem_one(A1Rem& A, const float* __restrict__ g1, unsigned voff) {
+  A.r[I] = gld<f32x4>(g1 + kG1Main, voff, I * 1024);
+}
+template <int I>   // piece I of the seven: 0..4 = m[I], 5 = sh, 6 = s2
+__device__ __forceinline__ void a1_load_one(A1Regs& A, const float* __restrict__ g1, unsigned voff) {
+  if constexpr (I < 5) A.m[I] = gld<f32x4>(g1, voff, I * 1024);
+  else if constexpr (I == 5) A.sh = gld<f32x4>(g1 + kG1Main + kG1Rem, (voff >> 4) & 0x30u, 0);
+  else A.s2 = gld<f32x2>(g1 + kG1Main + kG1Rem + 16, 0u, 0);
+}
+
+// Two fp32 values -> their three bf16 parts, packed (low half = the first value): x = h + m + l to 2^-24 (round to nearest
+// at every step).  Written element by element: left to itself hipcc joins the two subtractions into one v_pk_add_f32, which
+// beside MFMAs costs more than the two v_sub_f32 it replaces (MI355X guide, "packed f32 VALU ... an anti-lever").
+// An Inf gives h = Inf and m = l = NaN (Inf - Inf), a NaN three NaNs: non-finite values stay non-finite downstream.
+struct P3 {
+  unsigned h, m, l;
+};
+__device__ __forceinline__ float unpk(float v) {   // keep the optimiser from re-pairing the two lanes of a pack
+  asm volatile("" : "+v"(v));
+  return v;
+}
+#ifndef RCED_X6_EXP
+#define RCED_X6_EXP 0   // timing experiments only (wrong results): 1 = no split arithmetic, 2 = no spread loads in layer 1, 4 = none in layer 3,
+                        // 8 = one plane store instead of three, 16 = no remainder-row reads / merge in layer 2
+#endif
+__device__ __forceinline__ P3 split2(float x0, float x1) {
+  P3 p;
+  if (RCED_X6_EXP & 1) {
+    p.h = __builtin_bit_cast(unsigned, x0);
+    p.m = __builtin_bit_cast(unsigned, x1);
+    p.l = p.h ^ p.m;
+    return p;
+  }
+  const bf16x2 bh = {(__bf16)x0, (__bf16)x1};
+  p.h = __builtin_bit_cast(unsigned, bh);
+  const float r0 = unpk(x0 - __builtin_bit_cast(float, p.h << 16)), r1 = unpk(x1 - __builtin_bit_cast(float, p.h & 0xffff0000u));
+  const bf16x2 bm = {(__bf16)r0, (__bf16)r1};
+  p.m = __builtin_bit_cast(unsigned, bm);
+  const float s0 = unpk(r0 - __builtin_bit_cast(float, p.m << 16)), s1 = unpk(r1 - __builtin_bit_cast(float, p.m & 0xffff0000u));
+  const bf16x2 bl = {(__bf16)s0, (__bf16)s1};
+  p.l = __builtin_bit_cast(unsigned, bl);
+  return p;
+}
+
 // ---- layer 1: 8x9, 1 -> 18 on the input rows (block 0, FIRST) / 1x9, 8 -> 18 on B8 (blocks 1..4) -----------
 // Blocks 1..4: a slot is a b64 K-step (two k-quads; k = tap*8 + ci): 9 slots per main tile (channels 0..15 of 16
 // pixels), 16 per remainder tile (channels 16,17 of 128 pixels as 8 phases x 2 channels, K = 16 taps).  Block 0: a slot
 // is a b32 K-step (one k-quad = time taps 4*ih + kq at one frequency tap; B operand straight out of the staged input
 // rows X0): 18 / 32 slots.  Main tiles run in pairs (one A fragment for both); waves 0, 1 (tile 32 / 31) and wave 7
 // (three regular tiles) have one single tile.
-template <bool FIRST>
+template <class M, bool FIRST>
 struct L1Geo {
   static constexpr int SR = FIRST ? 32 : 16, SM = FIRST ? 18 : 9;      // slots of a remainder / main job
   static constexpr int kAStep = FIRST ? 64 : 128;                       // floats per K-step of A fragments
-  static constexpr int kTR = FIRST ? 128 * 4 : kT1R;                    // read-side byte stride between a wave's regular tiles
+  static constexpr int kTR = FIRST ? 128 * 4 : M::kT1R;                 // read-side byte stride between a wave's regular tiles
   static constexpr int kTileR = FIRST ? 16 * 4 : 16 * kB8S * 4;         // ... between adjacent 16-pixel tiles
   static constexpr int D = FIRST ? 2 * RCED_D1 : RCED_D1;
   // byte offset of K-step st inside a lane's window: blocks 1..4: one pixel per b64 step; block 0: (ih, j)
   static constexpr int koff(int st, int per) { return FIRST ? ((st / per) * 4 * kS + st % per) * 4 : kB8S * 4 * st; }
 };
+// K-step I of the A fragment kept in registers (X6 form): FIRST: one float per step, else two
+template <bool FIRST, bool REM, int I>
+__device__ __forceinline__ f32x2 a1_frag(const A1Regs& A, const A1Rem& R) {
+  if constexpr (FIRST) {
+    if constexpr (REM) return f32x2{R.r[I / 4][I % 4], 0.f};
+    else return f32x2{A.m[I / 4][I % 4], 0.f};
+  } else {
+    constexpr int i0 = 2 * I, i1 = 2 * I + 1;
+    if constexpr (REM) return f32x2{R.r[i0 / 4][i0 % 4], R.r[i1 / 4][i1 % 4]};
+    else return f32x2{A.m[i0 / 4][i0 % 4], A.m[i1 / 4][i1 % 4]};
+  }
+}
 
-template <bool FIRST, int NT, bool REM, class Pre>   // NT tiles in lockstep (1 or 2); REM: remainder tile (NT = 1)
-__device__ __forceinline__ void l1_job(unsigned wa, unsigned rdA, unsigned rdB, f32x4 init, f32x4 (&acc)[2], Pre& pre) {
-  using G = L1Geo<FIRST>;
+struct NoSpread {
+  template <class T>
+  __device__ __forceinline__ void operator()(T) const {}
+};
+// `sp(IC<k>)`, k < 18: the layer's spread hook (see layer1); a job with SM = 9 slots calls two per slot
+template <class M, bool FIRST, int NT, bool REM, class Pre, class Sp = NoSpread>   // NT tiles in lockstep (1 or 2); REM: remainder tile (NT = 1)
+__device__ __forceinline__ void l1_job(unsigned wa, const A1Regs& A, const A1Rem& AR, unsigned rdA, unsigned rdB, f32x4 init, f32x4 (&acc)[2],
+                                       Pre& pre, Sp sp = Sp{}) {
+  using G = L1Geo<M, FIRST>;
   constexpr int NS = REM ? G::SR : G::SM, D = G::D, RING = D + 1, PER = REM ? 16 : 9;
   f32x2 a[RING], b[RING][NT];
   acc[0] = init;
@@ -531,67 +743,111 @@ __device__ __forceinline__ void l1_job(unsigned wa, unsigned rdA, unsigned rdB, 
       [&](auto ic) {
         constexpr int i = decltype(ic)::value, r = i % RING, aoff = ((REM ? kW1Main : 0) + i * G::kAStep) * 4;
         if constexpr (FIRST) {
-          a[r].x = lds_ld<float>(wa, aoff);
+          if constexpr (!M::kX6) a[r].x = lds_ld<float>(wa, aoff);
           b[r][0].x = lds_ld<float>(rdA, G::koff(i, PER));
           if constexpr (NT > 1) b[r][1].x = lds_ld<float>(rdB, G::koff(i, PER));
         } else {
-          a[r] = lds_ld<f32x2>(wa, aoff);
+          if constexpr (!M::kX6) a[r] = lds_ld<f32x2>(wa, aoff);
           b[r][0] = lds_ld<f32x2>(rdA, G::koff(i, PER));
           if constexpr (NT > 1) b[r][1] = lds_ld<f32x2>(rdB, G::koff(i, PER));
         }
       },
       [&](auto ic) {
-        constexpr int r = decltype(ic)::value % RING;
-        acc[0] = mfma(a[r].x, b[r][0].x, acc[0]);
-        if constexpr (NT > 1) acc[1] = mfma(a[r].x, b[r][1].x, acc[1]);
+        constexpr int i = decltype(ic)::value, r = i % RING;
+        f32x2 av;
+        if constexpr (M::kX6) av = a1_frag<FIRST, REM, i>(A, AR);
+        else av = a[r];
+        acc[0] = mfma(av.x, b[r][0].x, acc[0]);
+        if constexpr (NT > 1) acc[1] = mfma(av.x, b[r][1].x, acc[1]);
         if constexpr (!FIRST) {
-          acc[0] = mfma(a[r].y, b[r][0].y, acc[0]);
-          if constexpr (NT > 1) acc[1] = mfma(a[r].y, b[r][1].y, acc[1]);
+          acc[0] = mfma(av.y, b[r][0].y, acc[0]);
+          if constexpr (NT > 1) acc[1] = mfma(av.y, b[r][1].y, acc[1]);
+        }
+        if constexpr (NS == 9) {
+          sp(IC<2 * i>{});
+          sp(IC<2 * i + 1>{});
+        } else if constexpr (i < 18) {
+          sp(IC<i>{});
         }
       },
       pre);
 }
 
-// [pixel][18] store of a main tile's channels 4kq..4kq+3 (masked: the tile has gap pixels; wave-uniform)
+// Store of a main tile's channels 4kq..4kq+3 (masked: the tile has gap pixels; wave-uniform).  F32 form: [pixel][18] fp32.
+// X6 form: ReLU, then the three-part split -- ONCE per element, here where it is produced -- and one 8-byte store per plane.
+template <class M>
 __device__ __forceinline__ void l1_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
   const f32x4 v = relu4(acc4);
-  if (!masked || vbit(L, vb)) {   // predication (exec mask from SGPRs), not a branch around two copies of the stores
-    lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
-    lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
+  if constexpr (M::kX6) {
+    const P3 p01 = split2(v.x, v.y), p23 = split2(v.z, v.w);
+    if (!masked || vbit(L, vb)) {
+      lds_st<u32x2>(wr, off, u32x2{p01.h, p23.h});
+      if (!(RCED_X6_EXP & 8)) {
+        lds_st<u32x2>(wr, off + M::kPlaneBytes, u32x2{p01.m, p23.m});
+        lds_st<u32x2>(wr, off + 2 * M::kPlaneBytes, u32x2{p01.l, p23.l});
+      }
+    }
+  } else {
+    if (!masked || vbit(L, vb)) {   // predication (exec mask from SGPRs), not a branch around two copies of the stores
+      lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
+      lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
+    }
   }
 }
 
-template <bool FIRST, class Dma>
-__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave, Dma dma DET_ARG) {
-  using G = L1Geo<FIRST>;
+// `dma` runs behind the first job's first operand reads; `sp(IC<k>)`, k = 0..17, is called once each from consecutive slots
+// of the wave's pair job(s) (every wave's FIRST job; the X6 form issues one register-bound weight load per slot there: issued
+// in one burst by eight waves they fill the vector-memory queue and block the waves' MFMAs behind them)
+template <class M, bool FIRST, class Dma, class Sp>
+__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, const A1Regs& A, const A1Rem& AR, int wave, Dma dma, Sp sp DET_ARG) {
+  using G = L1Geo<M, FIRST>;
   DET_BEGIN();
-  const unsigned wa = wbase + (FIRST ? L.a4 : L.a8);     // A fragments: main [s][lane], remainder from kW1Main
-  const f32x4 sh = lds_ld<f32x4>(wbase + L.kq16, kW1Data * 4);
-  const f32x2 s2 = lds_ld<f32x2>(wbase, (kW1Data + 16) * 4);
+  const unsigned wa = wbase + (FIRST ? L.a4 : L.a8);     // F32 form: A fragments in LDS: main [s][lane], remainder from kW1Main
+  f32x4 sh;
+  f32x2 s2;
+  if constexpr (M::kX6) {
+    sh = A.sh;
+    s2 = A.s2;
+  } else {
+    sh = lds_ld<f32x4>(wbase + L.kq16, kW1Data * 4);
+    s2 = lds_ld<f32x2>(wbase, (kW1Data + 16) * 4);
+  }
   f32x4 acc[2];
   auto pre = once(dma);
   const unsigned rd = FIRST ? L.rd0 : L.rd1, rdb = FIRST ? L.rd0b : L.rd1b;
+  constexpr int kTW = M::kT1W;
   // The wave's jobs, independent of each other.  Order (RCED_L1_ORDER, A/B on one box): pairs first, then the single tile,
   // then the remainder tiles is 0.6 % faster than the reverse -- the last job's epilogue is what sits exposed in front of
   // the layer's barrier, and a remainder tile's is two 8-byte stores against the four of a pair.
   auto do_rem = [&] {
   // ---- remainder tiles: waves 4, 5, 6 -> tiles 0, 1, 2; wave 7 -> tiles 3 and 4
   const int nrem = wave < 4 ? 0 : wave == 7 ? 2 : 1;
-  unsigned rdr = FIRST ? L.rd0r : L.rd1r, wrr = L.wr1r;
+  unsigned rdr = FIRST ? L.rd0r : L.rd1r, wrr = L.wr1r, wrl = L.wr1rl;
   int xr = wave == 7 ? 3 : wave - 4, vb = kVRem;
 #pragma unroll 1
   for (int r = 0; r < nrem; ++r) {
-    l1_job<FIRST, 1, true>(wa, rdr, 0u, f32x4{s2.x, s2.y, s2.x, s2.y}, acc, pre);
+    l1_job<M, FIRST, 1, true>(wa, A, AR, rdr, 0u, f32x4{s2.x, s2.y, s2.x, s2.y}, acc, pre);
     const f32x4 v = relu4(acc[0]);   // rows 4kq+jj = (phase 2kq + (jj>>1), channel 16 + (jj&1)): two pixels x channels 16,17
-    if (xr > 0) {   // every remainder tile but tile 0 contains gap pixels (tile 4 also runs past the tile): never written
-      if (vbit(L, vb)) lds_st<f32x2>(wrr, 0, f32x2{v.x, v.y});
-      if (vbit(L, vb + 1)) lds_st<f32x2>(wrr, 18 * 4, f32x2{v.z, v.w});
+    // every remainder tile but tile 0 contains gap pixels (tile 4 also runs past the tile): those are never written
+    const bool va = xr == 0 || vbit(L, vb), vbb = xr == 0 || vbit(L, vb + 1);
+    if constexpr (M::kX6) {
+      const P3 pa = split2(v.x, v.y), pb = split2(v.z, v.w);
+      if (va) {
+        lds_st<u32x2>(wrr, 0, u32x2{pa.h, pa.m});
+        lds_st<unsigned>(wrl, 0, pa.l);
+      }
+      if (vbb) {
+        lds_st<u32x2>(wrr, 8, u32x2{pb.h, pb.m});
+        lds_st<unsigned>(wrl, 4, pb.l);
+      }
+      wrr += 128 * 8;
+      wrl += 128 * 4;
     } else {
-      lds_st<f32x2>(wrr, 0, f32x2{v.x, v.y});
-      lds_st<f32x2>(wrr, 18 * 4, f32x2{v.z, v.w});
+      if (va) lds_st<f32x2>(wrr, 0, f32x2{v.x, v.y});
+      if (vbb) lds_st<f32x2>(wrr, 18 * 4, f32x2{v.z, v.w});
+      wrr += 8 * 16 * 18 * 4;
     }
     rdr += 8 * G::kTileR;            // wave 7's second tile: 4 = 3 + 1
-    wrr += 8 * 16 * 18 * 4;
     xr += 1;
     vb += 2;
   }
@@ -600,17 +856,17 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave, 
   // ---- the single main tile: waves 0 / 1 -> tile 32 / 31 (no gap pixels); wave 7 -> its third regular tile (23)
   if (wave < 2 || wave == 7) {
     const int dt = wave == 0 ? 32 : wave == 1 ? 30 : 16;   // tiles away from regular tile `wave`
-    l1_job<FIRST, 1, false>(wa, rd + dt * G::kTileR, 0u, sh, acc, pre);
-    l1_store(L, acc[0], L.wr1 + dt * (16 * 18 * 4), 0, false, 0);
+    l1_job<M, FIRST, 1, false>(wa, A, AR, rd + dt * G::kTileR, 0u, sh, acc, pre);
+    l1_store<M>(L, acc[0], L.wr1 + dt * M::kTileB18, 0, false, 0);
   }
   };
   auto do_pairs = [&] {
   // ---- pairs of regular tiles: (wave, wave+8), (wave+16, wave+24) as one stream with pair 0's stores between pair 1's
   //      MFMAs; wave 7 has only the first pair
   if (wave == 7) {
-    l1_job<FIRST, 2, false>(wa, rd, rdb, sh, acc, pre);
-    l1_store(L, acc[0], L.wr1, 0, false, 0);          // tiles 7, 15: no gap pixels
-    l1_store(L, acc[1], L.wr1, kT1W, false, 0);
+    l1_job<M, FIRST, 2, false>(wa, A, AR, rd, rdb, sh, acc, pre, sp);
+    l1_store<M>(L, acc[0], L.wr1, 0, false, 0);          // tiles 7, 15: no gap pixels
+    l1_store<M>(L, acc[1], L.wr1, kTW, false, 0);
   } else {
     constexpr int SM = G::SM, NT = 2 * SM, D = G::D, RING = D + 1;
     f32x2 a[RING], b[RING][2];
@@ -620,11 +876,11 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave, 
         [&](auto ic) {
           constexpr int i = decltype(ic)::value, r = i % RING, p = i / SM, st = i % SM, aoff = st * G::kAStep * 4;
           if constexpr (FIRST) {
-            a[r].x = lds_ld<float>(wa, aoff);
+            if constexpr (!M::kX6) a[r].x = lds_ld<float>(wa, aoff);
             b[r][0].x = lds_ld<float>(rd, 2 * p * G::kTR + G::koff(st, 9));
             b[r][1].x = lds_ld<float>(rdb, 2 * p * G::kTR + G::koff(st, 9));
           } else {
-            a[r] = lds_ld<f32x2>(wa, aoff);
+            if constexpr (!M::kX6) a[r] = lds_ld<f32x2>(wa, aoff);
             b[r][0] = lds_ld<f32x2>(rd, 2 * p * G::kTR + G::koff(st, 9));
             b[r][1] = lds_ld<f32x2>(rdb, 2 * p * G::kTR + G::koff(st, 9));
           }
@@ -632,18 +888,22 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave, 
         [&](auto ic) {
           constexpr int i = decltype(ic)::value, r = i % RING, p = i / SM, st = i % SM;
           if constexpr (st == 0) acc2[p][0] = acc2[p][1] = sh;
-          acc2[p][0] = mfma(a[r].x, b[r][0].x, acc2[p][0]);
-          acc2[p][1] = mfma(a[r].x, b[r][1].x, acc2[p][1]);
+          f32x2 av;
+          if constexpr (M::kX6) av = a1_frag<FIRST, false, st>(A, AR);
+          else av = a[r];
+          acc2[p][0] = mfma(av.x, b[r][0].x, acc2[p][0]);
+          acc2[p][1] = mfma(av.x, b[r][1].x, acc2[p][1]);
           if constexpr (!FIRST) {
-            acc2[p][0] = mfma(a[r].y, b[r][0].y, acc2[p][0]);
-            acc2[p][1] = mfma(a[r].y, b[r][1].y, acc2[p][1]);
+            acc2[p][0] = mfma(av.y, b[r][0].y, acc2[p][0]);
+            acc2[p][1] = mfma(av.y, b[r][1].y, acc2[p][1]);
           }
-          if constexpr (p == 1 && st == 1) l1_store(L, acc2[0][0], L.wr1, 0, false, kVMain);
-          if constexpr (p == 1 && st == 3) l1_store(L, acc2[0][1], L.wr1, kT1W, g1, kVMain + 1);
+          if constexpr (p == 1 && st == 1) l1_store<M>(L, acc2[0][0], L.wr1, 0, false, kVMain);
+          if constexpr (p == 1 && st == 3) l1_store<M>(L, acc2[0][1], L.wr1, kTW, g1, kVMain + 1);
+          if constexpr (i < 18) sp(IC<i>{});
         },
         pre);
-    l1_store(L, acc2[1][0], L.wr1, 2 * kT1W, g2, kVMain + 2);
-    l1_store(L, acc2[1][1], L.wr1, 3 * kT1W, g3, kVMain + 3);
+    l1_store<M>(L, acc2[1][0], L.wr1, 2 * kTW, g2, kVMain + 2);
+    l1_store<M>(L, acc2[1][1], L.wr1, 3 * kTW, g3, kVMain + 3);
   }
   };
 #if RCED_L1_ORDER == 1
@@ -664,28 +924,45 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, int wave, 
 }
 
 // ---- layer 2: 1x5, 18 -> 30 (two M-tiles) ------------------------------------------------------------
-// Every wave has four regular tiles, walked as two pair jobs (11 b64 slots + the b32 tail; both tiles, both M-tiles:
-// 8 / 4 MFMAs per slot on four accumulation chains, two A fragments for both tiles).  Tile 32 (pixels 512..527) is cut
-// in four equal pieces, one per SIMD, so that the layer's MFMA count is the same on every SIMD: M-tile XM x K-half.
-// Waves 0 / 1 are the helpers (slots [0, kL2Cut) of M-tile 0 / 1), waves 2 / 3 the reducers (slots [kL2Cut, 11) + tail
-// of M-tile 0 / 1; they add the helper's partial sums and own the epilogue).  The share is the wave's FIRST job: a helper
+// Tile 32 (pixels 512..527) is cut in four, one piece per SIMD, so that the layer's MFMA count is (about) the same on every
+// SIMD: M-tile XM x K-part.  Waves 0 / 1 are the helpers (the first K-part of M-tile 0 / 1), waves 2 / 3 the reducers (the
+// rest of M-tile 0 / 1; they add the helper's partial sums and own the epilogue).  The share is the wave's FIRST job: a helper
 // publishes it through LDS scratch + a tagged flag word before its regular tiles, and the reducer picks it up after
 // its last job, when it has long been there.  Scratch: in the B8 buffer, which is dead during layer 2 (layer 3
 // rewrites every real pixel of it).
-#ifndef RCED_V3_EXP_L2HALF
-#define RCED_V3_EXP_L2HALF 0   // timing experiment only (wrong results): layer 2's pair jobs issue half of their MFMAs -- what a form of
-                               // this layer with half the matrix-pipe cycles (the three-part bf16 form) could return at most
-#endif
 #ifndef RCED_L2_CUT
 #define RCED_L2_CUT 6
 #endif
-constexpr int kL2Cut = RCED_L2_CUT;
-constexpr int kScratch2Off = kB8Off + kB8Pad * kB8S + 8 * kB8S;   // B8 rows 8.. of frame 0 (2 x 256 floats + 2 flags)
-constexpr int kFlag2Off = kScratch2Off + 2 * 256;
-static_assert((kScratch2Off * 4) % 16 == 0, "scratch is read/written with b128");
-static_assert(8 + (2 * 256 + 2 + kB8S - 1) / kB8S <= kF, "layer-2 scratch stays inside frame 0's real pixels");
+constexpr int kL2Cut = RCED_L2_CUT;   // F32 form: the helper takes b64 slots [0, kL2Cut), the reducer [kL2Cut, 11) + the tail
 
-#if !RCED_V3_L2X6
+// one M-tile of one tile: ReLU, [pixel][30] stores; lanes kq = 3 of M-tile 1 hold channels 28,29 and the padding 30,31
+template <int MT>
+__device__ __forceinline__ void l2_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
+  const f32x4 v = relu4(acc4);
+  if (!masked || vbit(L, vb)) {
+    lds_st<f32x2>(wr, off + 64 * MT, f32x2{v.x, v.y});
+    if (MT == 0 || vbit(L, kVLt48)) lds_st<f32x2>(wr, off + 64 * MT + 8, f32x2{v.z, v.w});
+  }
+}
+// reducers (waves 2, 3): add the helper's share, store tile 32 (pixels 512..527: no gap inside)
+template <class M>
+__device__ __forceinline__ void l2_reduce(const Lane& L, unsigned lds0, int wave, unsigned tag, unsigned* err, f32x4 accx, f32x4 part,
+                                          unsigned pflag) {
+  if (wave == 2 || wave == 3) {
+    const int xm = wave - 2;
+    if (!__builtin_amdgcn_readfirstlane(pflag == tag)) {   // not there yet when fetched (not seen in practice)
+      flag_wait(lds0 + (M::kFlag2Off + xm) * 4, tag, err, 2u);
+      part = lds_ld<f32x4>(lds0 + L.scr + xm * 1024, M::kScratch2Off * 4);
+    }
+    const f32x4 v = accx + part;
+    const unsigned wrx = L.wr2 + (32 - wave) * (16 * 30 * 4);
+    if (xm == 0) l2_store<0>(L, v, wrx, 0, false, 0);
+    else l2_store<1>(L, v, wrx, 0, false, 0);
+  }
+}
+
+// ---- F32 form: every wave has four regular tiles, walked as two pair jobs (11 b64 slots + the b32 tail; both tiles, both
+// M-tiles: 8 / 4 MFMAs per slot on four accumulation chains, two A fragments for both tiles)
 template <int XM, bool HELPER, class Pre>   // the share of tile 32: M-tile XM, slots [0, kL2Cut) (helper) or [kL2Cut, 11) + tail
 __device__ __forceinline__ f32x4 l2_share(unsigned wa, unsigned wt, unsigned rdx, unsigned rdxt, f32x4 init, Pre& pre) {
   constexpr int S0 = HELPER ? 0 : kL2Cut, NS = HELPER ? kL2Cut : kL2Steps + 1 - kL2Cut, D = RCED_D2, RING = D + 1;
@@ -711,168 +988,10 @@ __device__ __forceinline__ f32x4 l2_share(unsigned wa, unsigned wt, unsigned rdx
   return acc;
 }
 
-#endif
-
-// one M-tile of one tile: ReLU, [pixel][30] stores; lanes kq = 3 of M-tile 1 hold channels 28,29 and the padding 30,31
-template <int MT>
-__device__ __forceinline__ void l2_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
-  const f32x4 v = relu4(acc4);
-  if (!masked || vbit(L, vb)) {
-    lds_st<f32x2>(wr, off + 64 * MT, f32x2{v.x, v.y});
-    if (MT == 0 || vbit(L, kVLt48)) lds_st<f32x2>(wr, off + 64 * MT + 8, f32x2{v.z, v.w});
-  }
-}
-
-#if RCED_V3_L2X6
-// ---- layer 2 in the x6 form ---------------------------------------------------------------------------------
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x4 mfma32(s16x8 a, s16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-struct Parts {
-  s16x8 h, m, l;
-};
-// eight consecutive fp32 of a window -> their three bf16 parts (x = h + m + l to 2^-24)
-__device__ __forceinline__ Parts split8(const f32x2 (&q)[4]) {
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-  s16x2 ph[4], pm[4], pl[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bf16x2 bh = {(__bf16)q[j].x, (__bf16)q[j].y};
-    const f32x2 r1 = {q[j].x - (float)bh.x, q[j].y - (float)bh.y};
-    const bf16x2 bm = {(__bf16)r1.x, (__bf16)r1.y};
-    const bf16x2 bl = {(__bf16)(r1.x - (float)bm.x), (__bf16)(r1.y - (float)bm.y)};
-    ph[j] = __builtin_bit_cast(s16x2, bh);      // (whole-vector casts: element-wise bit_cast of a bf16 vector's members miscompiled)
-    pm[j] = __builtin_bit_cast(s16x2, bm);
-    pl[j] = __builtin_bit_cast(s16x2, bl);
-  }
-  Parts r;
-  r.h = s16x8{ph[0].x, ph[0].y, ph[1].x, ph[1].y, ph[2].x, ph[2].y, ph[3].x, ph[3].y};
-  r.m = s16x8{pm[0].x, pm[0].y, pm[1].x, pm[1].y, pm[2].x, pm[2].y, pm[3].x, pm[3].y};
-  r.l = s16x8{pl[0].x, pl[0].y, pl[1].x, pl[1].y, pl[2].x, pl[2].y, pl[3].x, pl[3].y};
-  return r;
-}
-// six products (smallest first) of one A fragment triple and one B fragment triple
-__device__ __forceinline__ f32x4 mma6(const s16x8 (&a)[3], const Parts& b, f32x4 acc) {
-  acc = mfma32(a[1], b.m, acc);
-  acc = mfma32(a[2], b.h, acc);
-  acc = mfma32(a[0], b.l, acc);
-  acc = mfma32(a[1], b.h, acc);
-  acc = mfma32(a[0], b.m, acc);
-  acc = mfma32(a[0], b.h, acc);
-  return acc;
-}
-// A fragment (chunk c, M-tile mt, part p) of this lane: wa16 = packet + lane * 16
-__device__ __forceinline__ s16x8 l2x_a(unsigned wa16, int c, int mt, int p) { return lds_ld<s16x8>(wa16, ((c * 2 + mt) * 3 + p) * 1024); }
-// the share of tile 32: M-tile XM, chunk 0 (helper) or chunks 1, 2 (reducer)
-template <int XM, bool HELPER, class Pre>
-__device__ __forceinline__ f32x4 l2_share(unsigned wa16, unsigned rdx, f32x4 init, Pre& pre) {
-  constexpr int C0 = HELPER ? 0 : 1, NC = HELPER ? 1 : 2;
-  s16x8 a[2][3];
-  f32x2 b[2][4];
-  f32x4 acc = init;
-  run_job<NC, 1>(
-      [&](auto ic) {
-        constexpr int i = decltype(ic)::value, r = i % 2, c = C0 + i;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) a[r][p] = l2x_a(wa16, c, XM, p);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[r][j] = lds_ld<f32x2>(rdx, 128 * c + 8 * j);
-      },
-      [&](auto ic) {
-        constexpr int i = decltype(ic)::value, r = i % 2;
-        acc = mma6(a[r], split8(b[r]), acc);
-      },
-      pre);
-  return acc;
-}
-#endif
-
-template <class Dma>
-__device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wbase, int wave, unsigned tag, unsigned* err, Dma dma DET_ARG) {
-#if RCED_V3_L2X6
-  DET_BEGIN();
-  const unsigned wa16 = wbase + L.scr;            // packet + lane * 16: the lane's A fragments
-  f32x4 sh[2];
-  sh[0] = lds_ld<f32x4>(wbase + L.kq16, kW2Data * 4);
-  sh[1] = lds_ld<f32x4>(wbase + L.kq16, (kW2Data + 16) * 4);
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  // ---- the share of tile 32 (waves 0..3), first: M-tile x K-part (chunk 0 | chunks 1, 2)
-  f32x4 accx = zero4, part = zero4;
-  unsigned pflag = 0u;
-  auto pre = once(dma);
-  if (wave < 4) {
-    const unsigned rdx = L.rd2x + (32 - wave) * (16 * 18 * 4);
-    if (wave == 0) accx = l2_share<0, true>(wa16, rdx, zero4, pre);
-    else if (wave == 1) accx = l2_share<1, true>(wa16, rdx, zero4, pre);
-    else if (wave == 2) accx = l2_share<0, false>(wa16, rdx, sh[0], pre);
-    else accx = l2_share<1, false>(wa16, rdx, sh[1], pre);
-    if (wave < 2) {   // publish (LDS operations of a wave execute in order: data, then flag)
-      lds_st<f32x4>(lds0 + L.scr + wave * 1024, kScratch2Off * 4, accx);
-      cbar();
-      if (L.a4 == 0) lds_poke_a(lds0 + (kFlag2Off + wave) * 4, tag);
-    }
-  }
-  DET(7);
-  // ---- two pair jobs, tiles (wave, wave+8) and (wave+16, wave+24), as ONE stream of six K = 32 chunks: pair 0's stores
-  //      ride between pair 1's MFMAs
-  {
-    constexpr int NS = kL2Chunks, NT = 2 * NS;
-    f32x2 b[2][2][4];     // [ring][tile][four pairs of consecutive k]: the fp32 B fragments, read one chunk ahead
-    f32x4 acc[2][2][2];   // [pair][tile][M-tile]
-    const bool g1 = tile_has_gap(wave + 8), g2 = tile_has_gap(wave + 16), g3 = tile_has_gap(wave + 24);
-    run_job<NT, 1>(
-        [&](auto ic) {
-          constexpr int i = decltype(ic)::value, r = i % 2, p = i / NS, c = i % NS;
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[r][t][j] = lds_ld<f32x2>(L.rd2x, (2 * p + t) * kT2R + 128 * c + 8 * j);
-        },
-        [&](auto ic) {
-          constexpr int i = decltype(ic)::value, r = i % 2, p = i / NS, c = i % NS;
-          if constexpr (c == 0) {
-            acc[p][0][0] = acc[p][1][0] = sh[0];
-            acc[p][0][1] = acc[p][1][1] = sh[1];
-          }
-          // this chunk's A fragments: issued here, they land while the B fragments are split (no ring for them: 24 VGPRs)
-          s16x8 a[2][3];
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) a[mt][q] = l2x_a(wa16, c, mt, q);
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const Parts bp = split8(b[r][t]);
-            acc[p][t][0] = mma6(a[0], bp, acc[p][t][0]);
-            acc[p][t][1] = mma6(a[1], bp, acc[p][t][1]);
-          }
-          if constexpr (p == 1 && c == 0) {
-            l2_store<0>(L, acc[0][0][0], L.wr2, 0, false, kVMain);       // tile `wave`: no gap
-            l2_store<1>(L, acc[0][0][1], L.wr2, 0, false, kVMain);
-          }
-          if constexpr (p == 1 && c == 1) {
-            l2_store<0>(L, acc[0][1][0], L.wr2, kT2W, g1, kVMain + 1);
-            l2_store<1>(L, acc[0][1][1], L.wr2, kT2W, g1, kVMain + 1);
-          }
-          if constexpr (p == 1 && c == 2) {   // reducers: the helper's flag and partial sums, fetched inside the stream
-            if (wave == 2 || wave == 3) {
-              pflag = lds_peek_a(lds0 + (kFlag2Off + wave - 2) * 4);
-              cbar();
-              part = lds_ld<f32x4>(lds0 + L.scr + (wave - 2) * 1024, kScratch2Off * 4);
-            }
-          }
-        },
-        pre);
-    l2_store<0>(L, acc[1][0][0], L.wr2, 2 * kT2W, g2, kVMain + 2);
-    l2_store<1>(L, acc[1][0][1], L.wr2, 2 * kT2W, g2, kVMain + 2);
-    l2_store<0>(L, acc[1][1][0], L.wr2, 3 * kT2W, g3, kVMain + 3);
-    l2_store<1>(L, acc[1][1][1], L.wr2, 3 * kT2W, g3, kVMain + 3);
-  }
-#else
+template <class M, class Dma>
+__device__ __forceinline__ void layer2_f32(const Lane& L, unsigned lds0, unsigned wbase, int wave, unsigned tag, unsigned* err, Dma dma DET_ARG) {
   constexpr int D = RCED_D2, RING = D + 1, NS = kL2Steps + 1;
+  constexpr int kT2R = M::kT2R, kT2W = M::kT2W;
   DET_BEGIN();
   const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
   f32x4 sh[2];
@@ -890,9 +1009,9 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
     else if (wave == 2) accx = l2_share<0, false>(wa, wt, rdx, rdxt, sh[0], pre);  // the reducer's from the shift
     else accx = l2_share<1, false>(wa, wt, rdx, rdxt, sh[1], pre);
     if (wave < 2) {   // publish (LDS operations of a wave execute in order: data, then flag)
-      lds_st<f32x4>(lds0 + L.scr + wave * 1024, kScratch2Off * 4, accx);
+      lds_st<f32x4>(lds0 + L.scr + wave * 1024, M::kScratch2Off * 4, accx);
       cbar();
-      if (L.a4 == 0) lds_poke_a(lds0 + (kFlag2Off + wave) * 4, tag);
+      if (L.a4 == 0) lds_poke_a(lds0 + (M::kFlag2Off + wave) * 4, tag);
     }
   }
   DET(7);
@@ -928,7 +1047,7 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
           acc[p][0][1] = mfma(a[r][1].x, b[r][0].x, acc[p][0][1]);
           acc[p][1][0] = mfma(a[r][0].x, b[r][1].x, acc[p][1][0]);
           acc[p][1][1] = mfma(a[r][1].x, b[r][1].x, acc[p][1][1]);
-          if constexpr (st < kL2Steps && !RCED_V3_EXP_L2HALF) {
+          if constexpr (st < kL2Steps) {
             acc[p][0][0] = mfma(a[r][0].y, b[r][0].y, acc[p][0][0]);
             acc[p][0][1] = mfma(a[r][1].y, b[r][0].y, acc[p][0][1]);
             acc[p][1][0] = mfma(a[r][0].y, b[r][1].y, acc[p][1][0]);
@@ -940,9 +1059,9 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
           if constexpr (p == 1 && st == 7) l2_store<1>(L, acc[0][1][1], L.wr2, kT2W, g1, kVMain + 1);
           if constexpr (p == 1 && st == 9) {   // reducers: the helper's flag and partial sums, fetched inside the stream (see layer 3)
             if (wave == 2 || wave == 3) {
-              pflag = lds_peek_a(lds0 + (kFlag2Off + wave - 2) * 4);
+              pflag = lds_peek_a(lds0 + (M::kFlag2Off + wave - 2) * 4);
               cbar();
-              part = lds_ld<f32x4>(lds0 + L.scr + (wave - 2) * 1024, kScratch2Off * 4);
+              part = lds_ld<f32x4>(lds0 + L.scr + (wave - 2) * 1024, M::kScratch2Off * 4);
             }
           }
         },
@@ -952,18 +1071,165 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
     l2_store<0>(L, acc[1][1][0], L.wr2, 3 * kT2W, g3, kVMain + 3);
     l2_store<1>(L, acc[1][1][1], L.wr2, 3 * kT2W, g3, kVMain + 3);
   }
-#endif
-  // ---- reducers: add the helper's share, store tile 32 (pixels 512..527: no gap inside)
-  if (wave == 2 || wave == 3) {
-    const int xm = wave - 2;
-    if (!__builtin_amdgcn_readfirstlane(pflag == tag)) {   // not there yet when fetched (not seen in practice)
-      flag_wait(lds0 + (kFlag2Off + xm) * 4, tag, err, 2u);
-      part = lds_ld<f32x4>(lds0 + L.scr + xm * 1024, kScratch2Off * 4);
+  l2_reduce<M>(L, lds0, wave, tag, err, accx, part, pflag);
+}
+
+// ---- X6 form ------------------------------------------------------------------------------------------------
+// K = 96 slots in three K = 32 chunks; slot k = 32 c + 8 kq + e of the MFMA's K axis is
+//   c = 0, 1:        tap 2c + (kq >> 1), channel 8 (kq & 1) + e              (one 16-byte row half of a plane)
+//   c = 2, kq < 2:   tap 4, channel 8 kq + e
+//   c = 2, kq = 2:   tap e >> 1 (0..3), channel 16 + (e & 1)                 (the remainder channels' window, four rows)
+//   c = 2, kq = 3:   tap 4, channel 16 + e for e < 2; zero weights for e >= 2 (they meet the next three rows: finite values)
+// A wave computes ONE M-tile: waves 0..3 channels 0..15, waves 4..7 channels 16..29 (g = wave >> 2), each for the tiles
+// j + 4t (j = wave & 3, t < 8) -- half the A fragments per wave (36 registers, half the global loads) for twice the B reads,
+// which the LDS has room for: a slot of the stream = one chunk of one tile = three conflict-free ds_read_b128 (the fragment's
+// h, m, l parts; in the last chunk the remainder rows besides, selected into the upper lanes by 12 v_cndmask) for six MFMAs of
+// 16 cycles, 8 waves: half of the LDS's cycles.  No other VALU (beside bf16 MFMAs, which hold the SIMD's issue port for half of
+// their 16 cycles, up to two VALU per MFMA are nearly free -- MI355X guide -- but layer 1's epilogue already did the split).
+// Tile 32 is cut by chunk inside each M-tile group: members j = 0, 1 are the helpers (chunks 0, 1), j = 2 the reducer (chunk 2,
+// the shift, the epilogue): 150 / 150 / 150 / 144 MFMAs per wave.
+struct Parts {
+  s16x8 h, m, l;
+};
+struct RemRaw {          // the remainder channels' rows of one window half, as loaded: [h16 h17 | m16 m17] x 4, [l16 l17] x 4
+  u32x2 hm[4];
+  unsigned lq[4];
+};
+template <int C>
+__device__ __forceinline__ void l2x_load(unsigned rdm, unsigned rdr, unsigned rdrl, int om, int orr, int orl, Parts& b, RemRaw& rr) {
+  b.h = lds_ld<s16x8>(rdm, om + 64 * C);
+  if (RCED_X6_EXP & 32) {
+    b.m = b.l = b.h;
+  } else {
+    b.m = lds_ld<s16x8>(rdm, om + 64 * C + MapX6::kPlaneBytes);
+    b.l = lds_ld<s16x8>(rdm, om + 64 * C + 2 * MapX6::kPlaneBytes);
+  }
+  if constexpr (C == 2 && !(RCED_X6_EXP & 16)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rr.hm[j] = lds_ld<u32x2>(rdr, orr + 8 * j);
+      rr.lq[j] = lds_ld<unsigned>(rdrl, orl + 4 * j);
     }
-    const f32x4 v = accx + part;
-    const unsigned wrx = L.wr2 + (32 - wave) * (16 * 30 * 4);
-    if (xm == 0) l2_store<0>(L, v, wrx, 0, false, 0);
-    else l2_store<1>(L, v, wrx, 0, false, 0);
+  }
+}
+// last chunk: the upper lanes' slots are the remainder channels
+__device__ __forceinline__ void l2x_merge(Parts& b, const RemRaw& rr, bool upper) {
+  if (RCED_X6_EXP & 16) return;
+  u32x4 h = __builtin_bit_cast(u32x4, b.h), m = __builtin_bit_cast(u32x4, b.m), l = __builtin_bit_cast(u32x4, b.l);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = upper ? rr.hm[j].x : h[j];
+    m[j] = upper ? rr.hm[j].y : m[j];
+    l[j] = upper ? rr.lq[j] : l[j];
+  }
+  b.h = __builtin_bit_cast(s16x8, h);
+  b.m = __builtin_bit_cast(s16x8, m);
+  b.l = __builtin_bit_cast(s16x8, l);
+}
+// the six products of one chunk, smallest first
+__device__ __forceinline__ f32x4 l2x_mma(const s16x8 (&a)[3], const Parts& b, f32x4 acc) {
+  acc = mfma32(a[1], b.m, acc);
+  acc = mfma32(a[2], b.h, acc);
+  acc = mfma32(a[0], b.l, acc);
+  acc = mfma32(a[1], b.h, acc);
+  acc = mfma32(a[0], b.m, acc);
+  acc = mfma32(a[0], b.h, acc);
+  return acc;
+}
+// ReLU, [pixel][30] store of this wave's M-tile: lanes kq = 3 of M-tile 1 hold channels 28,29 and the padding 30,31
+__device__ __forceinline__ void l2x_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
+  if (RCED_X6_EXP & 64) {
+    if (acc4.x == 12345.678f) lds_st<float>(wr, off, acc4.y);
+    return;
+  }
+  const f32x4 v = relu4(acc4);
+  if (!masked || vbit(L, vb)) {
+    lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
+    if (vbit(L, kVSt2)) lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
+  }
+}
+// chunk C of tile 32 (this wave's M-tile)
+template <int C, class Pre>
+__device__ __forceinline__ f32x4 l2x_share(const Lane& L, const A2Regs& A, unsigned rdm, unsigned rdr, unsigned rdrl, f32x4 init, Pre& pre) {
+  Parts b;
+  RemRaw rr;
+  l2x_load<C>(rdm, rdr, rdrl, 0, 0, 0, b, rr);
+  pin();
+  pre();
+  pin();
+  if constexpr (C == 2) l2x_merge(b, rr, vbit(L, kVUpper));
+  return l2x_mma(A.a[C], b, init);
+}
+
+template <class M, class Dma>
+__device__ __forceinline__ void layer2_x6(const Lane& L, unsigned lds0, const A2Regs& A, int wave, unsigned tag, unsigned* err, Dma dma DET_ARG) {
+  constexpr int kT2R = M::kT2R, kT2W = M::kT2W;
+  DET_BEGIN();
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const bool upper = vbit(L, kVUpper);
+  const int g = wave >> 2, j = wave & 3;
+  // ---- the share of tile 32 (members 0..2 of either group), first
+  f32x4 accx = zero4, part0 = zero4, part1 = zero4;
+  unsigned pflag0 = 0u, pflag1 = 0u;
+  auto pre = once(dma);
+  if (j < 3) {
+    const int dt = 32 - j;   // tiles from this lane's tile j to tile 32
+    const unsigned rdm = L.rd2m + dt * 512, rdr = L.rd2r + dt * 128, rdrl = L.rd2rl + dt * 64;
+    if (j == 0) accx = l2x_share<0>(L, A, rdm, rdr, rdrl, zero4, pre);        // a helper's share starts from zero,
+    else if (j == 1) accx = l2x_share<1>(L, A, rdm, rdr, rdrl, zero4, pre);
+    else accx = l2x_share<2>(L, A, rdm, rdr, rdrl, A.sh, pre);                // the reducer's from the shift
+    if (j < 2) {   // publish (LDS operations of a wave execute in order: data, then flag)
+      lds_st<f32x4>(lds0 + L.scr + (2 * g + j) * 1024, M::kScratch2Off * 4, accx);
+      cbar();
+      if (L.a4 == 0) lds_poke_a(lds0 + (M::kFlag2Off + 2 * g + j) * 4, tag);
+    }
+  }
+  DET(7);
+  // ---- the eight regular tiles j + 4t as ONE stream of 24 chunk slots; tile t's stores ride behind tile t+1's first MFMAs
+  {
+    constexpr int NS = 8 * kL2Chunks, D = RCED_D2X, RING = D + 1;
+    static_assert(D < kL2Chunks, "one last-chunk fragment in flight at a time (RemRaw is not ringed)");
+    Parts b[RING];
+    RemRaw rr;
+    f32x4 acc[2];   // [tile & 1]
+    const bool gj = j == 0;   // tiles 8, 16, 24 (member 0's t = 2, 4, 6) contain gap pixels
+    run_job<NS, D>(
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, t = i / kL2Chunks, c = i % kL2Chunks;
+          l2x_load<c>(L.rd2m, L.rd2r, L.rd2rl, t * kT2R, t * 64 * 8, t * 64 * 4, b[i % RING], rr);
+        },
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, t = i / kL2Chunks, c = i % kL2Chunks, r = i % RING, u = t & 1;
+          if constexpr (c == 2) l2x_merge(b[r], rr, upper);
+          acc[u] = l2x_mma(A.a[c], b[r], c == 0 ? A.sh : acc[u]);
+          if constexpr (t > 0 && c == 0) {   // the previous tile's results
+            constexpr bool gt = t - 1 == 2 || t - 1 == 4 || t - 1 == 6;
+            l2x_store(L, acc[u ^ 1], L.wr2, (t - 1) * kT2W, gt && gj, kVL2 + t - 1);
+          }
+          if constexpr (t == 7 && c == 2) {   // reducers: the helpers' flags and partial sums, fetched inside the stream
+            if (j == 2) {
+              pflag0 = lds_peek_a(lds0 + (M::kFlag2Off + 2 * g) * 4);
+              pflag1 = lds_peek_a(lds0 + (M::kFlag2Off + 2 * g + 1) * 4);
+              cbar();
+              part0 = lds_ld<f32x4>(lds0 + L.scr + (2 * g) * 1024, M::kScratch2Off * 4);
+              part1 = lds_ld<f32x4>(lds0 + L.scr + (2 * g + 1) * 1024, M::kScratch2Off * 4);
+            }
+          }
+        },
+        pre);
+    l2x_store(L, acc[1], L.wr2, 7 * kT2W, false, kVL2 + 7);   // tile j + 28: no gap
+  }
+  // ---- reducers: add the helpers' shares (fixed order), store tile 32 (pixels 512..527: no gap inside)
+  if (j == 2) {
+    if (!__builtin_amdgcn_readfirstlane(pflag0 == tag && pflag1 == tag)) {   // not there yet when fetched (not seen in practice)
+      flag_wait(lds0 + (M::kFlag2Off + 2 * g) * 4, tag, err, 2u);
+      flag_wait(lds0 + (M::kFlag2Off + 2 * g + 1) * 4, tag, err, 2u);
+      part0 = lds_ld<f32x4>(lds0 + L.scr + (2 * g) * 1024, M::kScratch2Off * 4);
+      part1 = lds_ld<f32x4>(lds0 + L.scr + (2 * g + 1) * 1024, M::kScratch2Off * 4);
+    }
+    f32x4 v = accx + part0;
+    v += part1;
+    l2x_store(L, v, L.wr2 + (32 - j) * (16 * 30 * 4), 0, false, 0);
   }
 }
 
@@ -982,11 +1248,6 @@ __device__ __forceinline__ void layer2(const Lane& L, unsigned lds0, unsigned wb
 constexpr int kL3CutsArr[3] = {RCED_L3_CUTS};
 constexpr int kL3Cut1 = kL3CutsArr[0], kL3Cut2 = kL3CutsArr[1], kL3Cut3 = kL3CutsArr[2];
 constexpr int kL3Fetch = RCED_L3_FETCH;   // slot of the reducer's regular job at which it fetches the helpers' flags and partial sums
-constexpr int kScratchOff = kB18Off + kB18Pad * 18 + 8 * 18;   // pixels 8..51 of frame 0: always rewritten by layer 1
-constexpr int kFlagOff = kScratchOff + 3 * 256;
-static_assert((kScratchOff * 4) % 16 == 0, "scratch is read/written with b128");
-static_assert(8 + (3 * 256 + 3 + 17) / 18 <= kF, "scratch + flags stay inside frame 0's real pixels");
-static_assert(kFlagOff + 3 <= kHOff, "layer 3's hand-off scratch and the H image do not overlap");
 
 template <int S0, int S1, class Pre>   // the share of pair tile 16: slots [S0, S1) (slot kL3Steps = the tail)
 __device__ __forceinline__ f32x4 l3_share(unsigned wa, unsigned wt, unsigned rdx, unsigned rdxt, f32x4 init, Pre& pre) {
@@ -1019,7 +1280,7 @@ __device__ __forceinline__ f32x4 l3_share(unsigned wa, unsigned wt, unsigned rdx
 // lane's validity bit -- the compare is loop-invariant, hipcc keeps it as an exec mask in SGPRs -- rather than put
 // behind a wave-uniform "does this tile have a gap" branch.  Values of gap lanes in the skip registers are whatever was
 // computed: they only ever meet gap pixels again.
-template <int BLK>
+template <class M, int BLK>
 __device__ __forceinline__ void l3_epilogue(const Lane& L, int wave, f32x4 (&acc)[3], f32x4 (&skip_ce1)[3],
                                             f32x4 (&skip_ce2)[3]) {
   static_for<0, 3>([&](auto tc) {
@@ -1035,7 +1296,7 @@ __device__ __forceinline__ void l3_epilogue(const Lane& L, int wave, f32x4 (&acc
     int off = 0;
     if constexpr (BLK < 4) {
       wr = L.wr3;
-      off = t < 2 ? t * kT3W : 16 * (32 * kB8S * 4);
+      off = t < 2 ? t * M::kT3W : 16 * (32 * kB8S * 4);
     } else {
       wr = t == 0 ? L.wh0 : t == 1 ? L.wh1 : L.whx;
     }
@@ -1046,9 +1307,11 @@ __device__ __forceinline__ void l3_epilogue(const Lane& L, int wave, f32x4 (&acc
   });
 }
 
-template <class Dma>
+// LAST: block 4's instance (peeled out of the block loop: its epilogue feeds decode_final).  `sp(IC<k>)`, k = 0..6, is called
+// from every fourth slot of the regular job (X6 form: the next layer 1's main-pass A fragments, one load at a time).
+template <class M, bool LAST, class Dma, class Sp>
 __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned lds0, unsigned wbase, int blk, int wave,
-                                       unsigned tag, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3], Dma dma DET_ARG) {
+                                       unsigned tag, f32x4 (&skip_ce1)[3], f32x4 (&skip_ce2)[3], Dma dma, Sp sp DET_ARG) {
   constexpr int D = RCED_D3, RING = D + 1, NS = kL3Steps + 1;
   DET_BEGIN();
   const unsigned wa = wbase + L.a8, wt = wbase + L.a4;
@@ -1066,9 +1329,9 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
     else if (wave == 2) acc[2] = l3_share<kL3Cut2, kL3Cut3>(wa, wt, rdx, rdxt, zero4, pre);
     else acc[2] = l3_share<kL3Cut3, kL3Steps + 1>(wa, wt, rdx, rdxt, zero4, pre);
     if (wave > 0) {   // publish the partial sums
-      lds_st<f32x4>(lds0 + L.scr + (wave - 1) * 1024, kScratchOff * 4, acc[2]);
+      lds_st<f32x4>(lds0 + L.scr + (wave - 1) * 1024, M::kScratchOff * 4, acc[2]);
       cbar();
-      if (L.a4 == 0) lds_poke_a(lds0 + (kFlagOff + wave - 1) * 4, tag);
+      if (L.a4 == 0) lds_poke_a(lds0 + (M::kFlagOff + wave - 1) * 4, tag);
     }
   }
   DET(0);
@@ -1106,13 +1369,14 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
           // The helpers published their shares of pair tile 16 before their own regular tiles, i.e. long ago: the reducer
           // fetches flags and partial sums HERE, as three more loads in its operand stream, instead of in three serial
           // LDS round trips after its last MFMA, where every other wave of the workgroup waits for it at the barrier.
+          if constexpr (i % 4 == 1 && i / 4 < 7) sp(IC<i / 4>{});
           if constexpr (i == kL3Fetch) {
             if (wave == 0) {
 #pragma unroll
               for (int h = 0; h < 3; ++h) {
-                pflag[h] = lds_peek_a(lds0 + (kFlagOff + h) * 4);
+                pflag[h] = lds_peek_a(lds0 + (M::kFlagOff + h) * 4);
                 cbar();
-                part[h] = lds_ld<f32x4>(lds0 + L.scr + h * 1024, kScratchOff * 4);
+                part[h] = lds_ld<f32x4>(lds0 + L.scr + h * 1024, M::kScratchOff * 4);
               }
             }
           }
@@ -1128,9 +1392,9 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
     const bool early = pflag[0] == tag && pflag[1] == tag && pflag[2] == tag;   // the same words in every lane
     if (!__builtin_amdgcn_readfirstlane(early)) {   // not there yet at slot kL3Fetch (not seen in practice): wait, re-read
 #pragma unroll
-      for (int h = 0; h < 3; ++h) flag_wait(lds0 + (kFlagOff + h) * 4, tag, P.err, 4u);
+      for (int h = 0; h < 3; ++h) flag_wait(lds0 + (M::kFlagOff + h) * 4, tag, P.err, 4u);
 #pragma unroll
-      for (int h = 0; h < 3; ++h) part[h] = lds_ld<f32x4>(lds0 + L.scr + h * 1024, kScratchOff * 4);
+      for (int h = 0; h < 3; ++h) part[h] = lds_ld<f32x4>(lds0 + L.scr + h * 1024, M::kScratchOff * 4);
     }
     acc[2] += part[0];   // fixed order: the result does not depend on which path was taken
     acc[2] += part[1];
@@ -1141,30 +1405,32 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
   // wave-uniform switch on blk, then straight-line code.  This epilogue is every wave's tail in front of the layer's
   // barrier -- nothing overlaps it -- so it is kept free of branches: as one generic body with `blk ==` tests inside
   // it was ~40 scalar branches and 24 v_cndmask per wave (the skip registers were merged at every join).
-  if (blk == 0) l3_epilogue<0>(L, wave, acc, skip_ce1, skip_ce2);
-  else if (blk == 1) l3_epilogue<1>(L, wave, acc, skip_ce1, skip_ce2);
-  else if (blk == 2) l3_epilogue<2>(L, wave, acc, skip_ce1, skip_ce2);
-  else if (blk == 3) l3_epilogue<3>(L, wave, acc, skip_ce1, skip_ce2);
-  else l3_epilogue<4>(L, wave, acc, skip_ce1, skip_ce2);
+  if constexpr (LAST) l3_epilogue<M, 4>(L, wave, acc, skip_ce1, skip_ce2);
+  else if (blk == 0) l3_epilogue<M, 0>(L, wave, acc, skip_ce1, skip_ce2);
+  else if (blk == 1) l3_epilogue<M, 1>(L, wave, acc, skip_ce1, skip_ce2);
+  else if (blk == 2) l3_epilogue<M, 2>(L, wave, acc, skip_ce1, skip_ce2);
+  else l3_epilogue<M, 3>(L, wave, acc, skip_ce1, skip_ce2);
   DET(3);
 }
 
-// ---- decode_final inside the kernel (layout and decomposition: see kHS above) ---------------------------------
+// ---- decode_final inside the kernel (layout and decomposition: see above) ---------------------------------
 struct FinA {
   f32x2 a[kFinRun];   // this wave's 18 K-steps of A fragments
 };
 __device__ __forceinline__ void fin_prefetch(const Params& P, int wave, int lane, FinA& A) {
+  lane = opaque(lane);
   const f32x2* src = reinterpret_cast<const f32x2*>(P.fin) + (size_t)(kFinRun * wave) * 64 + lane;
 #pragma unroll
   for (int s = 0; s < kFinRun; ++s) A.a[s] = src[s * 64];
 }
 // zero the five 64-pixel pads of the H image (B18 holds layer-1 / layer-2 leftovers); block 4's layer 3 writes the bins
+template <class M>
 __device__ __forceinline__ void fin_zero_pads(unsigned lds0, int tid) {
   constexpr int kPadPairs = 64 * kHS / 2;   // b64 stores per pad
 #pragma unroll
   for (int i = 0; i < (5 * kPadPairs + kThreads - 1) / kThreads; ++i) {
     const int q = tid + i * kThreads, p = q / kPadPairs, e = q - p * kPadPairs;
-    if (q < 5 * kPadPairs) lds_st<f32x2>(lds0 + 4 * (kHOff + p * kHFrame * kHS + 2 * e), 0, f32x2{0.f, 0.f});
+    if (q < 5 * kPadPairs) lds_st<f32x2>(lds0 + 4 * (M::kHOff + p * kHFrame * kHS + 2 * e), 0, f32x2{0.f, 0.f});
   }
 }
 typedef f32x4 __attribute__((aligned(4))) f32x4_u;   // a [frame][129] row is only 4-byte aligned
@@ -1173,6 +1439,7 @@ __device__ __forceinline__ float row_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
+template <class M>
 __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsigned w128, int wave, int lane, int utt,
                                             int t0, const FinA& A, const XStage& xnext, float* x0) {
   const int n = lane & 15, kq = lane >> 4;
@@ -1186,8 +1453,8 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
     // predicated loop hipcc serialised it into ten LDS round trips in front of this wave's MFMA run, which every other
     // wave then waited for at the barrier).
     const int fi = kq, sub = n;
-    const unsigned hb = lds0 + 4 * (kHOff + (kHFrame * fi + 64 + 64 + sub) * kHS);
-    const unsigned wb = w128 + sub * 32;   // bin-128 weights: LDS-DMA'd behind the next tile's first packet
+    const unsigned hb = lds0 + 4 * (M::kHOff + (kHFrame * fi + 64 + 64 + sub) * kHS);
+    const unsigned wb = w128 + sub * 32;   // bin-128 weights: LDS-DMA'd during block 4's layer 3 (X6) / behind the next tile's first packet (F32)
     f32x4 hv[5][2], wv[5][2];
 #pragma unroll
     for (int m = 0; m < 5; ++m)
@@ -1216,7 +1483,7 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
     if (sub == 0 && fi < nfr) yt[fi * kF + 128] = sum + P.fin_bias;
   }
   {  // ---- this wave's run of K-steps, both column tiles: column n of tile ct = (frame n >> 2, block 4*ct + (n & 3))
-    const unsigned rd0 = lds0 + 4 * (kHOff + ((kHFrame * (n >> 2) + 16 * (n & 3)) * kHS + 2 * kq)) + wave * (kFinRun * kHS * 4);
+    const unsigned rd0 = lds0 + 4 * (M::kHOff + ((kHFrame * (n >> 2) + 16 * (n & 3)) * kHS + 2 * kq)) + wave * (kFinRun * kHS * 4);
     unsigned rd1 = rd0 + 64 * kHS * 4;
     asm volatile("" : "+v"(rd1));   // a base of its own (see make_lane)
     f32x4 acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
@@ -1237,8 +1504,8 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
         },
         [] {});
     const unsigned scr = lds0 + wave * 1024 + lane * 16;
-    lds_st<f32x4>(scr, 4 * kFinScr0, acc[0][0] + acc[0][1]);
-    lds_st<f32x4>(scr, 4 * kFinScr1, acc[1][0] + acc[1][1]);
+    lds_st<f32x4>(scr, 4 * M::kFinScr0, acc[0][0] + acc[0][1]);
+    lds_st<f32x4>(scr, 4 * M::kFinScr1, acc[1][0] + acc[1][1]);
   }
   // The next tile's input rows (in registers since block 4's layer 3) go to X0 here: X0 aliases the start of B30, dead
   // since the barrier that ended layer 3 and clear of the partial sums above.  The barrier below then also starts the
@@ -1246,7 +1513,7 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
   xstage_store(xnext, x0, wave * 64 + lane);
   __syncthreads();
   if (wave < 2) {   // ---- finish column tile `wave`: partial sums of waves 0..7, in that order, + bias
-    const unsigned scr = lds0 + 4 * (wave == 0 ? kFinScr0 : kFinScr1) + lane * 16;
+    const unsigned scr = lds0 + 4 * (wave == 0 ? M::kFinScr0 : M::kFinScr1) + lane * 16;
     f32x4 v = lds_ld<f32x4>(scr, 0);
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) v += lds_ld<f32x4>(scr, w * 1024);
@@ -1257,31 +1524,59 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
       store_wait_state();   // see lds_dma.h
     }
   } else if (wave == 3) {
-    // The H image lay over B18, whose gap pixels (4 per frame, 18 channels) every layer relies on being zero and no
-    // layer ever writes: put the zeros back (every wave finished its H reads before the barrier above).
-    constexpr int kGapPairs = 4 * 18 / 2;   // b64 stores per gap
+    // The H image (and, X6, the bin-128 weights behind it) lay over B18, whose gap pixels every layer relies on being zero
+    // and no layer ever writes: put the zeros back (every wave finished its H reads before the barrier above).
+    if constexpr (M::kX6) {
+      // per plane: the two leading pad rows and the four gap rows behind each frame = 18 rows of 32 bytes; 3 planes x 18 rows
+      // x 2 halves = 108 sixteen-byte stores (the remainder rows lie behind the planes, untouched by H)
+      constexpr int kRows = kB18Pad + 4 * kTF;
 #pragma unroll
-    for (int i = 0; i < (4 * kGapPairs + 63) / 64; ++i) {
-      const int q = lane + 64 * i, g = q / kGapPairs, e = q - g * kGapPairs;
-      if (q < 4 * kGapPairs)
-        lds_st<f32x2>(lds0 + 4 * (kB18Off + (kB18Pad + kF + kS * g) * 18 + 2 * e), 0, f32x2{0.f, 0.f});
+      for (int i = 0; i < (3 * kRows * 2 + 63) / 64; ++i) {
+        const int q = lane + 64 * i, pl = q / (kRows * 2), e = q - pl * (kRows * 2), rr = e >> 1, half = e & 1;
+        const int row = rr < kB18Pad ? rr : kB18Pad + kF + kS * ((rr - kB18Pad) >> 2) + ((rr - kB18Pad) & 3);
+        if (q < 3 * kRows * 2) lds_st<f32x4>(lds0 + 4 * M::kB18Off + pl * M::kPlaneBytes + row * 32 + half * 16, 0, zero4);
+      }
+    } else {
+      constexpr int kGapPairs = 4 * 18 / 2;   // b64 stores per gap
+#pragma unroll
+      for (int i = 0; i < (4 * kGapPairs + 63) / 64; ++i) {
+        const int q = lane + 64 * i, g = q / kGapPairs, e = q - g * kGapPairs;
+        if (q < 4 * kGapPairs)
+          lds_st<f32x2>(lds0 + 4 * (M::kB18Off + (kB18Pad + kF + kS * g) * 18 + 2 * e), 0, f32x2{0.f, 0.f});
+      }
     }
   }
 }
 
+template <class M>
 __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* const wbase = lds + kWOff;
+  float* const wbase = lds + M::kWOff;
 #define WREG(i) (wbase + (i) * kWRegion)
 
   // zero all of LDS once: gap pixels and margins are never written afterwards
-  for (int e = tid; e < kLdsFloats; e += kThreads) lds[e] = 0.f;
+  for (int e = tid; e < M::kLdsFloats; e += kThreads) lds[e] = 0.f;
   __syncthreads();
-  // packet of the very first layer into region 0; input rows of the first tile into registers
-  packet_dma<kW1>(P.wpack, WREG(0), wave, lane);
+  // F32 form: packet of the very first layer into region 0; X6 form: its A fragments into registers.  Input rows of the
+  // first tile into registers.
+  A1Regs A1;
+  A2Regs A2;
+  // piece k = 0..16 of a block's register-resident weights (X6 form; g = that block's images): layer 1's main pass (k < 7),
+  // layer 2's M-tile of this wave (7..16).  (Layer 1's remainder pass, 8 more pieces for waves 4..7: inside layer 1.)
+  auto wload = [&](auto kc, const float* g, unsigned voff) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k < 7) a1_load_one<k>(A1, g, voff);
+    else if constexpr (k < 17) a2_load_one<k - 7>(A2, g + kG1, wave >> 2, voff);
+  };
+  if constexpr (M::kX6) {
+    const unsigned voff = (unsigned)lane * 16u;
+    static_for<0, 7>([&](auto kc) { wload(kc, P.wpack, voff); });
+  } else {
+    packet_dma<kW1>(P.wpack, WREG(0), wave, lane);
+  }
   int wcur = 0;
   unsigned epoch = 0;   // layer-3 instances so far (tags the split-tile hand-offs)
   // This workgroup's tiles: a CONTIGUOUS range (balanced: the first total % grid workgroups take one more).  Consecutive
@@ -1302,30 +1597,48 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
 #ifdef RCED_PRIO
   if ((wave >= 4) == (RCED_PRIO > 0)) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for one half of the waves
 #endif
-  const Lane L = make_lane(lds, wave, lane, xr0 < 0 ? 0 : xr0);
+  const Lane L = make_lane<M>(lds, wave, lane, xr0 < 0 ? 0 : xr0);
   const unsigned lds0 = lds_addr(lds);
-  xstage_store(xst, lds + kX0Off, tid);   // the first tile's input rows; every later tile's are stored by final_phase
+  xstage_store(xst, lds + M::kX0Off, tid);   // the first tile's input rows; every later tile's are stored by final_phase
   __syncthreads();
+  constexpr int kBlockFloats = M::kX6 ? kGBlock : kWBlock;
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int utt = tile / P.tiles_per_utt;
     const int t0 = (tile - utt * P.tiles_per_utt) * kTF;   // first frame of the tile
     f32x4 skip_ce1[3], skip_ce2[3];
-    FinA finA;
 #pragma unroll
     for (int t = 0; t < 3; ++t) skip_ce1[t] = skip_ce2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* wsrc = P.wpack;
 
+    // Layer 3 of block BLK < 4 inside the loop, block 4's behind it: decode_final's operands (36 registers of A fragments)
+    // are fetched in front of THAT instance only; declared outside a five-iteration loop they were live through all of it.
 #pragma unroll 1
-    for (int blk = 0; blk < 5; ++blk) {
+    for (int blk = 0;; ++blk) {
       {  // ---- layer 1: (8x9, 1->18) for block 0, (1x9, 8->18) otherwise
         STAMP_BEGIN();
-        const float* w = WREG(wcur);
-        const unsigned wb = lds_addr(w);
-        auto dma = [&] { packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane); };   // next packet: layer 2's
-        if (blk == 0) layer1<true>(L, wb, wave, dma DET_PASS);
-        else layer1<false>(L, wb, wave, dma DET_PASS);
-        wcur ^= 1;
+        const unsigned wb = lds_addr(WREG(wcur));
+        // What is fetched for later once the layer's first operand reads are in flight.  F32 form: layer 2's packet.  X6 form:
+        // layer 3's packet (its one LDS region is dead until then).
+        auto dma = [&] {
+          if constexpr (M::kX6) packet_dma<kW3>(wsrc + kG1 + kG2, WREG(0), wave, lane);
+          else packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
+        };
+        // One load per slot of the pair job(s), k = 0..17: layer 2's fragments (k < 10) and this layer's remainder-pass fragments
+        // (k = 10..17, waves 4..7; used by the wave's last job).  (Measured: the same loads inside layer 3's stream, which has
+        // the room on the vector-memory path, cost 0.35 ms MORE -- its slots are the tightest in the kernel.)
+        A1Rem A1r;
+        const unsigned voff1 = (unsigned)opaque(lane) * 16u;
+        auto sp1 = [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if constexpr (M::kX6 && !(RCED_X6_EXP & 2)) {
+            if constexpr (k < 10) wload(IC<k + 7>{}, wsrc, voff1);
+            else if (wave >= 4) a1_load_rem_one<k - 10>(A1r, wsrc, voff1);
+          }
+        };
+        if (blk == 0) layer1<M, true>(L, wb, A1, A1r, wave, dma, sp1 DET_PASS);
+        else layer1<M, false>(L, wb, A1, A1r, wave, dma, sp1 DET_PASS);
+        if constexpr (!M::kX6) wcur ^= 1;
 #if RCED_STAMPS
         const unsigned long long st_b_ = stamp();
         tsum[blk == 0 ? 6 : 0] += st_b_ - st_a_;
@@ -1334,44 +1647,75 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
 #else
         layer_end_sync();
 #endif
+        // ---- layer 2: (1x5, 18->30)
+        {
+          STAMP_BEGIN();
+          const unsigned tag2 = 0xC0000000u | (epoch + 1u);   // distinct from layer 3's tags (0x8.......)
+          if constexpr (M::kX6) {
+            layer2_x6<M>(L, lds0, A2, wave, tag2, P.err, [] {} DET_PASS);
+          } else {
+            auto dma3 = [&] { packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane); };
+            layer2_f32<M>(L, lds0, lds_addr(WREG(wcur)), wave, tag2, P.err, dma3 DET_PASS);
+            wcur ^= 1;
+          }
+          STAMP_MATH(1);
+          layer_end_sync();
+          STAMP_WAIT(1);
+        }
       }
-      {  // ---- layer 2: (1x5, 18->30)
-        STAMP_BEGIN();
-        const float* w = WREG(wcur);
-        const unsigned tag2 = 0xC0000000u | (epoch + 1u);   // distinct from layer 3's tags (0x8.......)
-        auto dma = [&] { packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane); };
-        layer2(L, lds0, lds_addr(w), wave, tag2, P.err, dma DET_PASS);
-        wcur ^= 1;
-        STAMP_MATH(1);
-        layer_end_sync();
-        STAMP_WAIT(1);
-      }
+      if (blk == 4) break;
       {  // ---- layer 3: (1x9, 30->8) on pixel pairs; block skips; hand-off
         STAMP_BEGIN();
-        const float* w = WREG(wcur);
+        const unsigned wb = lds_addr(WREG(M::kX6 ? 0 : wcur));
         ++epoch;
         const unsigned tag = 0x80000000u | epoch;   // sign bit set: never the bits of a ReLU output
-        if (blk == 4) {   // once per tile: stays in front of the layer
-          xst = xstage_load(P, tile + 1 < tile_end ? tile + 1 : P.total_tiles, tid);   // next tile's input rows (none: no loads)
-          packet_dma<kFin128>(P.fin + kFinA, WREG(wcur ^ 1) + kW1, wave, lane);   // decode_final's bin-128 weights ride along
-          fin_prefetch(P, wave, lane, finA);   // decode_final's A fragments: in flight during this layer
-          fin_zero_pads(lds0, tid);            // B18 is dead from here on (layer 3's own scratch sits below the H image)
-        }
-        // next packet: layer 1 of the next block, or of block 0 of the next tile (the stream wraps)
-        const float* wnext = blk == 4 ? P.wpack : wsrc + kWBlock;
-        auto dma = [&] { packet_dma<kW1>(wnext, WREG(wcur ^ 1), wave, lane); };
-        layer3(P, L, lds0, lds_addr(w), blk, wave, tag, skip_ce1, skip_ce2, dma DET_PASS);
-        wcur ^= 1;
+        // next: layer 1 of the next block.  F32 form: its packet; X6 form: its main pass's A fragments into registers
+        const float* wnext = wsrc + kBlockFloats;
+        auto dma = [&] {
+          if constexpr (!M::kX6) packet_dma<kW1>(wnext, WREG(wcur ^ 1), wave, lane);
+        };
+        const unsigned voff = (unsigned)opaque(lane) * 16u;
+        auto sp = [&](auto kc) {
+          if constexpr (M::kX6 && !(RCED_X6_EXP & 4)) wload(kc, wnext, voff);   // k < 7: the next layer 1's main pass (inside layer 2's stream instead: no difference, A/B)
+        };
+        layer3<M, false>(P, L, lds0, wb, blk, wave, tag, skip_ce1, skip_ce2, dma, sp DET_PASS);
+        if constexpr (!M::kX6) wcur ^= 1;
         STAMP_MATH(2);
         layer_end_sync();
         STAMP_WAIT(2);
       }
-      wsrc += kWBlock;
+      wsrc += kBlockFloats;
+    }
+    FinA finA;
+    {  // ---- block 4's layer 3, and in front of it, once per tile: what decode_final and the next tile need
+      STAMP_BEGIN();
+      const unsigned wb = lds_addr(WREG(M::kX6 ? 0 : wcur));
+      ++epoch;
+      const unsigned tag = 0x80000000u | epoch;
+      xst = xstage_load(P, tile + 1 < tile_end ? tile + 1 : P.total_tiles, tid);   // next tile's input rows (none: no loads)
+      // decode_final's bin-128 weights ride along: X6 form: into B18 (dead from here on) behind the H image
+      if constexpr (M::kX6) packet_dma<kFin128>(P.fin + kFinA, lds + M::kFin128Off, wave, lane);
+      else packet_dma<kFin128>(P.fin + kFinA, WREG(wcur ^ 1) + kW1, wave, lane);
+      fin_prefetch(P, wave, lane, finA);   // decode_final's A fragments: in flight during this layer
+      fin_zero_pads<M>(lds0, tid);         // B18 is dead from here on (layer 3's own scratch sits below the H image)
+      auto dma = [&] {   // layer 1 of block 0 of the next tile (the stream wraps)
+        if constexpr (!M::kX6) packet_dma<kW1>(P.wpack, WREG(wcur ^ 1), wave, lane);
+      };
+      const unsigned voff = (unsigned)opaque(lane) * 16u;
+      auto sp = [&](auto kc) {
+        if constexpr (M::kX6 && !(RCED_X6_EXP & 4)) wload(kc, P.wpack, voff);
+      };
+      layer3<M, true>(P, L, lds0, wb, 4, wave, tag, skip_ce1, skip_ce2, dma, sp DET_PASS);
+      if constexpr (!M::kX6) wcur ^= 1;
+      STAMP_MATH(2);
+      layer_end_sync();
+      STAMP_WAIT(2);
     }
 #if RCED_STAMPS
     const unsigned long long st_f_ = stamp();
 #endif
-    final_phase(P, lds0, lds_addr(WREG(wcur) + kW1), wave, lane, utt, t0, finA, xst, lds + kX0Off);   // no barrier at its end: layer 1's covers it
+    const unsigned w128 = M::kX6 ? lds0 + 4 * M::kFin128Off : lds_addr(WREG(wcur) + kW1);
+    final_phase<M>(P, lds0, w128, wave, lane, utt, t0, finA, xst, lds + M::kX0Off);   // no barrier at its end: layer 1's covers it
 #if RCED_STAMPS
     tfin += stamp() - st_f_;
 #endif

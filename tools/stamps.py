@@ -9,6 +9,8 @@ import torch
 from fullycnnspeechenhancement_amd import build_model
 from fullycnnspeechenhancement_amd import weights as _weights
 m = build_model("FullyCNNV3", False, weights=_weights.synthetic_weights(3, seed=42))
+if os.environ.get("V3_L2X6") is not None:   # 0: the F32 form of the kernel (every layer on the fp32 MFMA)
+    m.set_option("v3_l2x6", int(os.environ["V3_L2X6"]))
 x = torch.randn((256, 512, 129, 1), device="cuda").abs_()
 y = m(x)
 torch.cuda.synchronize()
