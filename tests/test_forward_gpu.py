@@ -276,6 +276,178 @@ def test_full_size_config3_sampled_against_oracle(net_work, tag, variant, built)
         assert torch.equal(m(x), y)
 
 
+# the two forms of the CR-CED kernel (kernels_fused_v3.h): agree with each other to fp32 summation noise
+V3_FORMS_AGREE = 5e-6
+
+
+def v3_both_forms(w):
+    """(model running the product form -- 18 -> 30 layers as three-part bf16 products -- , model running every layer on the fp32 MFMA)"""
+    a, b = make_model(3, w), make_model(3, w)
+    assert a.get_option("v3_l2x6") == 1
+    b.set_option("v3_l2x6", 0)
+    assert b.get_option("v3_l2x6") == 0
+    return a, b
+
+
+def test_v3_kernel_forms_agree_with_the_oracle_and_each_other(built, capsys):
+    """rced_set_option(m, "v3_l2x6", 0 | 1): both kernels are in the library; same inputs through both -- the golden vectors
+    and a fuzz set (shapes across the tile size, input scales 1e-3 .. 30, silent frames) -- each held to the oracle (1e-4) and
+    the two to each other (5e-6 of the scale: fp32 summation noise; measured errors printed)."""
+    w, g = load_golden("v3")
+    x6, f32 = v3_both_forms(w)
+    worst = [0.0, 0.0, 0.0]
+    cases = [(w, g["x_small"], g["y_small"]), (w, g["x_long"], g["y_long"])]
+    rng = np.random.default_rng(4242)
+    for _ in range(8):
+        n, t = int(rng.integers(1, 5)), int(rng.integers(1, 41))
+        wf = rced_np.make_weights("FullyCNNV3", seed=int(rng.integers(1, 1 << 30)))
+        x = rced_np.make_input(n, t, seed=int(rng.integers(1, 1 << 30))) * np.float32(rng.choice([1e-3, 1.0, 30.0]))
+        if rng.random() < 0.5:
+            x[:, rng.integers(0, t)] = 0.0
+        cases.append((wf, x, rced_c.forward("FullyCNNV3", wf, x, np.float64)))
+    for wf, x, ref in cases:
+        if wf is not w:
+            x6, f32 = v3_both_forms(wf)
+        ya, yb = x6(x), f32(x)
+        worst[0] = max(worst[0], check_parity(ya, ref, what="x6 form"))
+        worst[1] = max(worst[1], check_parity(yb, ref, what="fp32 form"))
+        worst[2] = max(worst[2], rel_err(ya, yb))
+        assert rel_err(ya, yb) <= V3_FORMS_AGREE
+    with capsys.disabled():
+        print("\n[v3 forms] worst error of the scale: x6 vs oracle %.2e, fp32-MFMA vs oracle %.2e, x6 vs fp32-MFMA %.2e"
+              % tuple(worst))
+
+
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_whole_output_config3_against_the_fp64_restatement(net_work, tag, variant, built, capsys):
+    """BASELINE config 3 (batch 256, 129x512), EVERY one of the 131,072 output frames (the reference boundary returns all of
+    them: tester.py:85-90) against oracle/infer_ref.py run in float64 on the same GPU -- all three nets, and for CR-CED both
+    forms of the kernel, which must also agree with each other."""
+    import torch
+    import bench
+    from oracle import infer_ref
+    w = rced_np.make_weights(net_work, seed=42)
+    x = torch.from_numpy(bench.synthetic_magnitudes((256, 512, 129, 1), 1234)).cuda()
+    ref = infer_ref.forward(net_work, w, x, device="cuda", dtype=torch.float64).cpu().numpy()
+    torch.cuda.empty_cache()
+    if variant == 3:
+        x6, f32 = v3_both_forms(w)
+        ya, yb = x6(x).cpu().numpy(), f32(x).cpu().numpy()
+        ea, eb, ab = check_parity(ya, ref, what="x6 form"), check_parity(yb, ref, what="fp32 form"), rel_err(ya, yb)
+        assert ab <= V3_FORMS_AGREE
+        msg = "x6 %.2e, fp32-MFMA %.2e, between the two %.2e" % (ea, eb, ab)
+    else:
+        msg = "%.2e" % check_parity(make_model(variant, w)(x).cpu().numpy(), ref)
+    with capsys.disabled():
+        print("\n[config 3, all 131072 frames, %s] max error of the scale vs fp64: %s" % (net_work, msg))
+
+
+def test_results_do_not_depend_on_the_tile_to_workgroup_map(built):
+    """A persistent workgroup owns a contiguous range of tiles (balanced over the grid).  Whatever the grid -- every CU, 77,
+    3 or one workgroup -- a tile's arithmetic is the same, so the masks are bit-identical; and frames on both sides of every
+    range boundary of the 77-workgroup map are checked against the oracle."""
+    w = rced_np.make_weights("FullyCNNV3", seed=12)
+    n, t = 37, 200                       # 37 utterances x 50 tiles = 1850 tiles
+    x = rced_np.make_input(n, t, seed=99)
+    m = make_model(3, w)
+    y = m(x)
+    for grid in (77, 3, 1):
+        m.set_option("fused_grid", grid)
+        assert np.array_equal(m(x), y), grid
+    m.set_option("fused_grid", 0)
+    total, grid = n * 50, 77
+    base, rem = divmod(total, grid)
+    scale = np.abs(y).max()
+    for b in range(1, grid):
+        first = b * base + min(b, rem)                      # first tile of workgroup b
+        for tile in (first - 1, first):
+            u, t0 = divmod(tile, 50)
+            for fr in (4 * t0, 4 * t0 + 3):                 # first and last frame of the tile
+                lo, hi = max(fr - 3, 0), min(fr + 5, t)
+                ref = rced_c.forward("FullyCNNV3", w, x[u:u + 1, lo:hi], np.float64)[0, fr - lo]
+                assert np.abs(y[u, fr] - ref).max() <= RTOL * scale, (b, tile, fr)
+
+
+def _scaled_inner_channels(w, rng, lo=-4.0, hi=4.0):
+    """CR-CED weights in which every channel of the 18- and 30-channel tensors (one consumer each, no skip) carries its own
+    scale 10^U(lo, hi): BatchNorm gamma / beta of the producer are multiplied by it and the consumer's kernel slice divided,
+    so the net computes the same function (ReLU is positively homogeneous) while the values that meet in one K = 32 chunk of
+    the three-part products differ by up to eight orders of magnitude."""
+    w = {k: np.array(v, dtype=np.float64) for k, v in w.items()}
+    for blk in ("CE1", "CE2", "CE3", "CD1", "CD2"):
+        for prod, cons in (("%s_encode_1" % blk, "%s_encode_2" % blk), ("%s_encode_2" % blk, "%s_decode" % blk)):
+            s = 10.0 ** rng.uniform(lo, hi, w[prod + "/batch_norm/gamma"].shape[0])
+            w[prod + "/batch_norm/gamma"] *= s
+            w[prod + "/batch_norm/beta"] *= s
+            w[cons + "/kernel"] /= s[None, None, :, None]
+    return {k: v.astype(np.float32) for k, v in w.items()}
+
+
+def test_three_part_products_on_adversarial_magnitudes(built, capsys):
+    """The split x = h + m + l (bf16 parts) of the CR-CED kernel's 18-channel tensor under magnitudes the synthetic inputs never
+    produce: per-channel scales spanning 1e-4 .. 1e4 inside one K = 32 chunk, inputs x 1e-6 and x 1e4, a frame of exact zeros
+    next to a frame of 1e4.  Both forms of the kernel against the oracle (1e-4) and each other; measured errors printed."""
+    rng = np.random.default_rng(2024)
+    base = rced_np.make_weights("FullyCNNV3", seed=5)
+    rows = []
+    for name, w, x in (
+            ("channel scales 1e-4..1e4", _scaled_inner_channels(base, rng), rced_np.make_input(3, 21, seed=1)),
+            ("channel scales 1e-2..1e2, input x 30", _scaled_inner_channels(base, rng, -2, 2), rced_np.make_input(2, 9, seed=2) * np.float32(30)),
+            ("input x 1e-6", base, rced_np.make_input(2, 13, seed=3) * np.float32(1e-6)),
+            ("input x 1e4", base, rced_np.make_input(2, 13, seed=4) * np.float32(1e4)),
+            ("zero frame beside a 1e4 frame", base, None)):
+        if x is None:
+            x = rced_np.make_input(2, 16, seed=5)
+            x[:, 7] = 0.0
+            x[:, 8] *= np.float32(1e4)
+        ref = rced_c.forward("FullyCNNV3", w, x, np.float64)
+        x6, f32 = v3_both_forms(w)
+        ya, yb = x6(x), f32(x)
+        assert np.isfinite(ya).all() and np.isfinite(yb).all()
+        rows.append((name, check_parity(ya, ref, what=name + " (x6)"), check_parity(yb, ref, what=name + " (fp32)"), rel_err(ya, yb)))
+        assert rows[-1][3] <= 4 * V3_FORMS_AGREE, rows[-1]
+    with capsys.disabled():
+        print()
+        for r in rows:
+            print("[adversarial] %-40s x6 %.2e  fp32-MFMA %.2e  between %.2e" % r)
+
+
+@pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
+@pytest.mark.parametrize("form", [1, 0])
+def test_non_finite_input_stays_inside_its_tiles(bad, form, built):
+    """One Inf / NaN magnitude at (utterance 1, frame 21, bin 40).  Frame t of the output needs frames t-3 .. t+4 of the input
+    (only the first layer looks along time), so frames 17..24 of utterance 1 are the ones the oracle changes.  The kernel
+    works on tiles of 4 frames whose frames sit side by side in one pixel row, and its zero-weight padding slots (K rounded
+    up to the MFMA's K, SAME padding as rows of zeros) turn Inf x 0 into NaN: a non-finite value can reach the edge bins of
+    the other frames of its TILE (here tiles 16..19, 20..23, 24..27), never another tile.
+    What the values INSIDE the field are is not compared: ReLU is an integer max(bits, 0) here -- a NaN with the sign bit
+    clear stays NaN, one with the sign bit set becomes 0, which is also what IEEE maxNum(NaN, 0), CUDA's fmaxf and the plain-C
+    oracle give, while numpy's maximum (the other oracle) keeps every NaN; the reference's own answer (TF 1.14 `tf.nn.relu` on
+    a NaN) is not defined by anything in its source.  Checked: every frame outside those tiles is BIT-IDENTICAL to the run on
+    the clean input; the bad value does change its field; the call returns, rced_check is clean, and the next call on the
+    clean input gives the clean result."""
+    from fullycnnspeechenhancement_amd import _lib
+    w = rced_np.make_weights("FullyCNNV3", seed=8)
+    x = rced_np.make_input(3, 40, seed=6)
+    m = make_model(3, w)
+    m.set_option("v3_l2x6", form)
+    clean = m(x)
+    xb = x.copy()
+    xb[1, 21, 40, 0] = bad
+    y = m(xb)
+    assert _lib.load().rced_check(m._infer_handle()) == 0
+    with np.errstate(all="ignore"):
+        ref = rced_np.forward("FullyCNNV3", w, xb, np.float64)
+    field = np.zeros((3, 40), bool)
+    field[1, 17:25] = True                      # the oracle's receptive field
+    tiles = np.zeros((3, 40), bool)
+    tiles[1, 16:28] = True                      # the tiles that contain it
+    assert np.isfinite(ref[~field]).all() and not np.isfinite(ref[field]).all()
+    assert np.array_equal(y[~tiles], clean[~tiles])
+    assert not np.array_equal(y[field], clean[field])
+    assert np.array_equal(m(x), clean)
+
+
 @pytest.mark.parametrize("net_work,tag,variant", NETS)
 def test_repeated_launches_are_bit_identical(net_work, tag, variant, built):
     """Race screen: the fused kernels hand tiles between waves (K-split hand-off, LDS-DMA packets,

@@ -176,3 +176,18 @@ def test_same_padding_agrees_with_a_third_partys_same_rule():
                            torch.from_numpy(b), padding="same").permute(0, 2, 3, 1).numpy()
         assert np.abs(ours - theirs).max() < 1e-10 * np.abs(theirs).max(), (kh, kw)
         assert tuple(rced_np.same_pad(kh)) == ((kh - 1) // 2, kh - 1 - (kh - 1) // 2)
+
+
+@pytest.mark.parametrize("net_work,tag,_v", NETS)
+def test_matmul_restatement_agrees_with_the_numpy_one(net_work, tag, _v):
+    """oracle/infer_ref.py (tap-wise torch matmuls; what the GPU tests run in float64 on the device to check EVERY frame of
+    a full-size forward) against oracle/rced_np.py on shapes that cover the time halo, a batch that is cut into chunks,
+    and non-trivial BatchNorm statistics."""
+    from oracle import infer_ref
+    w = rced_np.make_weights(net_work, seed=77)
+    for n, t in ((1, 1), (3, 11), (5, 9)):
+        x = rced_np.make_input(n, t, seed=31 * n + t)
+        ref = rced_np.forward(net_work, w, x, np.float64)
+        got = infer_ref.forward(net_work, w, x, utterances_per_chunk=2).numpy()
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) < 1e-12
