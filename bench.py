@@ -29,7 +29,60 @@ sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X dense fp32, vector = matrix (MI355X_MICROARCH.md chip table)
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (same table); only for bf16 lines
+# Which matrix pipe a kernel's arithmetic runs on, and that pipe's ceiling in fp32-equivalent TFLOP/s:
+#   mfma_f32     v_mfma_f32_16x16x4_f32, the fp32 pipe: 157.3 (= the vector rate)
+#   mfma_bf16x6  fp32-quality products as six v_mfma_f32_16x16x32_bf16 over three-part operands: 386, MEASURED in a
+#                register-only loop on this part (profiles/r03_f32_on_bf16.txt; 2500 / 6 = 417 on paper)
+#   mfma_bf16    plain bf16 operands: 2500
+# `frac_fp32_peak` = achieved / 157.3 for every kernel (SURVEY 8(d3)'s figure, kept as roofline.frac); `frac_pipe_ceiling` =
+# (sum over pipes of FLOP_i / ceiling_i) / time: the time the kernel's own mix of pipes would need at their ceilings over
+# the time it takes -- the number that says how busy the machine is when part of the work runs on a faster pipe.
+PIPE_CEILING_TFLOPS = {"mfma_f32": FP32_PEAK_TFLOPS, "mfma_bf16x6": 386.0, "mfma_bf16": BF16_PEAK_TFLOPS}
 NET_WORK = {1: "FullyCNN", 2: "FullyCNNV2", 3: "FullyCNNV3"}
+
+
+def pipe_roofline(flop_by_pipe, seconds):
+    """flop_by_pipe: {pipe: nominal dense FLOP in `seconds`} -> the roofline fields every kernel entry of the line carries."""
+    flop_by_pipe = {k: float(v) for k, v in flop_by_pipe.items() if v > 0}
+    total = sum(flop_by_pipe.values())
+    achieved = total / seconds / 1e12
+    floor_s = sum(v / (PIPE_CEILING_TFLOPS[k] * 1e12) for k, v in flop_by_pipe.items())
+    return {"pipe": next(iter(flop_by_pipe)) if len(flop_by_pipe) == 1 else "mixed",
+            "pipe_mix": {k: v / total for k, v in flop_by_pipe.items()},
+            "pipe_ceilings_tflops": {k: PIPE_CEILING_TFLOPS[k] for k in flop_by_pipe},
+            "achieved": achieved, "unit": "TFLOP/s", "peak": FP32_PEAK_TFLOPS,
+            "frac_fp32_peak": achieved / FP32_PEAK_TFLOPS, "frac_pipe_ceiling": floor_s / seconds}
+
+
+def layer_flops(spec, variant):
+    """Nominal dense FLOP per frame of every layer (2 * MAC * 129 bins)."""
+    return [2 * spec.FEATURE_DIM * l.kh * l.kw * l.cin * l.cout for l in spec.layers(variant)]
+
+
+def forward_flops_by_pipe(spec, variant, kernel, dtype="f32", v3_l2x6=1):
+    """FLOP per frame of one forward kernel kind, split by the pipe each layer runs on."""
+    fl = layer_flops(spec, variant)
+    if kernel == "conv_layer_generic":
+        return {"mfma_f32": sum(fl)}            # direct fp32 FMA on the vector ALU: same 157.3 ceiling
+    if variant == 3:                            # one kernel, all 16 layers; the five 18 -> 30 layers in the x6 form
+        x6 = sum(f for f, l in zip(fl, spec.layers(3)) if (l.cin, l.cout) == (18, 30)) if v3_l2x6 else 0
+        return {"mfma_f32": sum(fl) - x6, "mfma_bf16x6": x6}
+    if kernel == "rced_final_gemm":             # R-CED's 1x129 output layer: x6::final_gemm_x6_kernel / chain16::final_gemm16_kernel
+        return {"mfma_bf16" if dtype == "bf16" else "mfma_bf16x6": fl[-1]}
+    if dtype == "bf16":                         # fused_chain16: the first layer (8 x k on the fp32 input) stays on the fp32 MFMA
+        return {"mfma_f32": fl[0], "mfma_bf16": sum(fl[1:-1])}
+    return {"mfma_f32": sum(fl[:-1])}
+
+
+def train_flops_by_pipe(spec):
+    """CR-CED training step, 3 x forward FLOPs (forward, dgrad, wgrad), by pipe: on the bf16 pipe in the
+    three-part form run the 18 -> 30 forward convolutions, the 8 -> 30 dgrad inside the 30 -> 8 fused backward kernel, 16 of
+    every 18 pixel groups of the 18 -> 30 wgrad, and the output layer's forward and dgrad; everything else on the fp32 MFMA."""
+    fl, ly = layer_flops(spec, 3), spec.layers(3)
+    f1830 = sum(f for f, l in zip(fl, ly) if (l.cin, l.cout) == (18, 30))
+    f308 = sum(f for f, l in zip(fl, ly) if (l.cin, l.cout) == (30, 8))
+    x6 = f1830 + f308 + f1830 * 16.0 / 18.0 + 2 * fl[-1]
+    return {"mfma_f32": 3 * sum(fl) - x6, "mfma_bf16x6": x6}
 
 
 def parse_args():
@@ -48,6 +101,9 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 2 / config 5 entries (N = 1 only)")
     ap.add_argument("--from-root-steps", type=int, default=5, help="timed forward_from_root calls at N > 1 (0 = skip)")
     ap.add_argument("--from-root-chunks", type=int, default=8, help="pipeline depth of forward_from_root")
+    ap.add_argument("--from-root-fail-status", type=int, default=0,
+                    help="exit status of every rank when forward_from_root stalls (the line is printed first; 0 keeps the headline "
+                         "valid for drivers that drop the output of failed runs)")
     ap.add_argument("--from-root-timeout", type=int, default=150,
                     help="seconds after which a stalled forward_from_root is abandoned and the line printed without it")
     return ap.parse_args()
@@ -232,24 +288,31 @@ def host_buffers_line(model, x, steps=5):
 def from_root_line(args, torch, dist, model, spec, world, rank, local_rank, B, T):
     """The reference's single-host-process convention over RCCL: rank 0 holds the whole batch, scatters batch slices,
     every rank computes, the masks gather back (fullycnnspeechenhancement_amd/dist.py)."""
-    from fullycnnspeechenhancement_amd.dist import BatchShardedForward
+    from fullycnnspeechenhancement_amd.dist import BatchShardedForward, reserved_cus
     eng = BatchShardedForward(model, device="cuda:%d" % local_rank, forward_into=lambda a, out: model(a, out=out))
     xr = None
     if rank == 0:
         xr = torch.from_numpy(synthetic_magnitudes((world * B, T, spec.FEATURE_DIM, 1), 1234)).cuda()   # SURVEY 8(d2) C4
-    for _ in range(2):
-        eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.from_root_steps):
-        eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks)
-    torch.cuda.synchronize()
-    dist.barrier()
-    el = time.perf_counter() - t0
-    tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    el = float(tmax.item())
+    # The fused kernel is a persistent grid of one workgroup per CU holding nearly all of the CU's LDS; RCCL's send / recv are
+    # kernels too and can only start on a CU a workgroup has left.  So the pipelined call is timed with r CUs left free for
+    # them (dist.reserved_cus: fused_grid = num_cus - r), r swept; the fastest is `value`, all are reported.
+    sweep = {}
+    for r in (0, 4, 8, 16):
+        with reserved_cus(model, r):
+            for _ in range(2 if r == 0 else 1):
+                eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.from_root_steps):
+                eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tm = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            sweep[r] = float(tm.item())
+    best_r = min(sweep, key=lambda k: sweep[k])
+    el = sweep[best_r]
     # compute-free passes: what the links alone take per direction, so that the overlap shows as
     # ms_per_step ~ max(compute, transfer) instead of being inferred
     probe = {}
@@ -273,10 +336,14 @@ def from_root_line(args, torch, dist, model, spec, world, rank, local_rank, B, T
             "ms_per_step": 1e3 * el / args.from_root_steps, "steps": args.from_root_steps,
             "chunks": args.from_root_chunks, "global_batch": world * B,
             "bytes_per_peer_each_way": B * T * spec.FEATURE_DIM * 4,
+            "reserved_cus": best_r,
+            "reserved_cus_sweep_ms_per_step": {str(r): 1e3 * v / args.from_root_steps for r, v in sweep.items()},
             "transfer_only": probe,
             "note": "BatchShardedForward.forward_from_root: rank 0 holds [N*B,T,129,1] in HBM, scatters batch "
                     "slices over RCCL send/recv (one peer per xGMI link), every rank computes, masks gather back "
-                    "to rank 0; chunked so that transfer overlaps compute.  Reported beside `value`, not as it.  "
+                    "to rank 0; chunked so that transfer overlaps compute; the forwards run on num_cus - reserved_cus "
+                    "workgroups so that RCCL's kernels find free CUs (sweep: reserved_cus_sweep_ms_per_step; the fastest is "
+                    "this entry's value).  Reported beside `value`, not as it.  "
                     "transfer_only: the same call with no compute, one direction at a time (3 calls each): with the "
                     "overlap working, ms_per_step ~ max(resident ms_per_step, scatter_only_ms, gather_only_ms) + "
                     "one chunk's transfer at each end."}
@@ -292,6 +359,11 @@ def secondary_config2(torch, build_model, spec, _lib, _weights, local_rank):
     flops = spec.flops_per_frame(2) * B * T
     ms = 1e3 * elapsed / steps
     dom = max(times, key=lambda k: times[k][0])
+    whole = {}
+    for k in ("rced_fused", "rced_final_gemm"):
+        for pipe, f in forward_flops_by_pipe(spec, 2, k, "bf16").items():
+            whole[pipe] = whole.get(pipe, 0) + f * B * T
+    pr = pipe_roofline(whole, ms * 1e-3)
     out = {"config": "R-CED V2 (16-layer) forward, batch 64, 129x512, bf16 activations/weights, fp32 accumulation "
                      "(BASELINE configs[1])",
            "metric": "spectrogram frames/sec (FullyCNNV2 fwd, 129-bin)", "value": B * T * steps / elapsed, "unit": "frames/s",
@@ -299,7 +371,12 @@ def secondary_config2(torch, build_model, spec, _lib, _weights, local_rank):
            "tflops": flops / (ms * 1e-3) / 1e12,
            "roofline": {"bound": "mfma", "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "achieved": flops / (ms * 1e-3) / 1e12, "frac": flops / (ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
-                        "note": "whole forward (nominal dense FLOPs) over wall time per step vs the dense bf16 MFMA peak"},
+                        "pipe": pr["pipe"], "pipe_mix": pr["pipe_mix"], "pipe_ceilings_tflops": pr["pipe_ceilings_tflops"],
+                        "frac_fp32_peak": pr["frac_fp32_peak"], "frac_pipe_ceiling": pr["frac_pipe_ceiling"],
+                        "note": "whole forward (nominal dense FLOPs) over wall time per step; frac = vs the dense bf16 MFMA peak "
+                                "(this line's dtype); the first layer (8 x 11 on the fp32 input) runs on the fp32 MFMA"},
+           "kernels": {k: dict(pipe_roofline({p: f * B * T * steps for p, f in forward_flops_by_pipe(spec, 2, k, "bf16").items()}, v[0] * 1e-3),
+                               avg_launch_ms=v[0] / v[1], launches=v[1]) for k, v in times.items() if v[1]},
            "kernels_ms_per_step": {k: v[0] / steps for k, v in times.items() if v[1]}, "dominant_kernel": dom}
     model.close()
     return out
@@ -325,12 +402,15 @@ def secondary_config5(torch, ge, FullyCNNTrainer, spec, _weights, local_rank):
     flops = 3 * spec.flops_per_frame(3) * B * T                 # forward + dgrad + wgrad, nominal
     free, total = torch.cuda.mem_get_info()
     pmc, pmc_src = pmc_record("pmc_train.json", ge.train_kernel_hash())
+    pr = pipe_roofline({p: f * B * T for p, f in train_flops_by_pipe(spec).items()}, ms * 1e-3)
     out = {"config": "CR-CED V3 training step (fwd+bwd+Adam), batch 256, 129x512, fp32 (BASELINE configs[4])",
            "metric": "training step time", "value": ms, "unit": "ms/step", "higher_is_better": False,
            "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "f32",
            "frames_per_s": B * T * steps / elapsed, "tflops": flops / (ms * 1e-3) / 1e12,
            "roofline": {"bound": "mfma", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "achieved": flops / (ms * 1e-3) / 1e12, "frac": flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                        "pipe": pr["pipe"], "pipe_mix": pr["pipe_mix"], "pipe_ceilings_tflops": pr["pipe_ceilings_tflops"],
+                        "frac_fp32_peak": pr["frac_fp32_peak"], "frac_pipe_ceiling": pr["frac_pipe_ceiling"],
                         "note": "3 x forward FLOPs (nominal) over wall time per step; the step is layer-by-layer and also "
                                 "HBM-heavy (hbm_gb_per_step)"},
            "hbm_gb_per_step": (pmc or {}).get("hbm_gb_per_step"),
@@ -357,18 +437,17 @@ def secondary_rced_fp32(torch, build_model, spec, _lib, _weights, local_rank, va
         if not launches:
             continue
         kf = final if k == "rced_final_gemm" else flops - final
-        ach = kf * B * T * steps / (tot * 1e-3) / 1e12
-        per_kernel[k] = {"avg_launch_ms": tot / launches, "launches": launches, "flop_per_frame": kf,
-                         "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS}
+        pr = pipe_roofline({p: f * B * T * steps for p, f in forward_flops_by_pipe(spec, variant, k).items()}, tot * 1e-3)
+        per_kernel[k] = dict(pr, avg_launch_ms=tot / launches, launches=launches, flop_per_frame=kf, frac=pr["frac_fp32_peak"])
     out = {"config": "%s (%d-layer R-CED) forward, batch 256, 129x512, fp32 (config 3's shape; model.py:%s)"
                      % (name, len(spec.layers(variant)), "6-29" if variant == 1 else "32-61"),
            "metric": "spectrogram frames/sec (%s fwd, 129-bin)" % name, "value": B * T * steps / elapsed, "unit": "frames/s",
            "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "f32",
            "tflops": flops * B * T / (ms * 1e-3) / 1e12,
-           "roofline": {"bound": "mfma", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "achieved": flops * B * T / (ms * 1e-3) / 1e12,
-                        "frac": flops * B * T / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                        "note": "whole forward over wall time per step; per kernel (HIP events on the launch stream) below"},
+           "roofline": dict(pipe_roofline({p: sum(forward_flops_by_pipe(spec, variant, k).get(p, 0) for k in ("rced_fused", "rced_final_gemm")) * B * T
+                                           for p in PIPE_CEILING_TFLOPS}, ms * 1e-3),
+                            bound="mfma", frac=flops * B * T / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                            note="whole forward over wall time per step; per kernel (HIP events on the launch stream) below"),
            "kernels": per_kernel}
     model.close()
     return out
@@ -450,10 +529,12 @@ def secondary_pipeline(torch, build_model, spec, _lib, _weights, local_rank, cpu
            "metric": "spectrogram frames/sec through the whole pipeline", "value": frames / (whole * 1e-3), "unit": "frames/s",
            "ms_per_step": whole, "steps": reps, "dtype": "f32",
            "kernels_ms": {"rced_stft": t_stft, "rced_forward": t_cnn, "rced_istft": t_istft},
-           "stft": {"tflops": frames * flop_dft / t_stft / 1e9, "frac_fp32_peak": frames * flop_dft / t_stft / 1e9 / FP32_PEAK_TFLOPS,
+           "stft": {"pipe": "mfma_f32", "frac_pipe_ceiling": frames * flop_dft / t_stft / 1e9 / FP32_PEAK_TFLOPS,
+                    "tflops": frames * flop_dft / t_stft / 1e9, "frac_fp32_peak": frames * flop_dft / t_stft / 1e9 / FP32_PEAK_TFLOPS,
                     "algorithmic_gbps": (N * L * 4 + frames * 129 * 12) / t_stft / 1e6,
                     "frac_hbm_8tbs": (N * L * 4 + frames * 129 * 12) / t_stft / 1e6 / 8000.0},
-           "istft": {"tflops": frames * flop_dft / t_istft / 1e9, "frac_fp32_peak": frames * flop_dft / t_istft / 1e9 / FP32_PEAK_TFLOPS,
+           "istft": {"pipe": "mfma_f32", "frac_pipe_ceiling": frames * flop_dft / t_istft / 1e9 / FP32_PEAK_TFLOPS,
+                     "tflops": frames * flop_dft / t_istft / 1e9, "frac_fp32_peak": frames * flop_dft / t_istft / 1e9 / FP32_PEAK_TFLOPS,
                      "algorithmic_gbps": (frames * 129 * 12 + N * (T + 1) * 128 * 4) / t_istft / 1e6,
                      "frac_hbm_8tbs": (frames * 129 * 12 + N * (T + 1) * 128 * 4) / t_istft / 1e6 / 8000.0},
            "finite": bool(torch.isfinite(wav).all()),
@@ -578,24 +659,32 @@ def main():
                 traffic, traffic_src = pmc_traffic(ge, variant, B, T, dom)
                 peak = FP32_PEAK_TFLOPS if args.dtype == "f32" else BF16_PEAK_TFLOPS
                 alg = 1032 * B * T if (dom != "rced_fused" or fused_all) else (516 + 516 * hand_ch) * B * T
+                v3x6 = int(model.get_option("v3_l2x6")) if variant == 3 else 0
+                pr = pipe_roofline({p_: f * B * T * args.steps
+                                    for p_, f in forward_flops_by_pipe(spec, variant, dom, args.dtype, v3x6).items()}, ms * 1e-3)
                 roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
-                        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                        "unit": "TFLOP/s", "frac": achieved / peak, "pipe": pr["pipe"], "pipe_mix": pr["pipe_mix"],
+                        "pipe_ceilings_tflops": pr["pipe_ceilings_tflops"], "frac_fp32_peak": pr["frac_fp32_peak"],
+                        "frac_pipe_ceiling": pr["frac_pipe_ceiling"], "traffic": traffic,
                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE: %s; this kernel's "
                                         "algorithmic bytes per launch = %d; whole forward = %d" % (traffic_src, alg, 1032 * B * T),
                         "avg_launch_ms": ms / launches, "launches": launches,
                         "flop_per_frame": kflops, "frames_per_forward": B * T,
                         "other_kernels_ms_per_step": {k: v[0] / args.steps for k, v in times.items() if k != dom and v[1]},
-                        "note": "compute-bound path (7950 FLOP/B): peak = dense fp32 MFMA 157.3 TFLOP/s, not HBM "
-                                "(CR-CED: the 18->30 layers, 43 % of the FLOPs, are computed at fp32 quality as six bf16 "
-                                "MFMAs per product over three-part operands -- DESIGN 3.1 / 3.4a; the fraction stays "
-                                "quoted against the fp32 pipe's peak); "
+                        "note": "compute-bound path (7950 FLOP/B): peak = dense fp32 MFMA 157.3 TFLOP/s, not HBM.  CR-CED: the "
+                                "18->30 layers (pipe_mix.mfma_bf16x6 of the FLOPs) are computed at fp32 quality as six bf16 "
+                                "MFMAs per product over three-part operands (DESIGN 3.1): `frac` = frac_fp32_peak stays quoted "
+                                "against the fp32 pipe's peak (SURVEY 8(d3)); frac_pipe_ceiling prices every layer against the "
+                                "pipe it runs on (386 TFLOP/s measured for the six-product form); "
                                 "algorithmic HBM bytes are 1032 B/frame"}
         out["roofline"] = roof
     # ---- the reference's single-host-process convention over RCCL: scatter from rank 0, compute, gather -------
     # The headline figures above are complete at this point.  from_root is the first code of a run that sends utterances
     # between GPUs; if it stalls (a link, a communicator that never forms), the collective would sit until the process
     # group's own watchdog ABORTS every rank -- and the line with it.  So a timer stands beside it: on expiry rank 0 prints
-    # the line as it is (from_root = the timeout) and every rank leaves with status 0.
+    # the line as it is (from_root = the timeout) and every rank leaves with status 0 by default: the HEADLINE is complete and
+    # valid, and a driver that discards the output of a run with a non-zero status would lose it; the failure is in the line
+    # (from_root.error).  --from-root-fail-status N makes the ranks leave with N instead, for callers that gate on the status.
     if world > 1 and args.from_root_steps > 0:
         import threading
 
@@ -606,9 +695,10 @@ def main():
                 out.setdefault("host_buffers", None)
                 out.setdefault("cpu_baseline", None)
                 print(json.dumps(out), flush=True)
-            sys.stderr.write("[bench] rank %d: from_root timed out after %d s, leaving\n" % (rank, args.from_root_timeout))
+            sys.stderr.write("[bench] rank %d: from_root timed out after %d s, leaving with status %d\n"
+                             % (rank, args.from_root_timeout, args.from_root_fail_status))
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(args.from_root_fail_status)
 
         timer = threading.Timer(args.from_root_timeout, give_up)
         timer.daemon = True
@@ -656,7 +746,7 @@ def main():
     if world > 1:
         # the line is out; a peer that is gone must not turn the run into a watchdog abort while everybody says goodbye
         import threading
-        bye = threading.Timer(60.0, lambda: os._exit(0))
+        bye = threading.Timer(60.0, lambda: os._exit(args.from_root_fail_status))   # a peer never reached the closing barrier
         bye.daemon = True
         bye.start()
         dist.barrier()

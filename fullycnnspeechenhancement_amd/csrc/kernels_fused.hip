@@ -29,6 +29,11 @@ struct rced_fused {
   size_t scratch_bytes = 0;
   float* wpack = nullptr;     // packed A-fragment stream (CR-CED: of the F32 form, built when that form is first selected)
   float* wpack_x6 = nullptr;  // CR-CED, X6 form (v3::kGTotal floats)
+  // Per-handle options of the R-CED output layer's kernel; the environment variables of the same meaning only supply the
+  // defaults, read when the handle is created (rced_create), never afterwards.
+  int final_x6 = 1;           // option "final_x6" (default: RCED_FINAL_X6): 1 = x6::final_gemm_x6_kernel (three-part bf16 products), 0 = fp32 MFMA
+  int final_lds = 1;          // option "final_lds" (default: RCED_FINAL_LDS): the fp32 kernel with (1) / without (0) LDS staging of its B operand
+  int bf16_final16 = 1;       // option "bf16_final16" (default: RCED_C16_FINAL16): bf16 mode: the output layer on the bf16 MFMA (1) or as above (0)
   int v3_l2x6 = 1;            // option "v3_l2x6": 1 = the 18 -> 30 layers at fp32 quality on the bf16 matrix pipe (the product), 0 = every
                               // layer on the fp32 MFMA (the comparator): kernels_fused_v3.h
   float* fin_apack = nullptr; // v3::kFinPack
@@ -278,23 +283,17 @@ void pack_chain(const rced_model* m, std::vector<float>* wpack, std::vector<floa
   *fin_bias = lf.host_shift[0];
 }
 
-// RCED_FINAL_LDS=0: the last layer's GEMM without LDS staging of its B operand (the first form; kept for A/B)
-inline bool final_lds_enabled() {
-  static const bool on = !(getenv("RCED_FINAL_LDS") && atoi(getenv("RCED_FINAL_LDS")) == 0);
-  return on;
-}
-// RCED_FINAL_X6=0: the output layer on the fp32 MFMA (chain::final_gemm_lds_kernel) instead of the three-part bf16 form
-inline bool final_x6_enabled() {
-  static const bool on = !(getenv("RCED_FINAL_X6") && atoi(getenv("RCED_FINAL_X6")) == 0);
-  return on;
+inline int env_default(const char* name, int dflt) {   // an environment variable as the DEFAULT of a per-handle option
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 template <int CH>
 void chain_final_layer(const rced_fused* f, float* y, int frames, hipStream_t st) {
   const dim3 grid((frames + chain::kFinFrames - 1) / chain::kFinFrames);
-  if (final_x6_enabled() && f->fin_apack_x6)
+  if (f->final_x6 && f->fin_apack_x6)
     hipLaunchKernelGGL(x6::final_gemm_x6_kernel<CH>, grid, dim3(chain::kFinThreads), 0, st, (const float*)f->h,
                        (const unsigned short*)f->fin_apack_x6, f->fin_bias, y, frames, (const float*)nullptr);
-  else if (final_lds_enabled())
+  else if (f->final_lds)
     hipLaunchKernelGGL(chain::final_gemm_lds_kernel<CH>, grid, dim3(chain::kFinThreads), 0, st, (const float*)f->h,
                        (const float*)f->fin_apack, f->fin_bias, y, frames);
   else
@@ -455,8 +454,7 @@ int chain16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int 
   HIP_TRY(hipGetLastError());
   const int frames = Nb * T;
   m->prof_begin(RCED_K_FINAL, st);
-  static const bool final16 = [] { const char* e = getenv("RCED_C16_FINAL16"); return !(e && atoi(e) == 0); }();
-  if (final16 && f->fin_apack16)
+  if (f->bf16_final16 && f->fin_apack16)
     hipLaunchKernelGGL(chain16::final_gemm16_kernel<N::kFinalCh>, dim3((frames + chain::kFinFrames - 1) / chain::kFinFrames),
                        dim3(chain::kFinThreads), 0, st, (const float*)f->h, (const unsigned short*)f->fin_apack16, f->fin_bias, y,
                        frames);
@@ -494,6 +492,9 @@ int v3_enable_f32(rced_model* m, rced_fused* f) {
 int fused_create(rced_model* m) {
   m->fused = nullptr;
   rced_fused* f = new rced_fused();
+  f->final_x6 = env_default("RCED_FINAL_X6", 1) != 0;
+  f->final_lds = env_default("RCED_FINAL_LDS", 1) != 0;
+  f->bf16_final16 = env_default("RCED_C16_FINAL16", 1) != 0;
   if (m->variant != RCED_V3) {
     m->fused = f;
     const int rc = m->variant == RCED_V1 ? chain_create<chain::NetV1>(m, f) : chain_create<chain::NetV2>(m, f);
@@ -506,12 +507,9 @@ int fused_create(rced_model* m) {
   int rc = upload(&f->wpack_x6, wpack);
   if (!rc) rc = upload(&f->fin_apack, fin);
   if (!rc) rc = v3_set_lds<v3::MapX6>();
-  if (!rc) {   // the environment only supplies the DEFAULT of the per-handle option, read when the handle is created
-    const char* e = getenv("RCED_V3_L2X6");
-    if (e && atoi(e) == 0) {
-      rc = v3_enable_f32(m, f);
-      if (!rc) f->v3_l2x6 = 0;
-    }
+  if (!rc && env_default("RCED_V3_L2X6", 1) == 0) {   // the environment only supplies the DEFAULT of the per-handle option
+    rc = v3_enable_f32(m, f);
+    if (!rc) f->v3_l2x6 = 0;
   }
   if (!rc) {
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&f->err_host), 64, hipHostMallocMapped);
@@ -617,6 +615,14 @@ int fused_set_option(rced_model* m, const char* key, int value) {
     m->fused->grid_limit = value;
     return RCED_OK;
   }
+  for (int i = 0; i < 3; ++i) {   // the R-CED output layer's kernel selection
+    static const char* const names[3] = {"final_x6", "final_lds", "bf16_final16"};
+    if (strcmp(key, names[i])) continue;
+    if (m->variant == RCED_V3) return rced_fail(RCED_ERR_ARG, "%s selects the R-CED V1 / V2 output-layer kernel; CR-CED's runs inside its fused kernel", key);
+    if (value != 0 && value != 1) return RCED_ERR_ARG;
+    (i == 0 ? m->fused->final_x6 : i == 1 ? m->fused->final_lds : m->fused->bf16_final16) = value;
+    return RCED_OK;
+  }
   if (!strcmp(key, "v3_l2x6")) {
     if (m->variant != RCED_V3) return rced_fail(RCED_ERR_ARG, "v3_l2x6 selects the form of the CR-CED kernel only");
     if (value != 0 && value != 1) return RCED_ERR_ARG;
@@ -664,6 +670,10 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
   }
   if (!strcmp(key, "v3_l2x6")) {
     *value = m->variant == RCED_V3 ? m->fused->v3_l2x6 : 0;
+    return RCED_OK;
+  }
+  if (!strcmp(key, "final_x6") || !strcmp(key, "final_lds") || !strcmp(key, "bf16_final16")) {
+    *value = !strcmp(key, "final_x6") ? m->fused->final_x6 : !strcmp(key, "final_lds") ? m->fused->final_lds : m->fused->bf16_final16;
     return RCED_OK;
   }
   if (!strcmp(key, "bf16")) {

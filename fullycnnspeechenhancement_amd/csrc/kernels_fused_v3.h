@@ -30,7 +30,7 @@
 //     packet still goes through LDS (one region, no ping-pong).
 //   X6 = false: every layer on v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32 fmaf chain), all weight packets streamed
 //     L2 -> LDS by LDS-DMA one layer ahead (ping-pong).  Rounds 1 / 2's kernel; kept as the in-build comparator of the
-//     X6 arithmetic (tests/test_forward_gpu.py holds the two against each other and both against the oracle).
+//     X6 arithmetic (tests/test_forward_gpu.py holds the two against each other and both against the fp64 restatement).
 //
 // Pixel space of a tile: kTF frames, frame i at flat pixels [i*kS, i*kS+129); the kS-129 = 4 gap
 // pixels between frames are always zero and serve as the SAME-padding halo of both neighbours.

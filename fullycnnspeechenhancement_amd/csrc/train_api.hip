@@ -133,17 +133,13 @@ int ensure_acts(rced_trainer* t, size_t P) {
   t->G.assign(L + 1, nullptr);
   t->z.assign(L, nullptr);
   int maxc = 1;
-  // RCED_TRAIN_SKEW (bytes, multiple of 256; experiment): every tensor starts at a different offset inside its allocation, so that
-  // the two to four tensors a kernel streams in lockstep do not walk the same HBM channel sequence
-  static const size_t skew = [] { const char* e = getenv("RCED_TRAIN_SKEW"); return e ? (size_t)atol(e) & ~(size_t)255 : (size_t)0; }();
-  int nalloc = 0;
+  // (Round 3 measured a different start offset inside its allocation for every tensor -- so that the tensors a kernel streams
+  // in lockstep do not walk the same HBM channel sequence -- as run-to-run noise; the switch is gone.)
   auto alloc = [&](float** out_ptr, size_t bytes) -> int {
     void* base = nullptr;
-    const size_t off = skew * (size_t)(nalloc % 61);
-    HIP_TRY(hipMalloc(&base, bytes + skew * 61));
+    HIP_TRY(hipMalloc(&base, bytes));
     t->act_bases.push_back(base);
-    *out_ptr = reinterpret_cast<float*>(static_cast<char*>(base) + off);
-    ++nalloc;
+    *out_ptr = reinterpret_cast<float*>(base);
     return RCED_OK;
   };
   for (int l = 0; l < L; ++l) {

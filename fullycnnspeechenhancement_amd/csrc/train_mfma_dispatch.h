@@ -71,15 +71,12 @@ inline void allow_lds(const void* kernel, size_t lds, unsigned long long& done) 
 
 // Persistent grids are sized from the occupancy the runtime reports for the kernel (registers + LDS): cus x resident
 // workgroups per CU, so every workgroup is resident from the start and walks the same number of tiles.
-// RCED_TM_GRID_MULT (experiments): oversubscribe by that factor.
 inline int resident_grid(const void* kernel, size_t lds, int cus, int& occ_cache, int threads = tmm::kThreads) {
   std::lock_guard<std::mutex> lock(g_launch_cache_mu);
   if (occ_cache <= 0) {
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds) != hipSuccess || occ < 1) occ = 1;
-    static const int mult = [] { const char* e = getenv("RCED_TM_GRID_MULT"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
-    static const int cap = [] { const char* e = getenv("RCED_TM_MAXOCC"); return e && atoi(e) > 0 ? atoi(e) : 64; }();
-    occ_cache = std::min(occ, cap) * mult;
+    occ_cache = occ;
   }
   return cus * occ_cache;
 }

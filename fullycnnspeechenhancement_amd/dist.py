@@ -23,6 +23,14 @@ Two things make that real on RCCL and not only on gloo:
 The same code runs on the "gloo" backend with CPU tensors, which is how tests/ cover the
 world_size > 1 logic without GPUs.
 
+CUs for the transfers.  The fused forward kernels are persistent grids of one workgroup per CU that take almost all of a
+CU's LDS, and RCCL's send / recv run as kernels that need CU slots of their own: with every CU taken they can only start
+when a persistent workgroup exits, and the "scatter c+1 || compute c || gather c-1" pipeline serialises.  `reserved_cus(model,
+r)` runs the forwards inside it on `num_cus - r` workgroups (the library's per-handle option "fused_grid"; the kernels'
+tile ranges are balanced over whatever grid they are launched with, and results do not depend on it), leaving r CUs to the
+communicators; bench.py's from_root leg sweeps r.  Fallback if no r hides the transfers: copies over IPC handles on the
+SDMA engines instead of RCCL kernels (not built: no multi-GPU box in the build pool to measure it on).
+
 Failures.  A forward that raises on one rank must not leave the others waiting for transfers that never come: the
 failing rank finishes the protocol with zero-filled results, every call ends with one status all-reduce on `group`, and
 then EVERY rank raises (the failing one its own exception, the others a RuntimeError naming the rank).  `timeout_s`
@@ -34,6 +42,24 @@ import datetime
 
 import torch
 import torch.distributed as dist
+
+
+class reserved_cus(object):
+    """with reserved_cus(model, r): ...  -- forwards of `model` (a fullycnnspeechenhancement_amd model) inside the block
+    run on num_cus - r workgroups, so that r CUs stay free for the communicators' kernels; r = 0 restores the default."""
+
+    def __init__(self, model, r):
+        self.model, self.r = model, int(r)
+
+    def __enter__(self):
+        self.prev = self.model.get_option("fused_grid")
+        cus = self.model.get_option("num_cus")
+        self.model.set_option("fused_grid", max(1, cus - self.r) if self.r > 0 else 0)
+        return self
+
+    def __exit__(self, *exc):
+        self.model.set_option("fused_grid", self.prev)
+        return False
 
 
 def shard_bounds(n, world):
@@ -67,13 +93,13 @@ class BatchShardedForward(object):
     Construction is COLLECTIVE OVER THE DEFAULT PROCESS GROUP unless `scatter_group` / `gather_group` are handed in:
     it creates the two direction groups with torch.distributed.new_group, which every process of the default group
     must enter -- also those that are not members of `group`.  With a real subgroup either construct the object on all
-    processes (non-members pass the same `group` and never call the forward methods), or create the two groups yourself
-    (collectively) and pass them.  `close()` destroys the groups this object created (their communicators hold device
+    processes (non-members pass `group_ranks=[...]`, the members' global ranks -- a non-member cannot ask the group for
+    them -- and never call the forward methods), or create the two groups yourself (collectively) and pass them.  `close()` destroys the groups this object created (their communicators hold device
     memory on RCCL).  `trace`, if given, is a list that receives ("recv"|"fwd"|"send"|"result", chunk) events in the
     order this rank passed them (tests use it to check the pipeline order)."""
 
     def __init__(self, forward, group=None, device=None, trace=None, forward_into=None, scatter_group=None,
-                 gather_group=None, timeout_s=None):
+                 gather_group=None, timeout_s=None, group_ranks=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (one process per GPU)")
         if (scatter_group is None) != (gather_group is None):
@@ -86,19 +112,30 @@ class BatchShardedForward(object):
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.trace = trace
         self.timeout = datetime.timedelta(seconds=timeout_s) if timeout_s else None
-        ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
+        member = self.rank >= 0
+        if group_ranks is not None:
+            ranks = [int(r) for r in group_ranks]
+        elif group is None:
+            ranks = list(range(dist.get_world_size()))
+        elif member:
+            ranks = dist.get_process_group_ranks(group)
+        else:
+            raise ValueError("this process is not a member of `group`: pass group_ranks (the members' global ranks) so that "
+                             "it can enter the two new_group calls, or create scatter_group / gather_group yourself")
         self._ranks = ranks
         self._own_groups = []
-        # scatter (root -> peers) and gather (peers -> root) each get a communicator of their own
+        # scatter (root -> peers) and gather (peers -> root) each get a communicator of their own.  new_group is collective
+        # over the DEFAULT group: members and non-members alike make both calls (a process that skipped them would be two
+        # group-name counters behind, and its next collective new_group would pair with the wrong one).
         if scatter_group is not None:
             self.scatter_group, self.gather_group = scatter_group, gather_group
-        elif self.world > 1:
+        elif dist.get_world_size() > 1 and len(ranks) > 1:
             self.scatter_group = dist.new_group(ranks=ranks)
             self.gather_group = dist.new_group(ranks=ranks)
             self._own_groups = [self.scatter_group, self.gather_group]
         else:
             self.scatter_group = self.gather_group = group
-        if self.world > 1 and self.rank >= 0:
+        if self.world > 1 and member:
             # The FIRST call on a group's communicator must involve all its ranks (torch.distributed.batch_isend_irecv:
             # otherwise "the behavior is undefined" on NCCL/RCCL), and forward_from_root's transfers only ever pair the
             # root with one peer: open both communicators with a collective here.
@@ -154,13 +191,22 @@ class BatchShardedForward(object):
         times bench.py reports next to the pipelined figure; the returned tensor is then meaningless."""
         if direction not in ("both", "scatter", "gather"):
             raise ValueError("direction must be 'both', 'scatter' or 'gather'")
-        meta = [None]
+        # what the root broadcasts is (shape, dtype) or the text of its own validation error: the peers are already waiting
+        # in the broadcast when the root looks at its input, and must fail with it rather than hang
+        meta, bad_input = [None], None
         if self.rank == root:
-            if x_root.dim() != 4 or x_root.shape[2] != 129 or x_root.shape[3] != 1:
-                raise ValueError("input must be [N, T, 129, 1], got %s" % (tuple(x_root.shape),))
-            meta = [(tuple(x_root.shape), str(x_root.dtype))]
+            if not torch.is_tensor(x_root) or x_root.dim() != 4 or x_root.shape[2] != 129 or x_root.shape[3] != 1:
+                bad_input = "input must be a tensor [N, T, 129, 1], got %s" % (
+                    tuple(x_root.shape) if torch.is_tensor(x_root) else type(x_root).__name__,)
+                meta = [("error", bad_input)]
+            else:
+                meta = [(tuple(x_root.shape), str(x_root.dtype))]
         if self.world > 1:
             dist.broadcast_object_list(meta, src=self._ranks[root], group=self.group)
+        if meta[0][0] == "error":
+            if self.rank == root:
+                raise ValueError(bad_input)
+            raise PeerForwardError("forward_from_root: the root refused its input (%s)" % meta[0][1])
         shape, dtype_name = meta[0]
         dtype = getattr(torch, dtype_name.split(".")[-1])
         n, t = shape[0], shape[1]
@@ -193,9 +239,12 @@ class BatchShardedForward(object):
                         self._note("fwd", i)
                 except Exception as e:   # the transfers in flight are still drained: the peers must not be left waiting
                     err = e
-            for c in range(depth):       # results stream back chunk by chunk
-                self._wait(send_works[c] + recv_works[c])
-                self._note("result", c)
+            try:
+                for c in range(depth):   # results stream back chunk by chunk
+                    self._wait(send_works[c] + recv_works[c])
+                    self._note("result", c)
+            except Exception as e:       # a transfer that timed out (gloo): the status all-reduce below still runs, so that
+                err = err or e           # the other ranks leave the call with an error instead of waiting in it
             self._finish(err)
             return y
 
@@ -211,7 +260,11 @@ class BatchShardedForward(object):
                       for buf in bufs]
         send_works, outs = [], []
         for c, buf in enumerate(bufs):
-            self._wait(recv_works[c])    # nccl: the current stream waits for THIS chunk only
+            try:
+                self._wait(recv_works[c])    # nccl: the current stream waits for THIS chunk only
+            except Exception as e:       # a receive that timed out: go on with zeros so that the protocol still ends
+                err = err or e
+                buf.zero_()
             self._note("recv", c)
             out = buf
             if do_compute:
@@ -230,6 +283,9 @@ class BatchShardedForward(object):
                 outs.append(out)         # keep alive until sent
                 send_works += dist.batch_isend_irecv([dist.P2POp(dist.isend, out, groot, self.gather_group)])
                 self._note("send", c)
-        self._wait(send_works)
+        try:
+            self._wait(send_works)
+        except Exception as e:
+            err = err or e
         self._finish(err)
         return None

@@ -96,11 +96,19 @@ int rced_reserve(rced_model* m, int N, int T);
  *   "fused_grid"  workgroups of the persistent fused kernel (0 = one per CU)
  *   "bf16"        R-CED V1 / V2 only: 1 = bf16 activations + inner-layer weights, fp32 accumulation (BASELINE config 2;
  *                 ~6e-3 of the largest output away from the fp32 result -- opt-in)
+ *   "v3_l2x6"     CR-CED only: which form of the fused kernel runs.  1 (default) = the 18 -> 30 layers at fp32 quality on the bf16
+ *                 matrix pipe (three-part operands, six products); 0 = every layer on the fp32 MFMA (bit-for-bit an fp32 fmaf
+ *                 chain; the in-build comparator: the two agree to ~1e-6 of the largest output).  Both kernels are in the library.
+ *   "final_x6", "final_lds", "bf16_final16"   R-CED V1 / V2 only: the 1x129 output layer's kernel -- three-part bf16 products (1,
+ *                 default) or the fp32 MFMA (0), the latter with (1) / without (0) LDS staging of its B operand; in "bf16" mode the
+ *                 bf16 MFMA (1) or the kernel the first two select (0)
  *   "inject_handoff_error"  set only, CR-CED: writes the value into the sticky hand-off error word as the kernel would on a
  *                 time-out (0 clears it) -- a test hook for rced_check / RCED_ERR_STATE handling
  *   "has_fused", "num_cus", "fused_final"  get only ("fused_final": the 1x129 output layer runs inside the fused kernel)
- * Environment: RCED_FINAL_LDS=0 (the last layer's GEMM without LDS staging; read at the first forward); for rced_train_create RCED_TRAIN_MFMA=0 (direct-conv
- * kernels only), RCED_TRAIN_FUSE_ACT=0, RCED_TRAIN_FUSE_DZ=0 (materialise activations / dz). */
+ * Options are PER HANDLE.  Environment variables only supply DEFAULTS, read once when a handle is created (rced_create /
+ * rced_train_create) and never afterwards: RCED_V3_L2X6, RCED_FINAL_X6, RCED_FINAL_LDS, RCED_C16_FINAL16 (the options of the
+ * same meaning above); for rced_train_create RCED_TRAIN_MFMA=0 (direct-conv kernels only), RCED_TRAIN_FUSE_ACT=0,
+ * RCED_TRAIN_FUSE_DZ=0 (materialise activations / dz), RCED_TRAIN_FUSE_SUMS, RCED_TRAIN_FUSE_BWD, RCED_TRAIN_DET, RCED_TRAIN_X6. */
 int rced_set_option(rced_model* m, const char* key, int value);
 int rced_get_option(rced_model* m, const char* key, int* value);
 

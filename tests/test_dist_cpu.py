@@ -250,3 +250,79 @@ def test_from_root_fails_on_every_rank_when_one_forward_raises(tmp_path, bad_ran
             assert what == "own"
         else:
             assert what.startswith("peer:") and "rank %d" % bad_rank in what, (r, what)
+
+
+def _bad_input_worker(rank, world, port, out_path):
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullycnnspeechenhancement_amd.dist import BatchShardedForward, PeerForwardError
+        eng = BatchShardedForward(lambda a: a + 1.0, device="cpu")
+        t0 = time.perf_counter()
+        what = "none"
+        try:
+            eng.forward_from_root(torch.zeros(4, 9, 128, 1) if rank == 0 else None, root=0, chunks=2)   # 128 bins: refused
+        except ValueError as e:
+            what = "own:%s" % e
+        except PeerForwardError as e:
+            what = "peer:%s" % e
+        open("%s.%d" % (out_path, rank), "w").write("%s|%.1f" % (what, time.perf_counter() - t0))
+        x = torch.ones(4, 9, 129, 1)
+        y = eng.forward_from_root(x if rank == 0 else None, root=0, chunks=2)    # the engine is still usable
+        if rank == 0:
+            assert torch.equal(y, x + 1.0)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_from_root_input_refused_by_the_root_fails_every_rank(tmp_path):
+    """The root validates its input while the peers already wait in the meta broadcast: what is broadcast is the shape OR the
+    refusal, so that the peers raise too (PeerForwardError) instead of waiting for a shape that never comes."""
+    out = str(tmp_path / "r")
+    mp.spawn(_bad_input_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    for r in range(3):
+        what, el = open("%s.%d" % (out, r)).read().split("|")
+        assert float(el) < 30.0
+        assert what.startswith("own:" if r == 0 else "peer:") and "129" in what, (r, what)
+
+
+def _subgroup_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullycnnspeechenhancement_amd.dist import BatchShardedForward
+        members = [1, 2]
+        sub = dist.new_group(ranks=members)
+        # every process of the default group constructs the object; the non-member names the members' ranks
+        eng = BatchShardedForward(lambda a: a * 2.0, group=sub, device="cpu", group_ranks=members)
+        if rank in members:
+            x = torch.arange(5 * 9 * 129, dtype=torch.float32).reshape(5, 9, 129, 1) if rank == 1 else None
+            y = eng.forward_from_root(x, root=0, chunks=2)           # root = rank 0 OF THE SUBGROUP = global rank 1
+            if rank == 1:
+                assert torch.equal(y, x * 2.0)
+        # the group-name counters of all three processes are still in step: a later collective new_group pairs up
+        late = dist.new_group(ranks=[0, 1, 2])
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t, group=late)
+        assert float(t) == 3.0
+        open("%s.%d" % (out_path, rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_from_root_on_a_subgroup_with_a_non_member_process(tmp_path):
+    """A real subgroup (ranks 1, 2 of 3): the non-member constructs the object too (group_ranks), entering both new_group
+    calls, so a LATER collective new_group over all three still pairs up."""
+    out = str(tmp_path / "r")
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    assert all(open("%s.%d" % (out, r)).read() == "ok" for r in range(3))

@@ -615,8 +615,44 @@ def test_from_root_on_rccl_world_size_1(built):
         torch.cuda.synchronize()
         assert torch.equal(y, m(x))
         assert torch.equal(eng.forward_resident(x), y)
+        # the CU reservation bench.py's from_root leg sweeps: inside the block the forwards run on num_cus - r workgroups
+        # (CUs left to RCCL's kernels), the masks are the same bits, and the option is restored afterwards
+        from fullycnnspeechenhancement_amd.dist import reserved_cus
+        cus = m.get_option("num_cus")
+        xb = torch.from_numpy(rced_np.make_input(64, 40, seed=9)).cuda()     # 640 tiles: every workgroup of either grid has work
+        yb = m(xb)
+        for r in (4, 16):
+            with reserved_cus(m, r):
+                assert m.get_option("fused_grid") == cus - r
+                assert torch.equal(eng.forward_from_root(xb, root=0, chunks=2), yb)
+            assert m.get_option("fused_grid") == 0
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("net_work,tag,variant", NETS)
+def test_integration_md_binding_runs_verbatim(net_work, tag, variant, built):
+    """INTEGRATION.md section 1 shows the ctypes binding a maintainer of the reference would add (`RcedSession`).  The code
+    block is extracted from the markdown AS PRINTED -- only the library's file name is made absolute -- executed, and its
+    `run()` held to the committed golden vectors: the document cannot drift from the ABI."""
+    import re
+    from conftest import ROOT
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = md[md.index("## 1."):md.index("## 2.")]
+    code = re.search(r"```python\n(.*?)```", section, re.S).group(1)
+    assert "class RcedSession" in code and 'ctypes.CDLL("librced_hip.so")' in code
+    code = code.replace('"librced_hip.so"', repr(os.path.join(ROOT, "fullycnnspeechenhancement_amd", "librced_hip.so")))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#1", "exec"), ns)
+    w, g = load_golden(tag)
+    sess = ns["RcedSession"](net_work, w)
+    try:
+        for key in ("small", "long"):
+            y = sess.run(g["x_" + key])
+            assert y.shape == g["y_" + key].shape and y.dtype == np.float32
+            check_parity(y, g["y_" + key])
+    finally:
+        sess.close()
 
 
 def test_rced_check_reports_the_sticky_handoff_error(built):
@@ -704,7 +740,11 @@ def test_bench_two_ranks_control_flow_rehearsal():
 @pytest.mark.gpu
 def test_bench_line_survives_a_from_root_that_never_returns():
     """The first exchange of utterances between GPUs must not be able to take the headline line down: with a from_root
-    that hangs, rank 0 prints the line (from_root = the timeout) and every rank leaves with status 0."""
+    that hangs, rank 0 prints the line (from_root = the timeout) and every rank leaves -- with status 0 by default (the
+    headline is valid), with --from-root-fail-status N for callers that gate on the exit code."""
+    r, d = _run_bench_rehearsal({"RCED_BENCH_REHEARSE_HANG": "1"}, 600, "--from-root-timeout", "5", "--from-root-fail-status", "3")
+    assert r.returncode == 3, r.stderr[-3000:]
+    assert d is not None and "timeout" in d["from_root"]["error"]
     r, d = _run_bench_rehearsal({"RCED_BENCH_REHEARSE_HANG": "1"}, 600, "--from-root-timeout", "5")
     assert r.returncode == 0, r.stderr[-3000:]
     assert d is not None and d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"] is not None
