@@ -747,9 +747,17 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
     ~WgScope() { rced::tmd::g_wgdet = rced::tmd::WgDet{}; }
   };
   if (t->det && !forward_only && !t->wpart) {
-    // start value: 64 MB = 4096 slices x up to 4096 floats (largest of CR-CED: 2048 x 2732, the 18 -> 30 layer); a launcher
-    // whose occupancy-sized grid needs more grows it (tmd::wg_launch)
-    t->wpart_floats = (size_t)16 << 20;
+    // Sized BEFORE the forward for the most any wgrad launcher can ask for: slices = workgroups (CUs x at most 4 resident per
+    // CU) x 8 waves x 2 pixel parities, slice stride = the net's largest kernel + bias.  A failure to allocate is therefore
+    // reported here, before this step has touched anything; growing inside tmd::wg_launch remains as a last resort (it
+    // synchronises, and if it fails the step returns RCED_ERR_ALLOC below with the moving statistics already advanced).
+    size_t maxps = 0;
+    for (int l = 0; l < L; ++l) {
+      const LayerSpec& s = net.layer[l];
+      const int cin = s.src == 0 ? 1 : (net.layer[s.src - 1].cout + 1) & ~1, cout = (s.cout + 1) & ~1;   // (R-CED V2: even-padded)
+      maxps = std::max(maxps, (size_t)s.kh * s.kw * cin * cout + cout + 4);
+    }
+    t->wpart_floats = (size_t)t->num_cus * 4 * 8 * 2 * maxps;
     HIP_TRY(hipMalloc(&t->wpart, t->wpart_floats * sizeof(float)));
   }
   const WgScope wg_scope(t);
@@ -1141,7 +1149,11 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
       }
     }
   }
-  if (t->wg_error) return rced_fail(RCED_ERR_ALLOC, "deterministic weight gradients: the per-wave slice buffer could not be grown");
+  if (t->wg_error) {   // (cannot happen with the up-front size above unless the runtime reports > 4 workgroups per CU)
+    (void)hipStreamSynchronize(st);   // nothing of this step is left in flight behind the error
+    return rced_fail(RCED_ERR_ALLOC, "deterministic weight gradients: the per-wave slice buffer could not be grown; the step was "
+                                     "abandoned before the optimizer ran, but the moving statistics have advanced by this batch");
+  }
   // ---- Adam (TF form), trainer.py:175-179
   // global_step: the reference fetches it in the same sess.run as train_op (trainer.py:186-191); TF1 orders a read and an
   // assign_add in one run only through control dependencies, and slim.learning.create_train_op makes train_op =

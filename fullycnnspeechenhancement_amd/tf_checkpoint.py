@@ -539,27 +539,28 @@ def load_training_state(path, variant):
     # train_op bumps global_step once per update, trainer.py:178).  A checkpoint without global_step resumes at
     # the t that beta1_power implies.
     # beta1_power is a float32: 0.9^(t+1) leaves the normal range near t = 830 and underflows to 0 near t = 980, so it is
-    # trusted only while it is comfortably normal; past that beta2_power (0.999^(t+1): normal for ~87 k updates) gives the
-    # count, and a checkpoint from which it cannot be recovered says so instead of silently resuming at step 0.
-    t_adam = None
-    if "beta1_power" in allv:
-        b1p = float(np.asarray(allv["beta1_power"]).reshape(-1)[0])
-        if 1e-30 < b1p < 1.0:
-            t_adam = int(round(np.log(b1p) / np.log(0.9))) - 1
-    if t_adam is None and "beta2_power" in allv:
-        b2p = float(np.asarray(allv["beta2_power"]).reshape(-1)[0])
-        if 1e-30 < b2p < 1.0:
-            t_adam = int(round(np.log(b2p) / np.log(0.999))) - 1
+    # trusted only while it is comfortably normal; past that beta2_power gives the count (it falls below the 1e-30 cut-off
+    # near t = 69 k), and a checkpoint from which it cannot be recovered says so instead of silently resuming at step 0.
+    # TF forms both powers by REPEATED float32 multiplication with float32(0.9) = 0.89999998 / float32(0.999) = 0.99900001,
+    # so the logarithm is taken to THOSE bases (with log(0.999) the estimate drifts by 1.3e-5 per step: one step off at
+    # t = 40 k), and what remains of the float32 rounding of ~t products is allowed for: |t_adam - global_step| <=
+    # 1 + 1e-4 * step passes without a warning.
+    t_adam, used = None, None
+    for key, base in (("beta1_power", np.float32(0.9)), ("beta2_power", np.float32(0.999))):
+        if t_adam is None and key in allv:
+            bp = float(np.asarray(allv[key]).reshape(-1)[0])
+            if 1e-30 < bp < 1.0:
+                t_adam, used = int(round(np.log(bp) / np.log(float(base)))) - 1, key
     if t_adam is None and ("beta1_power" in allv or "beta2_power" in allv) and "global_step" not in allv:
         import warnings
         warnings.warn("%s: the Adam update count cannot be recovered (beta1_power / beta2_power have underflowed and there is "
                       "no global_step); resuming at step 0 resets Adam's bias correction and the Noam learning rate" % path)
     if step is None:
         step = max(t_adam, 0) if t_adam is not None else 0
-    elif t_adam is not None and t_adam != step:
+    elif t_adam is not None and abs(t_adam - step) > 1 + 1e-4 * step:
         import warnings
-        warnings.warn("%s: beta1_power implies %d Adam updates but global_step is %d; resuming at global_step"
-                      % (path, t_adam, step))
+        warnings.warn("%s: %s implies %d Adam updates but global_step is %d; resuming at global_step"
+                      % (path, used, t_adam, step))
     return weights, slots[0], slots[1], step
 
 

@@ -152,3 +152,39 @@ def test_adam_step_is_recovered_past_the_underflow_of_beta1_power(tmp_path):
     with pytest.warns(UserWarning, match="cannot be recovered"):
         _, _, _, step = tfc.load_training_state(prefix, spec.V3)
     assert step == 0
+
+
+def test_adam_step_from_powers_formed_the_way_tensorflow_forms_them(tmp_path):
+    """TF builds beta1_power / beta2_power by REPEATED float32 multiplication with float32(0.9) / float32(0.999) (one per
+    update).  At t ~ 5e4 the count is recovered from such a beta2_power to within one step (with log(0.999) as the base it
+    was a step off from t = 40 k on), a checkpoint that also holds global_step loads without a spurious warning, and a real
+    disagreement is reported under the name of the accumulator that was used."""
+    import warnings
+    w = rced_np.make_weights("FullyCNNV3", seed=2)
+    t = 50000
+    b1, b2 = np.float32(0.9), np.float32(0.999)
+    p1, p2 = np.float32(1.0), np.float32(1.0)
+    for _ in range(t + 1):
+        p1 = np.float32(p1 * b1)
+        p2 = np.float32(p2 * b2)
+    assert p1 < 1e-30 and 1e-30 < p2 < 1e-20          # beta1_power is long gone (a denormal that 0.9 no longer moves)
+    extra = dict(w, beta1_power=np.asarray(p1), beta2_power=np.asarray(p2))
+    prefix = str(tmp_path / "no_step")
+    tfc.write_checkpoint(prefix, extra)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _, _, _, step = tfc.load_training_state(prefix, spec.V3)
+    assert abs(step - t) <= 1, step
+    extra["global_step"] = np.asarray(t, np.int64)
+    prefix = str(tmp_path / "with_step")
+    tfc.write_checkpoint(prefix, extra)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # agreement to within rounding: no warning
+        _, _, _, step = tfc.load_training_state(prefix, spec.V3)
+    assert step == t
+    extra["global_step"] = np.asarray(t + 500, np.int64)
+    prefix = str(tmp_path / "disagree")
+    tfc.write_checkpoint(prefix, extra)
+    with pytest.warns(UserWarning, match="beta2_power implies"):
+        _, _, _, step = tfc.load_training_state(prefix, spec.V3)
+    assert step == t + 500
