@@ -48,7 +48,7 @@
 #define RCED_D2 2
 #endif
 #ifndef RCED_D2X
-#define RCED_D2X 2  // ... of layer 2 in the X6 form (a slot = one K = 32 chunk of one tile: 12 MFMAs)
+#define RCED_D2X 1  // ... of layer 2 in the X6 form (a slot = one K = 32 chunk of one tile: 12 MFMAs = 192 cycles; depth 2 spills)
 #endif
 #ifndef RCED_D3
 #define RCED_D3 2
@@ -61,6 +61,11 @@
 #endif
 #ifndef RCED_L3_CHAINS
 #define RCED_L3_CHAINS 2   // accumulation chains of layer 3's regular job: 4 = (tile, k-quad of the slot), 2 = one per tile (A/B: -0.3 %)
+#endif
+#ifndef RCED_L2_BOTH
+#define RCED_L2_BOTH 1    // X6 form, layer 2: 1 = a wave computes both M-tiles of tiles w + 8t (72 registers of A fragments; every B fragment read
+                          // once); 0 = one M-tile of tiles j + 4t (36 registers, every B fragment read by two waves: the layer is bound by the
+                          // LDS then -- A/B on one box 8.36 against 8.18 ms)
 #endif
 #ifndef RCED_STAMPS
 #define RCED_STAMPS 0     // diagnostic build: s_memtime stamps around every layer's math and barrier
@@ -190,7 +195,8 @@ struct Map {
   static_assert(kFlagOff + 3 <= kHOff, "layer 3's hand-off scratch and the H image do not overlap");
   // byte strides between a wave's regular tiles (8 tiles = 128 pixels apart)
   static constexpr int kT1R = 128 * kB8S * 4, kT1W = X6 ? 128 * 32 : 128 * 18 * 4;
-  static constexpr int kT2R = X6 ? 64 * 32 : 128 * 18 * 4, kT2W = X6 ? 64 * 30 * 4 : 128 * 30 * 4;   // X6: a wave's layer-2 tiles are 4 apart
+  static constexpr int kT2R = !X6 ? 128 * 18 * 4 : RCED_L2_BOTH ? 128 * 32 : 64 * 32;   // X6, one M-tile per wave: its tiles are 4 apart
+  static constexpr int kT2W = X6 && !RCED_L2_BOTH ? 64 * 30 * 4 : 128 * 30 * 4;
   static constexpr int kT3R = 128 * 60 * 4, kT3W = 256 * kB8S * 4;
   static constexpr int kTileB18 = X6 ? 16 * 32 : 16 * 18 * 4;          // ... between adjacent 16-pixel tiles of B18
 };
@@ -474,7 +480,7 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
     L.wr1rl = PL + M::kRemLBytes + (rpx + 2 * kq + kB18Pad) * 4;
     // layer 2: wave (g = M-tile, j) walks tiles j + 4t; px2 = this lane's pixel of tile j
     // chunk c: tap 2c + (kq >> 1) = pixel px2 - 2 + tap = row px2 + tap, channels 8 (kq & 1)..+7
-    const int px2 = 16 * (wave & 3) + n;
+    const int px2 = RCED_L2_BOTH ? px0 : 16 * (wave & 3) + n;
     L.rd2m = PL + (px2 + (kq >> 1)) * 32 + (kq & 1) * 16;
     // the remainder channels' window of pixel px2 = rows px2 .. px2+4; lanes kq = 2 take rows px2..+3, kq = 3 rows px2+4..+7
     // (one real tap, three zero-weight slots); the lower lanes read their upper partners' rows (same addresses: broadcast)
@@ -489,7 +495,7 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
     L.rd2t = L.rd2 + 4 * (8 * kL2Steps + (kq < 1 ? kq : 1) - 2 * kq);   // K = 90: tail k = 88 + kq is real for kq < 2
     L.wr1rl = L.rd2m = L.rd2r = L.rd2rl = 0u;
   }
-  if constexpr (M::kX6) L.wr2 = B30 + 4 * ((16 * (wave & 3) + n) * 30 + 16 * (wave >> 2) + 4 * kq);   // channels 16 g + 4kq..
+  if constexpr (M::kX6 && !RCED_L2_BOTH) L.wr2 = B30 + 4 * ((16 * (wave & 3) + n) * 30 + 16 * (wave >> 2) + 4 * kq);   // channels 16 g + 4kq..
   else L.wr2 = B30 + 4 * (px0 * 30 + 4 * kq);
   L.rd3 = B30 + 4 * ((2 * px0 - 4) * 30 + 2 * kq);          // px0 doubles as the pixel-PAIR index of layer 3
   L.rd3t = L.rd3 + 4 * (8 * kL3Steps - kq);                 // K = 300: tail k = 296 + kq, all four real
@@ -630,9 +636,10 @@ __device__ __forceinline__ void a1_load(A1Regs& A, const float* __restrict__ g1,
   A.s2 = *reinterpret_cast<const f32x2*>(g1 + kG1Main + kG1Rem + 16);
 }
 // Layer 2: a wave computes ONE M-tile (waves 0..3: channels 0..15, waves 4..7: 16..29) -- 36 registers of A fragments.
+constexpr int kL2MT = RCED_L2_BOTH ? 2 : 1;   // M-tiles a wave computes
 struct A2Regs {
-  s16x8 a[kL2Chunks][3];   // [chunk][part h, m, l] of this wave's M-tile
-  f32x4 sh;                // shift[16 mt + 4kq ..]
+  s16x8 a[kL2MT][kL2Chunks][3];   // [M-tile slot][chunk][part h, m, l]
+  f32x4 sh[kL2MT];                // shift[16 mt + 4kq ..]
 };
 // All of these loads are written as (wave-uniform base) + (one 32-bit per-lane byte offset, computed once per layer behind
 // opaque()) + (constant): hipcc then issues them in the saddr form with the constant as the immediate -- no per-load address
@@ -643,13 +650,13 @@ __device__ __forceinline__ T gld(const float* __restrict__ base, unsigned voff, 
 }
 // piece I of the ten: 0..8 = (chunk I / 3, part I % 3), 9 = the shifts.  g2m = the block's layer-2 image + this wave's M-tile
 // offset (mt * 3 KiB); voff = lane * 16
-template <int I>
+template <int I, int SLOT = 0>   // SLOT: which of the wave's M-tile slots receives M-tile mt
 __device__ __forceinline__ void a2_load_one(A2Regs& A, const float* __restrict__ g2, int mt, unsigned voff) {
   if constexpr (I < 9) {
     constexpr int c = I / 3, q = I % 3;
-    A.a[c][q] = gld<s16x8>(g2 + mt * (3 * 256), voff, ((c * 2) * 3 + q) * 1024);
+    A.a[SLOT][c][q] = gld<s16x8>(g2 + mt * (3 * 256), voff, ((c * 2) * 3 + q) * 1024);
   } else {
-    A.sh = gld<f32x4>(g2 + kG2Data + 16 * mt, (voff >> 4) & 0x30u, 0);   // shift[16 mt + 4 kq ..]: (lane >> 4) * 16 bytes
+    A.sh[SLOT] = gld<f32x4>(g2 + kG2Data + 16 * mt, (voff >> 4) & 0x30u, 0);   // shift[16 mt + 4 kq ..]: (lane >> 4) * 16 bytes
   }
 }
 template <int I>
@@ -798,8 +805,9 @@ __device__ __forceinline__ void l1_store(const Lane& L, f32x4 acc4, unsigned wr,
 // `dma` runs behind the first job's first operand reads; `sp(IC<k>)`, k = 0..17, is called once each from consecutive slots
 // of the wave's pair job(s) (every wave's FIRST job; the X6 form issues one register-bound weight load per slot there: issued
 // in one burst by eight waves they fill the vector-memory queue and block the waves' MFMAs behind them)
-template <class M, bool FIRST, class Dma, class Sp>
-__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, const A1Regs& A, const A1Rem& AR, int wave, Dma dma, Sp sp DET_ARG) {
+// `late()` runs between the pair job(s) and the wave's last jobs.
+template <class M, bool FIRST, class Dma, class Sp, class Late>
+__device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, const A1Regs& A, const A1Rem& AR, int wave, Dma dma, Sp sp, Late late DET_ARG) {
   using G = L1Geo<M, FIRST>;
   DET_BEGIN();
   const unsigned wa = wbase + (FIRST ? L.a4 : L.a8);     // F32 form: A fragments in LDS: main [s][lane], remainder from kW1Main
@@ -909,6 +917,7 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, const A1Re
 #if RCED_L1_ORDER == 1
   do_pairs();
   DET(6);
+  late();
   do_single();
   DET(5);
   do_rem();
@@ -920,6 +929,7 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, const A1Re
   DET(5);
   do_pairs();
   DET(6);
+  late();
 #endif
 }
 
@@ -1158,7 +1168,7 @@ __device__ __forceinline__ f32x4 l2x_share(const Lane& L, const A2Regs& A, unsig
   pre();
   pin();
   if constexpr (C == 2) l2x_merge(b, rr, vbit(L, kVUpper));
-  return l2x_mma(A.a[C], b, init);
+  return l2x_mma(A.a[0][C], b, init);
 }
 
 template <class M, class Dma>
@@ -1177,7 +1187,7 @@ __device__ __forceinline__ void layer2_x6(const Lane& L, unsigned lds0, const A2
     const unsigned rdm = L.rd2m + dt * 512, rdr = L.rd2r + dt * 128, rdrl = L.rd2rl + dt * 64;
     if (j == 0) accx = l2x_share<0>(L, A, rdm, rdr, rdrl, zero4, pre);        // a helper's share starts from zero,
     else if (j == 1) accx = l2x_share<1>(L, A, rdm, rdr, rdrl, zero4, pre);
-    else accx = l2x_share<2>(L, A, rdm, rdr, rdrl, A.sh, pre);                // the reducer's from the shift
+    else accx = l2x_share<2>(L, A, rdm, rdr, rdrl, A.sh[0], pre);             // the reducer's from the shift
     if (j < 2) {   // publish (LDS operations of a wave execute in order: data, then flag)
       lds_st<f32x4>(lds0 + L.scr + (2 * g + j) * 1024, M::kScratch2Off * 4, accx);
       cbar();
@@ -1201,7 +1211,7 @@ __device__ __forceinline__ void layer2_x6(const Lane& L, unsigned lds0, const A2
         [&](auto ic) {
           constexpr int i = decltype(ic)::value, t = i / kL2Chunks, c = i % kL2Chunks, r = i % RING, u = t & 1;
           if constexpr (c == 2) l2x_merge(b[r], rr, upper);
-          acc[u] = l2x_mma(A.a[c], b[r], c == 0 ? A.sh : acc[u]);
+          acc[u] = l2x_mma(A.a[0][c], b[r], c == 0 ? A.sh[0] : acc[u]);
           if constexpr (t > 0 && c == 0) {   // the previous tile's results
             constexpr bool gt = t - 1 == 2 || t - 1 == 4 || t - 1 == 6;
             l2x_store(L, acc[u ^ 1], L.wr2, (t - 1) * kT2W, gt && gj, kVL2 + t - 1);
@@ -1231,6 +1241,87 @@ __device__ __forceinline__ void layer2_x6(const Lane& L, unsigned lds0, const A2
     v += part1;
     l2x_store(L, v, L.wr2 + (32 - j) * (16 * 30 * 4), 0, false, 0);
   }
+}
+
+// ---- the same layer with BOTH M-tiles per wave (RCED_L2_BOTH): tiles w + 8t, a slot = one chunk of one tile = 12 MFMAs on two
+// accumulation chains; tile 32 cut M-tile x K-part over waves 0..3 (helpers: chunk 0; reducers: chunks 1, 2)
+template <int XM, bool HELPER, class Pre>
+__device__ __forceinline__ f32x4 l2b_share(const Lane& L, const A2Regs& A, unsigned rdm, unsigned rdr, unsigned rdrl, f32x4 init, Pre& pre) {
+  constexpr int C0 = HELPER ? 0 : 1, NC = HELPER ? 1 : 2, XS = XM < kL2MT ? XM : 0;
+  Parts b[2];
+  RemRaw rr;
+  f32x4 acc = init;
+  const bool upper = vbit(L, kVUpper);
+  run_job<NC, 1>(
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        l2x_load<C0 + i>(rdm, rdr, rdrl, 0, 0, 0, b[i % 2], rr);
+      },
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value, c = C0 + i;
+        if constexpr (c == 2) l2x_merge(b[i % 2], rr, upper);
+        acc = l2x_mma(A.a[XS][c], b[i % 2], acc);
+      },
+      pre);
+  return acc;
+}
+template <class M, class Dma>
+__device__ __forceinline__ void layer2_x6_both(const Lane& L, unsigned lds0, const A2Regs& A, int wave, unsigned tag, unsigned* err, Dma dma DET_ARG) {
+  constexpr int kT2R = M::kT2R, kT2W = M::kT2W, S1 = kL2MT - 1;
+  DET_BEGIN();
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const bool upper = vbit(L, kVUpper);
+  f32x4 accx = zero4, part = zero4;
+  unsigned pflag = 0u;
+  auto pre = once(dma);
+  if (wave < 4) {
+    const int dt = 32 - wave;
+    const unsigned rdm = L.rd2m + dt * 512, rdr = L.rd2r + dt * 128, rdrl = L.rd2rl + dt * 64;
+    if (wave == 0) accx = l2b_share<0, true>(L, A, rdm, rdr, rdrl, zero4, pre);
+    else if (wave == 1) accx = l2b_share<1, true>(L, A, rdm, rdr, rdrl, zero4, pre);
+    else if (wave == 2) accx = l2b_share<0, false>(L, A, rdm, rdr, rdrl, A.sh[0], pre);
+    else accx = l2b_share<1, false>(L, A, rdm, rdr, rdrl, A.sh[S1], pre);
+    if (wave < 2) {
+      lds_st<f32x4>(lds0 + L.scr + wave * 1024, M::kScratch2Off * 4, accx);
+      cbar();
+      if (L.a4 == 0) lds_poke_a(lds0 + (M::kFlag2Off + wave) * 4, tag);
+    }
+  }
+  DET(7);
+  {
+    constexpr int NS = 4 * kL2Chunks, D = RCED_D2X, RING = D + 1;
+    Parts b[RING];
+    RemRaw rr;
+    f32x4 acc[2][2];   // [tile & 1][M-tile]
+    const bool g1 = tile_has_gap(wave + 8), g2 = tile_has_gap(wave + 16), g3 = tile_has_gap(wave + 24);
+    run_job<NS, D>(
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, t = i / kL2Chunks, c = i % kL2Chunks;
+          l2x_load<c>(L.rd2m, L.rd2r, L.rd2rl, t * kT2R, t * 128 * 8, t * 128 * 4, b[i % RING], rr);
+        },
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value, t = i / kL2Chunks, c = i % kL2Chunks, r = i % RING, u = t & 1;
+          if constexpr (c == 2) l2x_merge(b[r], rr, upper);
+          acc[u][0] = l2x_mma(A.a[0][c], b[r], c == 0 ? A.sh[0] : acc[u][0]);
+          acc[u][1] = l2x_mma(A.a[S1][c], b[r], c == 0 ? A.sh[S1] : acc[u][1]);
+          if constexpr (t > 0 && c < 2) {   // the previous tile's results: M-tile 0 behind this tile's first slot, M-tile 1 behind its second
+            const bool g = t == 2 ? g1 : t == 3 ? g2 : false;
+            if constexpr (c == 0) l2_store<0>(L, acc[u ^ 1][0], L.wr2, (t - 1) * kT2W, g, kVMain + t - 1);
+            else l2_store<1>(L, acc[u ^ 1][1], L.wr2, (t - 1) * kT2W, g, kVMain + t - 1);
+          }
+          if constexpr (t == 3 && c == 2) {
+            if (wave == 2 || wave == 3) {
+              pflag = lds_peek_a(lds0 + (M::kFlag2Off + wave - 2) * 4);
+              cbar();
+              part = lds_ld<f32x4>(lds0 + L.scr + (wave - 2) * 1024, M::kScratch2Off * 4);
+            }
+          }
+        },
+        pre);
+    l2_store<0>(L, acc[1][0], L.wr2, 3 * kT2W, g3, kVMain + 3);
+    l2_store<1>(L, acc[1][1], L.wr2, 3 * kT2W, g3, kVMain + 3);
+  }
+  l2_reduce<M>(L, lds0, wave, tag, err, accx, part, pflag);
 }
 
 // ---- layer 3: 1x9, 30 -> 8 on pixel pairs ------------------------------------------------------------
@@ -1442,6 +1533,7 @@ __device__ __forceinline__ float row_dpp(float v) {
 template <class M>
 __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsigned w128, int wave, int lane, int utt,
                                             int t0, const FinA& A, const XStage& xnext, float* x0) {
+  lane = opaque(lane);   // once per tile: nothing derived from the lane id here is worth a register across the tile loop
   const int n = lane & 15, kq = lane >> 4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   float* yt = P.y + ((size_t)utt * P.T + t0) * kF;   // the tile's first output row
@@ -1569,7 +1661,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   auto wload = [&](auto kc, const float* g, unsigned voff) {
     constexpr int k = decltype(kc)::value;
     if constexpr (k < 7) a1_load_one<k>(A1, g, voff);
-    else if constexpr (k < 17) a2_load_one<k - 7>(A2, g + kG1, wave >> 2, voff);
+    else if constexpr (k < 17) a2_load_one<k - 7>(A2, g + kG1, RCED_L2_BOTH ? 0 : wave >> 2, voff);
   };
   if constexpr (M::kX6) {
     const unsigned voff = (unsigned)lane * 16u;
@@ -1636,8 +1728,15 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
             else if (wave >= 4) a1_load_rem_one<k - 10>(A1r, wsrc, voff1);
           }
         };
-        if (blk == 0) layer1<M, true>(L, wb, A1, A1r, wave, dma, sp1 DET_PASS);
-        else layer1<M, false>(L, wb, A1, A1r, wave, dma, sp1 DET_PASS);
+        // The second M-tile's fragments (RCED_L2_BOTH) are fetched behind the pair jobs, whose registers (the main pass's A
+        // fragments, two pairs of accumulators) they take over; the waves' remaining jobs and the wait of the early finishers
+        // at the layer's barrier cover them.
+        auto late = [&] {
+          if constexpr (M::kX6 && RCED_L2_BOTH && !(RCED_X6_EXP & 2))
+            static_for<0, 10>([&](auto kc) { a2_load_one<decltype(kc)::value, kL2MT - 1>(A2, wsrc + kG1, 1, voff1); });
+        };
+        if (blk == 0) layer1<M, true>(L, wb, A1, A1r, wave, dma, sp1, late DET_PASS);
+        else layer1<M, false>(L, wb, A1, A1r, wave, dma, sp1, late DET_PASS);
         if constexpr (!M::kX6) wcur ^= 1;
 #if RCED_STAMPS
         const unsigned long long st_b_ = stamp();
@@ -1652,7 +1751,8 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
           STAMP_BEGIN();
           const unsigned tag2 = 0xC0000000u | (epoch + 1u);   // distinct from layer 3's tags (0x8.......)
           if constexpr (M::kX6) {
-            layer2_x6<M>(L, lds0, A2, wave, tag2, P.err, [] {} DET_PASS);
+            if constexpr (RCED_L2_BOTH) layer2_x6_both<M>(L, lds0, A2, wave, tag2, P.err, [] {} DET_PASS);
+            else layer2_x6<M>(L, lds0, A2, wave, tag2, P.err, [] {} DET_PASS);
           } else {
             auto dma3 = [&] { packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane); };
             layer2_f32<M>(L, lds0, lds_addr(WREG(wcur)), wave, tag2, P.err, dma3 DET_PASS);
