@@ -682,7 +682,8 @@ __device__ __forceinline__ float unpk(float v) {   // keep the optimiser from re
   return v;
 }
 #ifndef RCED_X6_EXP
-#define RCED_X6_EXP 0   // timing experiments only (wrong results): 1 = no split arithmetic, 2 = no spread loads in layer 1, 4 = none in layer 3,
+#define RCED_X6_EXP 0   // timing experiments only (wrong results): 1 = no split arithmetic, 2 = no weight loads in layer 1 (unreliable: the
+                        // fragments become undefined values and hipcc deletes work that depends on them), 4 = none in layer 3,
                         // 8 = one plane store instead of three, 16 = no remainder-row reads / merge in layer 2
 #endif
 __device__ __forceinline__ P3 split2(float x0, float x1) {
@@ -1718,7 +1719,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         };
         // One load per slot of the pair job(s), k = 0..17: layer 2's fragments (k < 10) and this layer's remainder-pass fragments
         // (k = 10..17, waves 4..7; used by the wave's last job).  (Measured: the same loads inside layer 3's stream, which has
-        // the room on the vector-memory path, cost 0.35 ms MORE -- its slots are the tightest in the kernel.)
+        // the room on the vector-memory path, cost 0.2 - 0.35 ms MORE -- its slots are the tightest in the kernel.)
         A1Rem A1r;
         const unsigned voff1 = (unsigned)opaque(lane) * 16u;
         auto sp1 = [&](auto kc) {
@@ -1776,7 +1777,8 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         };
         const unsigned voff = (unsigned)opaque(lane) * 16u;
         auto sp = [&](auto kc) {
-          if constexpr (M::kX6 && !(RCED_X6_EXP & 4)) wload(kc, wnext, voff);   // k < 7: the next layer 1's main pass (inside layer 2's stream instead: no difference, A/B)
+          if constexpr (M::kX6 && !(RCED_X6_EXP & 4) && decltype(kc)::value < 7) wload(kc, wnext, voff);   // the next layer 1's main pass (inside layer 2's stream instead: no difference;
+                                                                                                   // layer 2's fragments here too, instead of inside layer 1: 8.31 against 8.13 ms -- A/B on one box)
         };
         layer3<M, false>(P, L, lds0, wb, blk, wave, tag, skip_ce1, skip_ce2, dma, sp DET_PASS);
         if constexpr (!M::kX6) wcur ^= 1;
@@ -1803,7 +1805,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
       };
       const unsigned voff = (unsigned)opaque(lane) * 16u;
       auto sp = [&](auto kc) {
-        if constexpr (M::kX6 && !(RCED_X6_EXP & 4)) wload(kc, P.wpack, voff);
+        if constexpr (M::kX6 && !(RCED_X6_EXP & 4) && decltype(kc)::value < 7) wload(kc, P.wpack, voff);
       };
       layer3<M, true>(P, L, lds0, wb, 4, wave, tag, skip_ce1, skip_ce2, dma, sp DET_PASS);
       if constexpr (!M::kX6) wcur ^= 1;
