@@ -641,33 +641,36 @@ struct A2Regs {
   s16x8 a[kL2MT][kL2Chunks][3];   // [M-tile slot][chunk][part h, m, l]
   f32x4 sh[kL2MT];                // shift[16 mt + 4kq ..]
 };
-// All of these loads are written as (wave-uniform base) + (one 32-bit per-lane byte offset, computed once per layer behind
-// opaque()) + (constant): hipcc then issues them in the saddr form with the constant as the immediate -- no per-load address
-// arithmetic on the vector ALU, nothing for it to hoist out of the tile loop and spill.
+// All of these loads are buffer loads: (the weight stream's buffer resource) + (a wave-uniform byte offset: the block's image +
+// every constant, in an SGPR) + (one 32-bit per-lane byte offset, computed once per layer behind opaque()).  No address
+// arithmetic on the vector ALU -- as global loads with 64-bit per-lane addresses hipcc spent a two-instruction VALU add on
+// most of them, inside layer 1's fp32-MFMA stream where VALU issue is not hidden -- and nothing to hoist out of the tile loop.
+typedef __amdgpu_buffer_rsrc_t wrsrc_t;
 template <class T>
-__device__ __forceinline__ T gld(const float* __restrict__ base, unsigned voff, int off) {
-  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)voff + off);
+__device__ __forceinline__ T bld(wrsrc_t rs, unsigned voff, int sofs_floats) {
+  if constexpr (sizeof(T) == 16) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sofs_floats * 4, 0));
+  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, sofs_floats * 4, 0));
 }
-// piece I of the ten: 0..8 = (chunk I / 3, part I % 3), 9 = the shifts.  g2m = the block's layer-2 image + this wave's M-tile
-// offset (mt * 3 KiB); voff = lane * 16
-template <int I, int SLOT = 0>   // SLOT: which of the wave's M-tile slots receives M-tile mt
-__device__ __forceinline__ void a2_load_one(A2Regs& A, const float* __restrict__ g2, int mt, unsigned voff) {
+// piece I of the ten: 0..8 = (chunk I / 3, part I % 3), 9 = the shifts.  g2 = float offset of the block's layer-2 image in the
+// stream; voff = lane * 16.  SLOT: which of the wave's M-tile slots receives M-tile mt
+template <int I, int SLOT = 0>
+__device__ __forceinline__ void a2_load_one(A2Regs& A, wrsrc_t rs, int g2, int mt, unsigned voff) {
   if constexpr (I < 9) {
     constexpr int c = I / 3, q = I % 3;
-    A.a[SLOT][c][q] = gld<s16x8>(g2 + mt * (3 * 256), voff, ((c * 2) * 3 + q) * 1024);
+    A.a[SLOT][c][q] = bld<s16x8>(rs, voff, g2 + mt * (3 * 256) + ((c * 2) * 3 + q) * 256);
   } else {
-    A.sh[SLOT] = gld<f32x4>(g2 + kG2Data + 16 * mt, (voff >> 4) & 0x30u, 0);   // shift[16 mt + 4 kq ..]: (lane >> 4) * 16 bytes
+    A.sh[SLOT] = bld<f32x4>(rs, (voff >> 4) & 0x30u, g2 + kG2Data + 16 * mt);   // shift[16 mt + 4 kq ..]: (lane >> 4) * 16 bytes
   }
 }
 template <int I>
-__device__ __forceinline__ void a1_load_rem_one(A1Rem& A, const float* __restrict__ g1, unsigned voff) {
-  A.r[I] = gld<f32x4>(g1 + kG1Main, voff, I * 1024);
+__device__ __forceinline__ void a1_load_rem_one(A1Rem& A, wrsrc_t rs, int g1, unsigned voff) {
+  A.r[I] = bld<f32x4>(rs, voff, g1 + kG1Main + I * 256);
 }
 template <int I>   // piece I of the seven: 0..4 = m[I], 5 = sh, 6 = s2
-__device__ __forceinline__ void a1_load_one(A1Regs& A, const float* __restrict__ g1, unsigned voff) {
-  if constexpr (I < 5) A.m[I] = gld<f32x4>(g1, voff, I * 1024);
-  else if constexpr (I == 5) A.sh = gld<f32x4>(g1 + kG1Main + kG1Rem, (voff >> 4) & 0x30u, 0);
-  else A.s2 = gld<f32x2>(g1 + kG1Main + kG1Rem + 16, 0u, 0);
+__device__ __forceinline__ void a1_load_one(A1Regs& A, wrsrc_t rs, int g1, unsigned voff) {
+  if constexpr (I < 5) A.m[I] = bld<f32x4>(rs, voff, g1 + I * 256);
+  else if constexpr (I == 5) A.sh = bld<f32x4>(rs, (voff >> 4) & 0x30u, g1 + kG1Main + kG1Rem);
+  else A.s2 = bld<f32x2>(rs, 0u, g1 + kG1Main + kG1Rem + 16);
 }
 
 // Two fp32 values -> their three bf16 parts, packed (low half = the first value): x = h + m + l to 2^-24 (round to nearest
@@ -1659,14 +1662,15 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   A2Regs A2;
   // piece k = 0..16 of a block's register-resident weights (X6 form; g = that block's images): layer 1's main pass (k < 7),
   // layer 2's M-tile of this wave (7..16).  (Layer 1's remainder pass, 8 more pieces for waves 4..7: inside layer 1.)
-  auto wload = [&](auto kc, const float* g, unsigned voff) {
+  const wrsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wpack), 0, (M::kX6 ? kGTotal : kWTotal) * 4, 0x00020000);
+  auto wload = [&](auto kc, int g, unsigned voff) {   // g: float offset of the block's images in the stream
     constexpr int k = decltype(kc)::value;
-    if constexpr (k < 7) a1_load_one<k>(A1, g, voff);
-    else if constexpr (k < 17) a2_load_one<k - 7>(A2, g + kG1, RCED_L2_BOTH ? 0 : wave >> 2, voff);
+    if constexpr (k < 7) a1_load_one<k>(A1, wrs, g, voff);
+    else if constexpr (k < 17) a2_load_one<k - 7>(A2, wrs, g + kG1, RCED_L2_BOTH ? 0 : wave >> 2, voff);
   };
   if constexpr (M::kX6) {
     const unsigned voff = (unsigned)lane * 16u;
-    static_for<0, 7>([&](auto kc) { wload(kc, P.wpack, voff); });
+    static_for<0, 7>([&](auto kc) { wload(kc, 0, voff); });
   } else {
     packet_dma<kW1>(P.wpack, WREG(0), wave, lane);
   }
@@ -1703,6 +1707,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) skip_ce1[t] = skip_ce2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* wsrc = P.wpack;
+    int gofs = 0;   // float offset of the block's images in the weight stream (= wsrc - P.wpack)
 
     // Layer 3 of block BLK < 4 inside the loop, block 4's behind it: decode_final's operands (36 registers of A fragments)
     // are fetched in front of THAT instance only; declared outside a five-iteration loop they were live through all of it.
@@ -1725,8 +1730,8 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         auto sp1 = [&](auto kc) {
           constexpr int k = decltype(kc)::value;
           if constexpr (M::kX6 && !(RCED_X6_EXP & 2)) {
-            if constexpr (k < 10) wload(IC<k + 7>{}, wsrc, voff1);
-            else if (wave >= 4) a1_load_rem_one<k - 10>(A1r, wsrc, voff1);
+            if constexpr (k < 10) wload(IC<k + 7>{}, gofs, voff1);
+            else if (wave >= 4) a1_load_rem_one<k - 10>(A1r, wrs, gofs, voff1);
           }
         };
         // The second M-tile's fragments (RCED_L2_BOTH) are fetched behind the pair jobs, whose registers (the main pass's A
@@ -1734,7 +1739,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         // at the layer's barrier cover them.
         auto late = [&] {
           if constexpr (M::kX6 && RCED_L2_BOTH && !(RCED_X6_EXP & 2))
-            static_for<0, 10>([&](auto kc) { a2_load_one<decltype(kc)::value, kL2MT - 1>(A2, wsrc + kG1, 1, voff1); });
+            static_for<0, 10>([&](auto kc) { a2_load_one<decltype(kc)::value, kL2MT - 1>(A2, wrs, gofs + kG1, 1, voff1); });
         };
         if (blk == 0) layer1<M, true>(L, wb, A1, A1r, wave, dma, sp1, late DET_PASS);
         else layer1<M, false>(L, wb, A1, A1r, wave, dma, sp1, late DET_PASS);
@@ -1777,7 +1782,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         };
         const unsigned voff = (unsigned)opaque(lane) * 16u;
         auto sp = [&](auto kc) {
-          if constexpr (M::kX6 && !(RCED_X6_EXP & 4) && decltype(kc)::value < 7) wload(kc, wnext, voff);   // the next layer 1's main pass (inside layer 2's stream instead: no difference;
+          if constexpr (M::kX6 && !(RCED_X6_EXP & 4) && decltype(kc)::value < 7) wload(kc, gofs + kBlockFloats, voff);   // the next layer 1's main pass (inside layer 2's stream instead: no difference;
                                                                                                    // layer 2's fragments here too, instead of inside layer 1: 8.31 against 8.13 ms -- A/B on one box)
         };
         layer3<M, false>(P, L, lds0, wb, blk, wave, tag, skip_ce1, skip_ce2, dma, sp DET_PASS);
@@ -1787,6 +1792,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         STAMP_WAIT(2);
       }
       wsrc += kBlockFloats;
+      gofs += kBlockFloats;
     }
     FinA finA;
     {  // ---- block 4's layer 3, and in front of it, once per tile: what decode_final and the next tile need
@@ -1805,7 +1811,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
       };
       const unsigned voff = (unsigned)opaque(lane) * 16u;
       auto sp = [&](auto kc) {
-        if constexpr (M::kX6 && !(RCED_X6_EXP & 4) && decltype(kc)::value < 7) wload(kc, P.wpack, voff);
+        if constexpr (M::kX6 && !(RCED_X6_EXP & 4) && decltype(kc)::value < 7) wload(kc, 0, voff);
       };
       layer3<M, true>(P, L, lds0, wb, 4, wave, tag, skip_ce1, skip_ce2, dma, sp DET_PASS);
       if constexpr (!M::kX6) wcur ^= 1;
