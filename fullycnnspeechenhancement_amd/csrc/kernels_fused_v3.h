@@ -296,16 +296,15 @@ __device__ __forceinline__ int opaque(int v) {
 // at the end of the layer during which it was issued.
 template <int NFLOATS>
 __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float* dst, int wave, int lane) {
-  lane = opaque(lane);   // (or hipcc keeps one 64-bit source address per call site alive across the tile loop)
+  lane = opaque(lane);   // (or hipcc keeps per-lane source addresses of every call site alive across the tile loop)
   constexpr int n4 = NFLOATS / 4;
   constexpr int chunks = (n4 + 63) / 64;
 #pragma unroll
   for (int i = 0; i < (chunks + kWaves - 1) / kWaves; ++i) {
     const int c = wave + i * kWaves;
     if (c < chunks) {
-      const int idx = c * 64 + lane;
-      if (idx < n4)
-        lds_dma16(src + (size_t)idx * 4, dst + c * 256);
+      if (c * 64 + lane < n4)   // wave-uniform source in SGPRs + one 32-bit lane offset: no 64-bit VALU address per piece
+        lds_dma16s(src + c * 256, (unsigned)lane * 16u, dst + c * 256);
     }
   }
 }
@@ -625,16 +624,6 @@ struct A1Regs {
 struct A1Rem {
   f32x4 r[8];   // remainder pass (waves 4..7)
 };
-// (Every loader re-derives its lane offset behind opaque(): otherwise hipcc hoists one 64-bit address per load out of the tile
-// loop and spills them.)
-__device__ __forceinline__ void a1_load(A1Regs& A, const float* __restrict__ g1, int lane) {
-  lane = opaque(lane);
-  const f32x4* p = reinterpret_cast<const f32x4*>(g1) + lane;
-#pragma unroll
-  for (int j = 0; j < 5; ++j) A.m[j] = p[j * 64];
-  A.sh = reinterpret_cast<const f32x4*>(g1 + kG1Main + kG1Rem)[lane >> 4];
-  A.s2 = *reinterpret_cast<const f32x2*>(g1 + kG1Main + kG1Rem + 16);
-}
 // Layer 2: a wave computes ONE M-tile (waves 0..3: channels 0..15, waves 4..7: 16..29) -- 36 registers of A fragments.
 constexpr int kL2MT = RCED_L2_BOTH ? 2 : 1;   // M-tiles a wave computes
 struct A2Regs {
@@ -699,9 +688,11 @@ __device__ __forceinline__ P3 split2(float x0, float x1) {
   }
   const bf16x2 bh = {(__bf16)x0, (__bf16)x1};
   p.h = __builtin_bit_cast(unsigned, bh);
+  asm volatile("" : "+v"(p.h));   // (seen through, hipcc derives `h << 16` from a second, single-element conversion: +1 VALU per level)
   const float r0 = unpk(x0 - __builtin_bit_cast(float, p.h << 16)), r1 = unpk(x1 - __builtin_bit_cast(float, p.h & 0xffff0000u));
   const bf16x2 bm = {(__bf16)r0, (__bf16)r1};
   p.m = __builtin_bit_cast(unsigned, bm);
+  asm volatile("" : "+v"(p.m));
   const float s0 = unpk(r0 - __builtin_bit_cast(float, p.m << 16)), s1 = unpk(r1 - __builtin_bit_cast(float, p.m & 0xffff0000u));
   const bf16x2 bl = {(__bf16)s0, (__bf16)s1};
   p.l = __builtin_bit_cast(unsigned, bl);
