@@ -1721,8 +1721,11 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         auto sp1 = [&](auto kc) {
           constexpr int k = decltype(kc)::value;
           if constexpr (M::kX6 && !(RCED_X6_EXP & 2)) {
+            // (every wave fetches the remainder pass's fragments although only waves 4..7 use them: behind a wave-uniform
+            // branch each load cost two register copies of the "old" value, the MFMA -> VALU wait states in front of them
+            // and the branch -- more than the 8 KiB of L2 traffic per wave it saves)
             if constexpr (k < 10) wload(IC<k + 7>{}, gofs, voff1);
-            else if (wave >= 4) a1_load_rem_one<k - 10>(A1r, wrs, gofs, voff1);
+            else a1_load_rem_one<k - 10>(A1r, wrs, gofs, voff1);
           }
         };
         // The second M-tile's fragments (RCED_L2_BOTH) are fetched behind the pair jobs, whose registers (the main pass's A
