@@ -60,7 +60,7 @@ def layer_flops(spec, variant):
 
 
 def forward_flops_by_pipe(spec, variant, kernel, dtype="f32", v3_l2x6=1):
-    """FLOP per frame of one forward kernel kind, split by the pipe each layer runs on (DESIGN 3.1, 3.4, 3.4a, 3.4b)."""
+    """FLOP per frame of one forward kernel kind, split by the pipe each layer runs on (DESIGN 3.1, 3.3, 3.3a, 3.3b)."""
     fl = layer_flops(spec, variant)
     if kernel == "conv_layer_generic":
         return {"mfma_f32": sum(fl)}            # direct fp32 FMA on the vector ALU: same 157.3 ceiling
@@ -75,7 +75,7 @@ def forward_flops_by_pipe(spec, variant, kernel, dtype="f32", v3_l2x6=1):
 
 
 def train_flops_by_pipe(spec):
-    """CR-CED training step, 3 x forward FLOPs (forward, dgrad, wgrad), by pipe (DESIGN 3.6r3): on the bf16 pipe in the
+    """CR-CED training step, 3 x forward FLOPs (forward, dgrad, wgrad), by pipe (DESIGN 3.5): on the bf16 pipe in the
     three-part form run the 18 -> 30 forward convolutions, the 8 -> 30 dgrad inside the 30 -> 8 fused backward kernel, 16 of
     every 18 pixel groups of the 18 -> 30 wgrad, and the output layer's forward and dgrad; everything else on the fp32 MFMA."""
     fl, ly = layer_flops(spec, 3), spec.layers(3)

@@ -9,7 +9,7 @@
 //     ReLU; the skip fragments kept in the global scratch and the hand-off tensor hold those rounded values;
 //   * the first layer (8 x k on the fp32 input) and the final 1x129 layer stay on the fp32 MFMA with fp32 weights
 //     (their inputs / outputs are the network's fp32 boundary); their activations on the inside are bf16 values.
-// Precision contract: DESIGN.md 3.4b and tests/test_forward_gpu.py (the GPU result is tested against an emulation that
+// Precision contract: DESIGN.md 3.3b and tests/test_forward_gpu.py (the GPU result is tested against an emulation that
 // rounds at the same places) -- this path is NOT within the 1e-4 fp32 bar, it exists because config 2 names bf16.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -32,7 +32,7 @@
                            // Measured, round 3 (A/B on one box, bench.py --dtype bf16): R-CED V2 batch 64 (BASELINE config 2)
                            // fused kernel 0.890 vs 0.897 ms, batch 256 3.60 vs 3.67 ms; R-CED V1 batch 64 0.805 vs 0.700 ms
                            // (K rounds up to 32 per layer).  Halving the MFMA cycles buys < 1 %: this kernel is not bound by
-                           // the matrix pipe (DESIGN.md 3.4b) -- so the default stays the K = 16 form
+                           // the matrix pipe (DESIGN.md 3.3b) -- so the default stays the K = 16 form
 #endif
 #ifndef RCED_C16_DEPTH
 #define RCED_C16_DEPTH 1   // operand prefetch depth of the bf16 pass (steps)

@@ -544,7 +544,7 @@ struct SumState {
   }
 };
 // ---------------------------------------------------------------------------------------------
-// fp32 quality on the bf16 matrix pipe for the forward convolutions (DESIGN 3.4a, kernels_final_x6.h): the input tile lives
+// fp32 quality on the bf16 matrix pipe for the forward convolutions (DESIGN 3.3a, kernels_final_x6.h): the input tile lives
 // in LDS as THREE bf16 planes [pixel][channel] (x = h + m + l, exact to 2^-24; channel stride rounded to 4 so that a lane's
 // eight consecutive k of a pixel's im2col window start 8-byte aligned), the packet holds the weights the same way
 // ([step][M-tile][part][lane] x 8 bf16, k = 32 S + 8 kq + e), and a product is six v_mfma_f32_16x16x32_bf16 (m m, l h, h l,
@@ -1783,7 +1783,7 @@ template <int CIN, int TAPS, int COUT>
 constexpr int bwd_own() {
   return (CIN == 18 && TAPS == 5 && COUT == 30) ? RCED_TM_OWN_B : (CIN == 30 && TAPS == 9 && COUT == 8) ? RCED_TM_OWN_C : RCED_TM_OWN_OTHER;
 }
-// Measured alternatives (DESIGN 3.6): tile i+1 committed into a second pair of LDS buffers by the wgrad half alone while
+// Measured alternatives (DESIGN 3.5): tile i+1 committed into a second pair of LDS buffers by the wgrad half alone while
 // tile i is computed (one barrier per tile), with the staging behind or in front of that half's MFMAs, with s_setprio on
 // the staging half: 3.17 ms against 3.09 ms for this form -- the two waves of a SIMD do not overlap one's VALU / staging
 // work with the other's MFMA chain to any useful degree; what counts is the instruction total per SIMD.

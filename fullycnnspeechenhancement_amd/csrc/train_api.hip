@@ -1159,7 +1159,7 @@ int train_run(rced_trainer* t, const float* x_dev, const float* y_dev, float* pr
   // assign_add in one run only through control dependencies, and slim.learning.create_train_op makes train_op =
   // (increment global_step, then return the loss), so the fetched value is unordered against the increment in principle.
   // This library returns the POST-increment value, deterministically: after the first step train_step returns 1 and
-  // the loop's next learning rate is noam(1) (trainer.py:215, step = global_step + 1 = 2).  See DESIGN.md 3.6.
+  // the loop's next learning rate is noam(1) (trainer.py:215, step = global_step + 1 = 2).  See DESIGN.md 3.5.
   t->global_step += 1;
   const double tt = (double)t->global_step;
   const float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)kAdamB2, tt)) / (1.0 - std::pow((double)kAdamB1, tt)));

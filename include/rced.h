@@ -95,7 +95,7 @@ int rced_reserve(rced_model* m, int N, int T);
  *   "host_chunks" pipeline depth of rced_forward_host (0 = default 8, 1 = no overlap, <= 64)
  *   "fused_grid"  workgroups of the persistent fused kernel (0 = one per CU)
  *   "bf16"        R-CED V1 / V2 only: 1 = bf16 activations + inner-layer weights, fp32 accumulation (BASELINE config 2;
- *                 ~6e-3 of the largest output away from the fp32 result -- opt-in, see DESIGN.md 3.4b)
+ *                 ~6e-3 of the largest output away from the fp32 result -- opt-in, see DESIGN.md 3.3b)
  *   "v3_l2x6"     CR-CED only: which form of the fused kernel runs.  1 (default) = the 18 -> 30 layers at fp32 quality on the bf16
  *                 matrix pipe (three-part operands, six products); 0 = every layer on the fp32 MFMA (bit-for-bit an fp32 fmaf
  *                 chain; the in-build comparator: the two agree to ~1e-6 of the largest output).  Both kernels are in the library.
