@@ -59,13 +59,14 @@ def layer_flops(spec, variant):
     return [2 * spec.FEATURE_DIM * l.kh * l.kw * l.cin * l.cout for l in spec.layers(variant)]
 
 
-def forward_flops_by_pipe(spec, variant, kernel, dtype="f32", v3_l2x6=1):
+def forward_flops_by_pipe(spec, variant, kernel, dtype="f32", v3_l2x6=2):
     """FLOP per frame of one forward kernel kind, split by the pipe each layer runs on."""
     fl = layer_flops(spec, variant)
     if kernel == "conv_layer_generic":
         return {"mfma_f32": sum(fl)}            # direct fp32 FMA on the vector ALU: same 157.3 ceiling
-    if variant == 3:                            # one kernel, all 16 layers; the five 18 -> 30 layers in the x6 form
-        x6 = sum(f for f, l in zip(fl, spec.layers(3)) if (l.cin, l.cout) == (18, 30)) if v3_l2x6 else 0
+    if variant == 3:                            # one kernel, all 16 layers; in the x6 form: the five 18 -> 30 layers (option v3_l2x6 = 1)
+        on_x6 = {0: (), 1: ((18, 30),), 2: ((18, 30), (30, 8))}[int(v3_l2x6)]   # ... and the five 30 -> 8 layers behind them (2, the product)
+        x6 = sum(f for f, l in zip(fl, spec.layers(3)) if (l.cin, l.cout) in on_x6)
         return {"mfma_f32": sum(fl) - x6, "mfma_bf16x6": x6}
     if kernel == "rced_final_gemm":             # R-CED's 1x129 output layer: x6::final_gemm_x6_kernel / chain16::final_gemm16_kernel
         return {"mfma_bf16" if dtype == "bf16" else "mfma_bf16x6": fl[-1]}

@@ -28,14 +28,16 @@ struct rced_fused {
   float* scratch = nullptr;   // V1/V2: skip fragments, per workgroup
   size_t scratch_bytes = 0;
   float* wpack = nullptr;     // packed A-fragment stream (CR-CED: of the F32 form, built when that form is first selected)
-  float* wpack_x6 = nullptr;  // CR-CED, X6 form (v3::kGTotal floats)
+  float* wpack_x6 = nullptr;  // CR-CED, X6 form (v3::kGTotal floats; built when that form is first selected)
+  float* wpack_t = nullptr;   // CR-CED, fused form (v3::kTTotal floats)
   // Per-handle options of the R-CED output layer's kernel; the environment variables of the same meaning only supply the
   // defaults, read when the handle is created (rced_create), never afterwards.
   int final_x6 = 1;           // option "final_x6" (default: RCED_FINAL_X6): 1 = x6::final_gemm_x6_kernel (three-part bf16 products), 0 = fp32 MFMA
   int final_lds = 1;          // option "final_lds" (default: RCED_FINAL_LDS): the fp32 kernel with (1) / without (0) LDS staging of its B operand
   int bf16_final16 = 1;       // option "bf16_final16" (default: RCED_C16_FINAL16): bf16 mode: the output layer on the bf16 MFMA (1) or as above (0)
-  int v3_l2x6 = 1;            // option "v3_l2x6": 1 = the 18 -> 30 layers at fp32 quality on the bf16 matrix pipe (the product), 0 = every
-                              // layer on the fp32 MFMA (the comparator): kernels_fused_v3.h
+  int v3_l2x6 = 2;            // option "v3_l2x6": 2 = the 18 -> 30 AND 30 -> 8 layers at fp32 quality on the bf16 matrix pipe, as one stream (the
+                              // product), 1 = the 18 -> 30 layers only (round 4's first form), 0 = every layer on the fp32 MFMA (the
+                              // comparator): kernels_fused_v3.h
   float* fin_apack = nullptr; // v3::kFinPack
   float fin_bias = 0.f;
   float* h = nullptr;         // [frames, 129, 8] hand-off to the final layer
@@ -78,8 +80,9 @@ inline void split3(float v, unsigned short* h, unsigned short* mm, unsigned shor
 
 // CR-CED weight streams (kernels_fused_v3.h, "packed weight streams").  x6 = false: one LDS packet per layer (F32 form);
 // x6 = true: layer 1 / layer 2 as register images for 16-byte-per-lane global loads, layer 3's packet unchanged.
-void pack_v3(const rced_model* m, bool x6, std::vector<float>* wpack) {
-  wpack->assign(x6 ? v3::kGTotal : v3::kWTotal, 0.f);
+void pack_v3(const rced_model* m, int form, std::vector<float>* wpack) {
+  const bool x6 = form != 0, fusedf = form == 2;
+  wpack->assign(fusedf ? v3::kTTotal : x6 ? v3::kGTotal : v3::kWTotal, 0.f);
   auto put_shift = [&](float* at, int layer) {  // the packet's last 32 floats: shift[co]
     const int cout = m->net->layer[layer].cout;
     for (int c = 0; c < cout; ++c) at[c] = m->layers[layer].host_shift[c];
@@ -176,6 +179,23 @@ void pack_v3(const rced_model* m, bool x6, std::vector<float>* wpack) {
           dst[v3::kL2Steps * 2 * 128 + mt * 64 + lane] = w2(lane & 15, mt, 8 * v3::kL2Steps + (lane >> 4));
       put_shift(dst + v3::kW2Data, 3 * blk + 1);
       dst += v3::kW2;
+    }
+    // ---- layer 3, fused form: [M-tile j][part][lane] x 8 bf16.  Row i of M-tile j = (cout 2 (i >> 2) + ((i >> 1) & 1), tap 2j + (i & 1));
+    //      k-slot 8kq + e = channel (e < 4 ? 4kq + e : 16 + 4kq + e - 4): the registers layer 2's two M-tiles leave in a lane
+    if (fusedf) {
+      unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+      for (int j = 0; j < v3::kL3MT; ++j)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int i = lane & 15, kq = lane >> 4, co = 2 * (i >> 2) + ((i >> 1) & 1), tap = 2 * j + (i & 1);
+            const int ci = e < 4 ? 4 * kq + e : 16 + 4 * kq + (e - 4);
+            const float w = (tap < 9 && ci < 30) ? wq(l3, tap, ci, co, 30) : 0.f;
+            const size_t base = ((size_t)j * 3) * 512 + lane * 8 + e;
+            split3(w, &d16[base], &d16[base + 512], &d16[base + 1024]);
+          }
+      put_shift(dst + v3::kW3TData, 3 * blk + 2);
+      dst += v3::kW3T;
+      continue;
     }
     // ---- layer 3: 1x9, 30 -> 8 on pixel pairs: row i = (phase r, co), k = u*30 + ci, tap = u - r;
     //      37 b64 steps + b32 tail (k = 296 + kq)
@@ -480,13 +500,14 @@ int v3_set_lds() {
   if (e != hipSuccess) return rced_fail(RCED_ERR_HIP, "hipFuncSetAttribute(LDS %d): %s", M::kLdsBytes, hipGetErrorString(e));
   return RCED_OK;
 }
-// option "v3_l2x6" = 0: the F32 form's packets are built when it is first selected
-int v3_enable_f32(rced_model* m, rced_fused* f) {
-  if (f->wpack) return RCED_OK;
+// option "v3_l2x6": a form's weight stream is built when it is first selected
+int v3_enable_form(rced_model* m, rced_fused* f, int form) {
+  float** dev = form == 0 ? &f->wpack : form == 1 ? &f->wpack_x6 : &f->wpack_t;
+  if (*dev) return RCED_OK;
   std::vector<float> wpack;
-  pack_v3(m, false, &wpack);
-  if (int rc = upload(&f->wpack, wpack)) return rc;
-  return v3_set_lds<v3::MapF32>();
+  pack_v3(m, form, &wpack);
+  if (int rc = upload(dev, wpack)) return rc;
+  return form == 0 ? v3_set_lds<v3::MapF32>() : form == 1 ? v3_set_lds<v3::MapX6>() : v3_set_lds<v3::MapT>();
 }
 
 int fused_create(rced_model* m) {
@@ -501,15 +522,13 @@ int fused_create(rced_model* m) {
     if (rc) fused_destroy(m);
     return rc;
   }
-  std::vector<float> wpack, fin;
-  pack_v3(m, true, &wpack);
+  std::vector<float> fin;
   pack_v3_final(m, &fin, &f->fin_bias);
-  int rc = upload(&f->wpack_x6, wpack);
-  if (!rc) rc = upload(&f->fin_apack, fin);
-  if (!rc) rc = v3_set_lds<v3::MapX6>();
-  if (!rc && env_default("RCED_V3_L2X6", 1) == 0) {   // the environment only supplies the DEFAULT of the per-handle option
-    rc = v3_enable_f32(m, f);
-    if (!rc) f->v3_l2x6 = 0;
+  int rc = upload(&f->fin_apack, fin);
+  if (!rc) {   // the environment only supplies the DEFAULT of the per-handle option
+    const int form = env_default("RCED_V3_L2X6", 2);
+    f->v3_l2x6 = form < 0 || form > 2 ? 2 : form;
+    rc = v3_enable_form(m, f, f->v3_l2x6);
   }
   if (!rc) {
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&f->err_host), 64, hipHostMallocMapped);
@@ -535,6 +554,7 @@ void fused_destroy(rced_model* m) {
   if (!f) return;
   if (f->wpack) (void)hipFree(f->wpack);
   if (f->wpack_x6) (void)hipFree(f->wpack_x6);
+  if (f->wpack_t) (void)hipFree(f->wpack_t);
   if (f->wpack16) (void)hipFree(f->wpack16);
   if (f->fin_apack16) (void)hipFree(f->fin_apack16);
   if (f->fin_apack_x6) (void)hipFree(f->fin_apack_x6);
@@ -590,7 +610,7 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   P.err = f->err_dev;
   P.x = x;
   P.y = y;
-  P.wpack = f->v3_l2x6 ? f->wpack_x6 : f->wpack;
+  P.wpack = f->v3_l2x6 == 2 ? f->wpack_t : f->v3_l2x6 ? f->wpack_x6 : f->wpack;
   P.fin = f->fin_apack;
   P.fin_bias = f->fin_bias;
   P.N = N;
@@ -601,7 +621,8 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   const int cus = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
   const int grid = std::min(P.total_tiles, cus);
   m->prof_begin(RCED_K_FUSED, st);   // all 16 layers: decode_final is the kernel's last phase
-  if (f->v3_l2x6) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapX6>, dim3(grid), dim3(v3::kThreads), v3::MapX6::kLdsBytes, st, P);
+  if (f->v3_l2x6 == 2) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapT>, dim3(grid), dim3(v3::kThreads), v3::MapT::kLdsBytes, st, P);
+  else if (f->v3_l2x6) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapX6>, dim3(grid), dim3(v3::kThreads), v3::MapX6::kLdsBytes, st, P);
   else hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapF32>, dim3(grid), dim3(v3::kThreads), v3::MapF32::kLdsBytes, st, P);
   m->prof_end(RCED_K_FUSED, st);
   HIP_TRY(hipGetLastError());
@@ -625,9 +646,8 @@ int fused_set_option(rced_model* m, const char* key, int value) {
   }
   if (!strcmp(key, "v3_l2x6")) {
     if (m->variant != RCED_V3) return rced_fail(RCED_ERR_ARG, "v3_l2x6 selects the form of the CR-CED kernel only");
-    if (value != 0 && value != 1) return RCED_ERR_ARG;
-    if (!value)
-      if (int rc = v3_enable_f32(m, m->fused)) return rc;
+    if (value < 0 || value > 2) return RCED_ERR_ARG;
+    if (int rc = v3_enable_form(m, m->fused, value)) return rc;
     m->fused->v3_l2x6 = value;
     return RCED_OK;
   }

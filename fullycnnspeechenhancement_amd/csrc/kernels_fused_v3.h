@@ -67,6 +67,9 @@
                           // once); 0 = one M-tile of tiles j + 4t (36 registers, every B fragment read by two waves: the layer is bound by the
                           // LDS then -- A/B on one box 8.36 against 8.18 ms)
 #endif
+#ifndef RCED_V3_LB
+#define RCED_V3_LB kThreads   // (diagnostic: 256 lifts the 256-register cap, to see what the allocator would like to have)
+#endif
 #ifndef RCED_STAMPS
 #define RCED_STAMPS 0     // diagnostic build: s_memtime stamps around every layer's math and barrier
 #endif
@@ -143,9 +146,11 @@ constexpr int kFinPack = kFinA + kFin128;
 //             K = 32 chunk is ONE 16-byte-aligned ds_read_b128 (tap 2c + (kq >> 1), channels 8 (kq & 1)..+7), bank-conflict
 //             free in the instruction's lane groups -- and the two remainder channels 16, 17 beside them as rows of
 //             [h16 h17 m16 m17] (8 bytes) and [l16 l17] (4 bytes): their five taps ride in the last chunk's upper lanes.
-template <bool X6>
+// FORM: 0 = F32, 1 = X6, 2 = X6 with layers 2 and 3 fused (its map is the specialisation below)
+template <int FORM>
 struct Map {
-  static constexpr bool kX6 = X6;
+  static constexpr bool X6 = FORM != 0;
+  static constexpr bool kX6 = X6, kFused = false;
   static constexpr int kB8Off = 0;                                     // all offsets in floats unless named *Bytes
   static constexpr int kB18Off = kB8Off + kB8Rows * kB8S;
   static constexpr int kPlaneBytes = kB18Rows * 32;                    // one bf16 plane of 16 channels: 17,088
@@ -179,6 +184,8 @@ struct Map {
   static_assert(kFinScr0 >= kX0Off + kX0Floats && ((kFinScr0 * 4) % 16) == 0 && ((kFinScr1 * 4) % 16) == 0, "16-byte aligned, clear of X0");
   static_assert(kFinScr0 >= kB30Off + (kB30Pad + kF + 4) * 30 && kFinScr0 + 2048 <= kB30Off + (kB30Pad + kS + kF) * 30, "no gap row");
   static_assert(kFinScr1 >= kB30Off + (kB30Pad + kS + kF + 4) * 30 && kFinScr1 + 2048 <= kB30Off + (kB30Pad + 2 * kS + kF) * 30, "no gap row");
+  static constexpr int finscr0(int w) { return 4 * kFinScr0 + w * 1024; }   // byte offset of wave w's partial sums of column tile 0
+  static constexpr int kFinScrCt = 4 * (kFinScr1 - kFinScr0);               // ... + this for column tile 1
   // layer 2's split-tile hand-off: in the B8 buffer, which is dead during layer 2 (layer 3 rewrites every real pixel of it)
   static constexpr int kScr2Slots = X6 ? 4 : 2;                            // helpers of the split tile (1 KiB of partial sums each)
   static constexpr int kScratch2Off = kB8Off + kB8Pad * kB8S + 8 * kB8S;   // B8 rows 8.. of frame 0 (slots x 256 floats + flags)
@@ -200,8 +207,8 @@ struct Map {
   static constexpr int kT3R = 128 * 60 * 4, kT3W = 256 * kB8S * 4;
   static constexpr int kTileB18 = X6 ? 16 * 32 : 16 * 18 * 4;          // ... between adjacent 16-pixel tiles of B18
 };
-typedef Map<false> MapF32;
-typedef Map<true> MapX6;
+typedef Map<0> MapF32;
+typedef Map<1> MapX6;
 
 // ---- packed weight streams (floats), per block -----------------------------------------------
 //  first layer main (8x9x1 -> ch 0..15): 18 k-steps x 64 lanes (b32 steps, k = (time tap, freq tap))
@@ -236,6 +243,66 @@ constexpr int kGBlock = kG1 + kG2 + kW3;
 constexpr int kGTotal = 5 * kGBlock;
 static_assert(kG1 % 4 == 0 && kG2 % 4 == 0 && kW3 % 4 == 0, "16-byte aligned pieces");
 static_assert(kW1 + kFin128 <= kWRegion && (kW1 % 4) == 0, "F32 form: the bin-128 weights fit behind a layer-1 packet in its LDS region");
+
+// ---- FUSED form (Map<2>): layers 2 AND 3 on the bf16 pipe, the 30-channel tensor never stored ------------------------
+// Layer 3 (1x9, 30 -> 8) is computed TAP BY TAP from layer 2's accumulators: a wave that has layer 2's two M-tiles of a 16-pixel
+// tile in registers (lane (kq, n): channels 4kq..+3 and 16+4kq..+3 of pixel n) applies the ReLU, splits them into three bf16 parts
+// -- which IS the B fragment of a K = 32 MFMA whose k-slot 8kq + e is channel (e < 4 ? 4kq + e : 16 + 4kq + e - 4) -- and
+// multiplies by five M-tiles of layer-3 weights, rows (cout 2q + (i >> 1), tap 2j + (i & 1)) for row 4q + i of M-tile j: 30 bf16
+// MFMAs give, per lane, P[cout 2kq, 2kq+1][tap t] at INPUT pixel n for the ten taps.  out[cout][p] = sum_t P_t[cout][p + t - 4]:
+// every P value is added into the output accumulators of this tile and of one neighbour with DPP row shifts (v_add_f32_dpp,
+// 34 per lane and tile: beside bf16 MFMAs nearly free).  What the fp32 form spends on layer 3 -- 75 fp32 MFMAs of 32 cycles
+// per 32 pixels, the [pixel][30] stores and their re-reads, a barrier -- becomes 30 bf16 MFMAs of 16 cycles per 16 pixels.
+// Tiles are FRAME-ALIGNED here (frame f = waves f and f + 4: tiles 0..3 and 4..8 of its 129 bins; tile 8 has one real pixel):
+// no tile straddles a gap, the 4 zero gap pixels absorb every shift across frames, and the only partial sums that cross
+// waves are the two at the middle of each frame (LDS scratch + tagged flags, as the split tiles of the other forms).
+constexpr int kL3MT = 5;                                   // M-tiles of layer-3 weights (ten taps, the tenth zero)
+constexpr int kW3TData = kL3MT * 3 * 256;                  // floats: [M-tile][part h, m, l][lane] x 8 bf16
+constexpr int kW3T = kW3TData + kShiftPerLayer;            // 3872
+constexpr int kTBlock = kG1 + kG2 + kW3T;
+constexpr int kTTotal = 5 * kTBlock;
+template <>
+struct Map<2> {
+  static constexpr bool X6 = true, kX6 = true, kFused = true;
+  static constexpr int kB8Off = 0;
+  static constexpr int kB18Off = kB8Off + kB8Rows * kB8S;
+  // B18 here: three blocks (h, m, l), each = the plane [pixel][16] bf16 (32-byte rows) followed by the remainder channels' rows
+  // [c16 c17] (4 bytes per pixel).  With the same stride between the parts of both, the last K = 32 chunk of layer 2 is, for EVERY
+  // lane, four consecutive dwords from one per-lane address (lower lanes: tap 4 of the plane; upper lanes: the remainder channels'
+  // window) + the part's stride: four ds_read_b32 per part straight into the fragment, no select (the other X6 form reads 16 + 8 + 4
+  // bytes and merges them with 12 v_cndmask).
+  static constexpr int kRemOff = kB18Rows * 32;                                   // the remainder rows inside a block
+  static constexpr int kRemRows = kB18Rows + 6;
+  static constexpr int kPlaneBytes = ((kRemOff + kRemRows * 4 + 15) / 16) * 16;   // stride between the parts: 19,248
+  static constexpr int kRemHMBytes = 0, kRemLBytes = 0;                           // (the other X6 form's layout)
+  static constexpr int kB18Bytes = 3 * kPlaneBytes;
+  // one weight region: layer 2's A fragments + shifts, then layer 3's (the block's stream images of both, one LDS-DMA during layer 1).
+  // (Reads that run past B18 land here: masked pixels only.)
+  static constexpr int kWOff = kB18Off + kB18Bytes / 4;
+  static constexpr int kW3TOff = kWOff + kG2;
+  static constexpr int kWRegions = 1;
+  static constexpr int kB30Off = kWOff;                     // (no such buffer: make_lane's unused layer-2/3 addresses of the other forms)
+  static constexpr int kX0Off = kW3TOff + kW3T;             // the buffers below have places of their own: nothing aliases B18, nothing is re-zeroed
+  static constexpr int kHOff = kX0Off + kX0Floats;
+  static constexpr int kFin128Off = kHOff + kHPix * kHS;
+  static constexpr int kEdgeOff = kFin128Off + kFin128;     // [frame 4][direction 2][lane 64] x 8 bytes: the partial sums that cross the middle of a frame
+  static constexpr int kEdgeFlagOff = kEdgeOff + 4 * 2 * 128;
+  static constexpr int kLdsFloats = kEdgeFlagOff + 8;
+  static constexpr int kLdsBytes = kLdsFloats * 4;
+  static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+  static_assert((kWOff * 4) % 16 == 0 && (kW3TOff * 4) % 16 == 0 && (kB18Off * 4) % 16 == 0 && (kHOff % 2) == 0, "aligned buffers");
+  static_assert((kFin128Off * 4) % 16 == 0 && (kEdgeOff * 4) % 16 == 0, "aligned buffers");
+  // decode_final's partial sums (8 waves x 2 column tiles x 1 KiB) lie in B8, dead from block 4's layer 1 to the next tile's block 0
+  // (whose layers 2 + 3 rewrite every real pixel): 4 KiB in the rows of each frame's first 103 bins, never a gap row
+  static constexpr int finscr0(int w) { return (kB8Off + (kB8Pad + kS * (w >> 1)) * kB8S) * 4 + 8 * ((w >> 1) & 1) + (w & 1) * 2048; }
+  static constexpr int kFinScrCt = 1024;
+  static constexpr int kT1R = 128 * kB8S * 4, kT1W = 128 * 32;
+  static constexpr int kT2R = 0, kT2W = 0, kT3R = 0, kT3W = 0;   // (other forms' layers)
+  static constexpr int kTileB18 = 16 * 32;
+};
+typedef Map<2> MapT;
+static_assert(MapT::finscr0(7) % 16 == 0 && MapT::finscr0(2) % 16 == 0 && MapT::finscr0(1) + 2048 <= (kB8Pad + kF) * kB8S * 4, "decode_final's partial sums: 16-byte aligned, inside real rows of B8");
+static_assert(kW3T % 4 == 0 && kG2 + kW3T <= 2 * kWRegion, "layer 3's fused-form packet: 16-byte pieces, inside a weight region");
 
 // ---- decode_final (1x129, 8 -> 1, no BN, no ReLU; model.py:89-90) inside the kernel ----------------------------
 // The CD2 output of a tile never leaves the CU: block 4's layer 3 stores it to H, an LDS image that aliases the (by then
@@ -445,6 +512,7 @@ struct Lane {
   unsigned wr1rl;
   unsigned rd2, rd2b, rd2t, rd2tb, wr2; // layer 2 tile `wave` (/ + 8): B18 window start (b64 steps / tail), B30 output (F32 form)
   unsigned rd2m, rd2r, rd2rl;           // X6 form: this lane's fragment of chunk 0 in the h plane; its remainder rows ([h m] / [l])
+  unsigned rd2c, rd2cs;                 // fused form: this lane's four dwords of the last chunk (h part) and their byte stride from tile to tile
   unsigned rd3, rd3b, rd3t, rd3tb, wr3; // layer 3 pair tile `wave` (/ + 8): B30 window start (b64 steps / tail), B8 output
   unsigned wh0, wh1, whx;  // block 4's layer 3: where this lane's output pixel of pair tile 0 / 1 / 16 goes in the H image
   unsigned scr;            // lane*16: offset inside a hand-off scratch area
@@ -454,7 +522,8 @@ struct Lane {
 // 8,9: layer-3 pair tiles 0,1; 10: pair tile 16 (the split one); 11: lane < 48 (kq != 3: channels 28,29 vs padding 30,31);
 // 12: lane >= 32 (the lanes whose slots of layer 2's last chunk are the remainder channels); X6 form: 13: this lane's second
 // pair of layer-2 outputs is real (M-tile 0, or lane < 48); 16..23: pixel of layer-2 tile (wave & 3) + 4t is a real bin
-constexpr int kVMain = 0, kVRem = 4, kVL3 = 8, kVL3X = 10, kVLt48 = 11, kVUpper = 12, kVSt2 = 13, kVL2 = 16;
+// 24: lane & 15 == 0 (fused form: the one real pixel of a frame's last tile)
+constexpr int kVMain = 0, kVRem = 4, kVL3 = 8, kVL3X = 10, kVLt48 = 11, kVUpper = 12, kVSt2 = 13, kVL2 = 16, kVN0 = 24;
 
 template <class M>
 __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr0) {
@@ -477,14 +546,21 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
     L.wr1 = PL + (px0 + kB18Pad) * 32 + kq * 8;             // channels 4kq..4kq+3 of pixel px0
     L.wr1r = PL + M::kRemHMBytes + (rpx + 2 * kq + kB18Pad) * 8;   // channels 16,17 of pixels rpx+2kq, +1
     L.wr1rl = PL + M::kRemLBytes + (rpx + 2 * kq + kB18Pad) * 4;
+    if constexpr (M::kFused) L.wr1r = PL + M::kRemOff + (rpx + 2 * kq + kB18Pad) * 4;   // [c16 c17] of the h part; m, l: + the part stride
     // layer 2: wave (g = M-tile, j) walks tiles j + 4t; px2 = this lane's pixel of tile j
     // chunk c: tap 2c + (kq >> 1) = pixel px2 - 2 + tap = row px2 + tap, channels 8 (kq & 1)..+7
-    const int px2 = RCED_L2_BOTH ? px0 : 16 * (wave & 3) + n;
+    // (fused form: frame-aligned tiles -- waves 0..3: tiles 0..3 of frame `wave`, waves 4..7: tiles 4..8 of frame `wave - 4`)
+    const int px2 = M::kFused ? kS * (wave & 3) + 64 * (wave >> 2) + n : RCED_L2_BOTH ? px0 : 16 * (wave & 3) + n;
     L.rd2m = PL + (px2 + (kq >> 1)) * 32 + (kq & 1) * 16;
     // the remainder channels' window of pixel px2 = rows px2 .. px2+4; lanes kq = 2 take rows px2..+3, kq = 3 rows px2+4..+7
     // (one real tap, three zero-weight slots); the lower lanes read their upper partners' rows (same addresses: broadcast)
     L.rd2r = PL + M::kRemHMBytes + (px2 + 4 * (kq & 1)) * 8;
     L.rd2rl = PL + M::kRemLBytes + (px2 + 4 * (kq & 1)) * 4;
+    if constexpr (M::kFused) {   // lanes kq < 2: tap 4 (row px2 + 4), channels 8kq..; kq = 2: rows px2..px2+3 of [c16 c17]; kq = 3: rows px2+4..
+      L.rd2c = kq < 2 ? L.rd2m + 128 : PL + M::kRemOff + (px2 + 4 * (kq & 1)) * 4;
+      L.rd2cs = kq < 2 ? 512u : 64u;
+      asm volatile("" : "+v"(L.rd2c), "+v"(L.rd2cs));
+    }
     L.rd2 = L.rd2b = L.rd2t = L.rd2tb = 0u;
   } else {
     const unsigned B18 = lds_addr(lds + M::kB18Off + kB18Pad * 18);
@@ -499,6 +575,7 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   L.rd3 = B30 + 4 * ((2 * px0 - 4) * 30 + 2 * kq);          // px0 doubles as the pixel-PAIR index of layer 3
   L.rd3t = L.rd3 + 4 * (8 * kL3Steps - kq);                 // K = 300: tail k = 296 + kq, all four real
   L.wr3 = B8 + 4 * ((2 * px0 + (kq >> 1)) * kB8S + 4 * (kq & 1));
+  if constexpr (M::kFused) L.wr3 = B8 + 4 * ((kS * (wave & 3) + 64 * (wave >> 2) + n) * kB8S + 2 * kq);   // channels 2kq, 2kq+1 of this lane's pixel
   {
     const unsigned H = lds_addr(lds + M::kHOff);
     auto haddr = [&](int px) {   // px: tile-flat pixel of frame px / kS, bin px % kS
@@ -508,6 +585,7 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
     L.wh0 = haddr(2 * px0 + (kq >> 1));
     L.wh1 = haddr(2 * (px0 + 128) + (kq >> 1));
     L.whx = haddr(2 * (256 + n) + (kq >> 1));
+    if constexpr (M::kFused) L.wh0 = H + 4 * ((kHFrame * (wave & 3) + 64 + 64 * (wave >> 2) + n) * kHS + 2 * kq);
   }
   unsigned v = 0;
 #pragma unroll
@@ -523,6 +601,7 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   v |= (unsigned)px_valid(2 * (256 + n) + (kq >> 1)) << kVL3X;
   v |= (unsigned)(lane < 48) << kVLt48;
   v |= (unsigned)(lane >= 32) << kVUpper;
+  v |= (unsigned)(n == 0) << kVN0;
   if constexpr (M::kX6) {
     v |= (unsigned)(wave < 4 || lane < 48) << kVSt2;
 #pragma unroll
@@ -833,7 +912,20 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, const A1Re
     const f32x4 v = relu4(acc[0]);   // rows 4kq+jj = (phase 2kq + (jj>>1), channel 16 + (jj&1)): two pixels x channels 16,17
     // every remainder tile but tile 0 contains gap pixels (tile 4 also runs past the tile): those are never written
     const bool va = xr == 0 || vbit(L, vb), vbb = xr == 0 || vbit(L, vb + 1);
-    if constexpr (M::kX6) {
+    if constexpr (M::kFused) {
+      const P3 pa = split2(v.x, v.y), pb = split2(v.z, v.w);
+      if (va) {
+        lds_st<unsigned>(wrr, 0, pa.h);
+        lds_st<unsigned>(wrr, M::kPlaneBytes, pa.m);
+        lds_st<unsigned>(wrr, 2 * M::kPlaneBytes, pa.l);
+      }
+      if (vbb) {
+        lds_st<unsigned>(wrr, 4, pb.h);
+        lds_st<unsigned>(wrr, M::kPlaneBytes + 4, pb.m);
+        lds_st<unsigned>(wrr, 2 * M::kPlaneBytes + 4, pb.l);
+      }
+      wrr += 128 * 4;
+    } else if constexpr (M::kX6) {
       const P3 pa = split2(v.x, v.y), pb = split2(v.z, v.w);
       if (va) {
         lds_st<u32x2>(wrr, 0, u32x2{pa.h, pa.m});
@@ -1499,6 +1591,8 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
   DET(3);
 }
 
+#include "kernels_fused_v3_l23.h"
+
 // ---- decode_final inside the kernel (layout and decomposition: see above) ---------------------------------
 struct FinA {
   f32x2 a[kFinRun];   // this wave's 18 K-steps of A fragments
@@ -1590,9 +1684,9 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
           acc[1][1] = mfma(A.a[i].y, b[r][1].y, acc[1][1]);
         },
         [] {});
-    const unsigned scr = lds0 + wave * 1024 + lane * 16;
-    lds_st<f32x4>(scr, 4 * M::kFinScr0, acc[0][0] + acc[0][1]);
-    lds_st<f32x4>(scr, 4 * M::kFinScr1, acc[1][0] + acc[1][1]);
+    const unsigned scr = lds0 + M::finscr0(wave) + lane * 16;
+    lds_st<f32x4>(scr, 0, acc[0][0] + acc[0][1]);
+    lds_st<f32x4>(scr, M::kFinScrCt, acc[1][0] + acc[1][1]);
   }
   // The next tile's input rows (in registers since block 4's layer 3) go to X0 here: X0 aliases the start of B30, dead
   // since the barrier that ended layer 3 and clear of the partial sums above.  The barrier below then also starts the
@@ -1600,19 +1694,20 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
   xstage_store(xnext, x0, wave * 64 + lane);
   __syncthreads();
   if (wave < 2) {   // ---- finish column tile `wave`: partial sums of waves 0..7, in that order, + bias
-    const unsigned scr = lds0 + 4 * (wave == 0 ? M::kFinScr0 : M::kFinScr1) + lane * 16;
-    f32x4 v = lds_ld<f32x4>(scr, 0);
+    const unsigned scr = lds0 + wave * M::kFinScrCt + lane * 16;
+    f32x4 v = lds_ld<f32x4>(scr, M::finscr0(0));
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) v += lds_ld<f32x4>(scr, w * 1024);
+    for (int w = 1; w < kWaves; ++w) v += lds_ld<f32x4>(scr, M::finscr0(w));
     v += f32x4{P.fin_bias, P.fin_bias, P.fin_bias, P.fin_bias};
     const int fi = n >> 2, f0 = 16 * (4 * wave + (n & 3)) + 4 * kq;   // rows 4kq..4kq+3 = bins f0..f0+3 of frame fi
     if (fi < nfr) {
       *reinterpret_cast<f32x4_u*>(yt + fi * kF + f0) = v;
       store_wait_state();   // see lds_dma.h
     }
-  } else if (wave == 3) {
+  } else if (wave == 3 && !M::kFused) {
     // The H image (and, X6, the bin-128 weights behind it) lay over B18, whose gap pixels every layer relies on being zero
     // and no layer ever writes: put the zeros back (every wave finished its H reads before the barrier above).
+    // (Fused form: H has a place of its own.)
     if constexpr (M::kX6) {
       // per plane: the two leading pad rows and the four gap rows behind each frame = 18 rows of 32 bytes; 3 planes x 18 rows
       // x 2 halves = 108 sixteen-byte stores (the remainder rows lie behind the planes, untouched by H)
@@ -1635,8 +1730,10 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
   }
 }
 
+// (no packed fp32 VALU: hipcc pairs the fused form's shift-adds of a lane's two couts into v_pk_add_f32 fed by two v_mov_b32_dpp --
+// three instructions where two v_add_f32_dpp do, and the packed add is the slower instruction beside MFMAs)
 template <class M>
-__global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
+__global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-ops"))) void fused_v3_kernel(Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1653,7 +1750,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   A2Regs A2;
   // piece k = 0..16 of a block's register-resident weights (X6 form; g = that block's images): layer 1's main pass (k < 7),
   // layer 2's M-tile of this wave (7..16).  (Layer 1's remainder pass, 8 more pieces for waves 4..7: inside layer 1.)
-  const wrsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wpack), 0, (M::kX6 ? kGTotal : kWTotal) * 4, 0x00020000);
+  const wrsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wpack), 0, (M::kFused ? kTTotal : M::kX6 ? kGTotal : kWTotal) * 4, 0x00020000);
   auto wload = [&](auto kc, int g, unsigned voff) {   // g: float offset of the block's images in the stream
     constexpr int k = decltype(kc)::value;
     if constexpr (k < 7) a1_load_one<k>(A1, wrs, g, voff);
@@ -1662,6 +1759,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   if constexpr (M::kX6) {
     const unsigned voff = (unsigned)lane * 16u;
     static_for<0, 7>([&](auto kc) { wload(kc, 0, voff); });
+    if constexpr (M::kFused) packet_dma<kFin128>(P.fin + kFinA, lds + M::kFin128Off, wave, lane);   // decode_final's bin-128 weights: once, a place of their own
   } else {
     packet_dma<kW1>(P.wpack, WREG(0), wave, lane);
   }
@@ -1689,7 +1787,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
   const unsigned lds0 = lds_addr(lds);
   xstage_store(xst, lds + M::kX0Off, tid);   // the first tile's input rows; every later tile's are stored by final_phase
   __syncthreads();
-  constexpr int kBlockFloats = M::kX6 ? kGBlock : kWBlock;
+  constexpr int kBlockFloats = M::kFused ? kTBlock : M::kX6 ? kGBlock : kWBlock;
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int utt = tile / P.tiles_per_utt;
@@ -1697,6 +1795,9 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
     f32x4 skip_ce1[3], skip_ce2[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) skip_ce1[t] = skip_ce2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x2 sk1[5], sk2[5];   // fused form: CE1 / CE2 outputs of this wave's (up to) five tiles
+#pragma unroll
+    for (int t = 0; t < 5; ++t) sk1[t] = sk2[t] = f32x2{0.f, 0.f};
     const float* wsrc = P.wpack;
     int gofs = 0;   // float offset of the block's images in the weight stream (= wsrc - P.wpack)
 
@@ -1710,7 +1811,8 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         // What is fetched for later once the layer's first operand reads are in flight.  F32 form: layer 2's packet.  X6 form:
         // layer 3's packet (its one LDS region is dead until then).
         auto dma = [&] {
-          if constexpr (M::kX6) packet_dma<kW3>(wsrc + kG1 + kG2, WREG(0), wave, lane);
+          if constexpr (M::kFused) packet_dma<kG2 + kW3T>(wsrc + kG1, WREG(0), wave, lane);   // layer 2's and layer 3's images, adjacent in the stream
+          else if constexpr (M::kX6) packet_dma<kW3>(wsrc + kG1 + kG2, WREG(0), wave, lane);
           else packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
         };
         // One load per slot of the pair job(s), k = 0..17: layer 2's fragments (k < 10) and this layer's remainder-pass fragments
@@ -1724,15 +1826,15 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
             // (every wave fetches the remainder pass's fragments although only waves 4..7 use them: behind a wave-uniform
             // branch each load cost two register copies of the "old" value, the MFMA -> VALU wait states in front of them
             // and the branch -- more than the 8 KiB of L2 traffic per wave it saves)
-            if constexpr (k < 10) wload(IC<k + 7>{}, gofs, voff1);
-            else a1_load_rem_one<k - 10>(A1r, wrs, gofs, voff1);
+            if constexpr (k >= 10) a1_load_rem_one<k - 10>(A1r, wrs, gofs, voff1);
+            else if constexpr (!M::kFused || (RCED_T_A2REG >= 1 && k < 9)) wload(IC<k + 7>{}, gofs, voff1);   // (fused form: M-tile 0 only, without its shifts: the rest stays in LDS)
           }
         };
         // The second M-tile's fragments (RCED_L2_BOTH) are fetched behind the pair jobs, whose registers (the main pass's A
         // fragments, two pairs of accumulators) they take over; the waves' remaining jobs and the wait of the early finishers
         // at the layer's barrier cover them.
         auto late = [&] {
-          if constexpr (M::kX6 && RCED_L2_BOTH && !(RCED_X6_EXP & 2))
+          if constexpr (M::kX6 && (!M::kFused || RCED_T_A2REG >= 2) && RCED_L2_BOTH && !(RCED_X6_EXP & 2))
             static_for<0, 10>([&](auto kc) { a2_load_one<decltype(kc)::value, kL2MT - 1>(A2, wrs, gofs + kG1, 1, voff1); });
         };
         if (blk == 0) layer1<M, true>(L, wb, A1, A1r, wave, dma, sp1, late DET_PASS);
@@ -1747,7 +1849,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         layer_end_sync();
 #endif
         // ---- layer 2: (1x5, 18->30)
-        {
+        if constexpr (!M::kFused) {
           STAMP_BEGIN();
           const unsigned tag2 = 0xC0000000u | (epoch + 1u);   // distinct from layer 3's tags (0x8.......)
           if constexpr (M::kX6) {
@@ -1764,7 +1866,20 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
         }
       }
       if (blk == 4) break;
-      {  // ---- layer 3: (1x9, 30->8) on pixel pairs; block skips; hand-off
+      if constexpr (M::kFused) {   // ---- layers 2 + 3 as one stream (kernels_fused_v3_l23.h); the next layer 1's main-pass fragments ride in its last slots
+        STAMP_BEGIN();
+        ++epoch;
+        const unsigned voff = (unsigned)opaque(lane) * 16u;
+        auto sp = [&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (2 * j < 7) wload(IC<2 * j>{}, gofs + kBlockFloats, voff);
+          if constexpr (2 * j + 1 < 7) wload(IC<2 * j + 1>{}, gofs + kBlockFloats, voff);
+        };
+        layer23<M, false>(P, L, lds0, lds_addr(WREG(0)), A2, blk, wave, 0x80000000u | epoch, sk1, sk2, sp DET_PASS);
+        STAMP_MATH(2);
+        layer_end_sync();
+        STAMP_WAIT(2);
+      } else {  // ---- layer 3: (1x9, 30->8) on pixel pairs; block skips; hand-off
         STAMP_BEGIN();
         const unsigned wb = lds_addr(WREG(M::kX6 ? 0 : wcur));
         ++epoch;
@@ -1789,7 +1904,25 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
       gofs += kBlockFloats;
     }
     FinA finA;
-    {  // ---- block 4's layer 3, and in front of it, once per tile: what decode_final and the next tile need
+    if constexpr (M::kFused) {   // ---- block 4's layers 2 + 3; decode_final's A fragments ride in its last slots, the next tile's input rows in front
+      STAMP_BEGIN();
+      ++epoch;
+      xst = xstage_load(P, tile + 1 < tile_end ? tile + 1 : P.total_tiles, tid);
+      const int lane_o = opaque(lane);
+      auto sp = [&](auto jc) {
+        constexpr int j = decltype(jc)::value, s0 = (kFinRun * j) / 5, s1 = (kFinRun * (j + 1)) / 5;
+        const f32x2* src = reinterpret_cast<const f32x2*>(P.fin) + (size_t)(kFinRun * wave) * 64 + lane_o;
+#pragma unroll
+        for (int q = s0; q < s1; ++q) finA.a[q] = src[q * 64];
+      };
+      layer23<M, true>(P, L, lds0, lds_addr(WREG(0)), A2, 4, wave, 0x80000000u | epoch, sk1, sk2, sp DET_PASS);
+      STAMP_MATH(2);
+      layer_end_sync();
+      STAMP_WAIT(2);
+      // the next tile's first layer: its A fragments (the stream wraps); in flight during decode_final
+      const unsigned voff = (unsigned)opaque(lane) * 16u;
+      static_for<0, 7>([&](auto kc) { wload(kc, 0, voff); });
+    } else {  // ---- block 4's layer 3, and in front of it, once per tile: what decode_final and the next tile need
       STAMP_BEGIN();
       const unsigned wb = lds_addr(WREG(M::kX6 ? 0 : wcur));
       ++epoch;
@@ -1816,7 +1949,7 @@ __global__ __launch_bounds__(kThreads) void fused_v3_kernel(Params P) {
 #if RCED_STAMPS
     const unsigned long long st_f_ = stamp();
 #endif
-    const unsigned w128 = M::kX6 ? lds0 + 4 * M::kFin128Off : lds_addr(WREG(wcur) + kW1);
+    const unsigned w128 = M::kX6 ? lds0 + 4 * M::kFin128Off : lds_addr(WREG(wcur) + kW1);   // (fused form: loaded once, at the kernel's start)
     final_phase<M>(P, lds0, w128, wave, lane, utt, t0, finA, xst, lds + M::kX0Off);   // no barrier at its end: layer 1's covers it
 #if RCED_STAMPS
     tfin += stamp() - st_f_;

@@ -1,0 +1,289 @@
+// Fused form of the CR-CED kernel (Map<2>): layers 2 (1x5, 18 -> 30) and 3 (1x9, 30 -> 8) as ONE stream on the bf16 matrix pipe.
+// Included by kernels_fused_v3.h inside namespace rced::v3 (the design note sits there, at Map<2>).
+//
+// Per 16-pixel tile a wave issues
+//   X: layer 2, three K = 32 chunks x two M-tiles x six three-part products   = 36 MFMAs  -> acc2[M-tile]  (lane (kq, n): 4 channels each)
+//      ReLU + split2 of the eight accumulators (44 + 8 VALU)                              -> b3 = layer 3's B fragment, in registers
+//   Y: layer 3, five M-tiles of (cout, tap) rows x six products                = 30 MFMAs  -> P[j] (lane (kq, n): couts 2kq, 2kq+1 x taps 2j, 2j+1)
+//      shift-add: out[p] += P_t[p + t - 4], 34 v_add_f32_dpp
+// Layer 3 runs for TWO tiles at a time (YY): one set of A fragments from LDS per M-tile and pair -- read per tile they were a fifth of
+// the forward's time -- and two independent accumulation chains per slot.  Order: X0 X1 X2 YY01 X3 [X4] YY23 [Y4]; tile t's split
+// runs between the MFMAs of X(t+1), a pair's shift-adds between its own MFMAs, one M-tile behind.  Output accumulators
+// W / X / Y / Z = the pixels of the tile in front of the pair, of its two tiles and of the tile behind it; after a pair, W and X are
+// complete (epilogue: shift, ReLU, block skips, one 8-byte store per lane) and Y, Z become the next pair's W, X.
+#pragma once
+#ifndef RCED_T_A2REG
+#define RCED_T_A2REG 1   // layer 2's A fragments: 0 = all from LDS, one slot ahead; 1 = M-tile 0 in registers (36), M-tile 1 from LDS; 2 = all in registers
+#endif
+#ifndef RCED_T_PRIO
+#define RCED_T_PRIO 1    // the waves with five tiles (4..7) run this phase at raised priority: their SIMD partners (four tiles) are the older
+                         // waves, which the issue arbiter prefers -- left alone they finish at two thirds of the phase and the rest runs single
+#endif
+#ifndef RCED_T_EXP
+#define RCED_T_EXP 0   // timing experiments only (wrong results): 1 = no shift-adds, 2 = layer 3's A fragments read once, 4 = no split arithmetic,
+                       // 8 = layer 2's B fragments read once per tile
+#endif
+
+// a copy of v shifted along the 16-lane row, zero where the source lane lies outside the row
+template <int CTRL>
+__device__ __forceinline__ float dpp0(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// One tap's partial output p (at this lane's INPUT pixel) goes to output pixel (input pixel + S), S = 4 - tap: into this tile's
+// accumulator and, for the |S| lanes that leave the row, into the neighbour's.  row_shr:k = lane n reads lane n - k (0x110 + k),
+// row_shl:k = lane n reads lane n + k (0x100 + k).
+template <int S>
+__device__ __forceinline__ void tap_add(float p, float& oP, float& oC, float& oN) {
+  if constexpr (S == 0) {
+    oC += p;
+  } else if constexpr (S > 0) {
+    oC += dpp0<0x110 + S>(p);
+    oN += dpp0<0x100 + 16 - S>(p);
+  } else {
+    oC += dpp0<0x100 - S>(p);
+    oP += dpp0<0x110 + 16 + S>(p);
+  }
+}
+template <int J>
+__device__ __forceinline__ void shift_add(f32x4 pj, float& p0, float& p1, float& c0, float& c1, float& n0, float& n1) {
+  if (RCED_T_EXP & 1) {
+    c0 += pj.x;
+    c1 += pj.z;
+    return;
+  }
+  tap_add<4 - 2 * J>(pj.x, p0, c0, n0);
+  if constexpr (2 * J + 1 < 9) tap_add<3 - 2 * J>(pj.y, p0, c0, n0);   // (tap 9 is padding: zero weights)
+  tap_add<4 - 2 * J>(pj.z, p1, c1, n1);
+  if constexpr (2 * J + 1 < 9) tap_add<3 - 2 * J>(pj.w, p1, c1, n1);
+}
+
+// `sp(IC<j>)`, j < 5: called once from each layer-3 slot of the wave's LAST job (by then layer 2's operand registers are free):
+// the register-bound loads of what comes next.
+template <class M, bool LAST, class Sp>
+__device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned lds0, unsigned wbase, const A2Regs& A, int blk, int wave,
+                                        unsigned tag, f32x2 (&sk1)[5], f32x2 (&sk2)[5], Sp sp DET_ARG) {
+  DET_BEGIN();
+  const bool right = wave >= 4;
+  const int fr = wave & 3;
+  // A fragments of both layers come from LDS (the block's images, LDS-DMA'd during layer 1), one slot ahead of their use: held in
+  // registers (72 for layer 2) the kernel spilled; beside bf16 MFMAs six more conflict-free ds_read_b128 per slot cost next to nothing
+  // (tools/micro/bf16_stream_rate.hip: 3 -> 9 reads per 12-MFMA slot: +0 .. 5 %)
+  const unsigned a2 = wbase + L.scr, a3 = a2 + kG2 * 4;                           // this lane's 16 bytes of every A fragment
+  const f32x4 sh2[2] = {lds_ld<f32x4>(wbase + L.kq16, kG2Data * 4), lds_ld<f32x4>(wbase + L.kq16, (kG2Data + 16) * 4)};
+  const f32x2 sh3 = lds_ld<f32x2>(wbase + (L.kq16 >> 1), (kG2 + kW3TData) * 4);   // shift[2kq], shift[2kq + 1]
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x2 zero2 = {0.f, 0.f};
+  Parts b2[2];
+  s16x8 a2r[2][2][3];          // [ring][M-tile][part]
+  unsigned rdc = L.rd2c;       // the last chunk's four dwords of the tile whose layer 2 comes next
+  f32x4 acc2[2][2];            // [tile & 1][M-tile]
+  u32x4 b3h[2], b3m[2], b3l[2];   // [tile & 1]: layer 3's B fragment (three parts)
+  s16x8 a3r[2][3];
+  f32x4 pj[2][2], p4[2] = {zero4, zero4};   // [tile & 1]: P of M-tiles 0..3 (ring of two) / of M-tile 4, whose shift-adds run from inside the NEXT slot
+  float w0 = 0.f, w1 = 0.f, x0 = 0.f, x1 = 0.f, y0 = 0.f, y1 = 0.f, z0 = 0.f, z1 = 0.f;
+  f32x2 hold = zero2;
+
+  auto ldX = [&](auto tc, auto cc) {
+    constexpr int t = decltype(tc)::value, c = decltype(cc)::value;
+    if ((RCED_T_EXP & 8) && (c > 0 || t > 1)) return;
+    Parts& b = b2[(3 * t + c) & 1];
+#pragma unroll
+    for (int mt = RCED_T_A2REG; mt < 2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a2r[(3 * t + c) & 1][mt][q] = lds_ld<s16x8>(a2, ((2 * c + mt) * 3 + q) * 1024);
+    if constexpr (c < 2) {
+      b.h = lds_ld<s16x8>(L.rd2m, t * 512 + 64 * c);
+      b.m = lds_ld<s16x8>(L.rd2m, t * 512 + 64 * c + M::kPlaneBytes);
+      b.l = lds_ld<s16x8>(L.rd2m, t * 512 + 64 * c + 2 * M::kPlaneBytes);
+    } else {   // the same four dwords per part for every lane (see Map<2>): plane rows for the lower lanes, the remainder channels' for the upper
+      u32x4 h, m, l;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        h[i] = lds_ld<unsigned>(rdc, 4 * i);
+        m[i] = lds_ld<unsigned>(rdc, 4 * i + M::kPlaneBytes);
+        l[i] = lds_ld<unsigned>(rdc, 4 * i + 2 * M::kPlaneBytes);
+      }
+      b.h = __builtin_bit_cast(s16x8, h);
+      b.m = __builtin_bit_cast(s16x8, m);
+      b.l = __builtin_bit_cast(s16x8, l);
+      rdc += L.rd2cs;
+    }
+  };
+  auto doX = [&](auto tc, auto cc) {
+    constexpr int t = decltype(tc)::value, c = decltype(cc)::value, r = (3 * t + c) & 1, u = t & 1;
+    acc2[u][0] = l2x_mma(RCED_T_A2REG >= 1 ? A.a[0][c] : a2r[r][0], b2[r], c == 0 ? sh2[0] : acc2[u][0]);
+    acc2[u][1] = l2x_mma(RCED_T_A2REG >= 2 ? A.a[1][c] : a2r[r][1], b2[r], c == 0 ? sh2[1] : acc2[u][1]);
+  };
+  // ReLU + split of one pair of tile t's layer-2 outputs: piece q = 2 * M-tile + half -> k-slots 2q, 2q + 1 of the B fragment
+  auto split_piece = [&](auto tc, auto qc) {
+    constexpr int t = decltype(tc)::value, q = decltype(qc)::value, u = t & 1, mt = q >> 1;
+    float v0 = relu1((q & 1) ? acc2[u][mt].z : acc2[u][mt].x), v1 = relu1((q & 1) ? acc2[u][mt].w : acc2[u][mt].y);
+    if constexpr (t == 4) {   // a frame's last tile (waves 4..7 only): one real pixel, the rest is gap / the next frame -> zero
+      const bool ok = vbit(L, kVN0);
+      v0 = ok ? v0 : 0.f;
+      v1 = ok ? v1 : 0.f;
+    }
+    P3 p;
+    if (RCED_T_EXP & 4) {
+      p.h = __builtin_bit_cast(unsigned, v0);
+      p.m = __builtin_bit_cast(unsigned, v1);
+      p.l = p.h;
+    } else {
+      p = split2(v0, v1);
+    }
+    b3h[u][q] = p.h;
+    b3m[u][q] = p.m;
+    b3l[u][q] = p.l;
+  };
+  // layer 3's A fragments come from LDS one slot ahead, through a ring of two; five M-tiles per job: when one layer-3 job follows
+  // another directly, its ring positions are the other way round (PAR = 1) -- its M-tile 0 is read while M-tile 4 is in use
+  auto ldY = [&](auto jc, auto parc) {
+    constexpr int j = decltype(jc)::value, r = (j + decltype(parc)::value) & 1;
+    if ((RCED_T_EXP & 2) && j > 1) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a3r[r][q] = lds_ld<s16x8>(a3, (j * 3 + q) * 1024);
+  };
+  auto doY = [&](auto uc, auto jc, auto parc) {   // M-tile j of the tile in buffer u
+    constexpr int u = decltype(uc)::value, j = decltype(jc)::value, r = (j + decltype(parc)::value) & 1;
+    Parts b;
+    b.h = __builtin_bit_cast(s16x8, b3h[u]);
+    b.m = __builtin_bit_cast(s16x8, b3m[u]);
+    b.l = __builtin_bit_cast(s16x8, b3l[u]);
+    if constexpr (j == kL3MT - 1) p4[u] = l2x_mma(a3r[r], b, zero4);
+    else pj[u][j & 1] = l2x_mma(a3r[r], b, zero4);
+  };
+  // epilogue of local tile t (its sums are complete): shift, ReLU, block skips (model.py:84-88: CE1 / CE2 outputs are kept and
+  // added to CD2 / CD1 AFTER the ReLU), store -- to B8, block 4 to decode_final's H image
+  auto finish = [&](auto tc, float s0, float s1) {
+    constexpr int t = decltype(tc)::value;
+    f32x2 v = {relu1(s0 + sh3.x), relu1(s1 + sh3.y)};
+    if constexpr (LAST) {
+      v += sk1[t];
+    } else {
+      v += blk == 3 ? sk2[t] : zero2;
+      sk1[t] = blk == 0 ? v : sk1[t];
+      sk2[t] = blk == 1 ? v : sk2[t];
+    }
+    if (t < 4 || vbit(L, kVN0)) lds_st<f32x2>(LAST ? L.wh0 : L.wr3, t * (16 * kB8S * 4), v);
+  };
+  static_assert(kHS == kB8S, "one tile stride for both destinations");
+  const unsigned edge = lds0 + 4 * M::kEdgeOff + fr * 1024 + L.a8, eflag = lds0 + 4 * M::kEdgeFlagOff + fr * 8;
+  auto publish = [&](int dir, float v0, float v1) {   // LDS operations of a wave execute in order: data, then flag
+    lds_st<f32x2>(edge, dir * 512, f32x2{v0, v1});
+    cbar();
+    if (L.a4 == 0) lds_poke_a(eflag + dir * 4, tag);
+  };
+  auto fetch = [&](int dir) {
+    flag_wait(eflag + dir * 4, tag, P.err, 8u);
+    return lds_ld<f32x2>(edge, dir * 512);
+  };
+  // what follows a pair's last MFMAs, run from inside the NEXT slot: its last shift-adds; then the tile in front of the pair
+  // and the pair's first tile are complete
+  auto tail_pair = [&](auto ac) {
+    constexpr int a = decltype(ac)::value;   // the pair's first local tile (0 or 2)
+    shift_add<4>(p4[0], w0, w1, x0, x1, y0, y1);
+    shift_add<4>(p4[1], x0, x1, y0, y1, z0, z1);
+    if constexpr (a == 0) {
+      if (right) {
+        publish(1, w0, w1);                // tile 4's share of tile 3's last pixels (the left wave's last tile)
+        hold = f32x2{x0, x1};              // tile 4 itself waits for tile 3's share
+      } else {
+        finish(IC<0>{}, x0, x1);
+      }
+    } else {
+      finish(IC<a - 1>{}, w0, w1);
+      finish(IC<a>{}, x0, x1);
+    }
+    w0 = y0;
+    w1 = y1;
+    x0 = z0;
+    x1 = z1;
+    y0 = y1 = z0 = z1 = 0.f;
+  };
+  // X(t) with tile t - 1's split between its MFMAs.  NEXT: what the slot behind it is: 0 = X(t + 1), 1 = a layer-3 job
+  auto runX = [&](auto tc, auto nc, auto prev_tail) {
+    constexpr int t = decltype(tc)::value, next = decltype(nc)::value;
+    static_for<0, 3>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if constexpr (c < 2) ldX(tc, IC<c + 1>{});
+      else if constexpr (next == 0) ldX(IC<t + 1>{}, IC<0>{});
+      else ldY(IC<0>{}, IC<0>{});
+      pin();
+      doX(tc, cc);
+      if constexpr (c == 0) prev_tail();
+      if constexpr (t > 0) {
+        if constexpr (c == 0) {
+          split_piece(IC<t - 1>{}, IC<0>{});
+          split_piece(IC<t - 1>{}, IC<1>{});
+        } else if constexpr (c == 1) {
+          split_piece(IC<t - 1>{}, IC<2>{});
+          split_piece(IC<t - 1>{}, IC<3>{});
+        }
+      }
+      pin();
+    });
+  };
+  // layer 3 of the pair of tiles (a, a + 1) (PAIR) or of the single tile a.  NEXT: 0 = X(NX) follows, 1 = another layer-3 job, 2 = nothing
+  auto runY = [&](auto ac, auto pairc, auto nc, auto nxc, auto parc, auto prev_tail) {
+    constexpr int a = decltype(ac)::value, next = decltype(nc)::value, u0 = a & 1;
+    constexpr bool pair = decltype(pairc)::value != 0;
+    static_for<0, kL3MT>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j + 1 < kL3MT) ldY(IC<j + 1>{}, parc);
+      else if constexpr (next == 0) ldX(nxc, IC<0>{});
+      else if constexpr (next == 1) ldY(IC<0>{}, IC<1 - decltype(parc)::value>{});
+      pin();
+      doY(IC<u0>{}, jc, parc);
+      if constexpr (pair) doY(IC<u0 ^ 1>{}, jc, parc);
+      if constexpr (j == 0) {
+        prev_tail();
+      } else {
+        shift_add<j - 1>(pj[u0][(j - 1) & 1], w0, w1, x0, x1, y0, y1);
+        if constexpr (pair) shift_add<j - 1>(pj[u0 ^ 1][(j - 1) & 1], x0, x1, y0, y1, z0, z1);
+      }
+      if constexpr (next == 2) sp(jc);
+      pin();
+    });
+  };
+  auto none = [] {};
+  const IC<0> i0;
+  const IC<1> i1;
+  const IC<2> i2;
+  const IC<3> i3;
+  const IC<4> i4;
+
+  if (RCED_T_PRIO && right) __builtin_amdgcn_s_setprio(RCED_T_PRIO);
+  // ---- the stream.  Waves 0..3: tiles 0..3 of frame fr (X0 X1 X2 YY01 X3 YY23); waves 4..7: tiles 4..8 (X0 X1 X2 YY01 X3 X4 YY23 Y4)
+  ldX(i0, i0);
+  pin();
+  runX(i0, i0, none);
+  runX(i1, i0, none);
+  runX(i2, i1, none);
+  DET(0);
+  runY(i0, i1, i0, i3, i0, none);                          // YY01; X3 follows
+  DET(1);
+  if (!right) {
+    runX(i3, i1, [&] { tail_pair(i0); });
+    DET(2);
+    static_for<0, 4>([&](auto qc) { split_piece(i3, qc); });
+    runY(i2, i1, i2, i0, i0, none);                        // YY23
+    tail_pair(i2);                                         // finishes tiles 1, 2; w = tile 3 so far, x = its share of tile 4's first pixels
+    publish(0, x0, x1);
+    const f32x2 e = fetch(1);                              // published behind the right wave's FIRST pair: long there
+    finish(i3, w0 + e.x, w1 + e.y);
+  } else {
+    runX(i3, i0, [&] { tail_pair(i0); });
+    runX(i4, i1, none);
+    DET(2);
+    runY(i2, i1, i1, i0, i0, none);                        // YY23; Y4 follows
+    static_for<0, 4>([&](auto qc) { split_piece(i4, qc); });
+    runY(i4, i0, i2, i0, i1, [&] { tail_pair(i2); });      // Y4: w = local tile 3, x = local tile 4 (nothing lies behind it: the gap)
+    shift_add<4>(p4[0], w0, w1, x0, x1, y0, y1);
+    finish(i3, w0, w1);
+    finish(i4, x0, x1);
+    const f32x2 e = fetch(0);                              // the left wave has four tiles, this one five: long there
+    finish(i0, hold.x + e.x, hold.y + e.y);
+    if (RCED_T_PRIO) __builtin_amdgcn_s_setprio(0);
+  }
+  DET(3);
+}

@@ -276,26 +276,42 @@ def test_full_size_config3_sampled_against_oracle(net_work, tag, variant, built)
         assert torch.equal(m(x), y)
 
 
-# the two forms of the CR-CED kernel (kernels_fused_v3.h): agree with each other to fp32 summation noise
+# the three forms of the CR-CED kernel (kernels_fused_v3.h): agree with each other to fp32 summation noise
 V3_FORMS_AGREE = 5e-6
+V3_FORM_NAMES = ("fused x6", "x6", "fp32-MFMA")
 
 
-def v3_both_forms(w):
-    """(model running the product form -- 18 -> 30 layers as three-part bf16 products -- , model running every layer on the fp32 MFMA)"""
-    a, b = make_model(3, w), make_model(3, w)
-    assert a.get_option("v3_l2x6") == 1
-    b.set_option("v3_l2x6", 0)
-    assert b.get_option("v3_l2x6") == 0
-    return a, b
+def v3_forms(w):
+    """Models running (the product form: 18 -> 30 and 30 -> 8 layers as three-part bf16 products in one stream; round 4's first
+    form: the 18 -> 30 layers only; every layer on the fp32 MFMA) -- option v3_l2x6 = 2, 1, 0."""
+    ms = []
+    for form in (2, 1, 0):
+        m = make_model(3, w)
+        if form == 2:
+            assert m.get_option("v3_l2x6") == 2   # the default
+        else:
+            m.set_option("v3_l2x6", form)
+            assert m.get_option("v3_l2x6") == form
+        ms.append(m)
+    return ms
+
+
+def v3_check_forms(ms, x, ref, what=""):
+    """Every form against the oracle (RTOL) and against the fp32-MFMA form (V3_FORMS_AGREE); -> (errors vs the oracle, vs fp32)"""
+    ys = [m(x) for m in ms]
+    ys = [y.cpu().numpy() if hasattr(y, "cpu") else y for y in ys]
+    eo = [check_parity(y, ref, what="%s %s form" % (what, n)) for y, n in zip(ys, V3_FORM_NAMES)]
+    ef = [rel_err(y, ys[2]) for y in ys[:2]]
+    return ys, eo, ef
 
 
 def test_v3_kernel_forms_agree_with_the_oracle_and_each_other(built, capsys):
-    """rced_set_option(m, "v3_l2x6", 0 | 1): both kernels are in the library; same inputs through both -- the golden vectors
-    and a fuzz set (shapes across the tile size, input scales 1e-3 .. 30, silent frames) -- each held to the oracle (1e-4) and
-    the two to each other (5e-6 of the scale: fp32 summation noise; measured errors printed)."""
+    """rced_set_option(m, "v3_l2x6", 0 | 1 | 2): all three kernels are in the library; same inputs through all -- the golden
+    vectors and a fuzz set (shapes across the tile size, input scales 1e-3 .. 30, silent frames) -- each held to the oracle
+    (1e-4) and the x6 forms to the fp32-MFMA one (5e-6 of the scale: fp32 summation noise; measured errors printed)."""
     w, g = load_golden("v3")
-    x6, f32 = v3_both_forms(w)
-    worst = [0.0, 0.0, 0.0]
+    ms = v3_forms(w)
+    worst = [0.0] * 5
     cases = [(w, g["x_small"], g["y_small"]), (w, g["x_long"], g["y_long"])]
     rng = np.random.default_rng(4242)
     for _ in range(8):
@@ -307,22 +323,20 @@ def test_v3_kernel_forms_agree_with_the_oracle_and_each_other(built, capsys):
         cases.append((wf, x, rced_c.forward("FullyCNNV3", wf, x, np.float64)))
     for wf, x, ref in cases:
         if wf is not w:
-            x6, f32 = v3_both_forms(wf)
-        ya, yb = x6(x), f32(x)
-        worst[0] = max(worst[0], check_parity(ya, ref, what="x6 form"))
-        worst[1] = max(worst[1], check_parity(yb, ref, what="fp32 form"))
-        worst[2] = max(worst[2], rel_err(ya, yb))
-        assert rel_err(ya, yb) <= V3_FORMS_AGREE
+            ms = v3_forms(wf)
+        _, eo, ef = v3_check_forms(ms, x, ref)
+        worst = [max(a, b) for a, b in zip(worst, eo + ef)]
+        assert max(ef) <= V3_FORMS_AGREE, ef
     with capsys.disabled():
-        print("\n[v3 forms] worst error of the scale: x6 vs oracle %.2e, fp32-MFMA vs oracle %.2e, x6 vs fp32-MFMA %.2e"
-              % tuple(worst))
+        print("\n[v3 forms] worst error of the scale vs the oracle: fused x6 %.2e, x6 %.2e, fp32-MFMA %.2e; vs the fp32-MFMA form: "
+              "fused x6 %.2e, x6 %.2e" % tuple(worst))
 
 
 @pytest.mark.parametrize("net_work,tag,variant", NETS)
 def test_whole_output_config3_against_the_fp64_restatement(net_work, tag, variant, built, capsys):
     """BASELINE config 3 (batch 256, 129x512), EVERY one of the 131,072 output frames (the reference boundary returns all of
-    them: tester.py:85-90) against oracle/infer_ref.py run in float64 on the same GPU -- all three nets, and for CR-CED both
-    forms of the kernel, which must also agree with each other."""
+    them: tester.py:85-90) against oracle/infer_ref.py run in float64 on the same GPU -- all three nets, and for CR-CED all
+    three forms of the kernel, which must also agree with each other."""
     import torch
     import bench
     from oracle import infer_ref
@@ -331,11 +345,9 @@ def test_whole_output_config3_against_the_fp64_restatement(net_work, tag, varian
     ref = infer_ref.forward(net_work, w, x, device="cuda", dtype=torch.float64).cpu().numpy()
     torch.cuda.empty_cache()
     if variant == 3:
-        x6, f32 = v3_both_forms(w)
-        ya, yb = x6(x).cpu().numpy(), f32(x).cpu().numpy()
-        ea, eb, ab = check_parity(ya, ref, what="x6 form"), check_parity(yb, ref, what="fp32 form"), rel_err(ya, yb)
-        assert ab <= V3_FORMS_AGREE
-        msg = "x6 %.2e, fp32-MFMA %.2e, between the two %.2e" % (ea, eb, ab)
+        _, eo, ef = v3_check_forms(v3_forms(w), x, ref)
+        assert max(ef) <= V3_FORMS_AGREE, ef
+        msg = "fused x6 %.2e, x6 %.2e, fp32-MFMA %.2e; vs the fp32-MFMA form %.2e, %.2e" % tuple(eo + ef)
     else:
         msg = "%.2e" % check_parity(make_model(variant, w)(x).cpu().numpy(), ref)
     with capsys.disabled():
@@ -386,7 +398,7 @@ def _scaled_inner_channels(w, rng, lo=-4.0, hi=4.0):
 def test_three_part_products_on_adversarial_magnitudes(built, capsys):
     """The split x = h + m + l (bf16 parts) of the CR-CED kernel's 18-channel tensor under magnitudes the synthetic inputs never
     produce: per-channel scales spanning 1e-4 .. 1e4 inside one K = 32 chunk, inputs x 1e-6 and x 1e4, a frame of exact zeros
-    next to a frame of 1e4.  Both forms of the kernel against the oracle (1e-4) and each other; measured errors printed."""
+    next to a frame of 1e4.  All three forms of the kernel against the oracle (1e-4) and each other; measured errors printed."""
     rng = np.random.default_rng(2024)
     base = rced_np.make_weights("FullyCNNV3", seed=5)
     rows = []
@@ -401,19 +413,18 @@ def test_three_part_products_on_adversarial_magnitudes(built, capsys):
             x[:, 7] = 0.0
             x[:, 8] *= np.float32(1e4)
         ref = rced_c.forward("FullyCNNV3", w, x, np.float64)
-        x6, f32 = v3_both_forms(w)
-        ya, yb = x6(x), f32(x)
-        assert np.isfinite(ya).all() and np.isfinite(yb).all()
-        rows.append((name, check_parity(ya, ref, what=name + " (x6)"), check_parity(yb, ref, what=name + " (fp32)"), rel_err(ya, yb)))
-        assert rows[-1][3] <= 4 * V3_FORMS_AGREE, rows[-1]
+        ys, eo, ef = v3_check_forms(v3_forms(w), x, ref, what=name)
+        assert all(np.isfinite(y).all() for y in ys)
+        rows.append((name,) + tuple(eo + ef))
+        assert max(ef) <= 4 * V3_FORMS_AGREE, rows[-1]
     with capsys.disabled():
         print()
         for r in rows:
-            print("[adversarial] %-40s x6 %.2e  fp32-MFMA %.2e  between %.2e" % r)
+            print("[adversarial] %-40s fused x6 %.2e  x6 %.2e  fp32-MFMA %.2e  vs fp32-MFMA %.2e %.2e" % r)
 
 
 @pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
-@pytest.mark.parametrize("form", [1, 0])
+@pytest.mark.parametrize("form", [2, 1, 0])
 def test_non_finite_input_stays_inside_its_tiles(bad, form, built):
     """One Inf / NaN magnitude at (utterance 1, frame 21, bin 40).  Frame t of the output needs frames t-3 .. t+4 of the input
     (only the first layer looks along time), so frames 17..24 of utterance 1 are the ones the oracle changes.  The kernel
