@@ -18,8 +18,10 @@
 //   * a wave walks its tiles one after the other and stores tile j's results between the MFMAs of tile j+1
 //     ("slot streams", below): the epilogues' LDS stores no longer sit on every layer's tail.
 //
-// TWO FORMS of the kernel, one template (`Map<X6>`), both in the library (option "v3_l2x6"):
-//   X6 = true (the product): the 18 -> 30 layers -- 43 % of the net's multiply-adds and the only ones whose B fragment
+// THREE FORMS of the kernel, one template (`Map<FORM>`), all in the library (option "v3_l2x6" = FORM):
+//   FORM 2 (the product, "fused"): as FORM 1, and the 30 -> 8 layers too on the bf16 pipe, computed tap by tap from layer 2's accumulators
+//     in the same stream (kernels_fused_v3_l23.h; the note at Map<2> below): the 30-channel tensor is never stored.
+//   FORM 1 ("X6"): the 18 -> 30 layers -- 43 % of the net's multiply-adds and the only ones whose B fragment
 //     feeds two M-tiles -- run at fp32 quality on the bf16 matrix pipe: every operand as three bf16 parts (x = h + m + l,
 //     exact to 2^-24), every product as six v_mfma_f32_16x16x32_bf16 (m.m, l.h, h.l, m.h, h.m, h.h -- smallest first --
 //     into the fp32 accumulator).  The activation is split ONCE, where it is produced: layer 1's epilogue writes the
@@ -28,7 +30,7 @@
 //     planes are 19 KB more than the fp32 buffer; the LDS for them comes from the weights: layer 1's and layer 2's
 //     A fragments (50 + 72 registers) are loaded from global memory into VGPRs one layer ahead and only layer 3's
 //     packet still goes through LDS (one region, no ping-pong).
-//   X6 = false: every layer on v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32 fmaf chain), all weight packets streamed
+//   FORM 0 ("F32"): every layer on v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32 fmaf chain), all weight packets streamed
 //     L2 -> LDS by LDS-DMA one layer ahead (ping-pong).  Rounds 1 / 2's kernel; kept as the in-build comparator of the
 //     X6 arithmetic (tests/test_forward_gpu.py holds the two against each other and both against the fp64 restatement).
 //
@@ -757,6 +759,16 @@ __device__ __forceinline__ float unpk(float v) {   // keep the optimiser from re
                         // fragments become undefined values and hipcc deletes work that depends on them), 4 = none in layer 3,
                         // 8 = one plane store instead of three, 16 = no remainder-row reads / merge in layer 2
 #endif
+#ifndef RCED_SPLIT_DOT2
+#define RCED_SPLIT_DOT2 0   // 1 = the residual x - bf16(x) of either element of a pack as ONE v_dot2c_f32_bf16 (pack . (-1, 0) + x) instead of shift / mask
+                            // + v_sub_f32: 7 VALU per pair instead of 11, exact for finite values (tools/micro/dot2_split_test.hip: 4 M values,
+                            // bit-identical; differs only where the OTHER element of the pack rounds to Inf and below 1e-32) -- and SLOWER: 6.62 against
+                            // 6.52 ms (A/B on one box): the dot instruction does not issue at the rate of the two it replaces.  Not adopted.
+#endif
+__device__ __forceinline__ unsigned opaque_s(unsigned v) {   // a constant the compiler must keep in a register (not an inline operand)
+  asm volatile("" : "+s"(v));
+  return v;
+}
 __device__ __forceinline__ P3 split2(float x0, float x1) {
   P3 p;
   if (RCED_X6_EXP & 1) {
@@ -765,6 +777,18 @@ __device__ __forceinline__ P3 split2(float x0, float x1) {
     p.l = p.h ^ p.m;
     return p;
   }
+#if RCED_SPLIT_DOT2
+  const bf16x2 k0 = __builtin_bit_cast(bf16x2, opaque_s(0x0000BF80u)), k1 = __builtin_bit_cast(bf16x2, opaque_s(0xBF800000u));   // (-1, 0), (0, -1)
+  const bf16x2 bh = {(__bf16)x0, (__bf16)x1};
+  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(bh, k0, x0, false), r1 = __builtin_amdgcn_fdot2_f32_bf16(bh, k1, x1, false);
+  const bf16x2 bm = {(__bf16)r0, (__bf16)r1};
+  const float s0 = __builtin_amdgcn_fdot2_f32_bf16(bm, k0, r0, false), s1 = __builtin_amdgcn_fdot2_f32_bf16(bm, k1, r1, false);
+  const bf16x2 bl = {(__bf16)s0, (__bf16)s1};
+  p.h = __builtin_bit_cast(unsigned, bh);
+  p.m = __builtin_bit_cast(unsigned, bm);
+  p.l = __builtin_bit_cast(unsigned, bl);
+  return p;
+#else
   const bf16x2 bh = {(__bf16)x0, (__bf16)x1};
   p.h = __builtin_bit_cast(unsigned, bh);
   asm volatile("" : "+v"(p.h));   // (seen through, hipcc derives `h << 16` from a second, single-element conversion: +1 VALU per level)
@@ -776,6 +800,7 @@ __device__ __forceinline__ P3 split2(float x0, float x1) {
   const bf16x2 bl = {(__bf16)s0, (__bf16)s1};
   p.l = __builtin_bit_cast(unsigned, bl);
   return p;
+#endif
 }
 
 // ---- layer 1: 8x9, 1 -> 18 on the input rows (block 0, FIRST) / 1x9, 8 -> 18 on B8 (blocks 1..4) -----------

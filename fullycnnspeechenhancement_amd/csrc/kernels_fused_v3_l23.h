@@ -19,6 +19,9 @@
 #define RCED_T_PRIO 1    // the waves with five tiles (4..7) run this phase at raised priority: their SIMD partners (four tiles) are the older
                          // waves, which the issue arbiter prefers -- left alone they finish at two thirds of the phase and the rest runs single
 #endif
+#ifndef RCED_T_SGB
+#define RCED_T_SGB 1     // sched_group_barrier pattern inside the slots (see interleave())
+#endif
 #ifndef RCED_T_EXP
 #define RCED_T_EXP 0   // timing experiments only (wrong results): 1 = no shift-adds, 2 = layer 3's A fragments read once, 4 = no split arithmetic,
                        // 8 = layer 2's B fragments read once per tile
@@ -43,6 +46,34 @@ __device__ __forceinline__ void tap_add(float p, float& oP, float& oC, float& oN
     oC += dpp0<0x100 - S>(p);
     oP += dpp0<0x110 + 16 + S>(p);
   }
+}
+// two independent accumulation chains, their six products in lockstep (one chain's MFMAs back to back wait for each other:
+// left to itself hipcc sometimes emits the chains one after the other)
+__device__ __forceinline__ void mma2(const s16x8 (&a0)[3], const Parts& b0, f32x4& c0, const s16x8 (&a1)[3], const Parts& b1, f32x4& c1) {
+  c0 = mfma32(a0[1], b0.m, c0);
+  c1 = mfma32(a1[1], b1.m, c1);
+  c0 = mfma32(a0[2], b0.h, c0);
+  c1 = mfma32(a1[2], b1.h, c1);
+  c0 = mfma32(a0[0], b0.l, c0);
+  c1 = mfma32(a1[0], b1.l, c1);
+  c0 = mfma32(a0[1], b0.h, c0);
+  c1 = mfma32(a1[1], b1.h, c1);
+  c0 = mfma32(a0[0], b0.m, c0);
+  c1 = mfma32(a1[0], b1.m, c1);
+  c0 = mfma32(a0[0], b0.h, c0);
+  c1 = mfma32(a1[0], b1.h, c1);
+}
+// the order of a slot's instructions: NM times {one MFMA, up to NV VALU} (the VALU of a slot are the previous tile's split / the
+// previous M-tile's shift-adds: hipcc otherwise puts them in one block behind the slot's last MFMA, where nothing covers them)
+template <int NM, int NV>
+__device__ __forceinline__ void interleave() {
+#if RCED_T_SGB
+#pragma unroll
+  for (int i = 0; i < NM; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+  }
+#endif
 }
 template <int J>
 __device__ __forceinline__ void shift_add(f32x4 pj, float& p0, float& p1, float& c0, float& c1, float& n0, float& n1) {
@@ -111,8 +142,11 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
   };
   auto doX = [&](auto tc, auto cc) {
     constexpr int t = decltype(tc)::value, c = decltype(cc)::value, r = (3 * t + c) & 1, u = t & 1;
-    acc2[u][0] = l2x_mma(RCED_T_A2REG >= 1 ? A.a[0][c] : a2r[r][0], b2[r], c == 0 ? sh2[0] : acc2[u][0]);
-    acc2[u][1] = l2x_mma(RCED_T_A2REG >= 2 ? A.a[1][c] : a2r[r][1], b2[r], c == 0 ? sh2[1] : acc2[u][1]);
+    if constexpr (c == 0) {
+      acc2[u][0] = sh2[0];
+      acc2[u][1] = sh2[1];
+    }
+    mma2(RCED_T_A2REG >= 1 ? A.a[0][c] : a2r[r][0], b2[r], acc2[u][0], RCED_T_A2REG >= 2 ? A.a[1][c] : a2r[r][1], b2[r], acc2[u][1]);
   };
   // ReLU + split of one pair of tile t's layer-2 outputs: piece q = 2 * M-tile + half -> k-slots 2q, 2q + 1 of the B fragment
   auto split_piece = [&](auto tc, auto qc) {
@@ -151,6 +185,25 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
     b.l = __builtin_bit_cast(s16x8, b3l[u]);
     if constexpr (j == kL3MT - 1) p4[u] = l2x_mma(a3r[r], b, zero4);
     else pj[u][j & 1] = l2x_mma(a3r[r], b, zero4);
+  };
+  auto doYY = [&](auto jc, auto parc) {   // M-tile j of both tiles of a pair (buffers 0 and 1), the two chains in lockstep
+    constexpr int j = decltype(jc)::value, r = (j + decltype(parc)::value) & 1;
+    Parts ba, bb;
+    ba.h = __builtin_bit_cast(s16x8, b3h[0]);
+    ba.m = __builtin_bit_cast(s16x8, b3m[0]);
+    ba.l = __builtin_bit_cast(s16x8, b3l[0]);
+    bb.h = __builtin_bit_cast(s16x8, b3h[1]);
+    bb.m = __builtin_bit_cast(s16x8, b3m[1]);
+    bb.l = __builtin_bit_cast(s16x8, b3l[1]);
+    f32x4 ca = zero4, cb = zero4;
+    mma2(a3r[r], ba, ca, a3r[r], bb, cb);
+    if constexpr (j == kL3MT - 1) {
+      p4[0] = ca;
+      p4[1] = cb;
+    } else {
+      pj[0][j & 1] = ca;
+      pj[1][j & 1] = cb;
+    }
   };
   // epilogue of local tile t (its sums are complete): shift, ReLU, block skips (model.py:84-88: CE1 / CE2 outputs are kept and
   // added to CD2 / CD1 AFTER the ReLU), store -- to B8, block 4 to decode_final's H image
@@ -220,6 +273,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
           split_piece(IC<t - 1>{}, IC<3>{});
         }
       }
+      interleave<12, (c == 0 ? 5 : 3)>();
       pin();
     });
   };
@@ -233,8 +287,8 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
       else if constexpr (next == 0) ldX(nxc, IC<0>{});
       else if constexpr (next == 1) ldY(IC<0>{}, IC<1 - decltype(parc)::value>{});
       pin();
-      doY(IC<u0>{}, jc, parc);
-      if constexpr (pair) doY(IC<u0 ^ 1>{}, jc, parc);
+      if constexpr (pair) doYY(jc, parc);
+      else doY(IC<u0>{}, jc, parc);
       if constexpr (j == 0) {
         prev_tail();
       } else {
@@ -242,6 +296,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
         if constexpr (pair) shift_add<j - 1>(pj[u0 ^ 1][(j - 1) & 1], x0, x1, y0, y1, z0, z1);
       }
       if constexpr (next == 2) sp(jc);
+      interleave<(pair ? 12 : 6), (j == 0 ? 4 : 2)>();
       pin();
     });
   };

@@ -77,9 +77,8 @@ void run(float* d) {
 int main() {
   float* d;
   hipMalloc(&d, 4096);
-  run<3, 12, 0>(d); run<6, 12, 0>(d); run<9, 12, 0>(d); run<12, 12, 0>(d);
-  run<3, 12, 4>(d); run<3, 12, 8>(d); run<3, 12, 12>(d); run<3, 12, 16>(d); run<3, 12, 24>(d); run<3, 12, 36>(d);
-  run<9, 12, 12>(d); run<9, 12, 24>(d);
-  run<3, 6, 0>(d); run<3, 6, 8>(d); run<3, 24, 0>(d); run<3, 24, 24>(d);
+  run<0, 12, 4>(d); run<3, 12, 4>(d); run<6, 12, 4>(d); run<9, 12, 4>(d); run<12, 12, 4>(d);
+  run<0, 12, 0>(d); run<0, 12, 12>(d); run<0, 12, 24>(d); run<6, 12, 12>(d); run<6, 12, 24>(d); run<12, 12, 24>(d);
+  run<0, 24, 0>(d); run<6, 24, 8>(d); run<12, 24, 24>(d);
   return 0;
 }
