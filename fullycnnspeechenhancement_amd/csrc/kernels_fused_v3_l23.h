@@ -19,6 +19,9 @@
 #define RCED_T_PRIO 1    // the waves with five tiles (4..7) run this phase at raised priority: their SIMD partners (four tiles) are the older
                          // waves, which the issue arbiter prefers -- left alone they finish at two thirds of the phase and the rest runs single
 #endif
+#ifndef RCED_T_A3D
+#define RCED_T_A3D 1     // (2 measured: no gain -- it is not their latency) layer 3's A fragments are read this many slots ahead of their use (ring of RCED_T_A3D + 1)
+#endif
 #ifndef RCED_T_SGB
 #define RCED_T_SGB 1     // sched_group_barrier pattern inside the slots (see interleave())
 #endif
@@ -65,12 +68,15 @@ __device__ __forceinline__ void mma2(const s16x8 (&a0)[3], const Parts& b0, f32x
 }
 // the order of a slot's instructions: NM times {one MFMA, up to NV VALU} (the VALU of a slot are the previous tile's split / the
 // previous M-tile's shift-adds: hipcc otherwise puts them in one block behind the slot's last MFMA, where nothing covers them)
-template <int NM, int NV>
+// The next slot's LDS reads ride between the MFMAs too (ND per MFMA): issued in one block at the slot's start they are a stretch of
+// the wave's in-order issue in which none of its MFMAs can go (layer 3's three reads per slot cost 0.6 ms of the forward that way).
+template <int NM, int NV, int ND = 0>
 __device__ __forceinline__ void interleave() {
 #if RCED_T_SGB
 #pragma unroll
   for (int i = 0; i < NM; ++i) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if (ND > 0) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
     __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
   }
 #endif
@@ -109,9 +115,11 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
   unsigned rdc = L.rd2c;       // the last chunk's four dwords of the tile whose layer 2 comes next
   f32x4 acc2[2][2];            // [tile & 1][M-tile]
   u32x4 b3h[2], b3m[2], b3l[2];   // [tile & 1]: layer 3's B fragment (three parts)
-  s16x8 a3r[2][3];
+  s16x8 a3r[RCED_T_A3D + 1][3];
   f32x4 pj[2][2], p4[2] = {zero4, zero4};   // [tile & 1]: P of M-tiles 0..3 (ring of two) / of M-tile 4, whose shift-adds run from inside the NEXT slot
-  float w0 = 0.f, w1 = 0.f, x0 = 0.f, x1 = 0.f, y0 = 0.f, y1 = 0.f, z0 = 0.f, z1 = 0.f;
+  // (fresh accumulators hold -0.0, the identity of the IEEE addition: `-0.0 + x` folds to x, `0.0 + x` does not -- hipcc emitted a
+  // v_mov_b32_dpp + v_add_f32 0 pair for every first contribution)
+  float w0 = -0.f, w1 = -0.f, x0 = -0.f, x1 = -0.f, y0 = -0.f, y1 = -0.f, z0 = -0.f, z1 = -0.f;
   f32x2 hold = zero2;
 
   auto ldX = [&](auto tc, auto cc) {
@@ -169,16 +177,16 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
     b3m[u][q] = p.m;
     b3l[u][q] = p.l;
   };
-  // layer 3's A fragments come from LDS one slot ahead, through a ring of two; five M-tiles per job: when one layer-3 job follows
-  // another directly, its ring positions are the other way round (PAR = 1) -- its M-tile 0 is read while M-tile 4 is in use
+  // layer 3's A fragments come from LDS RCED_T_A3D slots ahead, through a ring; five M-tiles per job: when one layer-3 job follows
+  // another directly, its ring positions are shifted (PAR) -- its first M-tiles are read while the last ones of this job are in use
   auto ldY = [&](auto jc, auto parc) {
-    constexpr int j = decltype(jc)::value, r = (j + decltype(parc)::value) & 1;
+    constexpr int j = decltype(jc)::value, r = (j + decltype(parc)::value) % (RCED_T_A3D + 1);
     if ((RCED_T_EXP & 2) && j > 1) return;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) a3r[r][q] = lds_ld<s16x8>(a3, (j * 3 + q) * 1024);
+    for (int q = 0; q < 3; ++q) a3r[r][q] = lds_ld<s16x8>(a3, (((RCED_T_EXP & 32) ? 0 : j) * 3 + ((RCED_T_EXP & 64) ? 0 : q)) * 1024);
   };
   auto doY = [&](auto uc, auto jc, auto parc) {   // M-tile j of the tile in buffer u
-    constexpr int u = decltype(uc)::value, j = decltype(jc)::value, r = (j + decltype(parc)::value) & 1;
+    constexpr int u = decltype(uc)::value, j = decltype(jc)::value, r = (j + decltype(parc)::value) % (RCED_T_A3D + 1);
     Parts b;
     b.h = __builtin_bit_cast(s16x8, b3h[u]);
     b.m = __builtin_bit_cast(s16x8, b3m[u]);
@@ -187,7 +195,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
     else pj[u][j & 1] = l2x_mma(a3r[r], b, zero4);
   };
   auto doYY = [&](auto jc, auto parc) {   // M-tile j of both tiles of a pair (buffers 0 and 1), the two chains in lockstep
-    constexpr int j = decltype(jc)::value, r = (j + decltype(parc)::value) & 1;
+    constexpr int j = decltype(jc)::value, r = (j + decltype(parc)::value) % (RCED_T_A3D + 1);
     Parts ba, bb;
     ba.h = __builtin_bit_cast(s16x8, b3h[0]);
     ba.m = __builtin_bit_cast(s16x8, b3m[0]);
@@ -251,7 +259,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
     w1 = y1;
     x0 = z0;
     x1 = z1;
-    y0 = y1 = z0 = z1 = 0.f;
+    y0 = y1 = z0 = z1 = -0.f;
   };
   // X(t) with tile t - 1's split between its MFMAs.  NEXT: what the slot behind it is: 0 = X(t + 1), 1 = a layer-3 job
   auto runX = [&](auto tc, auto nc, auto prev_tail) {
@@ -260,8 +268,8 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
       constexpr int c = decltype(cc)::value;
       if constexpr (c < 2) ldX(tc, IC<c + 1>{});
       else if constexpr (next == 0) ldX(IC<t + 1>{}, IC<0>{});
-      else ldY(IC<0>{}, IC<0>{});
-      pin();
+      if constexpr (next == 1 && c + RCED_T_A3D >= 3) ldY(IC<c + RCED_T_A3D - 3>{}, IC<0>{});   // the layer-3 job behind this one: its first M-tile(s)
+      if (RCED_T_SGB < 2) pin();
       doX(tc, cc);
       if constexpr (c == 0) prev_tail();
       if constexpr (t > 0) {
@@ -273,7 +281,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
           split_piece(IC<t - 1>{}, IC<3>{});
         }
       }
-      interleave<12, (c == 0 ? 5 : 3)>();
+      interleave<12, (c == 0 ? 5 : 3), (RCED_T_SGB >= 2 ? 2 : 0)>();
       pin();
     });
   };
@@ -283,10 +291,11 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
     constexpr bool pair = decltype(pairc)::value != 0;
     static_for<0, kL3MT>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      if constexpr (j + 1 < kL3MT) ldY(IC<j + 1>{}, parc);
-      else if constexpr (next == 0) ldX(nxc, IC<0>{});
-      else if constexpr (next == 1) ldY(IC<0>{}, IC<1 - decltype(parc)::value>{});
-      pin();
+      constexpr int D = RCED_T_A3D, par = decltype(parc)::value, npar = (kL3MT + par) % (D + 1);   // (npar: the ring phase of a layer-3 job that follows directly)
+      if constexpr (j + D < kL3MT) ldY(IC<j + D>{}, parc);
+      else if constexpr (next == 1) ldY(IC<j + D - kL3MT>{}, IC<npar>{});
+      if constexpr (next == 0 && j == kL3MT - 1) ldX(nxc, IC<0>{});
+      if (RCED_T_SGB < 2) pin();
       if constexpr (pair) doYY(jc, parc);
       else doY(IC<u0>{}, jc, parc);
       if constexpr (j == 0) {
@@ -296,7 +305,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
         if constexpr (pair) shift_add<j - 1>(pj[u0 ^ 1][(j - 1) & 1], x0, x1, y0, y1, z0, z1);
       }
       if constexpr (next == 2) sp(jc);
-      interleave<(pair ? 12 : 6), (j == 0 ? 4 : 2)>();
+      interleave<(pair ? 12 : 6), (j == 0 ? 4 : 2), (RCED_T_SGB >= 2 ? 1 : 0)>();
       pin();
     });
   };
@@ -332,7 +341,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
     DET(2);
     runY(i2, i1, i1, i0, i0, none);                        // YY23; Y4 follows
     static_for<0, 4>([&](auto qc) { split_piece(i4, qc); });
-    runY(i4, i0, i2, i0, i1, [&] { tail_pair(i2); });      // Y4: w = local tile 3, x = local tile 4 (nothing lies behind it: the gap)
+    runY(i4, i0, i2, i0, IC<kL3MT % (RCED_T_A3D + 1)>{}, [&] { tail_pair(i2); });   // Y4: w = local tile 3, x = local tile 4 (nothing lies behind it: the gap)
     shift_add<4>(p4[0], w0, w1, x0, x1, y0, y1);
     finish(i3, w0, w1);
     finish(i4, x0, x1);
