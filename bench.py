@@ -673,10 +673,10 @@ def main():
                         "flop_per_frame": kflops, "frames_per_forward": B * T,
                         "other_kernels_ms_per_step": {k: v[0] / args.steps for k, v in times.items() if k != dom and v[1]},
                         "note": "compute-bound path (7950 FLOP/B): peak = dense fp32 MFMA 157.3 TFLOP/s, not HBM.  CR-CED: the "
-                                "18->30 layers (pipe_mix.mfma_bf16x6 of the FLOPs) are computed at fp32 quality as six bf16 "
+                                "18->30 and 30->8 layers (pipe_mix.mfma_bf16x6 of the FLOPs) are computed at fp32 quality as six bf16 "
                                 "MFMAs per product over three-part operands (DESIGN 3.1): `frac` = frac_fp32_peak stays quoted "
-                                "against the fp32 pipe's peak (SURVEY 8(d3)); frac_pipe_ceiling prices every layer against the "
-                                "pipe it runs on (386 TFLOP/s measured for the six-product form); "
+                                "against the fp32 pipe's peak (SURVEY 8(d3)) and can exceed 1; frac_pipe_ceiling prices every layer "
+                                "against the pipe it runs on (386 TFLOP/s measured for the six-product form); "
                                 "algorithmic HBM bytes are 1032 B/frame"}
         out["roofline"] = roof
     # ---- the reference's single-host-process convention over RCCL: scatter from rank 0, compute, gather -------
