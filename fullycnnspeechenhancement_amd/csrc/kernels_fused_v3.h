@@ -69,6 +69,9 @@
                           // once); 0 = one M-tile of tiles j + 4t (36 registers, every B fragment read by two waves: the layer is bound by the
                           // LDS then -- A/B on one box 8.36 against 8.18 ms)
 #endif
+#ifndef RCED_T_L1SWAP
+#define RCED_T_L1SWAP 1
+#endif
 #ifndef RCED_V3_LB
 #define RCED_V3_LB kThreads   // (diagnostic: 256 lifts the 256-register cap, to see what the allocator would like to have)
 #endif
@@ -528,10 +531,10 @@ struct Lane {
 constexpr int kVMain = 0, kVRem = 4, kVL3 = 8, kVL3X = 10, kVLt48 = 11, kVUpper = 12, kVSt2 = 13, kVL2 = 16, kVN0 = 24;
 
 template <class M>
-__device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr0) {
+__device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr0, int w1) {   // w1: the wave's role in layer 1 (fused form: != wave)
   const int n = lane & 15, kq = lane >> 4;
   const unsigned B8 = lds_addr(lds + M::kB8Off + kB8Pad * kB8S), B30 = lds_addr(lds + M::kB30Off + kB30Pad * 30);
-  const int px0 = 16 * wave + n;
+  const int px0 = 16 * w1 + n;
   Lane L;
   L.a8 = lane * 8;
   L.a4 = lane * 4;
@@ -1804,11 +1807,16 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
   layer_end_sync();
 
   // extra tiles of this wave (see the assignment comment above)
-  const int xr0 = wave == 7 ? 3 : wave - 4;                     // layer 1 remainder tile of waves 4..7 (wave 7 also 4)
+  // Fused form: layer 1's roles are swapped between the two waves of a SIMD (role = wave ^ 4): the issue arbiter prefers the OLDER
+  // wave, so the heavier roles 4..7 (remainder tiles) go to waves 0..3 -- the lighter wave then fills the gaps and both end together
+  // (6.52 -> 6.45 ms; s_setprio on top, or instead: nothing / worse.  In layers 2 + 3 it is the other way round: the five-tile halves on
+  // the older waves WITHOUT s_setprio 6.55 ms, with it 6.46, the same as on the younger waves with it)
+  const int w1 = M::kFused && RCED_T_L1SWAP ? wave ^ 4 : wave;
+  const int xr0 = w1 == 7 ? 3 : w1 - 4;                         // layer 1 remainder tile of roles 4..7 (role 7 also 4)
 #ifdef RCED_PRIO
   if ((wave >= 4) == (RCED_PRIO > 0)) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for one half of the waves
 #endif
-  const Lane L = make_lane<M>(lds, wave, lane, xr0 < 0 ? 0 : xr0);
+  const Lane L = make_lane<M>(lds, wave, lane, xr0 < 0 ? 0 : xr0, w1);
   const unsigned lds0 = lds_addr(lds);
   xstage_store(xst, lds + M::kX0Off, tid);   // the first tile's input rows; every later tile's are stored by final_phase
   __syncthreads();
@@ -1862,8 +1870,9 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
           if constexpr (M::kX6 && (!M::kFused || RCED_T_A2REG >= 2) && RCED_L2_BOTH && !(RCED_X6_EXP & 2))
             static_for<0, 10>([&](auto kc) { a2_load_one<decltype(kc)::value, kL2MT - 1>(A2, wrs, gofs + kG1, 1, voff1); });
         };
-        if (blk == 0) layer1<M, true>(L, wb, A1, A1r, wave, dma, sp1, late DET_PASS);
-        else layer1<M, false>(L, wb, A1, A1r, wave, dma, sp1, late DET_PASS);
+        if (blk == 0) layer1<M, true>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);
+        else layer1<M, false>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);
+
         if constexpr (!M::kX6) wcur ^= 1;
 #if RCED_STAMPS
         const unsigned long long st_b_ = stamp();
