@@ -111,7 +111,28 @@ void pack_v3(const rced_model* m, int form, std::vector<float>* wpack) {
       const int k = 8 * s + 2 * kq + e, tap = k / 8 - r;
       return (tap >= 0 && tap < 9) ? wq(l1, tap, k % 8, co, 8) : 0.f;
     };
-    if (x6) {
+    if (fusedf && RCED_T_L1X6 && blk > 0) {
+      // layer 1 on the bf16 pipe (kernels_fused_v3_l23.h, layer1_x6): main pass [chunk c][part][lane] x 8 bf16, row = channel lane & 15,
+      // k-slot 8kq + e = (tap 4c + kq, channel e); remainder pass [chunk c][part][lane] x 8 bf16, row i = (phase r = i >> 1, channel
+      // 16 + (i & 1)), k-slot = (window tap u = 4c + kq, channel e), frequency tap = u - r
+      unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int i = lane & 15, kq = lane >> 4;
+          for (int c = 0; c < 3; ++c) {
+            const int tap = 4 * c + kq;
+            const size_t base = (size_t)(c * 3) * 512 + lane * 8 + e;
+            split3(tap < 9 ? wq(l1, tap, e, i, 8) : 0.f, &d16[base], &d16[base + 512], &d16[base + 1024]);
+          }
+          for (int c = 0; c < 4; ++c) {
+            const int r = i >> 1, co = 16 + (i & 1), tap = 4 * c + kq - r;
+            const size_t base = (size_t)(9 + c * 3) * 512 + lane * 8 + e;
+            split3((tap >= 0 && tap < 9) ? wq(l1, tap, e, co, 8) : 0.f, &d16[base], &d16[base + 512], &d16[base + 1024]);
+          }
+        }
+      put_shift(dst + v3::kG1XMain + v3::kG1XRem, 3 * blk + 0);
+      dst += v3::kG1X;
+    } else if (x6) {
       // register images [j][lane][4 floats]: float 4j + q of a lane = its fragment of K-step 4j + q (block 0) or element
       // (4j + q) & 1 of K-step (4j + q) >> 1 (blocks 1..4)
       for (int lane = 0; lane < 64; ++lane) {

@@ -69,6 +69,9 @@
                           // once); 0 = one M-tile of tiles j + 4t (36 registers, every B fragment read by two waves: the layer is bound by the
                           // LDS then -- A/B on one box 8.36 against 8.18 ms)
 #endif
+#ifndef RCED_T_L1X6
+#define RCED_T_L1X6 0     // fused form: blocks 1..4's layer 1 (8 -> 18) on the bf16 pipe too, its input as bf16 planes with 16-byte rows
+#endif
 #ifndef RCED_T_L1SWAP
 #define RCED_T_L1SWAP 1
 #endif
@@ -265,12 +268,20 @@ constexpr int kL3MT = 5;                                   // M-tiles of layer-3
 constexpr int kW3TData = kL3MT * 3 * 256;                  // floats: [M-tile][part h, m, l][lane] x 8 bf16
 constexpr int kW3T = kW3TData + kShiftPerLayer;            // 3872
 constexpr int kTBlock = kG1 + kG2 + kW3T;
-constexpr int kTTotal = 5 * kTBlock;
+// layer 1 of blocks 1..4 in the three-part form (RCED_T_L1X6): main pass [chunk 3][part 3][lane] x 8 bf16 (k-slot 8kq + e = tap 4c + kq,
+// channel e; taps 9..11 zero), remainder pass [chunk 4][part 3][lane] x 8 bf16 (rows = 8 phases x channels 16, 17; k-slot = window tap
+// 4c + kq, channel e), 32 shifts
+constexpr int kG1XMain = 9 * 256, kG1XRem = 12 * 256;
+constexpr int kG1X = kG1XMain + kG1XRem + kShiftPerLayer;
+constexpr int kTBlockX = kG1X + kG2 + kW3T;                 // blocks 1..4 (block 0's first layer keeps the fp32 images)
+constexpr int kTTotal = RCED_T_L1X6 ? kTBlock + 4 * kTBlockX : 5 * kTBlock;
+constexpr int kB8PlaneBytes = kB8Rows * 16;                 // one bf16 plane of the 8-channel tensor: [pixel][8] = 16-byte rows
 template <>
 struct Map<2> {
   static constexpr bool X6 = true, kX6 = true, kFused = true;
   static constexpr int kB8Off = 0;
-  static constexpr int kB18Off = kB8Off + kB8Rows * kB8S;
+  static constexpr bool kL1X6 = RCED_T_L1X6 != 0;
+  static constexpr int kB18Off = kB8Off + (kL1X6 ? 3 * kB8PlaneBytes / 4 : kB8Rows * kB8S);
   // B18 here: three blocks (h, m, l), each = the plane [pixel][16] bf16 (32-byte rows) followed by the remainder channels' rows
   // [c16 c17] (4 bytes per pixel).  With the same stride between the parts of both, the last K = 32 chunk of layer 2 is, for EVERY
   // lane, four consecutive dwords from one per-lane address (lower lanes: tap 4 of the plane; upper lanes: the remainder channels'
@@ -299,14 +310,18 @@ struct Map<2> {
   static_assert((kFin128Off * 4) % 16 == 0 && (kEdgeOff * 4) % 16 == 0, "aligned buffers");
   // decode_final's partial sums (8 waves x 2 column tiles x 1 KiB) lie in B8, dead from block 4's layer 1 to the next tile's block 0
   // (whose layers 2 + 3 rewrite every real pixel): 4 KiB in the rows of each frame's first 103 bins, never a gap row
-  static constexpr int finscr0(int w) { return (kB8Off + (kB8Pad + kS * (w >> 1)) * kB8S) * 4 + 8 * ((w >> 1) & 1) + (w & 1) * 2048; }
+  // (planes: 2 KiB in the first 128 rows of frame w % 4 of plane w / 4)
+  static constexpr int finscr0(int w) {
+    return kL1X6 ? kB8Off * 4 + (w >> 2) * kB8PlaneBytes + (kB8Pad + kS * (w & 3)) * 16
+                 : (kB8Off + (kB8Pad + kS * (w >> 1)) * kB8S) * 4 + 8 * ((w >> 1) & 1) + (w & 1) * 2048;
+  }
   static constexpr int kFinScrCt = 1024;
   static constexpr int kT1R = 128 * kB8S * 4, kT1W = 128 * 32;
   static constexpr int kT2R = 0, kT2W = 0, kT3R = 0, kT3W = 0;   // (other forms' layers)
   static constexpr int kTileB18 = 16 * 32;
 };
 typedef Map<2> MapT;
-static_assert(MapT::finscr0(7) % 16 == 0 && MapT::finscr0(2) % 16 == 0 && MapT::finscr0(1) + 2048 <= (kB8Pad + kF) * kB8S * 4, "decode_final's partial sums: 16-byte aligned, inside real rows of B8");
+static_assert(MapT::finscr0(7) % 16 == 0 && MapT::finscr0(2) % 16 == 0 && (MapT::kL1X6 || MapT::finscr0(1) + 2048 <= (kB8Pad + kF) * kB8S * 4), "decode_final's partial sums: 16-byte aligned, inside real rows of B8");
 static_assert(kW3T % 4 == 0 && kG2 + kW3T <= 2 * kWRegion, "layer 3's fused-form packet: 16-byte pieces, inside a weight region");
 
 // ---- decode_final (1x129, 8 -> 1, no BN, no ReLU; model.py:89-90) inside the kernel ----------------------------
@@ -517,6 +532,7 @@ struct Lane {
   unsigned wr1rl;
   unsigned rd2, rd2b, rd2t, rd2tb, wr2; // layer 2 tile `wave` (/ + 8): B18 window start (b64 steps / tail), B30 output (F32 form)
   unsigned rd2m, rd2r, rd2rl;           // X6 form: this lane's fragment of chunk 0 in the h plane; its remainder rows ([h m] / [l])
+  unsigned rd1x, rd1xb, rd1xr, wr3p;    // fused form, layer 1 on the bf16 pipe: B8 plane row of main tile `role` (/ + 8) / remainder tile xr0, chunk 0; layers 2 + 3's output row
   unsigned rd2c, rd2cs;                 // fused form: this lane's four dwords of the last chunk (h part) and their byte stride from tile to tile
   unsigned rd3, rd3b, rd3t, rd3tb, wr3; // layer 3 pair tile `wave` (/ + 8): B30 window start (b64 steps / tail), B8 output
   unsigned wh0, wh1, whx;  // block 4's layer 3: where this lane's output pixel of pair tile 0 / 1 / 16 goes in the H image
@@ -581,6 +597,14 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   L.rd3t = L.rd3 + 4 * (8 * kL3Steps - kq);                 // K = 300: tail k = 296 + kq, all four real
   L.wr3 = B8 + 4 * ((2 * px0 + (kq >> 1)) * kB8S + 4 * (kq & 1));
   if constexpr (M::kFused) L.wr3 = B8 + 4 * ((kS * (wave & 3) + 64 * (wave >> 2) + n) * kB8S + 2 * kq);   // channels 2kq, 2kq+1 of this lane's pixel
+  if constexpr (M::kFused) {   // the 8-channel tensor as bf16 planes, row = pixel + kB8Pad; chunk c of layer 1 = taps 4c + kq = rows pixel - 4 + 4c + kq
+    const unsigned B8P = lds_addr(lds + M::kB8Off);
+    L.rd1x = B8P + (px0 - 4 + kq + kB8Pad) * 16;
+    L.rd1xb = L.rd1x + 128 * 16;
+    L.rd1xr = B8P + (rpx - 4 + kq + kB8Pad) * 16;
+    L.wr3p = B8P + (kS * (wave & 3) + 64 * (wave >> 2) + n + kB8Pad) * 16 + 4 * kq;
+    asm volatile("" : "+v"(L.rd1x), "+v"(L.rd1xb), "+v"(L.rd1xr), "+v"(L.wr3p));
+  }
   {
     const unsigned H = lds_addr(lds + M::kHOff);
     auto haddr = [&](int px) {   // px: tile-flat pixel of frame px / kS, bin px % kS
@@ -1779,10 +1803,11 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
   // piece k = 0..16 of a block's register-resident weights (X6 form; g = that block's images): layer 1's main pass (k < 7),
   // layer 2's M-tile of this wave (7..16).  (Layer 1's remainder pass, 8 more pieces for waves 4..7: inside layer 1.)
   const wrsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wpack), 0, (M::kFused ? kTTotal : M::kX6 ? kGTotal : kWTotal) * 4, 0x00020000);
-  auto wload = [&](auto kc, int g, unsigned voff) {   // g: float offset of the block's images in the stream
+  constexpr bool kL1X = M::kFused && RCED_T_L1X6;   // blocks 1..4's layer 1 on the bf16 pipe: their layer-1 images are kG1X floats, block 0's kG1
+  auto wload = [&](auto kc, int g, unsigned voff, int g1size = kG1) {   // g: float offset of the block's images in the stream
     constexpr int k = decltype(kc)::value;
     if constexpr (k < 7) a1_load_one<k>(A1, wrs, g, voff);
-    else if constexpr (k < 17) a2_load_one<k - 7>(A2, wrs, g + kG1, RCED_L2_BOTH ? 0 : wave >> 2, voff);
+    else if constexpr (k < 17) a2_load_one<k - 7>(A2, wrs, g + g1size, RCED_L2_BOTH ? 0 : wave >> 2, voff);
   };
   if constexpr (M::kX6) {
     const unsigned voff = (unsigned)lane * 16u;
@@ -1836,15 +1861,19 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
 
     // Layer 3 of block BLK < 4 inside the loop, block 4's behind it: decode_final's operands (36 registers of A fragments)
     // are fetched in front of THAT instance only; declared outside a five-iteration loop they were live through all of it.
-#pragma unroll 1
-    for (int blk = 0;; ++blk) {
+    // The layer-1 section of block blk (with the other forms' layer 2 behind it).  WHICH: 1 = block 0's first layer, 0 = one of blocks
+    // 1..4, 2 = decided at run time.  With layer 1 on the bf16 pipe (kL1X) block 0's instance runs in FRONT of the block loop: its fp32
+    // fragments (A1, loaded at the end of the previous tile) would otherwise be live through all five iterations.
+    A1X A1x;
+    auto l1_section = [&](auto whichc, int blk) __attribute__((always_inline)) {
+      constexpr int which = decltype(whichc)::value;
       {  // ---- layer 1: (8x9, 1->18) for block 0, (1x9, 8->18) otherwise
         STAMP_BEGIN();
         const unsigned wb = lds_addr(WREG(wcur));
         // What is fetched for later once the layer's first operand reads are in flight.  F32 form: layer 2's packet.  X6 form:
         // layer 3's packet (its one LDS region is dead until then).
         auto dma = [&] {
-          if constexpr (M::kFused) packet_dma<kG2 + kW3T>(wsrc + kG1, WREG(0), wave, lane);   // layer 2's and layer 3's images, adjacent in the stream
+          if constexpr (M::kFused) packet_dma<kG2 + kW3T>(wsrc + (kL1X && blk > 0 ? kG1X : kG1), WREG(0), wave, lane);   // layer 2's and layer 3's images, adjacent in the stream
           else if constexpr (M::kX6) packet_dma<kW3>(wsrc + kG1 + kG2, WREG(0), wave, lane);
           else packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
         };
@@ -1870,8 +1899,21 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
           if constexpr (M::kX6 && (!M::kFused || RCED_T_A2REG >= 2) && RCED_L2_BOTH && !(RCED_X6_EXP & 2))
             static_for<0, 10>([&](auto kc) { a2_load_one<decltype(kc)::value, kL2MT - 1>(A2, wrs, gofs + kG1, 1, voff1); });
         };
-        if (blk == 0) layer1<M, true>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);
-        else layer1<M, false>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);
+        A1XRem A1xr;
+        auto sp1x = [&](auto kc) {   // blocks 1..4 with layer 1 on the bf16 pipe: k < 12: the remainder pass's fragments; 12..20: layer 2's M-tile 0
+          constexpr int k = decltype(kc)::value;
+          if constexpr (kL1X) {
+            if constexpr (k < 12) a1x_load_rem_one<k>(A1xr, wrs, gofs, voff1);
+            else if constexpr (k < 21 && RCED_T_A2REG >= 1) wload(IC<k - 12 + 7>{}, gofs, voff1, kG1X);
+          }
+        };
+        if constexpr (kL1X) {
+          if constexpr (which == 1) layer1<M, true>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);
+          else layer1_x6<M>(L, A1x, A1xr, w1, dma, sp1x DET_PASS);
+        } else {
+          if (blk == 0) layer1<M, true>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);
+          else layer1<M, false>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);
+        }
 
         if constexpr (!M::kX6) wcur ^= 1;
 #if RCED_STAMPS
@@ -1898,6 +1940,15 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
           layer_end_sync();
           STAMP_WAIT(1);
         }
+            }
+    };
+    if constexpr (kL1X) l1_section(IC<1>{}, 0);
+#pragma unroll 1
+    for (int blk = 0;; ++blk) {
+      if constexpr (kL1X) {
+        if (blk > 0) l1_section(IC<0>{}, blk);
+      } else {
+        l1_section(IC<2>{}, blk);
       }
       if (blk == 4) break;
       if constexpr (M::kFused) {   // ---- layers 2 + 3 as one stream (kernels_fused_v3_l23.h); the next layer 1's main-pass fragments ride in its last slots
@@ -1906,8 +1957,15 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
         const unsigned voff = (unsigned)opaque(lane) * 16u;
         auto sp = [&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          if constexpr (2 * j < 7) wload(IC<2 * j>{}, gofs + kBlockFloats, voff);
-          if constexpr (2 * j + 1 < 7) wload(IC<2 * j + 1>{}, gofs + kBlockFloats, voff);
+          if constexpr (kL1X) {   // the next block's layer 1 (always one of blocks 1..4 here): eleven pieces over the five slots
+            const int gn = gofs + (blk == 0 ? kTBlock : kTBlockX);
+            if constexpr (2 * j < 11) a1x_load_one<2 * j>(A1x, wrs, gn, voff);
+            if constexpr (2 * j + 1 < 11) a1x_load_one<2 * j + 1>(A1x, wrs, gn, voff);
+            if constexpr (j == 4) a1x_load_one<10>(A1x, wrs, gn, voff);
+          } else {
+            if constexpr (2 * j < 7) wload(IC<2 * j>{}, gofs + kBlockFloats, voff);
+            if constexpr (2 * j + 1 < 7) wload(IC<2 * j + 1>{}, gofs + kBlockFloats, voff);
+          }
         };
         layer23<M, false>(P, L, lds0, lds_addr(WREG(0)), A2, blk, wave, 0x80000000u | epoch, sk1, sk2, sp DET_PASS);
         STAMP_MATH(2);
@@ -1934,8 +1992,8 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
         layer_end_sync();
         STAMP_WAIT(2);
       }
-      wsrc += kBlockFloats;
-      gofs += kBlockFloats;
+      wsrc += kL1X && blk > 0 ? kTBlockX : kBlockFloats;
+      gofs += kL1X && blk > 0 ? kTBlockX : kBlockFloats;
     }
     FinA finA;
     if constexpr (M::kFused) {   // ---- block 4's layers 2 + 3; decode_final's A fragments ride in its last slots, the next tile's input rows in front

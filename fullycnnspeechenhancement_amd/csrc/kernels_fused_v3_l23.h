@@ -225,7 +225,16 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
       sk1[t] = blk == 0 ? v : sk1[t];
       sk2[t] = blk == 1 ? v : sk2[t];
     }
-    if (t < 4 || vbit(L, kVN0)) lds_st<f32x2>(LAST ? L.wh0 : L.wr3, t * (16 * kB8S * 4), v);
+    if constexpr (RCED_T_L1X6 && !LAST) {   // the next layer 1 runs on the bf16 pipe: its input as three bf16 planes, 16-byte rows
+      const P3 p = split2(v.x, v.y);
+      if (t < 4 || vbit(L, kVN0)) {
+        lds_st<unsigned>(L.wr3p, t * 256, p.h);
+        lds_st<unsigned>(L.wr3p, t * 256 + kB8PlaneBytes, p.m);
+        lds_st<unsigned>(L.wr3p, t * 256 + 2 * kB8PlaneBytes, p.l);
+      }
+    } else {
+      if (t < 4 || vbit(L, kVN0)) lds_st<f32x2>(LAST ? L.wh0 : L.wr3, t * (16 * kB8S * 4), v);
+    }
   };
   static_assert(kHS == kB8S, "one tile stride for both destinations");
   const unsigned edge = lds0 + 4 * M::kEdgeOff + fr * 1024 + L.a8, eflag = lds0 + 4 * M::kEdgeFlagOff + fr * 8;
@@ -350,4 +359,157 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
     if (RCED_T_PRIO) __builtin_amdgcn_s_setprio(0);
   }
   DET(3);
+}
+
+
+// ---- layer 1 of blocks 1..4 (1x9, 8 -> 18) on the bf16 pipe (RCED_T_L1X6) --------------------------------------------------
+// Input: the 8-channel tensor as three bf16 planes [pixel][8] (16-byte rows: one pixel's channels = one octet of the K axis),
+// written by layers 2 + 3's epilogue.  K = 72 in three K = 32 chunks: k-slot 8kq + e = tap 4c + kq, channel e (taps 9..11: zero
+// weights): a lane's B fragment of a chunk is ONE aligned ds_read_b128 per part.  Channels 0..15 = one M-tile, 18 MFMAs per
+// 16-pixel tile; channels 16, 17 by the remainder pass (rows = 8 pixel phases x 2 channels, K = 16 window taps x 8 channels = four
+// chunks, 24 MFMAs per 128 pixels; its column stride of 8 pixels = 128 bytes makes its twelve reads per tile 8-way bank
+// conflicted: 60 reads per layer).  A fragments in registers (36; remainder pass 48, roles 4..7), from global memory.
+struct A1X {
+  s16x8 a[3][3];   // [chunk][part]
+  f32x4 sh;        // shift[4kq .. 4kq+3]
+  f32x2 s2;        // shift[16], shift[17]
+};
+struct A1XRem {
+  s16x8 r[4][3];
+};
+template <int I>   // piece I of eleven: 0..8 = a[I / 3][I % 3], 9 = sh, 10 = s2
+__device__ __forceinline__ void a1x_load_one(A1X& A, wrsrc_t rs, int g1, unsigned voff) {
+  if constexpr (I < 9) A.a[I / 3][I % 3] = bld<s16x8>(rs, voff, g1 + I * 256);
+  else if constexpr (I == 9) A.sh = bld<f32x4>(rs, (voff >> 4) & 0x30u, g1 + kG1XMain + kG1XRem);
+  else A.s2 = bld<f32x2>(rs, 0u, g1 + kG1XMain + kG1XRem + 16);
+}
+template <int I>   // piece I of twelve
+__device__ __forceinline__ void a1x_load_rem_one(A1XRem& A, wrsrc_t rs, int g1, unsigned voff) {
+  A.r[I / 3][I % 3] = bld<s16x8>(rs, voff, g1 + kG1XMain + I * 256);
+}
+__device__ __forceinline__ Parts b8_load(unsigned rd, int off) {
+  Parts b;
+  b.h = lds_ld<s16x8>(rd, off);
+  b.m = lds_ld<s16x8>(rd, off + kB8PlaneBytes);
+  b.l = lds_ld<s16x8>(rd, off + 2 * kB8PlaneBytes);
+  return b;
+}
+
+// `dma`; `sp(IC<k>)`, k < 21 (k < 12: the remainder pass's pieces, 12..20: layer 2's M-tile 0), seven per slot of the first pair's three
+// slots; `role`: the wave's role in layer 1 (see the kernel)
+template <class M, class Dma, class Sp>
+__device__ __forceinline__ void layer1_x6(const Lane& L, const A1X& A, const A1XRem& AR, int role, Dma dma, Sp sp DET_ARG) {
+  DET_BEGIN();
+  constexpr int kTW = M::kT1W, kTR = 128 * 16;   // byte strides between a wave's regular tiles (8 tiles = 128 pixels): B18 output / B8 input rows
+  auto pre = once(dma);
+  // ---- pairs of regular tiles (role, role+8), (role+16, role+24): slot = one chunk of one pair = 12 MFMAs on two chains;
+  //      pair 0's stores ride between pair 1's MFMAs.  Role 7 has only the first pair.
+  {
+    Parts b[2];        // one buffer per tile: the next slot's fragments are read behind this slot's MFMAs, into the registers they have
+                       // just been issued from (a ring of two was 24 registers more, and the kernel spilled its skip registers for them)
+    f32x4 acc[2][2];   // [pair][tile]
+    const bool two = role != 7;
+    const bool g1 = tile_has_gap(role + 8), g2 = tile_has_gap(role + 16), g3 = tile_has_gap(role + 24);
+    auto ld = [&](auto ic) {
+      constexpr int i = decltype(ic)::value, p = i / 3, c = i % 3;
+      b[0] = b8_load(L.rd1x, 2 * p * kTR + 64 * c);
+      b[1] = b8_load(L.rd1xb, 2 * p * kTR + 64 * c);
+    };
+    auto slot = [&](auto ic) {
+      constexpr int i = decltype(ic)::value, p = i / 3, c = i % 3;
+      if constexpr (c == 0) acc[p][0] = acc[p][1] = A.sh;
+      mma2(A.a[c], b[0], acc[p][0], A.a[c], b[1], acc[p][1]);
+      if constexpr (p == 0) {
+        static_for<0, 4>([&](auto qc) { sp(IC<4 * i + decltype(qc)::value>{}); });
+        static_for<0, 3>([&](auto qc) { sp(IC<12 + 3 * i + decltype(qc)::value>{}); });
+      }
+      if constexpr (p == 1 && c == 0) l1_store<M>(L, acc[0][0], L.wr1, 0, false, kVMain);
+      if constexpr (p == 1 && c == 1) l1_store<M>(L, acc[0][1], L.wr1, kTW, g1, kVMain + 1);
+      interleave<12, 3>();
+    };
+    ld(IC<0>{});
+    pin();
+    pre();
+    pin();
+    static_for<0, 3>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      slot(ic);
+      pin();
+      if constexpr (i < 2) ld(IC<i + 1>{});
+      else if (two) ld(IC<3>{});
+      pin();
+    });
+    if (two) {
+      static_for<3, 6>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        slot(ic);
+        pin();
+        if constexpr (i < 5) ld(IC<i + 1>{});
+        pin();
+      });
+      l1_store<M>(L, acc[1][0], L.wr1, 2 * kTW, g2, kVMain + 2);
+      l1_store<M>(L, acc[1][1], L.wr1, 3 * kTW, g3, kVMain + 3);
+    } else {
+      l1_store<M>(L, acc[0][0], L.wr1, 0, false, 0);          // tiles 7, 15: no gap pixels
+      l1_store<M>(L, acc[0][1], L.wr1, kTW, false, 0);
+    }
+  }
+  DET(6);
+  // ---- the single main tile: roles 0 / 1 -> tile 32 / 31 (no gap pixels); role 7 -> its third regular tile (23)
+  if (role < 2 || role == 7) {
+    const int dt = role == 0 ? 32 : role == 1 ? 30 : 16;   // tiles away from regular tile `role`
+    const unsigned rd = L.rd1x + dt * 256;
+    Parts b[2];
+    f32x4 acc = A.sh;
+    b[0] = b8_load(rd, 0);
+    pin();
+    static_for<0, 3>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if constexpr (c < 2) b[(c + 1) & 1] = b8_load(rd, 64 * (c + 1));
+      pin();
+      acc = l2x_mma(A.a[c], b[c & 1], acc);
+      pin();
+    });
+    l1_store<M>(L, acc, L.wr1 + dt * M::kTileB18, 0, false, 0);
+  }
+  DET(5);
+  // ---- remainder tiles: roles 4, 5, 6 -> tiles 0, 1, 2; role 7 -> tiles 3 and 4
+  {
+    const int nrem = role < 4 ? 0 : role == 7 ? 2 : 1;
+    unsigned rdr = L.rd1xr, wrr = L.wr1r;
+    int xr = role == 7 ? 3 : role - 4, vb = kVRem;
+    const f32x4 init = {A.s2.x, A.s2.y, A.s2.x, A.s2.y};
+#pragma unroll 1
+    for (int r = 0; r < nrem; ++r) {
+      Parts b[2];
+      f32x4 acc = init;
+      b[0] = b8_load(rdr, 0);
+      pin();
+      static_for<0, 4>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (c < 3) b[(c + 1) & 1] = b8_load(rdr, 64 * (c + 1));
+        pin();
+        acc = l2x_mma(AR.r[c], b[c & 1], acc);
+        pin();
+      });
+      const f32x4 v = relu4(acc);   // rows 4kq+jj = (phase 2kq + (jj>>1), channel 16 + (jj&1)): two pixels x channels 16,17
+      const bool va = xr == 0 || vbit(L, vb), vbb = xr == 0 || vbit(L, vb + 1);
+      const P3 pa = split2(v.x, v.y), pb = split2(v.z, v.w);
+      if (va) {
+        lds_st<unsigned>(wrr, 0, pa.h);
+        lds_st<unsigned>(wrr, M::kPlaneBytes, pa.m);
+        lds_st<unsigned>(wrr, 2 * M::kPlaneBytes, pa.l);
+      }
+      if (vbb) {
+        lds_st<unsigned>(wrr, 4, pb.h);
+        lds_st<unsigned>(wrr, M::kPlaneBytes + 4, pb.m);
+        lds_st<unsigned>(wrr, 2 * M::kPlaneBytes + 4, pb.l);
+      }
+      wrr += 128 * 4;
+      rdr += 128 * 16;
+      xr += 1;
+      vb += 2;
+    }
+  }
+  DET(4);
 }
