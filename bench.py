@@ -65,7 +65,9 @@ def forward_flops_by_pipe(spec, variant, kernel, dtype="f32", v3_l2x6=2):
     if kernel == "conv_layer_generic":
         return {"mfma_f32": sum(fl)}            # direct fp32 FMA on the vector ALU: same 157.3 ceiling
     if variant == 3:                            # one kernel, all 16 layers; in the x6 form: the five 18 -> 30 layers (option v3_l2x6 = 1)
-        on_x6 = {0: (), 1: ((18, 30),), 2: ((18, 30), (30, 8))}[int(v3_l2x6)]   # ... and the five 30 -> 8 layers behind them (2, the product)
+        # ... the five 30 -> 8 layers behind them and the four 8 -> 18 layers of blocks 1..4 too (2, the product; the first layer, 1 -> 18 over
+        # 8 x 9, stays on the fp32 MFMA)
+        on_x6 = {0: (), 1: ((18, 30),), 2: ((18, 30), (30, 8), (8, 18))}[int(v3_l2x6)]
         x6 = sum(f for f, l in zip(fl, spec.layers(3)) if (l.cin, l.cout) in on_x6)
         return {"mfma_f32": sum(fl) - x6, "mfma_bf16x6": x6}
     if kernel == "rced_final_gemm":             # R-CED's 1x129 output layer: x6::final_gemm_x6_kernel / chain16::final_gemm16_kernel
@@ -673,7 +675,7 @@ def main():
                         "flop_per_frame": kflops, "frames_per_forward": B * T,
                         "other_kernels_ms_per_step": {k: v[0] / args.steps for k, v in times.items() if k != dom and v[1]},
                         "note": "compute-bound path (7950 FLOP/B): peak = dense fp32 MFMA 157.3 TFLOP/s, not HBM.  CR-CED: the "
-                                "18->30 and 30->8 layers (pipe_mix.mfma_bf16x6 of the FLOPs) are computed at fp32 quality as six bf16 "
+                                "18->30, 30->8 and 8->18 layers (pipe_mix.mfma_bf16x6 of the FLOPs) are computed at fp32 quality as six bf16 "
                                 "MFMAs per product over three-part operands (DESIGN 3.1): `frac` = frac_fp32_peak stays quoted "
                                 "against the fp32 pipe's peak (SURVEY 8(d3)) and can exceed 1; frac_pipe_ceiling prices every layer "
                                 "against the pipe it runs on (386 TFLOP/s measured for the six-product form); "

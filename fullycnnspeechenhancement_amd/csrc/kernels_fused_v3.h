@@ -70,7 +70,8 @@
                           // LDS then -- A/B on one box 8.36 against 8.18 ms)
 #endif
 #ifndef RCED_T_L1X6
-#define RCED_T_L1X6 0     // fused form: blocks 1..4's layer 1 (8 -> 18) on the bf16 pipe too, its input as bf16 planes with 16-byte rows
+#define RCED_T_L1X6 1     // fused form: blocks 1..4's layer 1 (8 -> 18) on the bf16 pipe too, its input as bf16 planes with 16-byte rows (0: on the fp32
+                          // MFMA as the first layer, reading the 8-channel tensor as fp32 [pixel][10]: 6.43 against 6.15 ms)
 #endif
 #ifndef RCED_T_L1SWAP
 #define RCED_T_L1SWAP 1
@@ -1864,7 +1865,6 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
     // The layer-1 section of block blk (with the other forms' layer 2 behind it).  WHICH: 1 = block 0's first layer, 0 = one of blocks
     // 1..4, 2 = decided at run time.  With layer 1 on the bf16 pipe (kL1X) block 0's instance runs in FRONT of the block loop: its fp32
     // fragments (A1, loaded at the end of the previous tile) would otherwise be live through all five iterations.
-    A1X A1x;
     auto l1_section = [&](auto whichc, int blk) __attribute__((always_inline)) {
       constexpr int which = decltype(whichc)::value;
       {  // ---- layer 1: (8x9, 1->18) for block 0, (1x9, 8->18) otherwise
@@ -1899,17 +1899,13 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
           if constexpr (M::kX6 && (!M::kFused || RCED_T_A2REG >= 2) && RCED_L2_BOTH && !(RCED_X6_EXP & 2))
             static_for<0, 10>([&](auto kc) { a2_load_one<decltype(kc)::value, kL2MT - 1>(A2, wrs, gofs + kG1, 1, voff1); });
         };
-        A1XRem A1xr;
-        auto sp1x = [&](auto kc) {   // blocks 1..4 with layer 1 on the bf16 pipe: k < 12: the remainder pass's fragments; 12..20: layer 2's M-tile 0
+        auto sp1x = [&](auto kc) {   // blocks 1..4 with layer 1 on the bf16 pipe: k = 12..20: layer 2's M-tile 0 (three loads per slot)
           constexpr int k = decltype(kc)::value;
-          if constexpr (kL1X) {
-            if constexpr (k < 12) a1x_load_rem_one<k>(A1xr, wrs, gofs, voff1);
-            else if constexpr (k < 21 && RCED_T_A2REG >= 1) wload(IC<k - 12 + 7>{}, gofs, voff1, kG1X);
-          }
+          if constexpr (kL1X && k >= 12 && k < 21 && RCED_T_A2REG >= 1) wload(IC<k - 12 + 7>{}, gofs, voff1, kG1X);
         };
         if constexpr (kL1X) {
           if constexpr (which == 1) layer1<M, true>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);
-          else layer1_x6<M>(L, A1x, A1xr, w1, dma, sp1x DET_PASS);
+          else layer1_x6l<M>(L, lds0, w1, dma, sp1x DET_PASS);
         } else {
           if (blk == 0) layer1<M, true>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);
           else layer1<M, false>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);
@@ -1957,17 +1953,15 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
         const unsigned voff = (unsigned)opaque(lane) * 16u;
         auto sp = [&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          if constexpr (kL1X) {   // the next block's layer 1 (always one of blocks 1..4 here): eleven pieces over the five slots
-            const int gn = gofs + (blk == 0 ? kTBlock : kTBlockX);
-            if constexpr (2 * j < 11) a1x_load_one<2 * j>(A1x, wrs, gn, voff);
-            if constexpr (2 * j + 1 < 11) a1x_load_one<2 * j + 1>(A1x, wrs, gn, voff);
-            if constexpr (j == 4) a1x_load_one<10>(A1x, wrs, gn, voff);
-          } else {
+          if constexpr (!kL1X) {   // (with layer 1 on the bf16 pipe its images travel by LDS-DMA: dma1 below)
             if constexpr (2 * j < 7) wload(IC<2 * j>{}, gofs + kBlockFloats, voff);
             if constexpr (2 * j + 1 < 7) wload(IC<2 * j + 1>{}, gofs + kBlockFloats, voff);
           }
         };
-        layer23<M, false>(P, L, lds0, lds_addr(WREG(0)), A2, blk, wave, 0x80000000u | epoch, sk1, sk2, sp DET_PASS);
+        auto dma1 = [&] {   // layer 1 on the bf16 pipe: the next block's layer-1 image into the (now dead) input-row area and the H image's bins
+          if constexpr (kL1X) a1x_dma<M>(wsrc + (blk == 0 ? kTBlock : kTBlockX), lds, wave, lane);
+        };
+        layer23<M, false>(P, L, lds0, lds_addr(WREG(0)), A2, blk, wave, 0x80000000u | epoch, sk1, sk2, sp, dma1 DET_PASS);
         STAMP_MATH(2);
         layer_end_sync();
         STAMP_WAIT(2);
@@ -2007,7 +2001,7 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
 #pragma unroll
         for (int q = s0; q < s1; ++q) finA.a[q] = src[q * 64];
       };
-      layer23<M, true>(P, L, lds0, lds_addr(WREG(0)), A2, 4, wave, 0x80000000u | epoch, sk1, sk2, sp DET_PASS);
+      layer23<M, true>(P, L, lds0, lds_addr(WREG(0)), A2, 4, wave, 0x80000000u | epoch, sk1, sk2, sp, [] {} DET_PASS);
       STAMP_MATH(2);
       layer_end_sync();
       STAMP_WAIT(2);

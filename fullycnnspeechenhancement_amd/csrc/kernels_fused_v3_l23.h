@@ -96,9 +96,10 @@ __device__ __forceinline__ void shift_add(f32x4 pj, float& p0, float& p1, float&
 
 // `sp(IC<j>)`, j < 5: called once from each layer-3 slot of the wave's LAST job (by then layer 2's operand registers are free):
 // the register-bound loads of what comes next.
-template <class M, bool LAST, class Sp>
+// `dma1()`: called once, behind the first operand reads (RCED_T_L1X6: the next layer 1's images, LDS-DMA'd into areas that are dead now)
+template <class M, bool LAST, class Sp, class Dma1>
 __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned lds0, unsigned wbase, const A2Regs& A, int blk, int wave,
-                                        unsigned tag, f32x2 (&sk1)[5], f32x2 (&sk2)[5], Sp sp DET_ARG) {
+                                        unsigned tag, f32x2 (&sk1)[5], f32x2 (&sk2)[5], Sp sp, Dma1 dma1 DET_ARG) {
   DET_BEGIN();
   const bool right = wave >= 4;
   const int fr = wave & 3;
@@ -329,6 +330,8 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
   // ---- the stream.  Waves 0..3: tiles 0..3 of frame fr (X0 X1 X2 YY01 X3 YY23); waves 4..7: tiles 4..8 (X0 X1 X2 YY01 X3 X4 YY23 Y4)
   ldX(i0, i0);
   pin();
+  dma1();
+  pin();
   runX(i0, i0, none);
   runX(i1, i0, none);
   runX(i2, i1, none);
@@ -368,25 +371,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
 // weights): a lane's B fragment of a chunk is ONE aligned ds_read_b128 per part.  Channels 0..15 = one M-tile, 18 MFMAs per
 // 16-pixel tile; channels 16, 17 by the remainder pass (rows = 8 pixel phases x 2 channels, K = 16 window taps x 8 channels = four
 // chunks, 24 MFMAs per 128 pixels; its column stride of 8 pixels = 128 bytes makes its twelve reads per tile 8-way bank
-// conflicted: 60 reads per layer).  A fragments in registers (36; remainder pass 48, roles 4..7), from global memory.
-struct A1X {
-  s16x8 a[3][3];   // [chunk][part]
-  f32x4 sh;        // shift[4kq .. 4kq+3]
-  f32x2 s2;        // shift[16], shift[17]
-};
-struct A1XRem {
-  s16x8 r[4][3];
-};
-template <int I>   // piece I of eleven: 0..8 = a[I / 3][I % 3], 9 = sh, 10 = s2
-__device__ __forceinline__ void a1x_load_one(A1X& A, wrsrc_t rs, int g1, unsigned voff) {
-  if constexpr (I < 9) A.a[I / 3][I % 3] = bld<s16x8>(rs, voff, g1 + I * 256);
-  else if constexpr (I == 9) A.sh = bld<f32x4>(rs, (voff >> 4) & 0x30u, g1 + kG1XMain + kG1XRem);
-  else A.s2 = bld<f32x2>(rs, 0u, g1 + kG1XMain + kG1XRem + 16);
-}
-template <int I>   // piece I of twelve
-__device__ __forceinline__ void a1x_load_rem_one(A1XRem& A, wrsrc_t rs, int g1, unsigned voff) {
-  A.r[I / 3][I % 3] = bld<s16x8>(rs, voff, g1 + kG1XMain + I * 256);
-}
+// conflicted: 60 reads per layer).
 __device__ __forceinline__ Parts b8_load(unsigned rd, int off) {
   Parts b;
   b.h = lds_ld<s16x8>(rd, off);
@@ -395,34 +380,72 @@ __device__ __forceinline__ Parts b8_load(unsigned rd, int off) {
   return b;
 }
 
-// `dma`; `sp(IC<k>)`, k < 21 (k < 12: the remainder pass's pieces, 12..20: layer 2's M-tile 0), seven per slot of the first pair's three
-// slots; `role`: the wave's role in layer 1 (see the kernel)
+// ---- its A fragments live in LDS ---------------------------------------------------------------------------------------------
+// The 21 one-KiB pieces of a block's layer-1 image (main pass 9, remainder pass 12) + its shifts are LDS-DMA'd during the PREVIOUS
+// block's layers 2 + 3 into areas that are dead from then until this layer 1 has run: the input rows of the first layer (pieces 0..4 +
+// the shifts) and the bins of decode_final's image (four pieces per frame; its zero pads are not touched).  No weight registers at
+// all: a version with the fragments in registers (42 + 48, loaded from global memory like the first layer's) was parity-exact and
+// spilled (192 .. 336 B, the skip arrays reloaded inside the fused phase's epilogues: 7.7 ms against 6.15 for this one).
+template <class M>
+constexpr int a1x_off(int i) {   // byte offset of piece i from the start of LDS
+  return i < 5 ? M::kX0Off * 4 + i * 1024
+               : M::kHOff * 4 + (kHFrame * ((i - 5) / 4) + 64) * kHS * 4 + 8 * (((i - 5) / 4) & 1) + ((i - 5) % 4) * 1024;
+}
+template <class M>
+constexpr int a1x_shift_off() { return M::kX0Off * 4 + 5 * 1024; }
+static_assert(a1x_shift_off<MapT>() + 128 <= (MapT::kX0Off + kX0Floats) * 4 && a1x_off<MapT>(20) + 1024 <= (MapT::kHOff + (kHFrame * 3 + 64 + kF) * kHS) * 4 &&
+              a1x_off<MapT>(8) % 16 == 0 && a1x_off<MapT>(9) % 16 == 0 && a1x_off<MapT>(13) % 16 == 0 && a1x_off<MapT>(17) % 16 == 0,
+              "layer 1's LDS-resident images: inside the input-row area / the real bins of the H image, 16-byte aligned");
+// the DMA of one block's image (src = its first float in the weight stream): 22 chunks over the 8 waves
+template <class M>
+__device__ __forceinline__ void a1x_dma(const float* src, float* lds, int wave, int lane) {
+  lane = opaque(lane);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int ci = wave + 8 * k;
+    if (ci < 21) {
+      lds_dma16s(src + ci * 256, (unsigned)lane * 16u, lds + a1x_off<M>(ci) / 4);
+    } else if (ci == 21) {
+      if (lane < 8) lds_dma16s(src + 21 * 256, (unsigned)lane * 16u, lds + a1x_shift_off<M>() / 4);
+    }
+  }
+}
+template <class M, int I>
+__device__ __forceinline__ s16x8 a1x_ld(unsigned aX, unsigned aH) {   // aX / aH: this lane's 16 bytes in the input-row area / the H image
+  if constexpr (I < 5) return lds_ld<s16x8>(aX, I * 1024);
+  else return lds_ld<s16x8>(aH, a1x_off<M>(I) - M::kHOff * 4);
+}
 template <class M, class Dma, class Sp>
-__device__ __forceinline__ void layer1_x6(const Lane& L, const A1X& A, const A1XRem& AR, int role, Dma dma, Sp sp DET_ARG) {
+__device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int role, Dma dma, Sp sp DET_ARG) {
   DET_BEGIN();
-  constexpr int kTW = M::kT1W, kTR = 128 * 16;   // byte strides between a wave's regular tiles (8 tiles = 128 pixels): B18 output / B8 input rows
+  constexpr int kTW = M::kT1W, kTR = 128 * 16;
+  const unsigned aX = lds0 + M::kX0Off * 4 + L.scr, aH = lds0 + M::kHOff * 4 + L.scr;
+  const f32x4 sh = lds_ld<f32x4>(lds0 + a1x_shift_off<M>() + L.kq16, 0);
+  const f32x2 s2 = lds_ld<f32x2>(lds0 + a1x_shift_off<M>(), 64);
   auto pre = once(dma);
-  // ---- pairs of regular tiles (role, role+8), (role+16, role+24): slot = one chunk of one pair = 12 MFMAs on two chains;
-  //      pair 0's stores ride between pair 1's MFMAs.  Role 7 has only the first pair.
+  auto lda = [&](auto pc, s16x8 (&a)[3]) {   // the three parts of piece group G = pieces 3G..3G+2
+    constexpr int g = decltype(pc)::value;
+    a[0] = a1x_ld<M, 3 * g>(aX, aH);
+    a[1] = a1x_ld<M, 3 * g + 1>(aX, aH);
+    a[2] = a1x_ld<M, 3 * g + 2>(aX, aH);
+  };
   {
-    Parts b[2];        // one buffer per tile: the next slot's fragments are read behind this slot's MFMAs, into the registers they have
-                       // just been issued from (a ring of two was 24 registers more, and the kernel spilled its skip registers for them)
+    Parts b[2][2];
+    s16x8 a[2][3];
     f32x4 acc[2][2];   // [pair][tile]
     const bool two = role != 7;
     const bool g1 = tile_has_gap(role + 8), g2 = tile_has_gap(role + 16), g3 = tile_has_gap(role + 24);
     auto ld = [&](auto ic) {
       constexpr int i = decltype(ic)::value, p = i / 3, c = i % 3;
-      b[0] = b8_load(L.rd1x, 2 * p * kTR + 64 * c);
-      b[1] = b8_load(L.rd1xb, 2 * p * kTR + 64 * c);
+      lda(IC<c>{}, a[i & 1]);
+      b[i & 1][0] = b8_load(L.rd1x, 2 * p * kTR + 64 * c);
+      b[i & 1][1] = b8_load(L.rd1xb, 2 * p * kTR + 64 * c);
     };
     auto slot = [&](auto ic) {
       constexpr int i = decltype(ic)::value, p = i / 3, c = i % 3;
-      if constexpr (c == 0) acc[p][0] = acc[p][1] = A.sh;
-      mma2(A.a[c], b[0], acc[p][0], A.a[c], b[1], acc[p][1]);
-      if constexpr (p == 0) {
-        static_for<0, 4>([&](auto qc) { sp(IC<4 * i + decltype(qc)::value>{}); });
-        static_for<0, 3>([&](auto qc) { sp(IC<12 + 3 * i + decltype(qc)::value>{}); });
-      }
+      if constexpr (c == 0) acc[p][0] = acc[p][1] = sh;
+      mma2(a[i & 1], b[i & 1][0], acc[p][0], a[i & 1], b[i & 1][1], acc[p][1]);
+      if constexpr (p == 0) static_for<0, 3>([&](auto qc) { sp(IC<12 + 3 * i + decltype(qc)::value>{}); });
       if constexpr (p == 1 && c == 0) l1_store<M>(L, acc[0][0], L.wr1, 0, false, kVMain);
       if constexpr (p == 1 && c == 1) l1_store<M>(L, acc[0][1], L.wr1, kTW, g1, kVMain + 1);
       interleave<12, 3>();
@@ -433,66 +456,74 @@ __device__ __forceinline__ void layer1_x6(const Lane& L, const A1X& A, const A1X
     pin();
     static_for<0, 3>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      slot(ic);
-      pin();
       if constexpr (i < 2) ld(IC<i + 1>{});
       else if (two) ld(IC<3>{});
+      pin();
+      slot(ic);
       pin();
     });
     if (two) {
       static_for<3, 6>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        slot(ic);
-        pin();
         if constexpr (i < 5) ld(IC<i + 1>{});
+        pin();
+        slot(ic);
         pin();
       });
       l1_store<M>(L, acc[1][0], L.wr1, 2 * kTW, g2, kVMain + 2);
       l1_store<M>(L, acc[1][1], L.wr1, 3 * kTW, g3, kVMain + 3);
     } else {
-      l1_store<M>(L, acc[0][0], L.wr1, 0, false, 0);          // tiles 7, 15: no gap pixels
+      l1_store<M>(L, acc[0][0], L.wr1, 0, false, 0);
       l1_store<M>(L, acc[0][1], L.wr1, kTW, false, 0);
     }
   }
   DET(6);
-  // ---- the single main tile: roles 0 / 1 -> tile 32 / 31 (no gap pixels); role 7 -> its third regular tile (23)
-  if (role < 2 || role == 7) {
-    const int dt = role == 0 ? 32 : role == 1 ? 30 : 16;   // tiles away from regular tile `role`
+  if (role < 2 || role == 7) {   // the single main tile
+    const int dt = role == 0 ? 32 : role == 1 ? 30 : 16;
     const unsigned rd = L.rd1x + dt * 256;
     Parts b[2];
-    f32x4 acc = A.sh;
+    s16x8 a[2][3];
+    f32x4 acc = sh;
     b[0] = b8_load(rd, 0);
+    lda(IC<0>{}, a[0]);
     pin();
     static_for<0, 3>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
-      if constexpr (c < 2) b[(c + 1) & 1] = b8_load(rd, 64 * (c + 1));
+      if constexpr (c < 2) {
+        b[(c + 1) & 1] = b8_load(rd, 64 * (c + 1));
+        lda(IC<c + 1>{}, a[(c + 1) & 1]);
+      }
       pin();
-      acc = l2x_mma(A.a[c], b[c & 1], acc);
+      acc = l2x_mma(a[c & 1], b[c & 1], acc);
       pin();
     });
     l1_store<M>(L, acc, L.wr1 + dt * M::kTileB18, 0, false, 0);
   }
   DET(5);
-  // ---- remainder tiles: roles 4, 5, 6 -> tiles 0, 1, 2; role 7 -> tiles 3 and 4
-  {
+  {   // remainder tiles
     const int nrem = role < 4 ? 0 : role == 7 ? 2 : 1;
     unsigned rdr = L.rd1xr, wrr = L.wr1r;
     int xr = role == 7 ? 3 : role - 4, vb = kVRem;
-    const f32x4 init = {A.s2.x, A.s2.y, A.s2.x, A.s2.y};
+    const f32x4 init = {s2.x, s2.y, s2.x, s2.y};
 #pragma unroll 1
     for (int r = 0; r < nrem; ++r) {
       Parts b[2];
+      s16x8 a[2][3];
       f32x4 acc = init;
       b[0] = b8_load(rdr, 0);
+      lda(IC<3>{}, a[0]);
       pin();
       static_for<0, 4>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        if constexpr (c < 3) b[(c + 1) & 1] = b8_load(rdr, 64 * (c + 1));
+        if constexpr (c < 3) {
+          b[(c + 1) & 1] = b8_load(rdr, 64 * (c + 1));
+          lda(IC<3 + c + 1>{}, a[(c + 1) & 1]);
+        }
         pin();
-        acc = l2x_mma(AR.r[c], b[c & 1], acc);
+        acc = l2x_mma(a[c & 1], b[c & 1], acc);
         pin();
       });
-      const f32x4 v = relu4(acc);   // rows 4kq+jj = (phase 2kq + (jj>>1), channel 16 + (jj&1)): two pixels x channels 16,17
+      const f32x4 v = relu4(acc);
       const bool va = xr == 0 || vbit(L, vb), vbb = xr == 0 || vbit(L, vb + 1);
       const P3 pa = split2(v.x, v.y), pb = split2(v.z, v.w);
       if (va) {
