@@ -20,7 +20,8 @@
 //
 // THREE FORMS of the kernel, one template (`Map<FORM>`), all in the library (option "v3_l2x6" = FORM):
 //   FORM 2 (the product, "fused"): as FORM 1, and the 30 -> 8 layers too on the bf16 pipe, computed tap by tap from layer 2's accumulators
-//     in the same stream (kernels_fused_v3_l23.h; the note at Map<2> below): the 30-channel tensor is never stored.
+//     in the same stream (kernels_fused_v3_l23.h; the note at Map<2> below): the 30-channel tensor is never stored.  Blocks 1..4's
+//     layer 1 (8 -> 18) runs on the bf16 pipe as well, from bf16 planes of the 8-channel tensor (RCED_T_L1X6; layer1_x6l).
 //   FORM 1 ("X6"): the 18 -> 30 layers -- 43 % of the net's multiply-adds and the only ones whose B fragment
 //     feeds two M-tiles -- run at fp32 quality on the bf16 matrix pipe: every operand as three bf16 parts (x = h + m + l,
 //     exact to 2^-24), every product as six v_mfma_f32_16x16x32_bf16 (m.m, l.h, h.l, m.h, h.m, h.h -- smallest first --
