@@ -1890,19 +1890,19 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
             // branch each load cost two register copies of the "old" value, the MFMA -> VALU wait states in front of them
             // and the branch -- more than the 8 KiB of L2 traffic per wave it saves)
             if constexpr (k >= 10) a1_load_rem_one<k - 10>(A1r, wrs, gofs, voff1);
-            else if constexpr (!M::kFused || (RCED_T_A2REG >= 1 && k < 9)) wload(IC<k + 7>{}, gofs, voff1);   // (fused form: M-tile 0 only, without its shifts: the rest stays in LDS)
+            else if constexpr (!M::kFused || ((RCED_T_A2REG == 1 || RCED_T_A2REG == 2) && k < 9)) wload(IC<k + 7>{}, gofs, voff1);   // (fused form: M-tile 0 only, without its shifts: the rest stays in LDS)
           }
         };
         // The second M-tile's fragments (RCED_L2_BOTH) are fetched behind the pair jobs, whose registers (the main pass's A
         // fragments, two pairs of accumulators) they take over; the waves' remaining jobs and the wait of the early finishers
         // at the layer's barrier cover them.
         auto late = [&] {
-          if constexpr (M::kX6 && (!M::kFused || RCED_T_A2REG >= 2) && RCED_L2_BOTH && !(RCED_X6_EXP & 2))
+          if constexpr (M::kX6 && (!M::kFused || RCED_T_A2REG == 2) && RCED_L2_BOTH && !(RCED_X6_EXP & 2))
             static_for<0, 10>([&](auto kc) { a2_load_one<decltype(kc)::value, kL2MT - 1>(A2, wrs, gofs + kG1, 1, voff1); });
         };
         auto sp1x = [&](auto kc) {   // blocks 1..4 with layer 1 on the bf16 pipe: k = 12..20: layer 2's M-tile 0 (three loads per slot)
           constexpr int k = decltype(kc)::value;
-          if constexpr (kL1X && k >= 12 && k < 21 && RCED_T_A2REG >= 1) wload(IC<k - 12 + 7>{}, gofs, voff1, kG1X);
+          if constexpr (kL1X && k >= 12 && k < 21 && (RCED_T_A2REG == 1 || RCED_T_A2REG == 2)) wload(IC<k - 12 + 7>{}, gofs, voff1, kG1X);
         };
         if constexpr (kL1X) {
           if constexpr (which == 1) layer1<M, true>(L, wb, A1, A1r, w1, dma, sp1, late DET_PASS);

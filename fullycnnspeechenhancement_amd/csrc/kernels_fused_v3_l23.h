@@ -13,7 +13,9 @@
 // complete (epilogue: shift, ReLU, block skips, one 8-byte store per lane) and Y, Z become the next pair's W, X.
 #pragma once
 #ifndef RCED_T_A2REG
-#define RCED_T_A2REG 1   // layer 2's A fragments: 0 = all from LDS, one slot ahead; 1 = M-tile 0 in registers (36), M-tile 1 from LDS; 2 = all in registers
+#define RCED_T_A2REG 3   // layer 2's A fragments: 0 = all from LDS, one slot ahead; 1 = M-tile 0 in registers (36, loaded from global memory during
+                         // layer 1), M-tile 1 from LDS; 2 = all in registers; 3 = as 1, but the registers are filled from LDS (the block's image is
+                         // there anyway) when the phase starts: eight waves x 9 KB less on the vector-memory path during layer 1
 #endif
 #ifndef RCED_T_PRIO
 #define RCED_T_PRIO 1    // the waves with five tiles (4..7) run this phase at raised priority: their SIMD partners (four tiles) are the older
@@ -112,6 +114,13 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const f32x2 zero2 = {0.f, 0.f};
   Parts b2[2];
+  s16x8 a2m0[3][3];            // RCED_T_A2REG = 3: M-tile 0's fragments [chunk][part], read from LDS once per phase
+  if constexpr (RCED_T_A2REG == 3) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a2m0[c][q] = lds_ld<s16x8>(a2, ((2 * c) * 3 + q) * 1024);
+  }
   s16x8 a2r[2][2][3];          // [ring][M-tile][part]
   unsigned rdc = L.rd2c;       // the last chunk's four dwords of the tile whose layer 2 comes next
   f32x4 acc2[2][2];            // [tile & 1][M-tile]
@@ -128,7 +137,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
     if ((RCED_T_EXP & 8) && (c > 0 || t > 1)) return;
     Parts& b = b2[(3 * t + c) & 1];
 #pragma unroll
-    for (int mt = RCED_T_A2REG; mt < 2; ++mt)
+    for (int mt = (RCED_T_A2REG == 3 ? 1 : RCED_T_A2REG); mt < 2; ++mt)
 #pragma unroll
       for (int q = 0; q < 3; ++q) a2r[(3 * t + c) & 1][mt][q] = lds_ld<s16x8>(a2, ((2 * c + mt) * 3 + q) * 1024);
     if constexpr (c < 2) {
@@ -155,7 +164,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
       acc2[u][0] = sh2[0];
       acc2[u][1] = sh2[1];
     }
-    mma2(RCED_T_A2REG >= 1 ? A.a[0][c] : a2r[r][0], b2[r], acc2[u][0], RCED_T_A2REG >= 2 ? A.a[1][c] : a2r[r][1], b2[r], acc2[u][1]);
+    mma2(RCED_T_A2REG == 3 ? a2m0[c] : RCED_T_A2REG >= 1 ? A.a[0][c] : a2r[r][0], b2[r], acc2[u][0], RCED_T_A2REG == 2 ? A.a[1][c] : a2r[r][1], b2[r], acc2[u][1]);
   };
   // ReLU + split of one pair of tile t's layer-2 outputs: piece q = 2 * M-tile + half -> k-slots 2q, 2q + 1 of the B fragment
   auto split_piece = [&](auto tc, auto qc) {
