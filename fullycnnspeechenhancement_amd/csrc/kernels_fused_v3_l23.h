@@ -440,20 +440,20 @@ __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int rol
   };
   {
     Parts b[2][2];
-    s16x8 a[2][3];
+    s16x8 a[3][3];     // the main pass's nine fragments, read once per job
     f32x4 acc[2][2];   // [pair][tile]
     const bool two = role != 7;
     const bool g1 = tile_has_gap(role + 8), g2 = tile_has_gap(role + 16), g3 = tile_has_gap(role + 24);
     auto ld = [&](auto ic) {
       constexpr int i = decltype(ic)::value, p = i / 3, c = i % 3;
-      lda(IC<c>{}, a[i & 1]);
+      if constexpr (p == 0) lda(IC<c>{}, a[c]);
       b[i & 1][0] = b8_load(L.rd1x, 2 * p * kTR + 64 * c);
       b[i & 1][1] = b8_load(L.rd1xb, 2 * p * kTR + 64 * c);
     };
     auto slot = [&](auto ic) {
       constexpr int i = decltype(ic)::value, p = i / 3, c = i % 3;
       if constexpr (c == 0) acc[p][0] = acc[p][1] = sh;
-      mma2(a[i & 1], b[i & 1][0], acc[p][0], a[i & 1], b[i & 1][1], acc[p][1]);
+      mma2(a[c], b[i & 1][0], acc[p][0], a[c], b[i & 1][1], acc[p][1]);
       if constexpr (p == 0) static_for<0, 3>([&](auto qc) { sp(IC<12 + 3 * i + decltype(qc)::value>{}); });
       if constexpr (p == 1 && c == 0) l1_store<M>(L, acc[0][0], L.wr1, 0, false, kVMain);
       if constexpr (p == 1 && c == 1) l1_store<M>(L, acc[0][1], L.wr1, kTW, g1, kVMain + 1);
