@@ -597,6 +597,11 @@ def test_c_abi_status_codes_on_device(built):
     assert lib.rced_forward(h, None, None, 0, 7, None) == 0            # empty batch is fine
     assert lib.rced_forward(h, None, None, -1, 7, None) == _lib.RCED_ERR_ARG
     assert lib.rced_set_option(h, b"nonsense", 1) == _lib.RCED_ERR_ARG
+    v = ctypes.c_int(-1)
+    assert lib.rced_get_option(h, b"v3_l2x6", ctypes.byref(v)) == 0 and v.value == 2        # the product form is the default
+    assert lib.rced_set_option(h, b"v3_l2x6", 3) == _lib.RCED_ERR_ARG                       # 0, 1, 2 are the forms in the library
+    assert lib.rced_set_option(h, b"v3_l2x6", -1) == _lib.RCED_ERR_ARG
+    assert lib.rced_get_option(h, b"v3_l2x6", ctypes.byref(v)) == 0 and v.value == 2        # a refused value changes nothing
     lib.rced_destroy(h)
 
 
