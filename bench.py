@@ -29,29 +29,37 @@ sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X dense fp32, vector = matrix (MI355X_MICROARCH.md chip table)
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (same table); only for bf16 lines
-# Which matrix pipe a kernel's arithmetic runs on, and that pipe's ceiling in fp32-equivalent TFLOP/s:
+# Which matrix pipe a kernel's arithmetic runs on, and that pipe's peak in fp32-equivalent TFLOP/s, all from the guide's chip
+# table (MI355X_MICROARCH.md:41-43):
 #   mfma_f32     v_mfma_f32_16x16x4_f32, the fp32 pipe: 157.3 (= the vector rate)
-#   mfma_bf16x6  fp32-quality products as six v_mfma_f32_16x16x32_bf16 over three-part operands: 386, MEASURED in a
-#                register-only loop on this part (profiles/r03_f32_on_bf16.txt; 2500 / 6 = 417 on paper)
+#   mfma_bf16x6  fp32-quality products as six v_mfma_f32_16x16x32_bf16 over three-part operands: 2500 / 6 = 416.7
+#                (a register-only loop on this part MEASURES 386: profiles/r03_f32_on_bf16.txt, kept as `measured_ceiling`)
 #   mfma_bf16    plain bf16 operands: 2500
-# `frac_fp32_peak` = achieved / 157.3 for every kernel (SURVEY 8(d3)'s figure, kept as roofline.frac); `frac_pipe_ceiling` =
-# (sum over pipes of FLOP_i / ceiling_i) / time: the time the kernel's own mix of pipes would need at their ceilings over
-# the time it takes -- the number that says how busy the machine is when part of the work runs on a faster pipe.
-PIPE_CEILING_TFLOPS = {"mfma_f32": FP32_PEAK_TFLOPS, "mfma_bf16x6": 386.0, "mfma_bf16": BF16_PEAK_TFLOPS}
+# Every roofline entry of the line is priced on the pipes the kernel runs on: `peak` = total FLOP / (sum over pipes of
+# FLOP_i / peak_i), the rate a kernel with this mix of pipes reaches when each pipe runs at its spec peak, and `frac` =
+# achieved / peak = (sum FLOP_i / peak_i) / time.  For a kernel that is pure mfma_f32 that is SURVEY 8(d3)'s achieved / 157.3;
+# `frac_fp32_peak` (achieved / 157.3, may exceed 1 for a kernel on the faster pipe) stays beside it as an extra key.
+PIPE_CEILING_TFLOPS = {"mfma_f32": FP32_PEAK_TFLOPS, "mfma_bf16x6": BF16_PEAK_TFLOPS / 6.0, "mfma_bf16": BF16_PEAK_TFLOPS}
+MEASURED_CEILING_TFLOPS = {"mfma_bf16x6": 386.0}
 NET_WORK = {1: "FullyCNN", 2: "FullyCNNV2", 3: "FullyCNNV3"}
 
 
 def pipe_roofline(flop_by_pipe, seconds):
-    """flop_by_pipe: {pipe: nominal dense FLOP in `seconds`} -> the roofline fields every kernel entry of the line carries."""
+    """flop_by_pipe: {pipe: nominal dense FLOP in `seconds`} -> the roofline fields every kernel entry of the line carries:
+    achieved, peak (of this mix of pipes at the guide's spec peaks), frac = achieved / peak."""
     flop_by_pipe = {k: float(v) for k, v in flop_by_pipe.items() if v > 0}
     total = sum(flop_by_pipe.values())
     achieved = total / seconds / 1e12
     floor_s = sum(v / (PIPE_CEILING_TFLOPS[k] * 1e12) for k, v in flop_by_pipe.items())
-    return {"pipe": next(iter(flop_by_pipe)) if len(flop_by_pipe) == 1 else "mixed",
-            "pipe_mix": {k: v / total for k, v in flop_by_pipe.items()},
-            "pipe_ceilings_tflops": {k: PIPE_CEILING_TFLOPS[k] for k in flop_by_pipe},
-            "achieved": achieved, "unit": "TFLOP/s", "peak": FP32_PEAK_TFLOPS,
-            "frac_fp32_peak": achieved / FP32_PEAK_TFLOPS, "frac_pipe_ceiling": floor_s / seconds}
+    out = {"bound": "mfma", "pipe": next(iter(flop_by_pipe)) if len(flop_by_pipe) == 1 else "mixed",
+           "pipe_mix": {k: v / total for k, v in flop_by_pipe.items()},
+           "pipe_peaks_tflops": {k: PIPE_CEILING_TFLOPS[k] for k in flop_by_pipe},
+           "achieved": achieved, "unit": "TFLOP/s", "peak": total / floor_s / 1e12, "frac": floor_s / seconds,
+           "floor_ms": 1e3 * floor_s, "frac_fp32_peak": achieved / FP32_PEAK_TFLOPS}
+    if any(k in MEASURED_CEILING_TFLOPS for k in flop_by_pipe):
+        meas = sum(v / (MEASURED_CEILING_TFLOPS.get(k, PIPE_CEILING_TFLOPS[k]) * 1e12) for k, v in flop_by_pipe.items())
+        out["frac_measured_ceiling"] = meas / seconds
+    return out
 
 
 def layer_flops(spec, variant):
@@ -104,9 +112,9 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 2 / config 5 entries (N = 1 only)")
     ap.add_argument("--from-root-steps", type=int, default=5, help="timed forward_from_root calls at N > 1 (0 = skip)")
     ap.add_argument("--from-root-chunks", type=int, default=8, help="pipeline depth of forward_from_root")
-    ap.add_argument("--from-root-fail-status", type=int, default=0,
-                    help="exit status of every rank when forward_from_root stalls (the line is printed first; 0 keeps the headline "
-                         "valid for drivers that drop the output of failed runs)")
+    ap.add_argument("--from-root-fail-status", type=int, default=3,
+                    help="exit status of every rank when forward_from_root stalls (the line, with from_root.error, is printed "
+                         "first and `launch_ranks` relays it whatever the status; 0 = report the stall in the line only)")
     ap.add_argument("--from-root-timeout", type=int, default=150,
                     help="seconds after which a stalled forward_from_root is abandoned and the line printed without it")
     return ap.parse_args()
@@ -372,12 +380,10 @@ def secondary_config2(torch, build_model, spec, _lib, _weights, local_rank):
            "metric": "spectrogram frames/sec (FullyCNNV2 fwd, 129-bin)", "value": B * T * steps / elapsed, "unit": "frames/s",
            "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "bf16",
            "tflops": flops / (ms * 1e-3) / 1e12,
-           "roofline": {"bound": "mfma", "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "achieved": flops / (ms * 1e-3) / 1e12, "frac": flops / (ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
-                        "pipe": pr["pipe"], "pipe_mix": pr["pipe_mix"], "pipe_ceilings_tflops": pr["pipe_ceilings_tflops"],
-                        "frac_fp32_peak": pr["frac_fp32_peak"], "frac_pipe_ceiling": pr["frac_pipe_ceiling"],
-                        "note": "whole forward (nominal dense FLOPs) over wall time per step; frac = vs the dense bf16 MFMA peak "
-                                "(this line's dtype); the first layer (8 x 11 on the fp32 input) runs on the fp32 MFMA"},
+           "roofline": dict(pr, frac_bf16_peak=flops / (ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
+                            note="whole forward (nominal dense FLOPs) over wall time per step, priced on the pipes it runs on: the "
+                                 "first layer (8 x 11 on the fp32 input) on the fp32 MFMA, the rest on the plain bf16 MFMA; "
+                                 "frac_bf16_peak = every FLOP against the dense bf16 peak"),
            "kernels": {k: dict(pipe_roofline({p: f * B * T * steps for p, f in forward_flops_by_pipe(spec, 2, k, "bf16").items()}, v[0] * 1e-3),
                                avg_launch_ms=v[0] / v[1], launches=v[1]) for k, v in times.items() if v[1]},
            "kernels_ms_per_step": {k: v[0] / steps for k, v in times.items() if v[1]}, "dominant_kernel": dom}
@@ -410,12 +416,9 @@ def secondary_config5(torch, ge, FullyCNNTrainer, spec, _weights, local_rank):
            "metric": "training step time", "value": ms, "unit": "ms/step", "higher_is_better": False,
            "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "f32",
            "frames_per_s": B * T * steps / elapsed, "tflops": flops / (ms * 1e-3) / 1e12,
-           "roofline": {"bound": "mfma", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "achieved": flops / (ms * 1e-3) / 1e12, "frac": flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                        "pipe": pr["pipe"], "pipe_mix": pr["pipe_mix"], "pipe_ceilings_tflops": pr["pipe_ceilings_tflops"],
-                        "frac_fp32_peak": pr["frac_fp32_peak"], "frac_pipe_ceiling": pr["frac_pipe_ceiling"],
-                        "note": "3 x forward FLOPs (nominal) over wall time per step; the step is layer-by-layer and also "
-                                "HBM-heavy (hbm_gb_per_step)"},
+           "roofline": dict(pr, note="3 x forward FLOPs (nominal) over wall time per step, priced on the pipes the step's "
+                                      "convolutions run on (DESIGN 3.5); the step is layer-by-layer and also HBM-heavy "
+                                      "(hbm_gb_per_step)"),
            "hbm_gb_per_step": (pmc or {}).get("hbm_gb_per_step"),
            "hbm_note": ("rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE summed over the step's kernels, %s" % pmc_src
                         if pmc else "no PMC capture for this kernel build"),
@@ -441,7 +444,7 @@ def secondary_rced_fp32(torch, build_model, spec, _lib, _weights, local_rank, va
             continue
         kf = final if k == "rced_final_gemm" else flops - final
         pr = pipe_roofline({p: f * B * T * steps for p, f in forward_flops_by_pipe(spec, variant, k).items()}, tot * 1e-3)
-        per_kernel[k] = dict(pr, avg_launch_ms=tot / launches, launches=launches, flop_per_frame=kf, frac=pr["frac_fp32_peak"])
+        per_kernel[k] = dict(pr, avg_launch_ms=tot / launches, launches=launches, flop_per_frame=kf)
     out = {"config": "%s (%d-layer R-CED) forward, batch 256, 129x512, fp32 (config 3's shape; model.py:%s)"
                      % (name, len(spec.layers(variant)), "6-29" if variant == 1 else "32-61"),
            "metric": "spectrogram frames/sec (%s fwd, 129-bin)" % name, "value": B * T * steps / elapsed, "unit": "frames/s",
@@ -449,14 +452,13 @@ def secondary_rced_fp32(torch, build_model, spec, _lib, _weights, local_rank, va
            "tflops": flops * B * T / (ms * 1e-3) / 1e12,
            "roofline": dict(pipe_roofline({p: sum(forward_flops_by_pipe(spec, variant, k).get(p, 0) for k in ("rced_fused", "rced_final_gemm")) * B * T
                                            for p in PIPE_CEILING_TFLOPS}, ms * 1e-3),
-                            bound="mfma", frac=flops * B * T / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                             note="whole forward over wall time per step; per kernel (HIP events on the launch stream) below"),
            "kernels": per_kernel}
     model.close()
     return out
 
 
-def secondary_config1_latency(torch, build_model, spec, _lib, _weights, local_rank):
+def secondary_config1_latency(torch, build_model, spec, _lib, _weights, local_rank, cpu_seconds=3.0):
     """BASELINE configs[0]: R-CED V1 forward on ONE 129x256 spectrogram the way infer.py calls it (infer.py:62-65):
     numpy in, numpy out through rced_forward_host -- a latency, not a throughput."""
     import numpy as np
@@ -479,8 +481,32 @@ def secondary_config1_latency(torch, build_model, spec, _lib, _weights, local_ra
     torch.cuda.synchronize()
     dev_ms = 1e3 * (time.perf_counter() - t0) / reps
     model.close()
+    cpu = None
+    if cpu_seconds > 0:     # BASELINE.md section 3 plans a CPU timing for C1 too: the torch-CPU restatement on the same spectrogram
+        from oracle import torch_ref
+        ref = torch_ref.TorchRef("FullyCNN", _weights.synthetic_weights(1, seed=42))
+        xt = torch.from_numpy(xh)
+        best, default_threads = None, torch.get_num_threads()
+        for threads in sorted({1, 4, 8, 16, default_threads}):
+            if threads > (os.cpu_count() or 1):
+                continue
+            torch.set_num_threads(threads)
+            ref(xt)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < cpu_seconds / 5:
+                ref(xt)
+                n += 1
+            ms1 = 1e3 * (time.perf_counter() - t0) / n
+            if best is None or ms1 < best[0]:
+                best = (ms1, threads, n)
+        torch.set_num_threads(default_threads)
+        cpu = {"value": best[0], "unit": "ms", "cores": best[1], "kind": "port", "higher_is_better": False,
+               "frames_per_s": T / (best[0] * 1e-3),
+               "sample": "torch-CPU fp32 restatement (oracle/torch_ref.py) of R-CED V1 on the same [1,256,129,1] spectrogram, "
+                         "%d calls on %d threads (the fastest of 1/4/8/16/default threads; host has %d logical cpus)"
+                         % (best[2], best[1], os.cpu_count() or 1)}
     return {"config": "R-CED V1 (10-layer) forward on one 129x256 spectrogram, numpy in -> numpy out (BASELINE configs[0], "
-                      "infer.py:62-65)",
+                      "infer.py:62-65)", "cpu_baseline": cpu,
             "metric": "latency per utterance", "value": host_ms, "unit": "ms", "higher_is_better": False,
             "ms_per_step": host_ms, "steps": reps, "dtype": "f32", "frames_per_s": T / (host_ms * 1e-3),
             "device_resident_ms": dev_ms, "finite": bool(np.isfinite(yh).all()),
@@ -532,11 +558,11 @@ def secondary_pipeline(torch, build_model, spec, _lib, _weights, local_rank, cpu
            "metric": "spectrogram frames/sec through the whole pipeline", "value": frames / (whole * 1e-3), "unit": "frames/s",
            "ms_per_step": whole, "steps": reps, "dtype": "f32",
            "kernels_ms": {"rced_stft": t_stft, "rced_forward": t_cnn, "rced_istft": t_istft},
-           "stft": {"pipe": "mfma_f32", "frac_pipe_ceiling": frames * flop_dft / t_stft / 1e9 / FP32_PEAK_TFLOPS,
+           "stft": {"pipe": "mfma_f32", "frac": frames * flop_dft / t_stft / 1e9 / FP32_PEAK_TFLOPS,
                     "tflops": frames * flop_dft / t_stft / 1e9, "frac_fp32_peak": frames * flop_dft / t_stft / 1e9 / FP32_PEAK_TFLOPS,
                     "algorithmic_gbps": (N * L * 4 + frames * 129 * 12) / t_stft / 1e6,
                     "frac_hbm_8tbs": (N * L * 4 + frames * 129 * 12) / t_stft / 1e6 / 8000.0},
-           "istft": {"pipe": "mfma_f32", "frac_pipe_ceiling": frames * flop_dft / t_istft / 1e9 / FP32_PEAK_TFLOPS,
+           "istft": {"pipe": "mfma_f32", "frac": frames * flop_dft / t_istft / 1e9 / FP32_PEAK_TFLOPS,
                      "tflops": frames * flop_dft / t_istft / 1e9, "frac_fp32_peak": frames * flop_dft / t_istft / 1e9 / FP32_PEAK_TFLOPS,
                      "algorithmic_gbps": (frames * 129 * 12 + N * (T + 1) * 128 * 4) / t_istft / 1e6,
                      "frac_hbm_8tbs": (frames * 129 * 12 + N * (T + 1) * 128 * 4) / t_istft / 1e6 / 8000.0},
@@ -660,34 +686,32 @@ def main():
                 achieved = kflops * B * T * args.steps / (ms * 1e-3) / 1e12
                 hand_ch = spec.layers(variant)[-1].cin     # channels of the tensor handed to the final 1x129 layer
                 traffic, traffic_src = pmc_traffic(ge, variant, B, T, dom)
-                peak = FP32_PEAK_TFLOPS if args.dtype == "f32" else BF16_PEAK_TFLOPS
                 alg = 1032 * B * T if (dom != "rced_fused" or fused_all) else (516 + 516 * hand_ch) * B * T
                 v3x6 = int(model.get_option("v3_l2x6")) if variant == 3 else 0
                 pr = pipe_roofline({p_: f * B * T * args.steps
                                     for p_, f in forward_flops_by_pipe(spec, variant, dom, args.dtype, v3x6).items()}, ms * 1e-3)
-                roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
-                        "unit": "TFLOP/s", "frac": achieved / peak, "pipe": pr["pipe"], "pipe_mix": pr["pipe_mix"],
-                        "pipe_ceilings_tflops": pr["pipe_ceilings_tflops"], "frac_fp32_peak": pr["frac_fp32_peak"],
-                        "frac_pipe_ceiling": pr["frac_pipe_ceiling"], "traffic": traffic,
-                        "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE: %s; this kernel's "
-                                        "algorithmic bytes per launch = %d; whole forward = %d" % (traffic_src, alg, 1032 * B * T),
-                        "avg_launch_ms": ms / launches, "launches": launches,
-                        "flop_per_frame": kflops, "frames_per_forward": B * T,
-                        "other_kernels_ms_per_step": {k: v[0] / args.steps for k, v in times.items() if k != dom and v[1]},
-                        "note": "compute-bound path (7950 FLOP/B): peak = dense fp32 MFMA 157.3 TFLOP/s, not HBM.  CR-CED: the "
-                                "18->30, 30->8 and 8->18 layers (pipe_mix.mfma_bf16x6 of the FLOPs) are computed at fp32 quality as six bf16 "
-                                "MFMAs per product over three-part operands (DESIGN 3.1): `frac` = frac_fp32_peak stays quoted "
-                                "against the fp32 pipe's peak (SURVEY 8(d3)) and can exceed 1; frac_pipe_ceiling prices every layer "
-                                "against the pipe it runs on (386 TFLOP/s measured for the six-product form); "
-                                "algorithmic HBM bytes are 1032 B/frame"}
+                roof = dict(pr, kernel=dom, traffic=traffic,
+                            traffic_note="HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE: %s; this kernel's "
+                                         "algorithmic bytes per launch = %d; whole forward = %d" % (traffic_src, alg, 1032 * B * T),
+                            avg_launch_ms=ms / launches, launches=launches, flop_per_frame=kflops, frames_per_forward=B * T,
+                            other_kernels_ms_per_step={k: v[0] / args.steps for k, v in times.items() if k != dom and v[1]},
+                            note="compute-bound path (7950 FLOP/B): bound = matrix issue, not HBM.  CR-CED: every layer but the "
+                                 "first (1 -> 18 over 8 x 9, fp32 MFMA) is computed at fp32 quality as six bf16 MFMAs per product "
+                                 "over three-part operands (DESIGN 3.1).  `peak` = the rate this mix of pipes reaches with every "
+                                 "pipe at the guide's spec peak (157.3 fp32 MFMA; 2500 / 6 for the six-product form), `frac` = "
+                                 "achieved / peak = (sum FLOP_i / peak_i) / avg launch time; frac_fp32_peak = achieved / 157.3 "
+                                 "(SURVEY 8(d3)'s figure, above 1 for a kernel on the faster pipe); frac_measured_ceiling prices "
+                                 "the six-product form at the 386 TFLOP/s a register-only loop reaches; algorithmic HBM bytes "
+                                 "are 1032 B/frame")
+                assert abs(roof["achieved"] - achieved) < 1e-6 * achieved
         out["roofline"] = roof
     # ---- the reference's single-host-process convention over RCCL: scatter from rank 0, compute, gather -------
     # The headline figures above are complete at this point.  from_root is the first code of a run that sends utterances
     # between GPUs; if it stalls (a link, a communicator that never forms), the collective would sit until the process
     # group's own watchdog ABORTS every rank -- and the line with it.  So a timer stands beside it: on expiry rank 0 prints
-    # the line as it is (from_root = the timeout) and every rank leaves with status 0 by default: the HEADLINE is complete and
-    # valid, and a driver that discards the output of a run with a non-zero status would lose it; the failure is in the line
-    # (from_root.error).  --from-root-fail-status N makes the ranks leave with N instead, for callers that gate on the status.
+    # the line as it is (from_root.error = the timeout) and every rank EXITS (never restarts or re-execs) with
+    # --from-root-fail-status, 3 by default: a stalled scatter must not read as success to a caller that gates on the
+    # status.  The line is on stdout before the exit, and `launch_ranks` relays it whatever the status.
     if world > 1 and args.from_root_steps > 0:
         import threading
 
@@ -736,7 +760,8 @@ def main():
                           (secondary_config5, (torch, ge, FullyCNNTrainer, spec, _weights, local_rank)),
                           (secondary_rced_fp32, (torch, build_model, spec, _lib, _weights, local_rank, 1)),
                           (secondary_rced_fp32, (torch, build_model, spec, _lib, _weights, local_rank, 2)),
-                          (secondary_config1_latency, (torch, build_model, spec, _lib, _weights, local_rank)),
+                          (secondary_config1_latency, (torch, build_model, spec, _lib, _weights, local_rank,
+                                                       min(args.cpu_seconds, 3.0))),
                           (secondary_pipeline, (torch, build_model, spec, _lib, _weights, local_rank,
                                                 min(args.cpu_seconds, 6.0)))):
                 try:

@@ -560,7 +560,7 @@ int fused_create(rced_model* m) {
     if (e != hipSuccess) rc = rced_fail(RCED_ERR_HIP, "error word (pinned host memory): %s", hipGetErrorString(e));
   }
 #if RCED_STAMPS
-  if (!rc && hipMalloc(&f->stamps, (64 + 24 + 64) * sizeof(unsigned long long)) != hipSuccess) f->stamps = nullptr;
+  if (!rc && hipMalloc(&f->stamps, (64 + 24 + 128) * sizeof(unsigned long long)) != hipSuccess) f->stamps = nullptr;
 #endif
   m->fused = f;
   if (rc) {
@@ -693,10 +693,10 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
   if (!m->fused) return RCED_ERR_ARG;
 #if RCED_STAMPS
   if (!strncmp(key, "stamp", 5) && m->fused->stamps) {  // "stampNN": kilo-cycles, NN = wave*8 + slot
-    unsigned long long h[152];
+    unsigned long long h[216];
     if (hipMemcpy(h, m->fused->stamps, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return RCED_ERR_HIP;
     const int i = atoi(key + 5);
-    if (i < 0 || i >= 152) return RCED_ERR_ARG;
+    if (i < 0 || i >= 216) return RCED_ERR_ARG;
     *value = (int)(h[i] / 1000);
     return RCED_OK;
   }

@@ -99,11 +99,18 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define STAMP_MATH(i) const unsigned long long st_b_ = stamp(); tsum[i] += st_b_ - st_a_
 #define STAMP_WAIT(i) tsum[(i) + ((i) < 3 ? 3 : 1)] += stamp() - st_b_
 // finer stamps inside the layer functions: td[k] += cycles since the previous DET / DET_BEGIN of this function
-#define DET_ARG , unsigned long long (&td)[8]
+#define DET_ARG , unsigned long long (&td)[16]
 #define DET_PASS , tdet
 #define DET_BEGIN() unsigned long long dt_ = stamp()
 #define DET(k) do { const unsigned long long n_ = stamp(); td[k] += n_ - dt_; dt_ = n_; } while (0)
+// RCED_STAMPS == 2: the bf16-pipe layer 1's own breakdown (slot by slot) in td[8..15]
+#if RCED_STAMPS == 2
+#define DETX(k) DET(8 + (k))
 #else
+#define DETX(k)
+#endif
+#else
+#define DETX(k)
 #define STAMP_BEGIN()
 #define STAMP_MATH(i)
 #define STAMP_WAIT(i)
@@ -560,9 +567,14 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   L.scr = lane * 16;
   const unsigned X0 = lds_addr(lds + M::kX0Off);
   L.rd0 = X0 + 4 * (px0 + kq * kS);                         // lane kq <-> time taps 4*ih + kq
-  L.rd0r = X0 + 4 * (8 * (16 * xr0 + n) + kq * kS);
+  // Remainder tiles: column n of tile xr = the kRemPx pixels from kRemPx * (16 xr + n) on.  Fused form: SEVEN of the eight pixel phases
+  // are used (the rows of phase 7 are computed and dropped): a column stride of 7 rows puts the 16 columns of a ds_read_b128 lane
+  // group on 16 different 16-byte bank slots, where a stride of 8 rows = 128 bytes puts them on two (8-way conflicts: 60 reads per
+  // layer at 32 cycles each); five tiles still cover the 532 pixels (5 x 112), so the MFMA count is the same.
+  constexpr int kRemPx = M::kFused ? 7 : 8;
+  L.rd0r = X0 + 4 * (kRemPx * (16 * xr0 + n) + kq * kS);
   L.rd1 = B8 + 4 * ((px0 - 4) * kB8S + 2 * kq);
-  const int rpx = 8 * (16 * xr0 + n);                       // first pixel of this lane's octet in remainder tile xr0
+  const int rpx = kRemPx * (16 * xr0 + n);                  // first pixel of this lane's column in remainder tile xr0
   L.rd1r = B8 + 4 * ((rpx - 4) * kB8S + 2 * kq);
   if constexpr (M::kX6) {
     const unsigned PL = lds_addr(lds + M::kB18Off);         // the h plane; row r = pixel r - kB18Pad
@@ -623,9 +635,9 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   for (int t = 0; t < 4; ++t) v |= (unsigned)px_valid(px0 + 128 * t) << (kVMain + t);
 #pragma unroll
   for (int r = 0; r < 2; ++r) {   // remainder tiles xr0 and (wave 7 only) 4
-    const int p = 8 * (16 * (r == 0 ? xr0 : 4) + n) + 2 * kq;
+    const int p = kRemPx * (16 * (r == 0 ? xr0 : 4) + n) + 2 * kq;
     v |= (unsigned)(p >= 0 && px_valid(p)) << (kVRem + 2 * r);
-    v |= (unsigned)(p >= 0 && px_valid(p + 1)) << (kVRem + 2 * r + 1);
+    v |= (unsigned)(p >= 0 && px_valid(p + 1) && 2 * kq + 1 < kRemPx) << (kVRem + 2 * r + 1);   // (fused form: phase 7 belongs to the next column)
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t) v |= (unsigned)px_valid(2 * (px0 + 128 * t) + (kq >> 1)) << (kVL3 + t);
@@ -965,7 +977,7 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, const A1Re
     l1_job<M, FIRST, 1, true>(wa, A, AR, rdr, 0u, f32x4{s2.x, s2.y, s2.x, s2.y}, acc, pre);
     const f32x4 v = relu4(acc[0]);   // rows 4kq+jj = (phase 2kq + (jj>>1), channel 16 + (jj&1)): two pixels x channels 16,17
     // every remainder tile but tile 0 contains gap pixels (tile 4 also runs past the tile): those are never written
-    const bool va = xr == 0 || vbit(L, vb), vbb = xr == 0 || vbit(L, vb + 1);
+    const bool va = xr == 0 || vbit(L, vb), vbb = (!M::kFused && xr == 0) || vbit(L, vb + 1);
     if constexpr (M::kFused) {
       const P3 pa = split2(v.x, v.y), pb = split2(v.z, v.w);
       if (va) {
@@ -978,7 +990,7 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, const A1Re
         lds_st<unsigned>(wrr, M::kPlaneBytes + 4, pb.m);
         lds_st<unsigned>(wrr, 2 * M::kPlaneBytes + 4, pb.l);
       }
-      wrr += 128 * 4;
+      wrr += 112 * 4;
     } else if constexpr (M::kX6) {
       const P3 pa = split2(v.x, v.y), pb = split2(v.z, v.w);
       if (va) {
@@ -996,7 +1008,7 @@ __device__ __forceinline__ void layer1(const Lane& L, unsigned wbase, const A1Re
       if (vbb) lds_st<f32x2>(wrr, 18 * 4, f32x2{v.z, v.w});
       wrr += 8 * 16 * 18 * 4;
     }
-    rdr += 8 * G::kTileR;            // wave 7's second tile: 4 = 3 + 1
+    rdr += (M::kFused ? 7 : 8) * G::kTileR;   // wave 7's second tile: 4 = 3 + 1
     xr += 1;
     vb += 2;
   }
@@ -1829,7 +1841,7 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
   const int tile_end = tile_begin + tiles_base + ((int)blockIdx.x < tiles_rem ? 1 : 0);
   XStage xst = xstage_load(P, tile_begin < tile_end ? tile_begin : P.total_tiles, tid);
 #if RCED_STAMPS
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tfin = 0, tdet[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tfin = 0, tdet[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   layer_end_sync();
 
@@ -2048,7 +2060,7 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
     for (int i = 0; i < 8; ++i) P.stamps[wave * 8 + i] = tsum[i];
   if (P.stamps && blockIdx.x == 0 && lane == 0) P.stamps[64 + wave * 3] = tfin;
   if (P.stamps && blockIdx.x == 0 && lane == 0)
-    for (int i = 0; i < 8; ++i) P.stamps[88 + wave * 8 + i] = tdet[i];
+    for (int i = 0; i < 16; ++i) P.stamps[88 + wave * 16 + i] = tdet[i];
 #endif
 }
 

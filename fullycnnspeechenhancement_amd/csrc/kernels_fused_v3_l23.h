@@ -339,7 +339,7 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
   // ---- the stream.  Waves 0..3: tiles 0..3 of frame fr (X0 X1 X2 YY01 X3 YY23); waves 4..7: tiles 4..8 (X0 X1 X2 YY01 X3 X4 YY23 Y4)
   ldX(i0, i0);
   pin();
-  dma1();
+  if (!(RCED_T_EXP & 512)) dma1();   // (512: timing experiment, wrong results: no weight transfers at all)
   pin();
   runX(i0, i0, none);
   runX(i1, i0, none);
@@ -379,11 +379,15 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
 // written by layers 2 + 3's epilogue.  K = 72 in three K = 32 chunks: k-slot 8kq + e = tap 4c + kq, channel e (taps 9..11: zero
 // weights): a lane's B fragment of a chunk is ONE aligned ds_read_b128 per part.  Channels 0..15 = one M-tile, 18 MFMAs per
 // 16-pixel tile; channels 16, 17 by the remainder pass (rows = 8 pixel phases x 2 channels, K = 16 window taps x 8 channels = four
-// chunks, 24 MFMAs per 128 pixels; its column stride of 8 pixels = 128 bytes makes its twelve reads per tile 8-way bank
-// conflicted: 60 reads per layer).
+// chunks, 24 MFMAs per tile of 16 columns x SEVEN pixels: phase 7's rows are dropped -- a column stride of 7 rows = 112 bytes keeps
+// its reads free of bank conflicts (make_lane), 8 rows = 128 bytes made every one of them 8-way conflicted).
 __device__ __forceinline__ Parts b8_load(unsigned rd, int off) {
   Parts b;
   b.h = lds_ld<s16x8>(rd, off);
+  if (RCED_T_EXP & 256) {   // timing experiment (wrong results): a third of layer 1's B reads
+    b.m = b.l = b.h;
+    return b;
+  }
   b.m = lds_ld<s16x8>(rd, off + kB8PlaneBytes);
   b.l = lds_ld<s16x8>(rd, off + 2 * kB8PlaneBytes);
   return b;
@@ -461,7 +465,7 @@ __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int rol
     };
     ld(IC<0>{});
     pin();
-    pre();
+    if (!(RCED_T_EXP & 512)) pre();
     pin();
     static_for<0, 3>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -470,6 +474,7 @@ __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int rol
       pin();
       slot(ic);
       pin();
+      DETX(i);
     });
     if (two) {
       static_for<3, 6>([&](auto ic) {
@@ -478,9 +483,11 @@ __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int rol
         pin();
         slot(ic);
         pin();
+        DETX(i);
       });
       l1_store<M>(L, acc[1][0], L.wr1, 2 * kTW, g2, kVMain + 2);
       l1_store<M>(L, acc[1][1], L.wr1, 3 * kTW, g3, kVMain + 3);
+      DETX(6);
     } else {
       l1_store<M>(L, acc[0][0], L.wr1, 0, false, 0);
       l1_store<M>(L, acc[0][1], L.wr1, kTW, false, 0);
@@ -533,7 +540,7 @@ __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int rol
         pin();
       });
       const f32x4 v = relu4(acc);
-      const bool va = xr == 0 || vbit(L, vb), vbb = xr == 0 || vbit(L, vb + 1);
+      const bool va = xr == 0 || vbit(L, vb), vbb = vbit(L, vb + 1);   // (vb + 1: also "not phase 7")
       const P3 pa = split2(v.x, v.y), pb = split2(v.z, v.w);
       if (va) {
         lds_st<unsigned>(wrr, 0, pa.h);
@@ -545,8 +552,8 @@ __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int rol
         lds_st<unsigned>(wrr, M::kPlaneBytes + 4, pb.m);
         lds_st<unsigned>(wrr, 2 * M::kPlaneBytes + 4, pb.l);
       }
-      wrr += 128 * 4;
-      rdr += 128 * 16;
+      wrr += 112 * 4;
+      rdr += 112 * 16;
       xr += 1;
       vb += 2;
     }

@@ -25,8 +25,10 @@ def main():
         w = rced_np.make_weights(net_work, seed=42)
         x_small = rced_np.make_input(2, 16, seed=1234)
         x_long = rced_np.make_input(1, 40, seed=4321)
+        x_c1 = rced_np.make_input(1, 256, seed=1234)      # BASELINE configs[0]'s shape, [1,256,129,1] (SURVEY 8 c4 iii)
         out = {"x_small": x_small, "y_small": rced_np.forward(net_work, w, x_small),
-               "x_long": x_long, "y_long": rced_np.forward(net_work, w, x_long)}
+               "x_long": x_long, "y_long": rced_np.forward(net_work, w, x_long),
+               "x_c1": x_c1, "y_c1": rced_np.forward(net_work, w, x_c1)}
         for k, v in w.items():
             out["w:" + k] = v
         np.savez_compressed(os.path.join(HERE, "rced_%s.npz" % tag), **out)

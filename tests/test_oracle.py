@@ -119,7 +119,7 @@ def test_three_restatements_agree(net_work, tag, _v, built):
 @pytest.mark.parametrize("net_work,tag,_v", NETS)
 def test_oracle_matches_committed_golden(net_work, tag, _v, built):
     w, g = load_golden(tag)
-    for key in ("small", "long"):
+    for key in ("small", "long", "c1"):
         y = rced_c.forward(net_work, w, g["x_" + key], np.float64)
         assert rel_err(y, g["y_" + key]) < 1e-12
     assert sum(v.size for k, v in w.items() if not k.endswith(("moving_mean", "moving_variance"))) == \
