@@ -571,10 +571,14 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   // are used (the rows of phase 7 are computed and dropped): a column stride of 7 rows puts the 16 columns of a ds_read_b128 lane
   // group on 16 different 16-byte bank slots, where a stride of 8 rows = 128 bytes puts them on two (8-way conflicts: 60 reads per
   // layer at 32 cycles each); five tiles still cover the 532 pixels (5 x 112), so the MFMA count is the same.
+  // Which of the tile's 16 pixel columns a lane column n takes is permuted (nr): ds_read_b128 serves lanes {0-3, 12-15, 20-27} together,
+  // i.e. columns {0-3, 12-15} at tap kq and columns {4-11} at tap kq + 1 -- with rows 7 nr(n) + kq they meet on one bank slot per
+  // group instead of seven (nr maps {4..11} to rows 0..7 mod 16 and {0-3, 12-15} to 8..15).
   constexpr int kRemPx = M::kFused ? 7 : 8;
-  L.rd0r = X0 + 4 * (kRemPx * (16 * xr0 + n) + kq * kS);
+  const int nr = M::kFused ? (int)((0x92B41A3C5E70D6F8ull >> (4 * n)) & 15) : n;
+  L.rd0r = X0 + 4 * (kRemPx * (16 * xr0 + nr) + kq * kS);
   L.rd1 = B8 + 4 * ((px0 - 4) * kB8S + 2 * kq);
-  const int rpx = kRemPx * (16 * xr0 + n);                  // first pixel of this lane's column in remainder tile xr0
+  const int rpx = kRemPx * (16 * xr0 + nr);                 // first pixel of this lane's column in remainder tile xr0
   L.rd1r = B8 + 4 * ((rpx - 4) * kB8S + 2 * kq);
   if constexpr (M::kX6) {
     const unsigned PL = lds_addr(lds + M::kB18Off);         // the h plane; row r = pixel r - kB18Pad
@@ -635,7 +639,7 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   for (int t = 0; t < 4; ++t) v |= (unsigned)px_valid(px0 + 128 * t) << (kVMain + t);
 #pragma unroll
   for (int r = 0; r < 2; ++r) {   // remainder tiles xr0 and (wave 7 only) 4
-    const int p = kRemPx * (16 * (r == 0 ? xr0 : 4) + n) + 2 * kq;
+    const int p = kRemPx * (16 * (r == 0 ? xr0 : 4) + nr) + 2 * kq;
     v |= (unsigned)(p >= 0 && px_valid(p)) << (kVRem + 2 * r);
     v |= (unsigned)(p >= 0 && px_valid(p + 1) && 2 * kq + 1 < kRemPx) << (kVRem + 2 * r + 1);   // (fused form: phase 7 belongs to the next column)
   }
