@@ -67,15 +67,18 @@ def layer_flops(spec, variant):
     return [2 * spec.FEATURE_DIM * l.kh * l.kw * l.cin * l.cout for l in spec.layers(variant)]
 
 
-def forward_flops_by_pipe(spec, variant, kernel, dtype="f32", v3_l2x6=2):
+def forward_flops_by_pipe(spec, variant, kernel, dtype="f32", v3_l2x6=3):
     """FLOP per frame of one forward kernel kind, split by the pipe each layer runs on."""
     fl = layer_flops(spec, variant)
     if kernel == "conv_layer_generic":
         return {"mfma_f32": sum(fl)}            # direct fp32 FMA on the vector ALU: same 157.3 ceiling
-    if variant == 3:                            # one kernel, all 16 layers; in the x6 form: the five 18 -> 30 layers (option v3_l2x6 = 1)
-        # ... the five 30 -> 8 layers behind them and the four 8 -> 18 layers of blocks 1..4 too (2, the product; the first layer, 1 -> 18 over
-        # 8 x 9, stays on the fp32 MFMA)
-        on_x6 = {0: (), 1: ((18, 30),), 2: ((18, 30), (30, 8), (8, 18))}[int(v3_l2x6)]
+    if variant == 3:                            # one kernel, all 16 layers.  Option v3_l2x6: 3 (the product) = every layer in the six-product
+        # form; 2 = all but the first layer (1 -> 18 over 8 x 9) and decode_final, which stay on the fp32 MFMA; 1 = the five 18 -> 30 layers only;
+        # 0 = every layer on the fp32 MFMA
+        form = int(v3_l2x6)
+        if form == 3:
+            return {"mfma_bf16x6": sum(fl)}
+        on_x6 = {0: (), 1: ((18, 30),), 2: ((18, 30), (30, 8), (8, 18))}[form]
         x6 = sum(f for f, l in zip(fl, spec.layers(3)) if (l.cin, l.cout) in on_x6)
         return {"mfma_f32": sum(fl) - x6, "mfma_bf16x6": x6}
     if kernel == "rced_final_gemm":             # R-CED's 1x129 output layer: x6::final_gemm_x6_kernel / chain16::final_gemm16_kernel
@@ -695,9 +698,9 @@ def main():
                                          "algorithmic bytes per launch = %d; whole forward = %d" % (traffic_src, alg, 1032 * B * T),
                             avg_launch_ms=ms / launches, launches=launches, flop_per_frame=kflops, frames_per_forward=B * T,
                             other_kernels_ms_per_step={k: v[0] / args.steps for k, v in times.items() if k != dom and v[1]},
-                            note="compute-bound path (7950 FLOP/B): bound = matrix issue, not HBM.  CR-CED: every layer but the "
-                                 "first (1 -> 18 over 8 x 9, fp32 MFMA) is computed at fp32 quality as six bf16 MFMAs per product "
-                                 "over three-part operands (DESIGN 3.1).  `peak` = the rate this mix of pipes reaches with every "
+                            note="compute-bound path (7950 FLOP/B): bound = matrix issue, not HBM.  CR-CED: every layer is computed at "
+                                 "fp32 quality as six bf16 MFMAs per product over three-part operands (DESIGN 3.1; pipe_mix says "
+                                 "which share when another form of the kernel is selected).  `peak` = the rate this mix of pipes reaches with every "
                                  "pipe at the guide's spec peak (157.3 fp32 MFMA; 2500 / 6 for the six-product form), `frac` = "
                                  "achieved / peak = (sum FLOP_i / peak_i) / avg launch time; frac_fp32_peak = achieved / 157.3 "
                                  "(SURVEY 8(d3)'s figure, above 1 for a kernel on the faster pipe); frac_measured_ceiling prices "

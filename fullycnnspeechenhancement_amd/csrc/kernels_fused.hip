@@ -30,14 +30,16 @@ struct rced_fused {
   float* wpack = nullptr;     // packed A-fragment stream (CR-CED: of the F32 form, built when that form is first selected)
   float* wpack_x6 = nullptr;  // CR-CED, X6 form (v3::kGTotal floats; built when that form is first selected)
   float* wpack_t = nullptr;   // CR-CED, fused form (v3::kTTotal floats)
+  float* wpack_a = nullptr;   // CR-CED, all-x6 form (v3::kATotal floats)
+  float* fin_tab = nullptr;   // ... its decode_final tap table (v3::kFinTFloats)
   // Per-handle options of the R-CED output layer's kernel; the environment variables of the same meaning only supply the
   // defaults, read when the handle is created (rced_create), never afterwards.
   int final_x6 = 1;           // option "final_x6" (default: RCED_FINAL_X6): 1 = x6::final_gemm_x6_kernel (three-part bf16 products), 0 = fp32 MFMA
   int final_lds = 1;          // option "final_lds" (default: RCED_FINAL_LDS): the fp32 kernel with (1) / without (0) LDS staging of its B operand
   int bf16_final16 = 1;       // option "bf16_final16" (default: RCED_C16_FINAL16): bf16 mode: the output layer on the bf16 MFMA (1) or as above (0)
-  int v3_l2x6 = 2;            // option "v3_l2x6": 2 = the 18 -> 30 AND 30 -> 8 layers at fp32 quality on the bf16 matrix pipe, as one stream (the
-                              // product), 1 = the 18 -> 30 layers only (round 4's first form), 0 = every layer on the fp32 MFMA (the
-                              // comparator): kernels_fused_v3.h
+  int v3_l2x6 = 3;            // option "v3_l2x6": 3 = every layer at fp32 quality on the bf16 matrix pipe (the product); 2 = all but the first layer and
+                              // decode_final (round 4's product); 1 = the 18 -> 30 layers only (round 4's first form); 0 = every layer on the fp32
+                              // MFMA (the comparator): kernels_fused_v3.h
   float* fin_apack = nullptr; // v3::kFinPack
   float fin_bias = 0.f;
   float* h = nullptr;         // [frames, 129, 8] hand-off to the final layer
@@ -81,8 +83,8 @@ inline void split3(float v, unsigned short* h, unsigned short* mm, unsigned shor
 // CR-CED weight streams (kernels_fused_v3.h, "packed weight streams").  x6 = false: one LDS packet per layer (F32 form);
 // x6 = true: layer 1 / layer 2 as register images for 16-byte-per-lane global loads, layer 3's packet unchanged.
 void pack_v3(const rced_model* m, int form, std::vector<float>* wpack) {
-  const bool x6 = form != 0, fusedf = form == 2;
-  wpack->assign(fusedf ? v3::kTTotal : x6 ? v3::kGTotal : v3::kWTotal, 0.f);
+  const bool x6 = form != 0, fusedf = form >= 2, allx6 = form == 3;
+  wpack->assign(allx6 ? v3::kATotal : fusedf ? v3::kTTotal : x6 ? v3::kGTotal : v3::kWTotal, 0.f);
   auto put_shift = [&](float* at, int layer) {  // the packet's last 32 floats: shift[co]
     const int cout = m->net->layer[layer].cout;
     for (int c = 0; c < cout; ++c) at[c] = m->layers[layer].host_shift[c];
@@ -111,10 +113,12 @@ void pack_v3(const rced_model* m, int form, std::vector<float>* wpack) {
       const int k = 8 * s + 2 * kq + e, tap = k / 8 - r;
       return (tap >= 0 && tap < 9) ? wq(l1, tap, k % 8, co, 8) : 0.f;
     };
-    if (fusedf && RCED_T_L1X6 && blk > 0) {
+    if (fusedf && RCED_T_L1X6 && (blk > 0 || allx6)) {
       // layer 1 on the bf16 pipe (kernels_fused_v3_l23.h, layer1_x6): main pass [chunk c][part][lane] x 8 bf16, row = channel lane & 15,
       // k-slot 8kq + e = (tap 4c + kq, channel e); remainder pass [chunk c][part][lane] x 8 bf16, row i = (phase r = i >> 1, channel
-      // 16 + (i & 1)), k-slot = (window tap u = 4c + kq, channel e), frequency tap = u - r
+      // 16 + (i & 1)), k-slot = (window tap u = 4c + kq, channel e), frequency tap = u - r.
+      // All-x6 form, block 0 (8x9, 1 -> 18): "channel" e = time row e of the kernel (the planes hold x[t + e - 3][f] at entry e).
+      auto w1x = [&](int tap, int e, int co) { return blk == 0 ? wq(l1, e * 9 + tap, 0, co, 1) : wq(l1, tap, e, co, 8); };
       unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
       for (int lane = 0; lane < 64; ++lane)
         for (int e = 0; e < 8; ++e) {
@@ -122,12 +126,12 @@ void pack_v3(const rced_model* m, int form, std::vector<float>* wpack) {
           for (int c = 0; c < 3; ++c) {
             const int tap = 4 * c + kq;
             const size_t base = (size_t)(c * 3) * 512 + lane * 8 + e;
-            split3(tap < 9 ? wq(l1, tap, e, i, 8) : 0.f, &d16[base], &d16[base + 512], &d16[base + 1024]);
+            split3(tap < 9 ? w1x(tap, e, i) : 0.f, &d16[base], &d16[base + 512], &d16[base + 1024]);
           }
           for (int c = 0; c < 4; ++c) {
             const int r = i >> 1, co = 16 + (i & 1), tap = 4 * c + kq - r;
             const size_t base = (size_t)(9 + c * 3) * 512 + lane * 8 + e;
-            split3((tap >= 0 && tap < 9) ? wq(l1, tap, e, co, 8) : 0.f, &d16[base], &d16[base + 512], &d16[base + 1024]);
+            split3((tap >= 0 && tap < 9) ? w1x(tap, e, co) : 0.f, &d16[base], &d16[base + 512], &d16[base + 1024]);
           }
         }
       put_shift(dst + v3::kG1XMain + v3::kG1XRem, 3 * blk + 0);
@@ -251,6 +255,20 @@ void pack_v3_final(const rced_model* m, std::vector<float>* fin, float* fin_bias
   for (int t = 0; t <= 64; ++t)
     for (int c = 0; c < 8; ++c) (*fin)[v3::kFinA + t * 8 + c] = wq(lf, t, c, 0, 8);
   *fin_bias = lf.host_shift[0];
+}
+
+// All-x6 form: decode_final's tap table, [part h, m, l][row][8 channels] bf16: row t + 15 = the three-part split of W[tap t][c], zero
+// rows for t < 0 and t > 128 (kernels_fused_v3.h, Map<3>: the A fragment of lane (kq, m) in chunk q is row 4q + kq - m + 15)
+void pack_v3_fintab(const rced_model* m, std::vector<float>* tab) {
+  const rced_layer_dev& lf = m->layers[15];
+  tab->assign(v3::kFinTFloats, 0.f);
+  unsigned short* d16 = reinterpret_cast<unsigned short*>(tab->data());
+  constexpr int kPart16 = v3::kFinTPart / 2;
+  for (int t = 0; t < 129; ++t)
+    for (int c = 0; c < 8; ++c) {
+      const size_t at = (size_t)(t + 15) * 8 + c;
+      split3(wq(lf, t, c, 0, 8), &d16[at], &d16[at + kPart16], &d16[at + 2 * kPart16]);
+    }
 }
 
 int upload(float** dev, const std::vector<float>& host);
@@ -506,9 +524,15 @@ int chain16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int 
   return RCED_OK;
 }
 
-int upload(float** dev, const std::vector<float>& host) {
-  HIP_TRY(hipMalloc(dev, host.size() * sizeof(float)));
-  HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+int upload(float** dev, const std::vector<float>& host) {   // *dev is set only when the copy succeeded
+  float* p = nullptr;
+  HIP_TRY(hipMalloc(&p, host.size() * sizeof(float)));
+  const hipError_t e = hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return rced_fail(RCED_ERR_HIP, "hipMemcpy(weights): %s", hipGetErrorString(e));
+  }
+  *dev = p;
   return RCED_OK;
 }
 
@@ -522,13 +546,30 @@ int v3_set_lds() {
   return RCED_OK;
 }
 // option "v3_l2x6": a form's weight stream is built when it is first selected
+// (a form counts as built only when its upload AND its LDS attribute succeeded -- the device pointer is published last)
 int v3_enable_form(rced_model* m, rced_fused* f, int form) {
-  float** dev = form == 0 ? &f->wpack : form == 1 ? &f->wpack_x6 : &f->wpack_t;
+  float** dev = form == 0 ? &f->wpack : form == 1 ? &f->wpack_x6 : form == 2 ? &f->wpack_t : &f->wpack_a;
   if (*dev) return RCED_OK;
   std::vector<float> wpack;
   pack_v3(m, form, &wpack);
-  if (int rc = upload(dev, wpack)) return rc;
-  return form == 0 ? v3_set_lds<v3::MapF32>() : form == 1 ? v3_set_lds<v3::MapX6>() : v3_set_lds<v3::MapT>();
+  float* fresh = nullptr;
+  int rc = upload(&fresh, wpack);
+  if (!rc && form == 3 && !f->fin_tab) {
+    std::vector<float> tab;
+    pack_v3_fintab(m, &tab);
+    rc = upload(&f->fin_tab, tab);
+    if (rc && f->fin_tab) {
+      (void)hipFree(f->fin_tab);
+      f->fin_tab = nullptr;
+    }
+  }
+  if (!rc) rc = form == 0 ? v3_set_lds<v3::MapF32>() : form == 1 ? v3_set_lds<v3::MapX6>() : form == 2 ? v3_set_lds<v3::MapT>() : v3_set_lds<v3::MapA>();
+  if (rc) {
+    if (fresh) (void)hipFree(fresh);
+    return rc;
+  }
+  *dev = fresh;
+  return RCED_OK;
 }
 
 int fused_create(rced_model* m) {
@@ -547,8 +588,8 @@ int fused_create(rced_model* m) {
   pack_v3_final(m, &fin, &f->fin_bias);
   int rc = upload(&f->fin_apack, fin);
   if (!rc) {   // the environment only supplies the DEFAULT of the per-handle option
-    const int form = env_default("RCED_V3_L2X6", 2);
-    f->v3_l2x6 = form < 0 || form > 2 ? 2 : form;
+    const int form = env_default("RCED_V3_L2X6", 3);
+    f->v3_l2x6 = form < 0 || form > 3 ? 3 : form;
     rc = v3_enable_form(m, f, f->v3_l2x6);
   }
   if (!rc) {
@@ -576,6 +617,8 @@ void fused_destroy(rced_model* m) {
   if (f->wpack) (void)hipFree(f->wpack);
   if (f->wpack_x6) (void)hipFree(f->wpack_x6);
   if (f->wpack_t) (void)hipFree(f->wpack_t);
+  if (f->wpack_a) (void)hipFree(f->wpack_a);
+  if (f->fin_tab) (void)hipFree(f->fin_tab);
   if (f->wpack16) (void)hipFree(f->wpack16);
   if (f->fin_apack16) (void)hipFree(f->fin_apack16);
   if (f->fin_apack_x6) (void)hipFree(f->fin_apack_x6);
@@ -631,8 +674,8 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   P.err = f->err_dev;
   P.x = x;
   P.y = y;
-  P.wpack = f->v3_l2x6 == 2 ? f->wpack_t : f->v3_l2x6 ? f->wpack_x6 : f->wpack;
-  P.fin = f->fin_apack;
+  P.wpack = f->v3_l2x6 == 3 ? f->wpack_a : f->v3_l2x6 == 2 ? f->wpack_t : f->v3_l2x6 ? f->wpack_x6 : f->wpack;
+  P.fin = f->v3_l2x6 == 3 ? f->fin_tab : f->fin_apack;
   P.fin_bias = f->fin_bias;
   P.N = N;
   P.T = T;
@@ -642,7 +685,8 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   const int cus = f->grid_limit > 0 ? f->grid_limit : m->num_cus;
   const int grid = std::min(P.total_tiles, cus);
   m->prof_begin(RCED_K_FUSED, st);   // all 16 layers: decode_final is the kernel's last phase
-  if (f->v3_l2x6 == 2) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapT>, dim3(grid), dim3(v3::kThreads), v3::MapT::kLdsBytes, st, P);
+  if (f->v3_l2x6 == 3) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapA>, dim3(grid), dim3(v3::kThreads), v3::MapA::kLdsBytes, st, P);
+  else if (f->v3_l2x6 == 2) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapT>, dim3(grid), dim3(v3::kThreads), v3::MapT::kLdsBytes, st, P);
   else if (f->v3_l2x6) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapX6>, dim3(grid), dim3(v3::kThreads), v3::MapX6::kLdsBytes, st, P);
   else hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapF32>, dim3(grid), dim3(v3::kThreads), v3::MapF32::kLdsBytes, st, P);
   m->prof_end(RCED_K_FUSED, st);
@@ -667,7 +711,7 @@ int fused_set_option(rced_model* m, const char* key, int value) {
   }
   if (!strcmp(key, "v3_l2x6")) {
     if (m->variant != RCED_V3) return rced_fail(RCED_ERR_ARG, "v3_l2x6 selects the form of the CR-CED kernel only");
-    if (value < 0 || value > 2) return RCED_ERR_ARG;
+    if (value < 0 || value > 3) return RCED_ERR_ARG;
     if (int rc = v3_enable_form(m, m->fused, value)) return rc;
     m->fused->v3_l2x6 = value;
     return RCED_OK;

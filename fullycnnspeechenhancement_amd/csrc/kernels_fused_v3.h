@@ -167,7 +167,7 @@ constexpr int kFinPack = kFinA + kFin128;
 template <int FORM>
 struct Map {
   static constexpr bool X6 = FORM != 0;
-  static constexpr bool kX6 = X6, kFused = false;
+  static constexpr bool kX6 = X6, kFused = false, kAllX6 = false;
   static constexpr int kB8Off = 0;                                     // all offsets in floats unless named *Bytes
   static constexpr int kB18Off = kB8Off + kB8Rows * kB8S;
   static constexpr int kPlaneBytes = kB18Rows * 32;                    // one bf16 plane of 16 channels: 17,088
@@ -287,7 +287,7 @@ constexpr int kTTotal = RCED_T_L1X6 ? kTBlock + 4 * kTBlockX : 5 * kTBlock;
 constexpr int kB8PlaneBytes = kB8Rows * 16;                 // one bf16 plane of the 8-channel tensor: [pixel][8] = 16-byte rows
 template <>
 struct Map<2> {
-  static constexpr bool X6 = true, kX6 = true, kFused = true;
+  static constexpr bool X6 = true, kX6 = true, kFused = true, kAllX6 = false;
   static constexpr int kB8Off = 0;
   static constexpr bool kL1X6 = RCED_T_L1X6 != 0;
   static constexpr int kB18Off = kB8Off + (kL1X6 ? 3 * kB8PlaneBytes / 4 : kB8Rows * kB8S);
@@ -333,6 +333,73 @@ typedef Map<2> MapT;
 static_assert(MapT::finscr0(7) % 16 == 0 && MapT::finscr0(2) % 16 == 0 && (MapT::kL1X6 || MapT::finscr0(1) + 2048 <= (kB8Pad + kF) * kB8S * 4), "decode_final's partial sums: 16-byte aligned, inside real rows of B8");
 static_assert(kW3T % 4 == 0 && kG2 + kW3T <= 2 * kWRegion, "layer 3's fused-form packet: 16-byte pieces, inside a weight region");
 
+
+// ---- ALL-X6 form (Map<3>, the product): as the fused form, and the FIRST layer and decode_final on the bf16 pipe too ------------
+// * The first layer (8x9, 1 -> 18) is layer1_x6l like blocks 1..4's: its K axis (8 time rows x 9 frequency taps) becomes "8 channels x 9
+//   taps" once the input rows of a tile are laid out as bf16 planes [pixel (frame i, bin f)][8] with entry r = x[t0 + i + r - 3][f] -- an
+//   im2col along time only, written once per tile by convert_x0 (8 LDS reads, 4 splits, 3 sixteen-byte stores per pixel).  All five
+//   blocks then run ONE copy of layer-1 code, and no layer's weights live in registers.
+// * decode_final (1x129, 8 -> 1) reads block 4's output as three bf16 planes too.  GEMM as in the other forms -- rows = 16 bin phases m,
+//   columns = (frame, 16-bin block j), K = (144 window taps u) x 8 channels in 36 chunks of 4 taps, A[m][(u, c)] = W[u - m][c] -- but
+//     - the A fragment of lane (kq, m) for chunk q is W[4q + kq - m][0..7]: sixteen contiguous bytes of a [tap][8] table with zero rows
+//       around taps 0..128.  The whole Toeplitz operand is that 7.5-KB table, resident in LDS for the kernel's lifetime (the fp32 form
+//       streams 73.7 KB of fragments from the L2 into registers per tile);
+//     - the image ("H'") keeps bin b of frame f at row 140 f + b + (b >> 4): a pad row per 16 bins.  The 16 columns of a read are bins
+//       16 rows apart in up to four frames; at a plain stride of 16 rows = 256 bytes the four blocks of a frame would meet on one bank
+//       slot (4-way conflicts: the phase would be bound by the LDS), with 17 they sit on neighbouring slots and the four frames (140 = 12
+//       mod 16) four slots apart: one two-way meeting per read.  b >> 4 of a window tap is (j - 4) + (q >> 2): the same for every lane of a
+//       chunk, so the pad rows cost no per-lane arithmetic;
+//     - there are no zero pads around a frame: a lane whose tap lies outside bins 0..128 reads a zero row instead (one compare + select
+//       per chunk and column tile on the row address);
+//     - bin 128 is a third column tile (block 8: one row of 16 used, chunks 0..16 only) instead of a dot product on one wave's VALU.
+//   The image lies over the 8-channel planes (dead once block 4's layer 1 has run); convert_x0 rewrites them for the next tile and puts
+//   the zeros back into their gap rows.  K is cut in eight runs, one per wave (4 chunks x 3 column tiles on waves 0..3, 5 chunks x 2
+//   on waves 4..7: 22 / 23 six-MFMA sets per SIMD); partial sums meet in LDS (rows of the 18-channel planes, dead by then).
+constexpr int kHFr = 140;                        // H' rows per frame (137 used: bin 128 sits at row 136; rows 137..139 spare)
+constexpr int kHRows = kTF * kHFr;               // 560
+constexpr int kHPlaneBytes = kHRows * 16;        // one part of the image: 8,960
+constexpr int kHZeroRow = kHRows - 1;            // the zero row out-of-range taps read (frame 3's last spare row; zeroed once per tile)
+constexpr int kFinTRows = 160;                   // table rows: tap t at row t + 15, t = -15 .. 144
+constexpr int kFinTPart = kFinTRows * 16;        // bytes per part
+constexpr int kFinTFloats = 3 * kFinTPart / 4;   // 1,920
+constexpr int kATotal = 5 * kTBlockX;            // the weight stream of this form: every block in the bf16-pipe format
+template <>
+struct Map<3> {
+  static constexpr bool X6 = true, kX6 = true, kFused = true, kAllX6 = true, kL1X6 = true;
+  static_assert(RCED_T_L1X6 != 0, "the all-x6 form is built on layer1_x6l");
+  static constexpr int kB8Off = 0;                                              // the 8-channel planes (3 x 8,640 B) / decode_final's image (3 x 8,960 B)
+  static constexpr int kB8RegionBytes = 3 * (kHPlaneBytes > kB8PlaneBytes ? kHPlaneBytes : kB8PlaneBytes);
+  static constexpr int kB18Off = kB8Off + kB8RegionBytes / 4;
+  static constexpr int kRemOff = kB18Rows * 32;
+  static constexpr int kRemRows = kB18Rows + 6;
+  static constexpr int kPlaneBytes = ((kRemOff + kRemRows * 4 + 15) / 16) * 16;
+  static constexpr int kRemHMBytes = 0, kRemLBytes = 0;
+  static constexpr int kB18Bytes = 3 * kPlaneBytes;
+  static constexpr int kWOff = kB18Off + kB18Bytes / 4;                         // layer 2's + layer 3's images of the block
+  static constexpr int kW3TOff = kWOff + kG2;
+  static constexpr int kWRegions = 1;
+  static constexpr int kB30Off = kWOff;
+  static constexpr int kW1Off = kW3TOff + kW3T;                                 // layer 1's image of the block (21 pieces + shifts)
+  static constexpr int kFinTOff = kW1Off + kG1X;                                // decode_final's tap table
+  static constexpr int kX0Off = kFinTOff + kFinTFloats;                         // the next tile's input rows, fp32 (convert_x0's source)
+  static constexpr int kHOff = kB8Off, kFin128Off = kB8Off;                     // (other forms' buffers: make_lane's unused addresses)
+  static constexpr int kEdgeOff = kX0Off + kX0Floats;
+  static constexpr int kEdgeFlagOff = kEdgeOff + 4 * 2 * 128;
+  static constexpr int kLdsFloats = kEdgeFlagOff + 8;
+  static constexpr int kLdsBytes = kLdsFloats * 4;
+  static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+  static_assert((kB18Off * 4) % 16 == 0 && (kWOff * 4) % 16 == 0 && (kW3TOff * 4) % 16 == 0 && (kW1Off * 4) % 16 == 0 && (kFinTOff * 4) % 16 == 0 &&
+                (kX0Off * 4) % 16 == 0 && (kEdgeOff * 4) % 16 == 0, "aligned buffers");
+  // decode_final's partial sums: 8 waves x 3 column tiles x 1 KiB in rows of the 18-channel planes' REAL pixels (their gap rows must stay
+  // zero): column tile ct in part ct, wave w in the first 64 rows of frame w & 3 (two slots)
+  static constexpr int finscr(int w, int ct) { return kB18Off * 4 + ct * kPlaneBytes + (kB18Pad + kS * (w & 3)) * 32 + (w >> 2) * 1024; }
+  static constexpr int kT1R = 128 * kB8S * 4, kT1W = 128 * 32;
+  static constexpr int kT2R = 0, kT2W = 0, kT3R = 0, kT3W = 0;
+  static constexpr int kTileB18 = 16 * 32;
+};
+typedef Map<3> MapA;
+static_assert(MapA::finscr(7, 2) % 16 == 0 && MapA::finscr(7, 0) + 1024 <= MapA::kB18Off * 4 + (kB18Pad + kS * 3 + kF) * 32, "partial sums: aligned, inside real rows");
+
 // ---- decode_final (1x129, 8 -> 1, no BN, no ReLU; model.py:89-90) inside the kernel ----------------------------
 // The CD2 output of a tile never leaves the CU: block 4's layer 3 stores it to H, an LDS image that aliases the (by then
 // dead) B18 buffer: H pixel 193*i + 64 + f holds bin f of frame i, channel stride kHS; the 64 pixels in front of every
@@ -362,7 +429,7 @@ struct Params {
   const float* x;       // [N, T, 129]
   float* y;             // [N, T, 129]    the mask (output of decode_final)
   const float* wpack;   // kWTotal (F32 form) / kGTotal (X6 form) floats
-  const float* fin;     // kFinPack floats: decode_final's A fragments + its bin-128 weights (pack_v3)
+  const float* fin;     // kFinPack floats: decode_final's A fragments + its bin-128 weights (pack_v3); all-x6 form: kFinTFloats, its tap table
   float fin_bias;
   int N, T;
   int tiles_per_utt;    // ceil(T / kTF)
@@ -633,6 +700,8 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
     L.wh1 = haddr(2 * (px0 + 128) + (kq >> 1));
     L.whx = haddr(2 * (256 + n) + (kq >> 1));
     if constexpr (M::kFused) L.wh0 = H + 4 * ((kHFrame * (wave & 3) + 64 + 64 * (wave >> 2) + n) * kHS + 2 * kq);
+    // all-x6 form: decode_final's image H': bin b = 64 (wave >> 2) + 16 t + n of frame wave & 3 at row 140 f + b + (b >> 4) = this + 17 t; channels 2kq, 2kq + 1
+    if constexpr (M::kAllX6) L.wh0 = lds_addr(lds + M::kB8Off) + (kHFr * (wave & 3) + 68 * (wave >> 2) + n) * 16 + 4 * kq;
   }
   unsigned v = 0;
 #pragma unroll
@@ -1800,6 +1869,8 @@ __device__ __forceinline__ void final_phase(const Params& P, unsigned lds0, unsi
   }
 }
 
+#include "kernels_fused_v3_allx6.h"
+
 // (no packed fp32 VALU: hipcc pairs the fused form's shift-adds of a lane's two couts into v_pk_add_f32 fed by two v_mov_b32_dpp --
 // three instructions where two v_add_f32_dpp do, and the packed add is the slower instruction beside MFMAs)
 template <class M>
@@ -1820,14 +1891,17 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
   A2Regs A2;
   // piece k = 0..16 of a block's register-resident weights (X6 form; g = that block's images): layer 1's main pass (k < 7),
   // layer 2's M-tile of this wave (7..16).  (Layer 1's remainder pass, 8 more pieces for waves 4..7: inside layer 1.)
-  const wrsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wpack), 0, (M::kFused ? kTTotal : M::kX6 ? kGTotal : kWTotal) * 4, 0x00020000);
+  const wrsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wpack), 0, (M::kAllX6 ? kATotal : M::kFused ? kTTotal : M::kX6 ? kGTotal : kWTotal) * 4, 0x00020000);
   constexpr bool kL1X = M::kFused && RCED_T_L1X6;   // blocks 1..4's layer 1 on the bf16 pipe: their layer-1 images are kG1X floats, block 0's kG1
   auto wload = [&](auto kc, int g, unsigned voff, int g1size = kG1) {   // g: float offset of the block's images in the stream
     constexpr int k = decltype(kc)::value;
     if constexpr (k < 7) a1_load_one<k>(A1, wrs, g, voff);
     else if constexpr (k < 17) a2_load_one<k - 7>(A2, wrs, g + g1size, RCED_L2_BOTH ? 0 : wave >> 2, voff);
   };
-  if constexpr (M::kX6) {
+  if constexpr (M::kAllX6) {   // no weight lives in registers: decode_final's tap table (once) and block 0's layer-1 image by LDS-DMA
+    packet_dma<kFinTFloats>(P.fin, lds + M::kFinTOff, wave, lane);
+    a1x_dma<M>(P.wpack, lds, wave, lane);
+  } else if constexpr (M::kX6) {
     const unsigned voff = (unsigned)lane * 16u;
     static_for<0, 7>([&](auto kc) { wload(kc, 0, voff); });
     if constexpr (M::kFused) packet_dma<kFin128>(P.fin + kFinA, lds + M::kFin128Off, wave, lane);   // decode_final's bin-128 weights: once, a place of their own
@@ -1863,6 +1937,10 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
   const unsigned lds0 = lds_addr(lds);
   xstage_store(xst, lds + M::kX0Off, tid);   // the first tile's input rows; every later tile's are stored by final_phase
   __syncthreads();
+  if constexpr (M::kAllX6) {                 // ... and laid out as the first layer's planes
+    convert_x0<M>(lds0, wave, lane);
+    __syncthreads();
+  }
   constexpr int kBlockFloats = M::kFused ? kTBlock : M::kX6 ? kGBlock : kWBlock;
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -1890,7 +1968,7 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
         // What is fetched for later once the layer's first operand reads are in flight.  F32 form: layer 2's packet.  X6 form:
         // layer 3's packet (its one LDS region is dead until then).
         auto dma = [&] {
-          if constexpr (M::kFused) packet_dma<kG2 + kW3T>(wsrc + (kL1X && blk > 0 ? kG1X : kG1), WREG(0), wave, lane);   // layer 2's and layer 3's images, adjacent in the stream
+          if constexpr (M::kFused) packet_dma<kG2 + kW3T>(wsrc + (M::kAllX6 || (kL1X && blk > 0) ? kG1X : kG1), WREG(0), wave, lane);   // layer 2's and layer 3's images, adjacent in the stream
           else if constexpr (M::kX6) packet_dma<kW3>(wsrc + kG1 + kG2, WREG(0), wave, lane);
           else packet_dma<kW2>(wsrc + kW1, WREG(wcur ^ 1), wave, lane);
         };
@@ -1955,7 +2033,8 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
         }
             }
     };
-    if constexpr (kL1X) l1_section(IC<1>{}, 0);
+    if constexpr (M::kAllX6) l1_section(IC<0>{}, 0);   // (the first layer is layer1_x6l too)
+    else if constexpr (kL1X) l1_section(IC<1>{}, 0);
 #pragma unroll 1
     for (int blk = 0;; ++blk) {
       if constexpr (kL1X) {
@@ -1976,7 +2055,7 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
           }
         };
         auto dma1 = [&] {   // layer 1 on the bf16 pipe: the next block's layer-1 image into the (now dead) input-row area and the H image's bins
-          if constexpr (kL1X) a1x_dma<M>(wsrc + (blk == 0 ? kTBlock : kTBlockX), lds, wave, lane);
+          if constexpr (kL1X) a1x_dma<M>(wsrc + (blk == 0 && !M::kAllX6 ? kTBlock : kTBlockX), lds, wave, lane);
         };
         layer23<M, false>(P, L, lds0, lds_addr(WREG(0)), A2, blk, wave, 0x80000000u | epoch, sk1, sk2, sp, dma1 DET_PASS);
         STAMP_MATH(2);
@@ -2003,11 +2082,22 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
         layer_end_sync();
         STAMP_WAIT(2);
       }
-      wsrc += kL1X && blk > 0 ? kTBlockX : kBlockFloats;
-      gofs += kL1X && blk > 0 ? kTBlockX : kBlockFloats;
+      wsrc += M::kAllX6 || (kL1X && blk > 0) ? kTBlockX : kBlockFloats;
+      gofs += M::kAllX6 || (kL1X && blk > 0) ? kTBlockX : kBlockFloats;
     }
     FinA finA;
-    if constexpr (M::kFused) {   // ---- block 4's layers 2 + 3; decode_final's A fragments ride in its last slots, the next tile's input rows in front
+    if constexpr (M::kAllX6) {   // ---- block 4's layers 2 + 3 (its output goes to decode_final's image H'), then decode_final and the next tile's planes
+      STAMP_BEGIN();
+      ++epoch;
+      xst = xstage_load(P, tile + 1 < tile_end ? tile + 1 : P.total_tiles, tid);
+      // the zero row out-of-range taps read: the image lies over the 8-channel planes (dead since block 4's layer 1), whose old contents are there
+      if (wave == 0 && lane < 3) lds_st<u32x4>(lds0 + 4 * M::kB8Off + kHZeroRow * 16 + (unsigned)lane * kHPlaneBytes, 0, u32x4{0u, 0u, 0u, 0u});
+      auto dma1 = [&] { a1x_dma<M>(P.wpack, lds, wave, lane); };   // the next tile's first layer: block 0's image (the stream wraps)
+      layer23<M, true>(P, L, lds0, lds_addr(WREG(0)), A2, 4, wave, 0x80000000u | epoch, sk1, sk2, [](auto) {}, dma1 DET_PASS);
+      STAMP_MATH(2);
+      layer_end_sync();
+      STAMP_WAIT(2);
+    } else if constexpr (M::kFused) {   // ---- block 4's layers 2 + 3; decode_final's A fragments ride in its last slots, the next tile's input rows in front
       STAMP_BEGIN();
       ++epoch;
       xst = xstage_load(P, tile + 1 < tile_end ? tile + 1 : P.total_tiles, tid);
@@ -2052,8 +2142,12 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
 #if RCED_STAMPS
     const unsigned long long st_f_ = stamp();
 #endif
-    const unsigned w128 = M::kX6 ? lds0 + 4 * M::kFin128Off : lds_addr(WREG(wcur) + kW1);   // (fused form: loaded once, at the kernel's start)
-    final_phase<M>(P, lds0, w128, wave, lane, utt, t0, finA, xst, lds + M::kX0Off);   // no barrier at its end: layer 1's covers it
+    if constexpr (M::kAllX6) {
+      final_phase_x6<M>(P, lds0, wave, lane, utt, t0, xst, lds + M::kX0Off DET_PASS);
+    } else {
+      const unsigned w128 = M::kX6 ? lds0 + 4 * M::kFin128Off : lds_addr(WREG(wcur) + kW1);   // (fused form: loaded once, at the kernel's start)
+      final_phase<M>(P, lds0, w128, wave, lane, utt, t0, finA, xst, lds + M::kX0Off);   // no barrier at its end: layer 1's covers it
+    }
 #if RCED_STAMPS
     tfin += stamp() - st_f_;
 #endif

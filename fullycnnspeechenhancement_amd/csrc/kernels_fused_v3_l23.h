@@ -235,7 +235,14 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
       sk1[t] = blk == 0 ? v : sk1[t];
       sk2[t] = blk == 1 ? v : sk2[t];
     }
-    if constexpr (RCED_T_L1X6 && !LAST) {   // the next layer 1 runs on the bf16 pipe: its input as three bf16 planes, 16-byte rows
+    if constexpr (M::kAllX6 && LAST) {      // decode_final's image H': three bf16 planes, bin b at row b + (b >> 4) of its frame (Map<3>)
+      const P3 p = split2(v.x, v.y);
+      if (t < 4 || vbit(L, kVN0)) {
+        lds_st<unsigned>(L.wh0, t * 272, p.h);
+        lds_st<unsigned>(L.wh0, t * 272 + kHPlaneBytes, p.m);
+        lds_st<unsigned>(L.wh0, t * 272 + 2 * kHPlaneBytes, p.l);
+      }
+    } else if constexpr (RCED_T_L1X6 && !LAST) {   // the next layer 1 runs on the bf16 pipe: its input as three bf16 planes, 16-byte rows
       const P3 p = split2(v.x, v.y);
       if (t < 4 || vbit(L, kVN0)) {
         lds_st<unsigned>(L.wr3p, t * 256, p.h);
@@ -399,13 +406,18 @@ __device__ __forceinline__ Parts b8_load(unsigned rd, int off) {
 // the shifts) and the bins of decode_final's image (four pieces per frame; its zero pads are not touched).  No weight registers at
 // all: a version with the fragments in registers (42 + 48, loaded from global memory like the first layer's) was parity-exact and
 // spilled (192 .. 336 B, the skip arrays reloaded inside the fused phase's epilogues: 7.7 ms against 6.15 for this one).
+// (All-x6 form: a region of its own, the 21 pieces back to back and the shifts behind them.)
 template <class M>
 constexpr int a1x_off(int i) {   // byte offset of piece i from the start of LDS
-  return i < 5 ? M::kX0Off * 4 + i * 1024
-               : M::kHOff * 4 + (kHFrame * ((i - 5) / 4) + 64) * kHS * 4 + 8 * (((i - 5) / 4) & 1) + ((i - 5) % 4) * 1024;
+  if constexpr (M::kAllX6) return M::kW1Off * 4 + i * 1024;
+  else return i < 5 ? M::kX0Off * 4 + i * 1024
+                    : M::kHOff * 4 + (kHFrame * ((i - 5) / 4) + 64) * kHS * 4 + 8 * (((i - 5) / 4) & 1) + ((i - 5) % 4) * 1024;
 }
 template <class M>
-constexpr int a1x_shift_off() { return M::kX0Off * 4 + 5 * 1024; }
+constexpr int a1x_shift_off() {
+  if constexpr (M::kAllX6) return M::kW1Off * 4 + 21 * 1024;
+  else return M::kX0Off * 4 + 5 * 1024;
+}
 static_assert(a1x_shift_off<MapT>() + 128 <= (MapT::kX0Off + kX0Floats) * 4 && a1x_off<MapT>(20) + 1024 <= (MapT::kHOff + (kHFrame * 3 + 64 + kF) * kHS) * 4 &&
               a1x_off<MapT>(8) % 16 == 0 && a1x_off<MapT>(9) % 16 == 0 && a1x_off<MapT>(13) % 16 == 0 && a1x_off<MapT>(17) % 16 == 0,
               "layer 1's LDS-resident images: inside the input-row area / the real bins of the H image, 16-byte aligned");
@@ -424,15 +436,15 @@ __device__ __forceinline__ void a1x_dma(const float* src, float* lds, int wave, 
   }
 }
 template <class M, int I>
-__device__ __forceinline__ s16x8 a1x_ld(unsigned aX, unsigned aH) {   // aX / aH: this lane's 16 bytes in the input-row area / the H image
-  if constexpr (I < 5) return lds_ld<s16x8>(aX, I * 1024);
+__device__ __forceinline__ s16x8 a1x_ld(unsigned aX, unsigned aH) {   // aX / aH: this lane's 16 bytes in the input-row area / the H image (all-x6 form: aX = its own region)
+  if constexpr (I < 5 || M::kAllX6) return lds_ld<s16x8>(aX, I * 1024);
   else return lds_ld<s16x8>(aH, a1x_off<M>(I) - M::kHOff * 4);
 }
 template <class M, class Dma, class Sp>
 __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int role, Dma dma, Sp sp DET_ARG) {
   DET_BEGIN();
   constexpr int kTW = M::kT1W, kTR = 128 * 16;
-  const unsigned aX = lds0 + M::kX0Off * 4 + L.scr, aH = lds0 + M::kHOff * 4 + L.scr;
+  const unsigned aX = lds0 + (M::kAllX6 ? a1x_off<M>(0) : M::kX0Off * 4) + L.scr, aH = lds0 + M::kHOff * 4 + L.scr;
   const f32x4 sh = lds_ld<f32x4>(lds0 + a1x_shift_off<M>() + L.kq16, 0);
   const f32x2 s2 = lds_ld<f32x2>(lds0 + a1x_shift_off<M>(), 64);
   auto pre = once(dma);

@@ -24,7 +24,7 @@ print("detail (kilo-cycles; the stamps themselves cost ~100 cycles each and seri
 for w in range(8):
     v = [m.get_option("stamp%d" % (88 + w * 16 + i)) for i in range(8)]
     print("%4d  %7d %7d %7d %7d | %7d %7d %7d | %7d" % (w, *v))
-print("RCED_STAMPS=2 builds: the bf16-pipe layer 1's pair job, slot by slot (six slots, then the last pair's epilogue), kilo-cycles over all tiles")
+print("slots 8..15 (all-x6 form: decode_final's GEMM / barrier / reduce / convert / barrier; RCED_STAMPS=2 builds: the bf16-pipe layer 1's pair job, slot by slot (six slots, then the last pair's epilogue), kilo-cycles over all tiles")
 for w in range(8):
     v = [m.get_option("stamp%d" % (88 + w * 16 + 8 + i)) for i in range(8)]
     print("%4d  " % w + " ".join("%7d" % x for x in v))
