@@ -370,9 +370,16 @@ struct Map<3> {
   static constexpr int kB8Off = 0;                                              // the 8-channel planes (3 x 8,640 B) / decode_final's image (3 x 8,960 B)
   static constexpr int kB8RegionBytes = 3 * (kHPlaneBytes > kB8PlaneBytes ? kHPlaneBytes : kB8PlaneBytes);
   static constexpr int kB18Off = kB8Off + kB8RegionBytes / 4;
-  static constexpr int kRemOff = kB18Rows * 32;
+  // B18 here: per part (h, m, l) TWO half-planes [pixel][8 channels] (16-byte rows: channels 0..7 / 8..15) and the remainder channels' rows
+  // [c16 c17].  A lane of layer 1's epilogue owns 4 channels of a pixel = 8 bytes; with [pixel][16] rows of 32 bytes the 16 lanes one
+  // ds_write_b64 group serves sat 32 bytes apart -- on 4 of the 16 eight-byte bank slots, 4-way conflicts on every one of the layer's 99
+  // plane stores (1 k of its 6 k cycles); with 16-byte rows they sit 16 bytes apart: 2-way, which a ds_write_b64 absorbs.  Layer 2's
+  // fragment (8 channels of a pixel) is still one aligned ds_read_b128; half-planes a multiple of 256 bytes apart keep the lane groups
+  // of that read conflict-free.
+  static constexpr int kHalfBytes = ((kB18Rows * 16 + 255) / 256) * 256;       // 8,704
+  static constexpr int kRemOff = 2 * kHalfBytes;
   static constexpr int kRemRows = kB18Rows + 6;
-  static constexpr int kPlaneBytes = ((kRemOff + kRemRows * 4 + 15) / 16) * 16;
+  static constexpr int kPlaneBytes = ((kRemOff + kRemRows * 4 + 15) / 16) * 16;   // stride between the parts: 19,568
   static constexpr int kRemHMBytes = 0, kRemLBytes = 0;
   static constexpr int kB18Bytes = 3 * kPlaneBytes;
   static constexpr int kWOff = kB18Off + kB18Bytes / 4;                         // layer 2's + layer 3's images of the block
@@ -391,14 +398,14 @@ struct Map<3> {
   static_assert((kB18Off * 4) % 16 == 0 && (kWOff * 4) % 16 == 0 && (kW3TOff * 4) % 16 == 0 && (kW1Off * 4) % 16 == 0 && (kFinTOff * 4) % 16 == 0 &&
                 (kX0Off * 4) % 16 == 0 && (kEdgeOff * 4) % 16 == 0, "aligned buffers");
   // decode_final's partial sums: 8 waves x 3 column tiles x 1 KiB in rows of the 18-channel planes' REAL pixels (their gap rows must stay
-  // zero): column tile ct in part ct, wave w in the first 64 rows of frame w & 3 (two slots)
-  static constexpr int finscr(int w, int ct) { return kB18Off * 4 + ct * kPlaneBytes + (kB18Pad + kS * (w & 3)) * 32 + (w >> 2) * 1024; }
-  static constexpr int kT1R = 128 * kB8S * 4, kT1W = 128 * 32;
+  // zero): column tile ct in part ct, wave w in the first 64 rows of frame w & 3 of half-plane w >> 2
+  static constexpr int finscr(int w, int ct) { return kB18Off * 4 + ct * kPlaneBytes + (w >> 2) * kHalfBytes + (kB18Pad + kS * (w & 3)) * 16; }
+  static constexpr int kT1R = 128 * kB8S * 4, kT1W = 128 * 16;
   static constexpr int kT2R = 0, kT2W = 0, kT3R = 0, kT3W = 0;
-  static constexpr int kTileB18 = 16 * 32;
+  static constexpr int kTileB18 = 16 * 16;
 };
 typedef Map<3> MapA;
-static_assert(MapA::finscr(7, 2) % 16 == 0 && MapA::finscr(7, 0) + 1024 <= MapA::kB18Off * 4 + (kB18Pad + kS * 3 + kF) * 32, "partial sums: aligned, inside real rows");
+static_assert(MapA::finscr(7, 2) % 16 == 0 && MapA::finscr(3, 0) + 1024 <= MapA::kB18Off * 4 + (kB18Pad + kS * 3 + kF) * 16, "partial sums: aligned, inside real rows");
 
 // ---- decode_final (1x129, 8 -> 1, no BN, no ReLU; model.py:89-90) inside the kernel ----------------------------
 // The CD2 output of a tile never leaves the CU: block 4's layer 3 stores it to H, an LDS image that aliases the (by then
@@ -650,6 +657,7 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
   if constexpr (M::kX6) {
     const unsigned PL = lds_addr(lds + M::kB18Off);         // the h plane; row r = pixel r - kB18Pad
     L.wr1 = PL + (px0 + kB18Pad) * 32 + kq * 8;             // channels 4kq..4kq+3 of pixel px0
+    if constexpr (M::kAllX6) L.wr1 = PL + (kq >> 1) * M::kHalfBytes + (px0 + kB18Pad) * 16 + (kq & 1) * 8;   // (half-planes: Map<3>)
     L.wr1r = PL + M::kRemHMBytes + (rpx + 2 * kq + kB18Pad) * 8;   // channels 16,17 of pixels rpx+2kq, +1
     L.wr1rl = PL + M::kRemLBytes + (rpx + 2 * kq + kB18Pad) * 4;
     if constexpr (M::kFused) L.wr1r = PL + M::kRemOff + (rpx + 2 * kq + kB18Pad) * 4;   // [c16 c17] of the h part; m, l: + the part stride
@@ -658,13 +666,14 @@ __device__ __forceinline__ Lane make_lane(float* lds, int wave, int lane, int xr
     // (fused form: frame-aligned tiles -- waves 0..3: tiles 0..3 of frame `wave`, waves 4..7: tiles 4..8 of frame `wave - 4`)
     const int px2 = M::kFused ? kS * (wave & 3) + 64 * (wave >> 2) + n : RCED_L2_BOTH ? px0 : 16 * (wave & 3) + n;
     L.rd2m = PL + (px2 + (kq >> 1)) * 32 + (kq & 1) * 16;
+    if constexpr (M::kAllX6) L.rd2m = PL + (kq & 1) * M::kHalfBytes + (px2 + (kq >> 1)) * 16;
     // the remainder channels' window of pixel px2 = rows px2 .. px2+4; lanes kq = 2 take rows px2..+3, kq = 3 rows px2+4..+7
     // (one real tap, three zero-weight slots); the lower lanes read their upper partners' rows (same addresses: broadcast)
     L.rd2r = PL + M::kRemHMBytes + (px2 + 4 * (kq & 1)) * 8;
     L.rd2rl = PL + M::kRemLBytes + (px2 + 4 * (kq & 1)) * 4;
     if constexpr (M::kFused) {   // lanes kq < 2: tap 4 (row px2 + 4), channels 8kq..; kq = 2: rows px2..px2+3 of [c16 c17]; kq = 3: rows px2+4..
-      L.rd2c = kq < 2 ? L.rd2m + 128 : PL + M::kRemOff + (px2 + 4 * (kq & 1)) * 4;
-      L.rd2cs = kq < 2 ? 512u : 64u;
+      L.rd2c = kq < 2 ? L.rd2m + (M::kAllX6 ? 64 : 128) : PL + M::kRemOff + (px2 + 4 * (kq & 1)) * 4;
+      L.rd2cs = kq < 2 ? (unsigned)M::kTileB18 : 64u;
       asm volatile("" : "+v"(L.rd2c), "+v"(L.rd2cs));
     }
     L.rd2 = L.rd2b = L.rd2t = L.rd2tb = 0u;

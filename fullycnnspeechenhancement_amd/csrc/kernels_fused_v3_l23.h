@@ -141,9 +141,10 @@ __device__ __forceinline__ void layer23(const Params& P, const Lane& L, unsigned
 #pragma unroll
       for (int q = 0; q < 3; ++q) a2r[(3 * t + c) & 1][mt][q] = lds_ld<s16x8>(a2, ((2 * c + mt) * 3 + q) * 1024);
     if constexpr (c < 2) {
-      b.h = lds_ld<s16x8>(L.rd2m, t * 512 + 64 * c);
-      b.m = lds_ld<s16x8>(L.rd2m, t * 512 + 64 * c + M::kPlaneBytes);
-      b.l = lds_ld<s16x8>(L.rd2m, t * 512 + 64 * c + 2 * M::kPlaneBytes);
+      constexpr int off = t * M::kTileB18 + (M::kAllX6 ? 32 : 64) * c;   // 16 rows per tile, two rows (taps) per chunk
+      b.h = lds_ld<s16x8>(L.rd2m, off);
+      b.m = lds_ld<s16x8>(L.rd2m, off + M::kPlaneBytes);
+      b.l = lds_ld<s16x8>(L.rd2m, off + 2 * M::kPlaneBytes);
     } else {   // the same four dwords per part for every lane (see Map<2>): plane rows for the lower lanes, the remainder channels' for the upper
       u32x4 h, m, l;
 #pragma unroll
