@@ -299,68 +299,81 @@ def host_buffers_line(model, x, steps=5):
                     "model(x, out=buf)"}
 
 
-def from_root_line(args, torch, dist, model, spec, world, rank, local_rank, B, T):
-    """The reference's single-host-process convention over RCCL: rank 0 holds the whole batch, scatters batch slices,
-    every rank computes, the masks gather back (fullycnnspeechenhancement_amd/dist.py)."""
+def from_root_line(args, torch, dist, model, spec, world, rank, dev_index, B, T, ctl="cuda", transports=("rccl", "copy")):
+    """The reference's single-host-process convention: rank 0 holds the whole batch, every rank computes its batch slice, the masks
+    end up on rank 0 (fullycnnspeechenhancement_amd/dist.py) -- over RCCL send / recv (transport "rccl", with r CUs left to the
+    communicators' kernels, r swept) and as peer copies through IPC handles (transport "copy": no CU needed)."""
     from fullycnnspeechenhancement_amd.dist import BatchShardedForward, reserved_cus
-    eng = BatchShardedForward(model, device="cuda:%d" % local_rank, forward_into=lambda a, out: model(a, out=out))
+
+    def timed(eng, steps, warm, **kw):
+        for _ in range(warm):
+            eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks, **kw)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks, **kw)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tm = torch.tensor([time.perf_counter() - t0], device=ctl, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return float(tm.item())
+
     xr = None
     if rank == 0:
         xr = torch.from_numpy(synthetic_magnitudes((world * B, T, spec.FEATURE_DIM, 1), 1234)).cuda()   # SURVEY 8(d2) C4
-    # The fused kernel is a persistent grid of one workgroup per CU holding nearly all of the CU's LDS; RCCL's send / recv are
-    # kernels too and can only start on a CU a workgroup has left.  So the pipelined call is timed with r CUs left free for
-    # them (dist.reserved_cus: fused_grid = num_cus - r), r swept; the fastest is `value`, all are reported.
-    sweep = {}
-    for r in (0, 4, 8, 16):
-        with reserved_cus(model, r):
-            for _ in range(2 if r == 0 else 1):
-                eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks)
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.from_root_steps):
-                eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks)
-            torch.cuda.synchronize()
-            dist.barrier()
-            tm = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            sweep[r] = float(tm.item())
-    best_r = min(sweep, key=lambda k: sweep[k])
-    el = sweep[best_r]
-    # compute-free passes: what the links alone take per direction, so that the overlap shows as
-    # ms_per_step ~ max(compute, transfer) instead of being inferred
-    probe = {}
-    for direction in ("scatter", "gather"):
+    steps = args.from_root_steps
+    res = {}
+    if "rccl" in transports:
+        eng = BatchShardedForward(model, device="cuda:%d" % dev_index, forward_into=lambda a, out: model(a, out=out))
+        # The fused kernel is a persistent grid of one workgroup per CU holding nearly all of the CU's LDS; RCCL's send / recv are
+        # kernels too and can only start on a CU a workgroup has left.  So the pipelined call is timed with r CUs left free for
+        # them (dist.reserved_cus: fused_grid = num_cus - r), r swept: every point is reported, `value` is the r = 0 figure and
+        # `best` the fastest point of the sweep (a best-of-4: labelled as such).
+        sweep = {}
+        for r in (0, 4, 8, 16):
+            with reserved_cus(model, r):
+                sweep[r] = timed(eng, steps, 2 if r == 0 else 1)
+        best_r = min(sweep, key=lambda k: sweep[k])
+        # compute-free passes: what the links alone take per direction, so that the overlap shows as
+        # ms_per_step ~ max(compute, transfer) instead of being inferred
+        probe = {}
+        for direction in ("scatter", "gather"):
+            try:
+                probe[direction + "_only_ms"] = 1e3 * timed(eng, 3, 1, direction=direction) / 3
+            except Exception as e:
+                probe[direction + "_only_ms"] = "%s: %s" % (type(e).__name__, e)
+        eng.close()
+        res["rccl"] = {"value": world * B * T * steps / sweep[0], "ms_per_step": 1e3 * sweep[0] / steps,
+                       "reserved_cus_sweep_ms_per_step": {str(r): 1e3 * v / steps for r, v in sweep.items()},
+                       "best": {"reserved_cus": best_r, "ms_per_step": 1e3 * sweep[best_r] / steps,
+                                "value": world * B * T * steps / sweep[best_r], "note": "the fastest of the four sweep points"},
+                       "transfer_only": probe}
+    if "copy" in transports:
         try:
-            eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks, direction=direction)
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                eng.forward_from_root(xr, root=0, chunks=args.from_root_chunks, direction=direction)
-            torch.cuda.synchronize()
-            dist.barrier()
-            tp = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
-            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-            probe[direction + "_only_ms"] = 1e3 * float(tp.item()) / 3
+            eng = BatchShardedForward(model, device="cuda:%d" % dev_index, forward_into=lambda a, out: model(a, out=out), transport="copy")
+            el = timed(eng, steps, 2)
+            probe = {}
+            for direction in ("scatter", "gather"):
+                probe[direction + "_only_ms"] = 1e3 * timed(eng, 3, 1, direction=direction) / 3
+            eng.close()
+            res["copy"] = {"value": world * B * T * steps / el, "ms_per_step": 1e3 * el / steps, "transfer_only": probe}
         except Exception as e:
-            probe[direction + "_only_ms"] = "%s: %s" % (type(e).__name__, e)
-    eng.close()
-    return {"value": world * B * T * args.from_root_steps / el, "unit": "frames/s",
-            "ms_per_step": 1e3 * el / args.from_root_steps, "steps": args.from_root_steps,
-            "chunks": args.from_root_chunks, "global_batch": world * B,
-            "bytes_per_peer_each_way": B * T * spec.FEATURE_DIM * 4,
-            "reserved_cus": best_r,
-            "reserved_cus_sweep_ms_per_step": {str(r): 1e3 * v / args.from_root_steps for r, v in sweep.items()},
-            "transfer_only": probe,
-            "note": "BatchShardedForward.forward_from_root: rank 0 holds [N*B,T,129,1] in HBM, scatters batch "
-                    "slices over RCCL send/recv (one peer per xGMI link), every rank computes, masks gather back "
-                    "to rank 0; chunked so that transfer overlaps compute; the forwards run on num_cus - reserved_cus "
-                    "workgroups so that RCCL's kernels find free CUs (sweep: reserved_cus_sweep_ms_per_step; the fastest is "
-                    "this entry's value).  Reported beside `value`, not as it.  "
-                    "transfer_only: the same call with no compute, one direction at a time (3 calls each): with the "
-                    "overlap working, ms_per_step ~ max(resident ms_per_step, scatter_only_ms, gather_only_ms) + "
-                    "one chunk's transfer at each end."}
+            res["copy"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    ok = {k: v for k, v in res.items() if "value" in v}
+    fastest = max(ok, key=lambda k: ok[k]["value"]) if ok else None
+    return {"value": ok[fastest]["value"] if fastest else None, "unit": "frames/s",
+            "ms_per_step": ok[fastest]["ms_per_step"] if fastest else None, "transport": fastest, "steps": steps,
+            "chunks": args.from_root_chunks, "global_batch": world * B, "bytes_per_peer_each_way": B * T * spec.FEATURE_DIM * 4,
+            "transports": res,
+            "note": "BatchShardedForward.forward_from_root: rank 0 holds [N*B,T,129,1] in HBM, every rank computes its batch slice, "
+                    "the masks end up on rank 0; chunked so that transfer overlaps compute.  transports.rccl: slices scattered / "
+                    "gathered by RCCL send/recv on two communicators (one peer per xGMI link); `value` there is measured with every CU "
+                    "given to the forward (reserved_cus 0), the sweep leaves r CUs to RCCL's kernels.  transports.copy: the peers pull "
+                    "/ push through IPC handles to rank 0's tensors with device-to-device copies (SDMA engines, no CU).  This entry's "
+                    "value = the faster transport's.  Reported beside the headline `value`, not as it.  transfer_only: the same call "
+                    "with no compute, one direction at a time (3 calls each): with the overlap working, ms_per_step ~ max(resident "
+                    "ms_per_step, scatter_only_ms, gather_only_ms) + one chunk's transfer at each end."}
 
 
 def secondary_config2(torch, build_model, spec, _lib, _weights, local_rank):
@@ -738,9 +751,11 @@ def main():
                 if os.environ.get("RCED_BENCH_REHEARSE_HANG", "0") == "1":     # tests: a from_root that never returns
                     while True:
                         time.sleep(1.0)
-                out["from_root"] = {"skipped": "rehearsal: gloo does not move device tensors between ranks"}
+                # gloo does not move device tensors between ranks; the copy transport needs no communicator: the ranks share this box's
+                # GPU(s) and the IPC-handle path runs for real
+                out["from_root"] = from_root_line(args, torch, dist, model, spec, world, rank, dev_index, B, T, ctl="cpu", transports=("copy",))
             else:
-                out["from_root"] = from_root_line(args, torch, dist, model, spec, world, rank, local_rank, B, T)
+                out["from_root"] = from_root_line(args, torch, dist, model, spec, world, rank, dev_index, B, T)
         except Exception as e:      # the headline line must survive a failure of the secondary figure
             out["from_root"] = {"error": "%s: %s" % (type(e).__name__, e)}
         timer.cancel()

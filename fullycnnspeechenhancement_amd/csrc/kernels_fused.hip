@@ -538,6 +538,9 @@ int upload(float** dev, const std::vector<float>& host) {   // *dev is set only 
 
 }  // namespace
 
+// tools/summarize_prof.py prints these next to a profile (the kernel-trace CSV reports 0 for dynamic LDS)
+static_assert(v3::MapA::kLdsBytes == 159024 && v3::MapT::kLdsBytes == 163792 && v3::MapX6::kLdsBytes == 162976 && v3::MapF32::kLdsBytes == 163024,
+              "update DYNAMIC_LDS in tools/summarize_prof.py");
 template <class M>
 int v3_set_lds() {
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3::fused_v3_kernel<M>),
@@ -694,10 +697,13 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   return RCED_OK;
 }
 
+// Returns RCED_OPT_UNKNOWN (rced_internal.h) for a key that is not an option of the fused runtime; for a key that is, RCED_OK or a failure
+// whose message rced_fail() has set -- rced_set_option overwrites the message only in the first case (the specific refusals,
+// "v3_l2x6 selects the form of the CR-CED kernel only" ..., used to be replaced by the generic "unknown option" text).
 int fused_set_option(rced_model* m, const char* key, int value) {
-  if (!m->fused) return RCED_ERR_ARG;
+  if (!m->fused) return RCED_OPT_UNKNOWN;
   if (!strcmp(key, "fused_grid")) {
-    if (value < 0) return RCED_ERR_ARG;
+    if (value < 0) return rced_fail(RCED_ERR_ARG, "fused_grid must be >= 0 (0 = one workgroup per CU), got %d", value);
     m->fused->grid_limit = value;
     return RCED_OK;
   }
@@ -705,13 +711,13 @@ int fused_set_option(rced_model* m, const char* key, int value) {
     static const char* const names[3] = {"final_x6", "final_lds", "bf16_final16"};
     if (strcmp(key, names[i])) continue;
     if (m->variant == RCED_V3) return rced_fail(RCED_ERR_ARG, "%s selects the R-CED V1 / V2 output-layer kernel; CR-CED's runs inside its fused kernel", key);
-    if (value != 0 && value != 1) return RCED_ERR_ARG;
+    if (value != 0 && value != 1) return rced_fail(RCED_ERR_ARG, "%s takes 0 or 1, got %d", key, value);
     (i == 0 ? m->fused->final_x6 : i == 1 ? m->fused->final_lds : m->fused->bf16_final16) = value;
     return RCED_OK;
   }
   if (!strcmp(key, "v3_l2x6")) {
     if (m->variant != RCED_V3) return rced_fail(RCED_ERR_ARG, "v3_l2x6 selects the form of the CR-CED kernel only");
-    if (value < 0 || value > 3) return RCED_ERR_ARG;
+    if (value < 0 || value > 3) return rced_fail(RCED_ERR_ARG, "v3_l2x6 takes 0 .. 3 (the forms of the CR-CED kernel), got %d", value);
     if (int rc = v3_enable_form(m, m->fused, value)) return rc;
     m->fused->v3_l2x6 = value;
     return RCED_OK;
@@ -730,7 +736,7 @@ int fused_set_option(rced_model* m, const char* key, int value) {
     *reinterpret_cast<volatile unsigned*>(m->fused->err_host) = (unsigned)value;
     return RCED_OK;
   }
-  return RCED_ERR_ARG;
+  return RCED_OPT_UNKNOWN;
 }
 
 int fused_get_option(rced_model* m, const char* key, int* value) {

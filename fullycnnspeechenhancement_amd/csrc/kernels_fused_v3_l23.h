@@ -28,8 +28,13 @@
 #define RCED_T_SGB 1     // sched_group_barrier pattern inside the slots (see interleave())
 #endif
 #ifndef RCED_T_EXP
-#define RCED_T_EXP 0   // timing experiments only (wrong results): 1 = no shift-adds, 2 = layer 3's A fragments read once, 4 = no split arithmetic,
-                       // 8 = layer 2's B fragments read once per tile
+#define RCED_T_EXP 0   // timing experiments only (WRONG RESULTS): 1 = no shift-adds, 2 = layer 3's A fragments read once (round 5: this build's
+                       // 10 % are not the reads -- with equal fragments hipcc merges the MFMAs of M-tiles 2..4 into those of 0, 1: 252 of the
+                       // kernel's 1,218 static MFMAs disappear), 4 = no split arithmetic, 8 = layer 2's B fragments read once per tile,
+                       // 256 = a third of layer 1's B reads, 512 = no weight transfers
+#endif
+#if (RCED_T_EXP != 0 || RCED_X6_EXP != 0) && !defined(RCED_TIMING_ONLY)
+#error "RCED_T_EXP / RCED_X6_EXP builds compute wrong results: timing experiments only (tools/mkexp.sh ... -DRCED_TIMING_ONLY -DRCED_T_EXP=...)"
 #endif
 
 // a copy of v shifted along the 16-lane row, zero where the source lane lies outside the row

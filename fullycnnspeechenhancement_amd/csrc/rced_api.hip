@@ -358,7 +358,7 @@ int rced_set_option(rced_model* m, const char* key, int value) {
   {
     DeviceGuard g(m->device);   // some fused options allocate / upload (e.g. "bf16")
     const int rc = fused_set_option(m, key, value);
-    if (rc != RCED_ERR_ARG) return rc;   // RCED_OK, or a failure whose message the fused runtime already set
+    if (rc != RCED_OPT_UNKNOWN) return rc;   // RCED_OK, or a failure whose (specific) message the fused runtime has set
   }
   return fail(RCED_ERR_ARG, "unknown option '%s' (or a value it does not take: %d)", key, value);
 }

@@ -60,6 +60,7 @@ void fused_destroy(rced_model* m);
 int fused_reserve(rced_model* m, int N, int T);
 int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStream_t st);
 int fused_check(rced_model* m);   // RCED_ERR_STATE if an earlier launch recorded a hand-off time-out
+#define RCED_OPT_UNKNOWN (-1)   // fused_set_option: "not a key of mine" (internal; never crosses the C ABI)
 int fused_set_option(rced_model* m, const char* key, int value);
 int fused_get_option(rced_model* m, const char* key, int* value);
 int rced_fail(int code, const char* fmt, ...);

@@ -89,7 +89,7 @@ inline size_t tm_packet_floats(int cin, int taps, int cout) {     // Geo::kPacke
   return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + (R ? (size_t)(KR / 8) * 128 + (size_t)((KR % 8 + 3) / 4) * 64 : 0) + 32;
 }
 
-// ---- the forward convolutions in the three-part bf16 form (tmm::conv_x6_fwd; DESIGN 3.3a / 3.6r3) ----
+// ---- the forward convolutions in the three-part bf16 form (tmm::conv_x6_fwd; DESIGN 3.3a / 3.5) ----
 inline size_t tm_packet_x6_floats(int cin, int taps, int cout) {   // tmm::GeoX6::kPacket
   const int ph = tm_packet_parities(cout), cs = tmm::x6_cs(cin, ph), K = (taps + ph - 1) * cs;
   const int R = ph == 1 ? tmm::tm_rem(cout) : 0, P = R ? 16 / R : 0, KR = R ? (taps + P - 1) * cs : 0;

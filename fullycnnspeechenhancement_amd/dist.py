@@ -28,17 +28,30 @@ CU's LDS, and RCCL's send / recv run as kernels that need CU slots of their own:
 when a persistent workgroup exits, and the "scatter c+1 || compute c || gather c-1" pipeline serialises.  `reserved_cus(model,
 r)` runs the forwards inside it on `num_cus - r` workgroups (the library's per-handle option "fused_grid"; the kernels'
 tile ranges are balanced over whatever grid they are launched with, and results do not depend on it), leaving r CUs to the
-communicators; bench.py's from_root leg sweeps r.  Fallback if no r hides the transfers: copies over IPC handles on the
-SDMA engines instead of RCCL kernels (not built: no multi-GPU box in the build pool to measure it on).
+communicators; bench.py's from_root leg sweeps r.
+
+Plan B: transport="copy".  No communicator kernels at all on the data path: the root hands the peers handles to its input
+and output tensors (CUDA IPC memory handles, pickled by torch.multiprocessing's reductions and broadcast over the control
+group; under gloo with CPU tensors: shared-memory files, the same code) and every peer PULLS its chunks out of the root's
+input and PUSHES its results into the root's output with plain device-to-device copies -- hipMemcpyAsync between peers, which
+the runtime puts on the SDMA engines -- on two side streams, pipelined pull c+1 || compute c || push c-1 like the RCCL form.
+The copies need no CU, so the persistent forward grids keep every CU (no `reserved_cus`).  Opened handles are cached by torch per
+storage: a caller that reuses its input tensor (and this object's output buffer, kept per shape) pays the open once.
+bench.py's from_root leg times both transports; tests hold them bit-equal (gloo world 2..4 on CPU; two processes sharing one GPU
+through IPC handles on the GPU box).
 
 Failures.  A forward that raises on one rank must not leave the others waiting for transfers that never come: the
 failing rank finishes the protocol with zero-filled results, every call ends with one status all-reduce on `group`, and
-then EVERY rank raises (the failing one its own exception, the others a RuntimeError naming the rank).  `timeout_s`
-bounds each wait on a transfer where the backend supports it (gloo; on RCCL a wait only orders the stream, and the
-process group's own timeout / watchdog applies).
+then EVERY rank raises (the failing one its own exception, the others a RuntimeError naming the rank), and the object stays
+usable.  `timeout_s` bounds each wait on a transfer where the backend supports it (gloo; on RCCL a wait only orders the
+stream, and the process group's own timeout / watchdog applies).  A transfer TIME-OUT is different: the call still ends on
+every rank with an exception, but transfers may be left pending on the direction groups (gloo closes the pair), so the object
+is poisoned -- later forward_from_root calls raise TransferTimeout until it is closed and built again.
 """
 
 import datetime
+import io
+import pickle
 
 import torch
 import torch.distributed as dist
@@ -86,6 +99,52 @@ class PeerForwardError(RuntimeError):
     """forward_from_root: the forward of another rank raised; this rank's result is incomplete."""
 
 
+class TransferTimeout(RuntimeError):
+    """A transfer of forward_from_root timed out (gloo).  The call ended on every rank, but its sends / receives may still be
+    pending on the two direction groups: a late message could land in a LATER call's buffers, so the object refuses further
+    forward_from_root calls until it is closed and built again (new direction groups)."""
+
+
+def _share(t):
+    """A DEVICE tensor -> bytes another process of this node can turn back into a tensor over THE SAME memory
+    (torch.multiprocessing.reductions: a CUDA IPC memory handle)."""
+    from multiprocessing.reduction import ForkingPickler
+    buf = io.BytesIO()
+    ForkingPickler(buf, pickle.HIGHEST_PROTOCOL).dump(t)
+    return buf.getvalue()
+
+
+def _open_shared(blob):
+    return pickle.loads(blob)
+
+
+class _ShmTensor(object):
+    """CPU stand-in for a device buffer other processes can map (the gloo tests of transport="copy"): a tensor over a named
+    POSIX shared-memory block; `handle` is what a peer needs to map it."""
+
+    def __init__(self, shape=None, dtype=None, handle=None):
+        from multiprocessing import shared_memory
+        if handle is None:
+            nbytes = max(int(torch.empty((), dtype=dtype).element_size()) * int(torch.Size(shape).numel()), 1)
+            self.shm, self.owner = shared_memory.SharedMemory(create=True, size=nbytes), True
+            self.handle = ("shm", self.shm.name, tuple(shape), str(dtype))
+        else:
+            _, name, shape, dtype_name = handle
+            dtype = getattr(torch, dtype_name.split(".")[-1])
+            self.shm, self.owner, self.handle = shared_memory.SharedMemory(name=name), False, handle
+        n = int(torch.Size(shape).numel())
+        self.tensor = torch.frombuffer(self.shm.buf, dtype=dtype, count=n).reshape(shape) if n else torch.empty(shape, dtype=dtype)
+
+    def close(self):
+        self.tensor = None
+        try:
+            self.shm.close()
+            if self.owner:
+                self.shm.unlink()
+        except Exception:
+            pass
+
+
 class BatchShardedForward(object):
     """forward: callable mapping a [n, T, 129, 1] tensor on this rank's device to the same shape
     (a fullycnnspeechenhancement_amd model on GPU; any stand-in under gloo in tests).
@@ -99,9 +158,18 @@ class BatchShardedForward(object):
     order this rank passed them (tests use it to check the pipeline order)."""
 
     def __init__(self, forward, group=None, device=None, trace=None, forward_into=None, scatter_group=None,
-                 gather_group=None, timeout_s=None, group_ranks=None):
+                 gather_group=None, timeout_s=None, group_ranks=None, transport="rccl"):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (one process per GPU)")
+        if transport not in ("rccl", "copy"):
+            raise ValueError("transport must be 'rccl' (send / recv on the two direction groups) or 'copy' (peers pull / push "
+                             "through handles to the root's tensors)")
+        self.transport = transport
+        self._poisoned = None        # set by a transfer time-out: see TransferTimeout
+        self._pending = []           # works / buffers of a timed-out call, kept alive until close()
+        self._out_cache = {}         # transport "copy": the root's output buffer (CPU: also its shared input copy) per (shape, dtype)
+        self._opened = {}            # transport "copy" on CPU: shared-memory blocks of the root this peer has mapped, by name
+        self._streams = None         # transport "copy" on CUDA: (pull stream, push stream)
         if (scatter_group is None) != (gather_group is None):
             raise ValueError("pass both scatter_group and gather_group, or neither")
         self.forward = forward
@@ -127,15 +195,23 @@ class BatchShardedForward(object):
         # scatter (root -> peers) and gather (peers -> root) each get a communicator of their own.  new_group is collective
         # over the DEFAULT group: members and non-members alike make both calls (a process that skipped them would be two
         # group-name counters behind, and its next collective new_group would pair with the wrong one).
+        # control-plane tensors (the status all-reduce) live where the control group's backend can move them
+        try:
+            self._ctl_device = self.device if (self.device.type != "cuda" or "nccl" in str(dist.get_backend(group if member else None))) \
+                else torch.device("cpu")
+        except Exception:
+            self._ctl_device = self.device
         if scatter_group is not None:
             self.scatter_group, self.gather_group = scatter_group, gather_group
+        elif transport == "copy":
+            self.scatter_group = self.gather_group = group     # no data-path communicators at all (and no collective new_group)
         elif dist.get_world_size() > 1 and len(ranks) > 1:
             self.scatter_group = dist.new_group(ranks=ranks)
             self.gather_group = dist.new_group(ranks=ranks)
             self._own_groups = [self.scatter_group, self.gather_group]
         else:
             self.scatter_group = self.gather_group = group
-        if self.world > 1 and member:
+        if self.world > 1 and member and transport != "copy":
             # The FIRST call on a group's communicator must involve all its ranks (torch.distributed.batch_isend_irecv:
             # otherwise "the behavior is undefined" on NCCL/RCCL), and forward_from_root's transfers only ever pair the
             # root with one peer: open both communicators with a collective here.
@@ -146,6 +222,11 @@ class BatchShardedForward(object):
         """Destroy the two direction groups this object created (collective over their ranks on some backends: call it
         on every rank).  Groups handed in by the caller are the caller's."""
         groups, self._own_groups = self._own_groups, []
+        for v in list(self._out_cache.values()) + list(self._opened.values()):
+            for o in (v if isinstance(v, tuple) else (v,)):
+                if isinstance(o, _ShmTensor):
+                    o.close()
+        self._pending, self._out_cache, self._opened = [], {}, {}
         for g in groups:
             try:
                 dist.destroy_process_group(g)
@@ -167,7 +248,7 @@ class BatchShardedForward(object):
         """End of a forward_from_root call on every rank: one status all-reduce (MAX over 1 + failing rank), then raise
         where something failed."""
         if self.world > 1:
-            flag = torch.tensor([0 if err is None else self.rank + 1], dtype=torch.int32, device=self.device)
+            flag = torch.tensor([0 if err is None else self.rank + 1], dtype=torch.int32, device=self._ctl_device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
             bad = int(flag.item())
         else:
@@ -191,6 +272,11 @@ class BatchShardedForward(object):
         times bench.py reports next to the pipelined figure; the returned tensor is then meaningless."""
         if direction not in ("both", "scatter", "gather"):
             raise ValueError("direction must be 'both', 'scatter' or 'gather'")
+        if self._poisoned is not None:
+            raise TransferTimeout("forward_from_root: an earlier call on this object ended with a transfer time-out (%s); its transfers "
+                                  "may still be pending -- close() it and build a new one" % self._poisoned)
+        if self.transport == "copy":
+            return self._from_root_copy(x_root, root, chunks, direction)
         # what the root broadcasts is (shape, dtype) or the text of its own validation error: the peers are already waiting
         # in the broadcast when the root looks at its input, and must fail with it rather than hang
         meta, bad_input = [None], None
@@ -226,8 +312,16 @@ class BatchShardedForward(object):
                          for r, p in pieces.items() if c < len(p)]
                 recvs = [dist.P2POp(dist.irecv, y[p[c][0]:p[c][1]], self._ranks[r], self.gather_group)
                          for r, p in pieces.items() if c < len(p)]
-                send_works.append(dist.batch_isend_irecv(sends) if do_scatter else [])
-                recv_works.append(dist.batch_isend_irecv(recvs) if do_gather else [])
+                try:
+                    send_works.append(dist.batch_isend_irecv(sends) if do_scatter else [])
+                    recv_works.append(dist.batch_isend_irecv(recvs) if do_gather else [])
+                except Exception as e:   # a direction group that a time-out broke: finish the call (status all-reduce), refuse later ones
+                    err = err or e
+                    self._poison(e, send_works, recv_works, x_root, y)
+                    while len(send_works) <= c:
+                        send_works.append([])
+                    while len(recv_works) <= c:
+                        recv_works.append([])
             lo, hi = bounds[root]
             if hi > lo and do_compute:   # the root's own slice computes while its links carry the others'
                 try:
@@ -245,6 +339,7 @@ class BatchShardedForward(object):
                     self._note("result", c)
             except Exception as e:       # a transfer that timed out (gloo): the status all-reduce below still runs, so that
                 err = err or e           # the other ranks leave the call with an error instead of waiting in it
+                self._poison(e, send_works, recv_works, x_root, y)
             self._finish(err)
             return y
 
@@ -264,7 +359,8 @@ class BatchShardedForward(object):
                 self._wait(recv_works[c])    # nccl: the current stream waits for THIS chunk only
             except Exception as e:       # a receive that timed out: go on with zeros so that the protocol still ends
                 err = err or e
-                buf.zero_()
+                self._poison(e, recv_works, bufs)
+                buf = bufs[c] = torch.zeros_like(buf)   # (not the buffer the late message may still land in)
             self._note("recv", c)
             out = buf
             if do_compute:
@@ -281,11 +377,158 @@ class BatchShardedForward(object):
                 self._note("fwd", c)
             if do_gather:
                 outs.append(out)         # keep alive until sent
-                send_works += dist.batch_isend_irecv([dist.P2POp(dist.isend, out, groot, self.gather_group)])
+                try:
+                    send_works += dist.batch_isend_irecv([dist.P2POp(dist.isend, out, groot, self.gather_group)])
+                except Exception as e:   # gloo: the root's timed-out wait has closed the pair -- the send fails when it is issued
+                    err = err or e
+                    self._poison(e, outs)
                 self._note("send", c)
         try:
             self._wait(send_works)
         except Exception as e:
             err = err or e
+            self._poison(e, send_works, outs)
+        self._finish(err)
+        return None
+
+    def _poison(self, exc, *keep):
+        """A wait on a transfer raised (time-out): remember why, and keep the works and buffers of this call alive -- the
+        transfer may still complete into them."""
+        if self._poisoned is None:
+            self._poisoned = "%s: %s" % (type(exc).__name__, exc)
+        self._pending.extend(keep)
+
+    # -- transport "copy": the peers pull / push through handles to the root's tensors ---------------------------
+    def _from_root_copy(self, x_root, root, chunks, direction):
+        cuda = self.device.type == "cuda"
+        meta, bad_input = [None], None
+        y = None
+        if self.rank == root:
+            if not torch.is_tensor(x_root) or x_root.dim() != 4 or x_root.shape[2] != 129 or x_root.shape[3] != 1:
+                bad_input = "input must be a tensor [N, T, 129, 1], got %s" % (
+                    tuple(x_root.shape) if torch.is_tensor(x_root) else type(x_root).__name__,)
+                meta = [("error", bad_input)]
+            else:
+                try:
+                    x_root = x_root.contiguous()
+                    key = (tuple(x_root.shape), x_root.dtype)
+                    if cuda:
+                        y = self._out_cache.get(key)
+                        if y is None:
+                            y = torch.empty_like(x_root)
+                            self._out_cache = {key: y}
+                        torch.cuda.current_stream().synchronize()    # the input is complete before a peer reads it
+                        meta = [(tuple(x_root.shape), str(x_root.dtype), _share(x_root), _share(y))]
+                    else:                                            # CPU / gloo: named shared-memory blocks; the input is copied in
+                        pair = self._out_cache.get(key)
+                        if pair is None:
+                            for v in self._out_cache.values():
+                                v[0].close()
+                                v[1].close()
+                            pair = (_ShmTensor(x_root.shape, x_root.dtype), _ShmTensor(x_root.shape, x_root.dtype))
+                            self._out_cache = {key: pair}
+                        pair[0].tensor.copy_(x_root)
+                        x_root, y = pair[0].tensor, pair[1].tensor
+                        meta = [(tuple(x_root.shape), str(x_root.dtype), pair[0].handle, pair[1].handle)]
+                except Exception as e:
+                    bad_input = "cannot share the root's tensors: %s: %s" % (type(e).__name__, e)
+                    meta = [("error", bad_input)]
+        if self.world > 1:
+            dist.broadcast_object_list(meta, src=self._ranks[root], group=self.group)
+        if meta[0][0] == "error":
+            if self.rank == root:
+                raise ValueError(bad_input)
+            raise PeerForwardError("forward_from_root: the root refused its input (%s)" % meta[0][1])
+        shape, dtype_name, xb, yb = meta[0]
+        n = shape[0]
+        bounds = shard_bounds(n, self.world)
+        do_scatter, do_gather, do_compute = direction != "gather", direction != "scatter", direction == "both"
+        err = None
+        lo, hi = bounds[self.rank]
+        pieces = chunk_bounds(lo, hi, chunks)
+        if self.rank == root:
+            if do_compute:
+                try:
+                    for i, (a, b) in enumerate(pieces):
+                        if self.forward_into is not None:
+                            self.forward_into(x_root[a:b], y[a:b])
+                        else:
+                            y[a:b] = self.forward(x_root[a:b])
+                        self._note("fwd", i)
+                except Exception as e:
+                    err = e
+            self._finish(err)          # the peers join it when their last push has completed
+            if cuda:
+                torch.cuda.current_stream().synchronize()
+            return y
+        if not pieces:
+            self._finish(None)
+            return None
+        try:                           # views of the root's memory
+            if cuda:
+                xv, yv = _open_shared(xb), _open_shared(yb)   # (opened IPC handles are cached by torch per storage)
+            else:
+                for h in (xb, yb):
+                    if h[1] not in self._opened:
+                        self._opened[h[1]] = _ShmTensor(handle=h)
+                xv, yv = self._opened[xb[1]].tensor, self._opened[yb[1]].tensor
+        except Exception as e:
+            self._finish(e)            # raises
+        dtype = xv.dtype
+        t = shape[1]
+        alloc = torch.empty if do_scatter else torch.zeros
+        bufs = [alloc((b - a, t) + tuple(shape[2:]), dtype=dtype, device=self.device) for a, b in pieces]
+        if cuda:
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            pull_s, push_s = self._streams
+            cur = torch.cuda.current_stream()
+            pull_s.wait_stream(cur)
+            push_s.wait_stream(cur)
+            pulled = []
+            if do_scatter:
+                for (a, b), buf in zip(pieces, bufs):     # every pull is queued up front: chunk c+1 lands while chunk c computes
+                    with torch.cuda.stream(pull_s):
+                        buf.copy_(xv[a:b], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(pull_s)
+                    pulled.append(ev)
+        outs = []
+        for c, ((a, b), buf) in enumerate(zip(pieces, bufs)):
+            if do_scatter:
+                if cuda:
+                    cur.wait_event(pulled[c])
+                else:
+                    buf.copy_(xv[a:b])
+            self._note("recv", c)
+            out = buf
+            if do_compute:
+                if err is None:
+                    try:
+                        out = self.forward(buf).contiguous()
+                        if out.shape != buf.shape or out.dtype != buf.dtype:
+                            raise ValueError("forward returned %s %s for an input of %s %s"
+                                             % (tuple(out.shape), out.dtype, tuple(buf.shape), buf.dtype))
+                    except Exception as e:
+                        err = e
+                if err is not None:
+                    out = torch.zeros_like(buf)
+                self._note("fwd", c)
+            if do_gather:
+                outs.append(out)
+                if cuda:
+                    done = torch.cuda.Event()
+                    done.record(cur)
+                    with torch.cuda.stream(push_s):
+                        push_s.wait_event(done)
+                        yv[a:b].copy_(out, non_blocking=True)
+                else:
+                    yv[a:b].copy_(out)
+                self._note("send", c)
+        if cuda:
+            cur.wait_stream(push_s)        # the status all-reduce below is behind the last push on this rank's stream ...
+            cur.wait_stream(pull_s)
+            cur.synchronize()              # ... and this rank does not enter it before its copies have completed
+        del xv, yv
         self._finish(err)
         return None

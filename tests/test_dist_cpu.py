@@ -326,3 +326,110 @@ def test_from_root_on_a_subgroup_with_a_non_member_process(tmp_path):
     out = str(tmp_path / "r")
     mp.spawn(_subgroup_worker, args=(3, _free_port(), out), nprocs=3, join=True)
     assert all(open("%s.%d" % (out, r)).read() == "ok" for r in range(3))
+
+
+def _copy_worker(rank, world, port, n, t, chunks, root, out_path):
+    """transport="copy" (peers pull / push through handles to the root's tensors) against transport="rccl" on the same input."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullycnnspeechenhancement_amd.dist import BatchShardedForward, PeerForwardError, shard_bounds
+        sizes, trace = [], []
+
+        def forward(x):
+            sizes.append(int(x.shape[0]))
+            return torch.sin(x) * 3.0 + 1.0
+
+        ref_eng = BatchShardedForward(forward, device="cpu", timeout_s=60)
+        eng = BatchShardedForward(forward, device="cpu", transport="copy", trace=trace)
+        x = (torch.arange(n * t * 129, dtype=torch.float32).reshape(n, t, 129, 1) * 1e-3) if rank == root else None
+        y_ref = ref_eng.forward_from_root(x, root=root, chunks=chunks)
+        del sizes[:]
+        for _ in range(2):        # reusable; the second call reuses the root's output buffer and the opened handles
+            y = eng.forward_from_root(x, root=root, chunks=chunks)
+        lo, hi = shard_bounds(n, world)[rank]
+        assert sum(sizes) == 2 * (hi - lo), (rank, sizes)
+        if rank == root:
+            assert torch.equal(y, y_ref) and torch.equal(y, torch.sin(x) * 3.0 + 1.0)     # bit-equal with the send / recv transport
+            open(out_path, "w").write("ok")
+        else:
+            assert y is None
+            if hi > lo:           # pull, compute, push -- chunk by chunk
+                k = min(chunks, hi - lo)
+                assert [w for w, _ in trace[:3 * k]] == ["recv", "fwd", "send"] * k
+        # the compute-free probes and a root that refuses its input leave the engine usable
+        eng.forward_from_root(x, root=root, chunks=chunks, direction="scatter")
+        eng.forward_from_root(x, root=root, chunks=chunks, direction="gather")
+        with pytest.raises((ValueError, PeerForwardError)):
+            eng.forward_from_root(torch.zeros(2, 3) if rank == root else None, root=root)
+        y = eng.forward_from_root(x, root=root, chunks=chunks)
+        if rank == root:
+            assert torch.equal(y, y_ref)
+        dist.barrier()
+        eng.close()
+        ref_eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,chunks,root", [(2, 5, 2, 0), (4, 7, 8, 0), (3, 3, 2, 2), (4, 10, 3, 1)])
+def test_copy_transport_equals_send_recv(tmp_path, world, n, chunks, root):
+    """dist.py's plan B -- no communicator kernels on the data path: the root shares handles to its tensors, the peers copy their
+    slices out of its input and their results into its output -- gives the same bits as the send / recv form; uneven and empty
+    shards, more chunks than utterances, a root that is not rank 0.  (gloo + CPU tensors: the handles are shared-memory files; on a
+    GPU they are CUDA IPC memory handles and the copies hipMemcpyAsync between peers -- tests/test_forward_gpu.py has that leg.)"""
+    out = str(tmp_path / "ok")
+    mp.spawn(_copy_worker, args=(world, _free_port(), n, 4, chunks, root, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+def _poison_worker(rank, world, port, out_path):
+    """A transfer that times out ends the call on every rank with an error AND poisons the object: its sends / receives may
+    still be pending on the direction groups, so later calls are refused until it is closed and rebuilt."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullycnnspeechenhancement_amd.dist import BatchShardedForward, TransferTimeout
+
+        def forward(x):
+            if rank == 1:
+                time.sleep(3.0)       # the root's wait for this peer's result (timeout 1 s) gives up first
+            return x + 1.0
+
+        eng = BatchShardedForward(forward, device="cpu", timeout_s=1.0)
+        x = torch.ones(4, 2, 129, 1) if rank == 0 else None
+        failed = False
+        try:
+            eng.forward_from_root(x, root=0, chunks=1)
+        except Exception:
+            failed = True
+        assert failed                                         # every rank leaves the call with an exception
+        if rank == 0:
+            assert eng._poisoned is not None and eng._pending
+            with pytest.raises(TransferTimeout):
+                eng.forward_from_root(x, root=0, chunks=1)    # refused without touching the groups
+            open(out_path, "w").write("ok")
+        time.sleep(3.5)                                       # let the late message drain before the groups go away
+        eng.close()
+        fresh = BatchShardedForward(lambda v: v + 1.0, device="cpu", timeout_s=30)
+        y = fresh.forward_from_root(x, root=0, chunks=1)      # a new object (new direction groups) works
+        if rank == 0:
+            assert torch.equal(y, x + 1.0)
+        fresh.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transfer_timeout_poisons_the_engine(tmp_path):
+    out = str(tmp_path / "ok")
+    mp.spawn(_poison_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"

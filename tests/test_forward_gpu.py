@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import NETS, RTOL, check_parity, load_golden, rel_err
+from conftest import NETS, ROOT as ROOT_DIR, RTOL, check_parity, load_golden, rel_err
 from oracle import layers as L, rced_c, rced_np
 
 pytestmark = pytest.mark.gpu
@@ -600,6 +600,9 @@ def test_c_abi_status_codes_on_device(built):
     v = ctypes.c_int(-1)
     assert lib.rced_get_option(h, b"v3_l2x6", ctypes.byref(v)) == 0 and v.value == 3        # the product form is the default
     assert lib.rced_set_option(h, b"v3_l2x6", 4) == _lib.RCED_ERR_ARG                       # 0 .. 3 are the forms in the library
+    assert b"v3_l2x6 takes 0 .. 3" in lib.rced_last_error()                                 # the specific refusal, not "unknown option"
+    assert lib.rced_set_option(h, b"final_x6", 1) == _lib.RCED_ERR_ARG and b"R-CED V1 / V2 output-layer" in lib.rced_last_error()
+    assert lib.rced_set_option(h, b"nonsense", 1) == _lib.RCED_ERR_ARG and b"unknown option" in lib.rced_last_error()
     assert lib.rced_set_option(h, b"v3_l2x6", -1) == _lib.RCED_ERR_ARG
     assert lib.rced_get_option(h, b"v3_l2x6", ctypes.byref(v)) == 0 and v.value == 3        # a refused value changes nothing
     lib.rced_destroy(h)
@@ -749,7 +752,8 @@ def test_bench_two_ranks_control_flow_rehearsal():
     assert d["config"]["global_batch"] == 16 and d["config"]["rccl_world_size"] == 2 and "rehearsal" in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 64 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["kernel"] == "rced_fused" and d["roofline"]["launches"] == 3
-    assert d["from_root"] == {"skipped": "rehearsal: gloo does not move device tensors between ranks"}
+    fr = d["from_root"]          # the copy transport (IPC handles, device-to-device copies) runs for real between two processes on one GPU
+    assert fr["transport"] == "copy" and fr["value"] > 0 and fr["global_batch"] == 16 and "error" not in fr["transports"]["copy"], fr
     assert "of WORLD_SIZE=2 started" in r.stderr
 
 
@@ -765,3 +769,51 @@ def test_bench_line_survives_a_from_root_that_never_returns():
     r, d = _run_bench_rehearsal({"RCED_BENCH_REHEARSE_HANG": "1"}, 600, "--from-root-timeout", "5", "--from-root-fail-status", "0")
     assert r.returncode == 0, r.stderr[-3000:]
     assert d is not None and "timeout" in d["from_root"]["error"]
+
+
+def _copy_gpu_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT_DIR)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only: RCCL refuses two ranks on one device
+    try:
+        from fullycnnspeechenhancement_amd import build_model
+        from fullycnnspeechenhancement_amd.dist import BatchShardedForward
+        torch.cuda.set_device(0)
+        w = rced_np.make_weights("FullyCNNV3", seed=42)
+        model = build_model("FullyCNNV3", False, weights=w, device=0)
+        eng = BatchShardedForward(model, device="cuda:0", forward_into=lambda a, out: model(a, out=out), transport="copy")
+        x = torch.from_numpy(rced_np.make_input(7, 24, seed=31)).cuda() if rank == 0 else None
+        for chunks in (1, 3):
+            y = eng.forward_from_root(x, root=0, chunks=chunks)
+            if rank == 0:
+                ref = model(x)
+                assert torch.equal(y, ref), chunks        # the peers' slices came back through the root's IPC-shared output, bit for bit
+        if rank == 0:
+            check_parity(y.cpu().numpy(), rced_c.forward("FullyCNNV3", w, x.cpu().numpy(), np.float64))
+            open(out_path, "w").write("ok")
+        dist.barrier()
+        eng.close()
+        model.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_from_root_copy_transport_through_ipc_handles(built, tmp_path):
+    """dist.py's transport="copy" on device tensors: two processes share this box's GPU; the root exports CUDA IPC memory handles of
+    its input and output, the peer pulls its utterances and pushes its masks with device-to-device copies on side streams.  The
+    gathered result is bit-equal to the root computing the whole batch itself.  (Between two GPUs the same copies run over xGMI;
+    that leg has no box in the build pool.)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ok")
+    mp.spawn(_copy_gpu_worker, args=(2, port, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"

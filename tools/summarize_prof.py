@@ -53,6 +53,41 @@ def traffic_json(out, path):
         json.dump(rec, fh, indent=1)
 
 
+def code_object_resources():
+    """{short kernel name: dict} from the amdhsa metadata of the shipped library: what the kernel-trace CSV does not carry (its VGPR_Count is
+    the allocation granule count, its LDS_Block_Size the STATIC size: the fused kernels' LDS is dynamic)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "fullycnnspeechenhancement_amd", "librced_hip.so")
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    out = {}
+    if not os.path.exists(so):
+        return out
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(so, local)
+        subprocess.run([llvm + "llvm-objdump", "--offloading", local], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for co in glob.glob(local + ".*gfx950*"):
+            txt = subprocess.run([llvm + "llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+            for blk in txt.split("- .agpr_count:")[1:]:
+                blk = ".agpr_count:" + blk
+                g = lambda k: (re.search(r"\.%s:\s*(\S+)" % k, blk) or [None, "?"])[1]
+                name = subprocess.run(["c++filt", g("name")], capture_output=True, text=True).stdout.strip()
+                out[name.split("(")[0].replace("void ", "")] = {k: g(k) for k in ("vgpr_count", "agpr_count", "sgpr_count", "private_segment_fixed_size",
+                                                                                 "group_segment_fixed_size")}
+    return out
+
+
+# dynamic LDS of the CR-CED kernels (bytes): the launch's third parameter = Map<FORM>::kLdsBytes of kernels_fused_v3.h; kept here by hand and
+# pinned by static_asserts in kernels_fused.hip ("tools/summarize_prof.py prints these")
+DYNAMIC_LDS = {"Map<3>": 159024, "Map<2>": 163792, "Map<1>": 162976, "Map<0>": 163024}
+
+WARMUP_DISPATCHES = 3      # tools/profile.sh runs bench.py --steps 10 --warmup 3: the first dispatches of a kernel include cold caches / clocks
+
+
 def main(out):
     print("# rocprofv3 summary:", os.path.basename(out))
     for f in find(os.path.join(out, "trace"), "*kernel_stats.csv"):
@@ -64,20 +99,34 @@ def main(out):
                     print("%-22s calls=%s total_ns=%s avg_ns=%s min_ns=%s max_ns=%s pct=%s" % (
                         short(n), row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"),
                         row.get("MinNs"), row.get("MaxNs"), row.get("Percentage")))
+    res = code_object_resources()
     for f in find(os.path.join(out, "trace"), "*kernel_trace.csv"):
         with open(f) as fh:
             rows = list(csv.DictReader(fh))
-        seen = {}
+        per = defaultdict(list)
         for r in rows:
-            k = short(r.get("Kernel_Name", ""))
-            if k not in seen and any(s in k for s in ("fused", "final", "conv_layer")):
-                seen[k] = r
-        print("\n## dispatch resources (kernel_trace.csv)")
-        for k, r in seen.items():
-            print("%-22s grid=%s wg=%s VGPR=%s accum=%s SGPR=%s LDS=%s scratch=%s" % (
-                k, r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("VGPR_Count"), r.get("Accum_VGPR_Count"),
-                r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size")))
+            n = r.get("Kernel_Name", "")
+            if any(s in n for s in ("fused", "final", "conv_layer")):
+                per[n].append(r)
+        print("\n## dispatches (kernel_trace.csv): steady state = without each kernel's first %d dispatches" % WARMUP_DISPATCHES)
+        for n, rs in per.items():
+            d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs]
+            steady = d[WARMUP_DISPATCHES:] or d
+            r0 = rs[-1]
+            full = n.split("(")[0].replace("void ", "")
+            co = res.get(full, {})
+            lds_dyn = next((v for k, v in DYNAMIC_LDS.items() if k in full), None)
+            print("%s" % full)
+            print("    calls=%d  avg_all_ns=%.0f  avg_steady_ns=%.0f  min_ns=%d  max_ns=%d" % (len(d), sum(d) / len(d), sum(steady) / len(steady), min(d), max(d)))
+            print("    grid=%s workgroup=%s (= %d workgroups)  trace: VGPR_Count=%s SGPR_Count=%s LDS_Block_Size=%s Scratch_Size=%s" % (
+                r0.get("Grid_Size_X"), r0.get("Workgroup_Size_X"), int(r0.get("Grid_Size_X", 0)) // max(int(r0.get("Workgroup_Size_X", 1)), 1),
+                r0.get("VGPR_Count"), r0.get("SGPR_Count"), r0.get("LDS_Block_Size"), r0.get("Scratch_Size")))
+            if co:
+                print("    code object: vgpr=%s agpr=%s sgpr=%s scratch=%s static_lds=%s%s" % (
+                    co["vgpr_count"], co["agpr_count"], co["sgpr_count"], co["private_segment_fixed_size"], co["group_segment_fixed_size"],
+                    "  dynamic_lds=%d B (the launch's; Map<FORM>::kLdsBytes)" % lds_dyn if lds_dyn and "fused_v3" in full else ""))
     print("\n## PMC (average per dispatch)")
+    pmc = {}
     for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         if not os.path.isdir(d):
             continue
@@ -91,6 +140,21 @@ def main(out):
                         acc[k][1] += 1
         for (k, c), (tot, n) in sorted(acc.items()):
             print("%-22s %-28s avg=%.6g  (n=%d)" % (k, c, tot / max(n, 1), n))
+            pmc[(k, c)] = tot / max(n, 1)
+    # derived: how many of the issued MFMAs the nominal FLOPs need, how busy the matrix pipe was
+    for k in sorted({k for k, _ in pmc}):
+        mf, busy, gui = pmc.get((k, "SQ_INSTS_MFMA")), pmc.get((k, "SQ_VALU_MFMA_BUSY_CYCLES")), pmc.get((k, "GRBM_GUI_ACTIVE"))
+        valu = pmc.get((k, "SQ_INSTS_VALU"))
+        if mf and k == "fused_v3_kernel":
+            frames, flop_frame = 256 * 512, 8207496
+            # every product of the default form is six 16x16x32 bf16 MFMAs (16,384 FLOP each): MFMAs the nominal FLOPs need = FLOP / 16384 * 6
+            needed = frames * flop_frame / 16384.0 * 6.0
+            line = "%-22s derived: mfma_issued=%.4g  mfma_needed(all layers as six bf16 products)=%.4g  padding=%.1f %%" % (k, mf, needed, 100.0 * (1 - needed / mf))
+            if valu:
+                line += "  other_valu_per_mfma=%.2f" % ((valu - mf) / mf)
+            if busy and gui:
+                line += "  mfma_pipe_busy=%.1f %% (BUSY_CYCLES / (1024 SIMDs x GUI_ACTIVE / 8))" % (100.0 * busy / (1024.0 * gui / 8.0))
+            print(line)
 
 
 if __name__ == "__main__":
