@@ -93,3 +93,22 @@ def test_pipeline_denoise_pcm_matches_oracle_chain(gold, built):
     pred = rced_c.forward("FullyCNNV3", w, mag.astype(np.float32)[None, :, :, None], np.float64)[0, :, :, 0]
     ref = audio_np.rebuild(pred, phase, len(sig))
     assert out.shape == sig.shape and np.abs(out - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_rebuild_fused_and_split_paths_agree(built):
+    """The three-part ISTFT kernel has two shapes (audio_api.hip): with enough utterances one workgroup walks a whole utterance and
+    does de_frame and de_emphasis itself (a blocked scan with the carry across its 64-frame blocks); a small batch is cut into frame
+    ranges over more workgroups and the head / de_emphasis kernels follow.  Same spectra through both: equal to fp32 scan noise, and
+    both against the numpy restatement of the reference's rebuild."""
+    import torch
+    from fullycnnspeechenhancement_amd.audio import istft_batch, stft_batch
+    rng = np.random.default_rng(11)
+    sig = (0.2 * rng.standard_normal((3, 20000))).astype(np.float32)     # T = 156 frames: three 64-frame blocks
+    mag, ph = stft_batch(torch.from_numpy(sig).cuda())
+    small = istft_batch(mag, ph, nfft=512).cpu().numpy()                 # 3 utterances: split over frame ranges
+    big = istft_batch(mag.repeat(100, 1, 1, 1), ph.repeat(100, 1, 1), nfft=512).cpu().numpy()   # 300 utterances: one workgroup each
+    assert np.array_equal(big[:3], big[297:]) and np.array_equal(big[:3], big[150:153])
+    scale = np.abs(small).max()
+    assert np.abs(big[:3] - small).max() <= 2e-6 * scale
+    ref = audio_np.rebuild(*audio_np.stft(sig[2]), length=sig.shape[1], nfft=512)
+    assert np.abs(big[2, :sig.shape[1]] - ref).max() <= 5e-5 * np.abs(ref).max()
