@@ -539,6 +539,15 @@ def test_engine_test_step_surface(built):
     assert eng.param_count() == 32653
     out = eng.test_step(g["x_small"])
     assert isinstance(out, np.ndarray) and rel_err(out, g["y_small"]) < RTOL
+    again = eng.test_step(g["x_small"])
+    assert again is not out and np.array_equal(again, out)            # a fresh array per call, as sess.run returns one
+    mine = np.empty_like(out)
+    assert eng.test_step(g["x_small"], out=mine) is mine and np.array_equal(mine, out)     # a caller-owned output array
+    pooled = FullyCNNTester(cfg, weights=w, reuse_output=True)        # opt-in: two pooled arrays per shape, alternating
+    a = pooled.test_step(g["x_small"])
+    b = pooled.test_step(g["x_small"])
+    c = pooled.test_step(g["x_small"])
+    assert a is not b and c is a and np.array_equal(a, out) and np.array_equal(b, out)
 
 
 @pytest.mark.parametrize("net_work,tag,variant", NETS)
