@@ -103,6 +103,18 @@ __device__ unsigned long long g_tm[4][4];   // [wave][gemm, barrier 2, epilogue,
 #define RCED_TM_REM 1
 #endif
 __host__ __device__ constexpr int tm_rem(int cout) { return (RCED_TM_REM && cout == 18) ? 2 : 0; }
+// Pixel phases per remainder column.  16 / R = 8 rows pairs fill the M-tile, but a column stride of 8 pixels puts the 16 columns of an
+// operand read on the same banks whenever 8 * cin floats is a multiple of 256 bytes (cin = 8: 16-way conflicts -- 71 % of the LDS
+// cycles of the 8 -> 18 forward convolution were conflict cycles, profiles/r04_rocprof_train_step.txt; cin = 30: 4-way).  SEVEN phases
+// (the rows of phase 7 are zero and dropped) where the 8-pixel stride is a multiple of 256 bytes (cinp % 8 == 0: the 8 -> 18 forward
+// convolutions, 0.66 -> 0.62 / 0.62 -> 0.57 ms): a stride of 224 bytes, 2-way; K shrinks by one tap and three tiles still cover the 266
+// pixels of a two-frame tile (round 5; the inference kernel's layer 1 does the same, kernels_fused_v3.h).  NOT for cin = 30 (the
+// 30 -> 18 dgrad inside bwd_fused_mfma<18,5,30>: 4-way at 8 phases, conflict-free at 7 -- and 12 % SLOWER, 2.24 -> 2.51 ms: that
+// kernel's waves are balanced to the MFMA counts of the 8-phase form).
+#ifndef RCED_TM_REM_P
+#define RCED_TM_REM_P 7
+#endif
+__host__ __device__ constexpr int tm_rem_p(int r, int cinp) { return r == 2 && cinp % 8 == 0 ? RCED_TM_REM_P : (r ? 16 / r : 0); }
 
 template <int CIN, int TAPS, int COUT>
 struct Geo {
@@ -123,7 +135,7 @@ struct Geo {
   static constexpr int kKP = (TAPS + kPH - 1) * kCinP;   // K of the conv packet
   static constexpr int kNB64 = kKP / 8, kNTail = (kKP % 8 + 3) / 4;
   // remainder pass: R channels past the first M-tile, P pixel phases per column, its K and its tiles per two-frame tile
-  static constexpr int kR = tm_rem(COUT), kP = kR ? 16 / kR : 0;
+  static constexpr int kR = tm_rem(COUT), kP = tm_rem_p(kR, kCinP);
   static constexpr int kKR = kR ? (TAPS + kP - 1) * kCinP : 0;
   static constexpr int kNRT = kR ? (kNPX + 16 * kP - 1) / (16 * kP) : 0;
   static constexpr int kMTm = kR ? 1 : kMT;              // M-tiles of the MAIN pass
@@ -146,7 +158,7 @@ struct Geo {
 // kernel of output co shifted by p taps; shift[8 p + co] = shift[co].
 static __global__ void pack_packet(const float* __restrict__ w, const float* __restrict__ shift, int taps, int cin, int cout,
                             int transpose, int ph, float* __restrict__ packet) {
-  const int R = ph == 1 ? tm_rem(cout) : 0, P = R ? 16 / R : 0;
+  const int R = ph == 1 ? tm_rem(cout) : 0, P = tm_rem_p(R, (cin + 1) & ~1);   // (as Geo::kP)
   const int cinp = (cin + 1) & ~1, K = (taps + ph - 1) * cinp, MT = R ? 1 : (cout + 15) / 16;
   const int NB = K / 8, NTL = (K % 8 + 3) / 4, dmain = NB * MT * 128 + NTL * MT * 64;
   const int KR = R ? (taps + P - 1) * cinp : 0, NBR = KR / 8, NTR = (KR % 8 + 3) / 4, drem = R ? NBR * 128 + NTR * 64 : 0;
@@ -186,7 +198,7 @@ static __global__ void pack_packet(const float* __restrict__ w, const float* __r
     const int i = lane & 15;
     tap_shift = i / R;
     co = 16 + i % R;
-    klim = KR;
+    klim = tap_shift < P ? KR : 0;      // (rows of a dropped phase: zero)
   }
   float v = 0.f;
   int tap = k / cinp;
@@ -711,7 +723,7 @@ __device__ __forceinline__ void tile_commit_x6(unsigned short* planes, int tid, 
 // transpose = 1: the dgrad's packet (pack_packet's convention: cin / cout are those of the conv being packed).
 static __global__ void pack_packet_x6(const float* __restrict__ w, const float* __restrict__ shift, int taps, int cin, int cout,
                                       int ph, float* __restrict__ packet, int transpose = 0) {
-  const int R = ph == 1 ? tm_rem(cout) : 0, P = R ? 16 / R : 0;
+  const int R = ph == 1 ? tm_rem(cout) : 0, P = tm_rem_p(R, (cin + 1) & ~1);   // (as Geo::kP)
   const int cs = x6_cs(cin, ph), K = (taps + ph - 1) * cs, steps = (K + 31) / 32, MT = R ? 1 : (cout + 15) / 16;
   const int KR = R ? (taps + P - 1) * cs : 0, stepsR = (KR + 31) / 32;
   const int nmain = steps * MT * 64 * 8, nrem = stepsR * 64 * 8;   // one thread per (S, mt, lane, e); the three parts by the same thread
@@ -738,7 +750,7 @@ static __global__ void pack_packet_x6(const float* __restrict__ w, const float* 
     k = 32 * S + 8 * (lane >> 4) + e;
     tap_shift = i / R;
     co = 16 + i % R;
-    klim = KR;
+    klim = tap_shift < P ? KR : 0;      // (rows of a dropped phase: zero)
     base = ((size_t)steps * MT * 3 + (size_t)S * 3) * 512 + lane * 8 + e;
   }
   int tap = k / cs;
@@ -1097,6 +1109,7 @@ __device__ __forceinline__ void conv_tile(const float* lds_in, const float* lds_
       const float vv[4] = {racc[0][0].x, racc[0][0].y, racc[0][0].z, racc[0][0].w};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {                         // the lane's two pixels
+        if (2 * kq + h >= P) continue;                       // (a dropped phase: tm_rem_p)
         const int px = pb + 2 * kq + h;
         const int fr = px >= G::kS ? 1 : 0, f = px - (fr ? G::kS : 0);
         if (px >= G::kNPX || f >= kF || frame0 + fr >= frames) continue;
