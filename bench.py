@@ -55,7 +55,7 @@ def pipe_roofline(flop_by_pipe, seconds):
            "pipe_mix": {k: v / total for k, v in flop_by_pipe.items()},
            "pipe_peaks_tflops": {k: PIPE_CEILING_TFLOPS[k] for k in flop_by_pipe},
            "achieved": achieved, "unit": "TFLOP/s", "peak": total / floor_s / 1e12, "frac": floor_s / seconds,
-           "floor_ms": 1e3 * floor_s, "frac_fp32_peak": achieved / FP32_PEAK_TFLOPS}
+           "frac_fp32_peak": achieved / FP32_PEAK_TFLOPS}
     if any(k in MEASURED_CEILING_TFLOPS for k in flop_by_pipe):
         meas = sum(v / (MEASURED_CEILING_TFLOPS.get(k, PIPE_CEILING_TFLOPS[k]) * 1e12) for k, v in flop_by_pipe.items())
         out["frac_measured_ceiling"] = meas / seconds
@@ -711,7 +711,8 @@ def main():
                 roof = dict(pr, kernel=dom, traffic=traffic,
                             traffic_note="HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE: %s; this kernel's "
                                          "algorithmic bytes per launch = %d; whole forward = %d" % (traffic_src, alg, 1032 * B * T),
-                            avg_launch_ms=ms / launches, launches=launches, flop_per_frame=kflops, frames_per_forward=B * T,
+                            avg_launch_ms=ms / launches, floor_ms_per_launch=pr["frac"] * ms / launches, launches=launches,
+                            flop_per_frame=kflops, frames_per_forward=B * T,
                             other_kernels_ms_per_step={k: v[0] / args.steps for k, v in times.items() if k != dom and v[1]},
                             note="compute-bound path (7950 FLOP/B): bound = matrix issue, not HBM.  CR-CED: every layer is computed at "
                                  "fp32 quality as six bf16 MFMAs per product over three-part operands (DESIGN 3.1; pipe_mix says "
