@@ -1006,6 +1006,10 @@ __device__ __forceinline__ void l1_job(unsigned wa, const A1Regs& A, const A1Rem
 // X6 form: ReLU, then the three-part split -- ONCE per element, here where it is produced -- and one 8-byte store per plane.
 template <class M>
 __device__ __forceinline__ void l1_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
+#if defined(RCED_T_EXP) && (RCED_T_EXP & 4096)
+  if (acc4.x == 12345.678f) lds_st<float>(wr, off, acc4.y);   // timing experiment (wrong results): layer 1 without its epilogues
+  return;
+#endif
   const f32x4 v = relu4(acc4);
   if constexpr (M::kX6) {
     const P3 p01 = split2(v.x, v.y), p23 = split2(v.z, v.w);

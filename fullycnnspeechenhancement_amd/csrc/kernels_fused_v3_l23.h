@@ -27,11 +27,14 @@
 #ifndef RCED_T_SGB
 #define RCED_T_SGB 1     // sched_group_barrier pattern inside the slots (see interleave())
 #endif
+#ifndef RCED_T_L1PF
+#define RCED_T_L1PF 1    // all-x6 form, layer 1: a job's first operands are read in front of the previous job's epilogue (layer1_x6l)
+#endif
 #ifndef RCED_T_EXP
 #define RCED_T_EXP 0   // timing experiments only (WRONG RESULTS): 1 = no shift-adds, 2 = layer 3's A fragments read once (round 5: this build's
                        // 10 % are not the reads -- with equal fragments hipcc merges the MFMAs of M-tiles 2..4 into those of 0, 1: 252 of the
                        // kernel's 1,218 static MFMAs disappear), 4 = no split arithmetic, 8 = layer 2's B fragments read once per tile,
-                       // 256 = a third of layer 1's B reads, 512 = no weight transfers
+                       // 256 = a third of layer 1's B reads, 512 = no weight transfers, 4096 = layer 1 without its main tiles' epilogues, 8192 = layer 1's pair jobs only
 #endif
 #if (RCED_T_EXP != 0 || RCED_X6_EXP != 0) && !defined(RCED_TIMING_ONLY)
 #error "RCED_T_EXP / RCED_X6_EXP builds compute wrong results: timing experiments only (tools/mkexp.sh ... -DRCED_TIMING_ONLY -DRCED_T_EXP=...)"
@@ -460,6 +463,19 @@ __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int rol
     a[1] = a1x_ld<M, 3 * g + 1>(aX, aH);
     a[2] = a1x_ld<M, 3 * g + 2>(aX, aH);
   };
+  // The first operands of a wave's NEXT job are read in front of the epilogue of the current one (all-x6 form): a job that starts by
+  // issuing its reads waits a full LDS round trip with nothing of its own to issue (the single-tile and remainder jobs ran at a third
+  // of their MFMA rate); behind 26 .. 52 VALU of split + stores the reads have landed when the job begins.
+  constexpr bool kPF = M::kAllX6 && RCED_T_L1PF;
+  const bool has_single = role < 2 || role == 7, has_rem = role >= 4;
+  const unsigned rd_single = L.rd1x + (role == 0 ? 32 : role == 1 ? 30 : 16) * 256;
+  Parts nb;
+  s16x8 na[3];
+  auto prefetch = [&](unsigned rd, int aoff) {   // aoff: byte offset of the job's first piece group (single tile: pieces 0..2, remainder: 9..11)
+    nb = b8_load(rd, 0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) na[q] = lds_ld<s16x8>(aX + aoff, q * 1024);
+  };
   {
     Parts b[2][2];
     s16x8 a[3][3];     // the main pass's nine fragments, read once per job
@@ -503,23 +519,40 @@ __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int rol
         pin();
         DETX(i);
       });
+      if constexpr (kPF) {
+        if (has_single) prefetch(rd_single, 0);
+        else if (has_rem) prefetch(L.rd1xr, 9 * 1024);
+        pin();
+      }
       l1_store<M>(L, acc[1][0], L.wr1, 2 * kTW, g2, kVMain + 2);
       l1_store<M>(L, acc[1][1], L.wr1, 3 * kTW, g3, kVMain + 3);
       DETX(6);
     } else {
+      if constexpr (kPF) {
+        prefetch(rd_single, 0);   // role 7: its single tile is next
+        pin();
+      }
       l1_store<M>(L, acc[0][0], L.wr1, 0, false, 0);
       l1_store<M>(L, acc[0][1], L.wr1, kTW, false, 0);
     }
   }
   DET(6);
+  if (RCED_T_EXP & 8192) return;   // timing experiment (wrong results): the pair jobs only
   if (role < 2 || role == 7) {   // the single main tile
     const int dt = role == 0 ? 32 : role == 1 ? 30 : 16;
     const unsigned rd = L.rd1x + dt * 256;
     Parts b[2];
     s16x8 a[2][3];
     f32x4 acc = sh;
-    b[0] = b8_load(rd, 0);
-    lda(IC<0>{}, a[0]);
+    if constexpr (kPF) {
+      b[0] = nb;
+      a[0][0] = na[0];
+      a[0][1] = na[1];
+      a[0][2] = na[2];
+    } else {
+      b[0] = b8_load(rd, 0);
+      lda(IC<0>{}, a[0]);
+    }
     pin();
     static_for<0, 3>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
@@ -531,6 +564,10 @@ __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int rol
       acc = l2x_mma(a[c & 1], b[c & 1], acc);
       pin();
     });
+    if constexpr (kPF) {
+      if (has_rem) prefetch(L.rd1xr, 9 * 1024);   // role 7: its first remainder tile is next
+      pin();
+    }
     l1_store<M>(L, acc, L.wr1 + dt * M::kTileB18, 0, false, 0);
   }
   DET(5);
@@ -544,8 +581,15 @@ __device__ __forceinline__ void layer1_x6l(const Lane& L, unsigned lds0, int rol
       Parts b[2];
       s16x8 a[2][3];
       f32x4 acc = init;
-      b[0] = b8_load(rdr, 0);
-      lda(IC<3>{}, a[0]);
+      if (kPF && r == 0) {
+        b[0] = nb;
+        a[0][0] = na[0];
+        a[0][1] = na[1];
+        a[0][2] = na[2];
+      } else {
+        b[0] = b8_load(rdr, 0);
+        lda(IC<3>{}, a[0]);
+      }
       pin();
       static_for<0, 4>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
