@@ -569,7 +569,7 @@ def secondary_pipeline(torch, build_model, spec, _lib, _weights, local_rank, cpu
     whole = 1e3 * (time.perf_counter() - t0) / reps
     frames = N * T
     flop_dft = 2 * 256 * 258
-    audio_pipe = "mfma_bf16x6" if os.environ.get("RCED_AUDIO_X6", "1") != "0" else "mfma_f32"   # (the library reads the same default)
+    audio_pipe = "mfma_bf16x6" if audio.kernel_option("x6") else "mfma_f32"
     out = {"config": "PCM -> STFT -> CR-CED V3 -> ISTFT -> PCM, 256 utterances x 65,664 samples (512 frames), device-resident "
                      "(SURVEY 8(f) N1 + a5 + N2; infer.py:54-71)",
            "metric": "spectrogram frames/sec through the whole pipeline", "value": frames / (whole * 1e-3), "unit": "frames/s",
@@ -585,7 +585,7 @@ def secondary_pipeline(torch, build_model, spec, _lib, _weights, local_rank, cpu
                               "computes only those (and de_emphasis in the same pass)"),
            "finite": bool(torch.isfinite(wav).all()),
            "note": "dense-DFT GEMMs (K = 256) in the three-part bf16 form, one M-tile per wave with its fragments in registers "
-                   "(kernels_audio_x6.h; RCED_AUDIO_X6=0 selects the fp32-MFMA comparators): 0.17 ms kernels, reported against the "
+                   "(kernels_audio_x6.h; rced_audio_option("x6", 0) selects the fp32-MFMA comparators): 0.17 ms kernels, reported against the "
                    "matrix pipe and against HBM"}
     if cpu_seconds > 0:
         from oracle import audio_np

@@ -21,6 +21,15 @@ def num_frames(length):
     return int(_lib.load().rced_stft_num_frames(int(length)))
 
 
+def kernel_option(key, value=None):
+    """rced_audio_option: which kernels stft_batch / istft_batch launch (process-wide).  key "x6": 1 (default) = the three-part bf16
+    kernels, 0 = the fp32-MFMA comparators.  Returns the value in force (value=None only queries)."""
+    r = int(_lib.load().rced_audio_option(key.encode(), -1 if value is None else int(value)))
+    if r < 0:
+        raise ValueError("rced_audio_option(%r, %r): unknown key or bad value" % (key, value))
+    return r
+
+
 def _check_cfg(sample_rate, window_s, stride_s, nfft=None):
     if int(round(window_s * sample_rate)) != FRAME or int(round(stride_s * sample_rate)) != STEP:
         raise ValueError("only 256-sample windows with a 128-sample stride are built (8 kHz, 32 ms / 16 ms)")

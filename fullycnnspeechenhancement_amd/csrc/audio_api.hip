@@ -1,6 +1,7 @@
 // C ABI of the STFT front-end / ISTFT rebuild (include/rced.h, "audio" section): host side.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -154,10 +155,17 @@ int build_x6(AudioTables& t) {
   return RCED_OK;
 }
 
-// RCED_AUDIO_X6 (default 1): the three-part bf16 kernels; 0 = the fp32-MFMA kernels (the in-build comparator).  Read once per process.
+// rced_audio_option("x6"): 1 = the three-part bf16 kernels, 0 = the fp32-MFMA kernels (the in-build comparator).  The environment
+// variable RCED_AUDIO_X6 only supplies the default, read once.
+std::atomic<int> g_x6{-1};
 bool use_x6() {
-  static const bool v = [] { const char* e = getenv("RCED_AUDIO_X6"); return e ? atoi(e) != 0 : true; }();
-  return v;
+  int v = g_x6.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("RCED_AUDIO_X6");
+    v = e ? (atoi(e) != 0) : 1;
+    g_x6.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
 }
 // frame-range split of an utterance over workgroups: enough workgroups for every CU when the batch is small
 int range_split(int N, int T) {
@@ -205,6 +213,13 @@ struct DeviceGuard {
 extern "C" {
 
 int rced_stft_num_frames(int length) { return length > 0 ? audio::num_frames(length) : 0; }
+
+int rced_audio_option(const char* key, int value) {
+  if (!key || strcmp(key, "x6") || value < -1 || value > 1) return -1;
+  const bool now = use_x6();
+  if (value >= 0) g_x6.store(value, std::memory_order_relaxed);
+  return value >= 0 ? value : (now ? 1 : 0);
+}
 
 int rced_stft(const float* pcm_dev, const int* lengths_dev, int N, int L, int T, float* mag_dev, float* phase_dev,
               int device, void* stream) {

@@ -485,7 +485,11 @@ __device__ __forceinline__ void layer_end_sync() {
   // where N counts only the loads it knows: in hardware that waits for the prefetches just issued for the NEXT layer.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+#if defined(RCED_T_EXP) && (RCED_T_EXP & 16384)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // timing experiment (WRONG RESULTS): no workgroup barrier between the phases
+#else
   __syncthreads();
+#endif
 }
 
 

@@ -148,6 +148,12 @@ int rced_stft(const float* pcm_dev, const int* lengths_dev, int N, int L, int T,
 int rced_istft(const float* mag_dev, const float* phase_dev, int N, int T, int nfft, float* audio_dev,
                int device, void* stream);
 
+/* Which kernels rced_stft / rced_istft launch (process-wide: these entry points have no handle).  key "x6": 1 (default) = the
+ * three-part bf16 kernels (fp32 quality on the bf16 matrix pipe, kernels_audio_x6.h), 0 = the fp32-MFMA kernels (the in-build
+ * comparator; both pass the same reference-pinned tests).  value 0 / 1 sets, -1 only queries; returns the value now in force, or
+ * -1 for an unknown key / a bad value.  The environment variable RCED_AUDIO_X6 supplies the default, read once. */
+int rced_audio_option(const char* key, int value);
+
 /* ---- training step: FullyCNNTrainer.creat_graph + train_step,
  * model_utils/trainer.py:156-192, over Model(is_training=True).  Layer-by-layer, correctness first. ---- */
 typedef struct rced_trainer rced_trainer;

@@ -13,6 +13,25 @@ from oracle import audio_np
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 0], ids=["x6", "fp32-mfma"], autouse=True)
+def audio_kernels(request, built):
+    """Every test of this file runs with both kernel families: the three-part bf16 kernels (the default) and the fp32-MFMA
+    comparators (rced_audio_option "x6" = 0) -- same reference-pinned tolerances."""
+    from fullycnnspeechenhancement_amd import audio
+    prev = audio.kernel_option("x6")
+    assert audio.kernel_option("x6", request.param) == request.param
+    yield request.param
+    audio.kernel_option("x6", prev)
+
+
+def test_audio_option_contract(built):
+    from fullycnnspeechenhancement_amd import _lib
+    lib = _lib.load()
+    now = lib.rced_audio_option(b"x6", -1)
+    assert now in (0, 1) and lib.rced_audio_option(b"x6", 7) == -1 and lib.rced_audio_option(b"nonsense", 1) == -1
+    assert lib.rced_audio_option(b"x6", -1) == now            # a refused call changes nothing
+
+
 @pytest.fixture(scope="module")
 def gold():
     z = np.load(os.path.join(ROOT, "tests", "golden", "audio_stft.npz"))
