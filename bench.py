@@ -585,7 +585,7 @@ def secondary_pipeline(torch, build_model, spec, _lib, _weights, local_rank, cpu
                               "computes only those (and de_emphasis in the same pass)"),
            "finite": bool(torch.isfinite(wav).all()),
            "note": "dense-DFT GEMMs (K = 256) in the three-part bf16 form, one M-tile per wave with its fragments in registers "
-                   "(kernels_audio_x6.h; rced_audio_option("x6", 0) selects the fp32-MFMA comparators): 0.17 ms kernels, reported against the "
+                   "(kernels_audio_x6.h; rced_audio_option('x6', 0) selects the fp32-MFMA comparators): 0.17 ms kernels, reported against the "
                    "matrix pipe and against HBM"}
     if cpu_seconds > 0:
         from oracle import audio_np
