@@ -24,6 +24,10 @@ inline unsigned short bf16_rne(float f) {
   return (unsigned short)(u >> 16);
 }
 
+inline int env_default_early(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 struct rced_fused {
   float* scratch = nullptr;   // V1/V2: skip fragments, per workgroup
   size_t scratch_bytes = 0;
@@ -52,6 +56,8 @@ struct rced_fused {
   float* scratch16 = nullptr; // skip fragments for 2 workgroups per CU
   int bf16_wgs_per_cu = 1;
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
+  int latency_form = env_default_early("RCED_LATENCY_FORM", 1);   // option "latency_form" (V1/V2, fp32): one-frame tiles for calls with fewer
+                                                                  // 3-frame tiles than CUs (chain_forward)
   unsigned* err_host = nullptr;   // sticky error word of the CR-CED kernel's wave-to-wave hand-offs: pinned host memory the
   unsigned* err_dev = nullptr;    // kernel reaches through its device alias, so the host reads it without a device sync
 };
@@ -360,9 +366,12 @@ void chain_final_layer(const rced_fused* f, float* y, int frames, hipStream_t st
                        (const float*)f->fin_apack, f->fin_bias, y, frames);
 }
 
-template <class N>
-int chain_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
+// N0: the net as built (3-frame tiles); N = N0, or its latency form (below)
+template <class N0, class N>
+int chain_forward_tf(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
   using G = chain::Geo<N>;
+  static_assert(G::kWTotal == chain::Geo<N0>::kWTotal && G::kScratchFloatsPerWg <= chain::Geo<N0>::kScratchFloatsPerWg,
+                "the forms of one net share its packets and its skip scratch");
   chain::Params P;
   P.x = x;
   P.h = f->h;
@@ -384,6 +393,18 @@ int chain_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb
   m->prof_end(RCED_K_FINAL, st);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
+}
+// Latency form: a call with fewer 3-frame tiles than the part has CUs (BASELINE config 1: one utterance of 256 frames = 86 tiles)
+// leaves CUs idle while every busy one walks a tile's layers at a third of its rate; with ONE-frame tiles the same call is 3 x
+// the workgroups of a third of the work each.  Same packets, same arithmetic per pixel (the remainder pass's columns are frame-aligned:
+// chain::Geo::CPF): the results are bit-identical (test).
+constexpr int kLatencyTF = 1;
+template <class N>
+int chain_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
+  const int cus = f->grid_limit > 0 ? std::min(f->grid_limit, m->num_cus) : m->num_cus;
+  if (f->latency_form && Nb * ((T + N::kTF - 1) / N::kTF) < cus)
+    return chain_forward_tf<N, chain::WithTF<N, kLatencyTF>>(m, f, x, y, Nb, T, st);
+  return chain_forward_tf<N, N>(m, f, x, y, Nb, T, st);
 }
 
 template <class N>
@@ -422,6 +443,9 @@ int chain_create(rced_model* m, rced_fused* f) {
   HIP_TRY(hipMalloc(&f->scratch, f->scratch_bytes));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain::fused_chain_kernel<N>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+  using NL = chain::WithTF<N, kLatencyTF>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain::fused_chain_kernel<NL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, chain::Geo<NL>::kLdsBytes));
   return RCED_OK;
 }
 
@@ -715,6 +739,12 @@ int fused_set_option(rced_model* m, const char* key, int value) {
     (i == 0 ? m->fused->final_x6 : i == 1 ? m->fused->final_lds : m->fused->bf16_final16) = value;
     return RCED_OK;
   }
+  if (!strcmp(key, "latency_form")) {
+    if (m->variant == RCED_V3) return rced_fail(RCED_ERR_ARG, "latency_form selects the R-CED V1 / V2 kernel's one-frame tiles; CR-CED has one form of tile");
+    if (value != 0 && value != 1) return rced_fail(RCED_ERR_ARG, "latency_form takes 0 or 1, got %d", value);
+    m->fused->latency_form = value;
+    return RCED_OK;
+  }
   if (!strcmp(key, "v3_l2x6")) {
     if (m->variant != RCED_V3) return rced_fail(RCED_ERR_ARG, "v3_l2x6 selects the form of the CR-CED kernel only");
     if (value < 0 || value > 3) return rced_fail(RCED_ERR_ARG, "v3_l2x6 takes 0 .. 3 (the forms of the CR-CED kernel), got %d", value);
@@ -769,6 +799,10 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
   }
   if (!strcmp(key, "bf16")) {
     *value = m->fused->bf16;
+    return RCED_OK;
+  }
+  if (!strcmp(key, "latency_form")) {
+    *value = m->variant == RCED_V3 ? 0 : m->fused->latency_form;
     return RCED_OK;
   }
   return RCED_ERR_ARG;

@@ -24,7 +24,13 @@
 
 #ifndef RCED_CHAIN_EXP
 #define RCED_CHAIN_EXP 0     // timing experiments only (wrong results): 1 = no skip-fragment stores, 2 = no skip-fragment loads,
-                             // 4 = the two-M-tile layers issue half of their MFMAs (the bound on a bf16-pipe form of those layers)
+                             // 4 = the two-M-tile layers issue half of their MFMAs (the bound on a bf16-pipe form of those layers),
+                             // 8 = every wave runs the extra-tile copy of a layer's code (the kernels are 88 / 109 KB of code for a 64-KB
+                             //     instruction cache: one copy per layer is 50 / 63 KB -- and 13 / 16 % SLOWER with a fourth tile on every
+                             //     wave, + 23 % MFMAs on the fullest SIMD: the cache is worth single digits here)
+#endif
+#if RCED_CHAIN_EXP != 0 && !defined(RCED_TIMING_ONLY)
+#error "RCED_CHAIN_EXP builds compute wrong results: timing experiments only (tools/mkexp.sh ... -DRCED_TIMING_ONLY -DRCED_CHAIN_EXP=...)"
 #endif
 #ifndef RCED_CHAIN_DEPTH
 #define RCED_CHAIN_DEPTH 1   // operand prefetch depth (b64 steps) of the fp32 R-CED passes
@@ -81,6 +87,13 @@ struct NetV2 {
       {15, 16, 5, 14, 14, 2, 0},   {14, 14, 7, 12, 12, 1, 0},   {12, 12, 11, 10, 10, 0, 0}};
 };
 
+// The same net with another number of frames per tile: geometry only (the packets do not depend on it).  Used by the bf16 kernel
+// (kernels_fused_chain16.h) and by the fp32 kernel's latency form (one-frame tiles when a call has fewer tiles than the part has CUs).
+template <class N, int TF>
+struct WithTF : N {
+  static constexpr int kTF = TF;
+};
+
 // ---- derived geometry ------------------------------------------------------------------------
 template <class N>
 struct Geo {
@@ -113,7 +126,13 @@ struct Geo {
   }
   static constexpr int PH(int l) { return R(l) ? 16 / R(l) : 0; }
   static constexpr int KR(int l) { return (N::layer[l].taps + PH(l) - 1) * N::layer[l].cinp; }
-  static constexpr int NRT(int l) { return R(l) ? (kNPX + 16 * PH(l) - 1) / (16 * PH(l)) : 0; }
+  // Remainder columns are FRAME-ALIGNED: column c = (frame c / CPF, pixels PH (c % CPF) .. + PH - 1 of it), CPF = ceil(kS / PH) columns per
+  // frame: bins AND gap pixels (a layer rewrites every pixel of its buffer, whose previous contents are another layer's layout; the gap
+  // pixels get zeros), the last column's pixels past the frame's stride dropped -- so a bin's phase in its column, and with it the
+  // grouping of its taps into K-steps, does not depend on where the frame sits in the tile: a frame's result is the same bits in a tile
+  // of one frame (the latency form) and of three.  As many tiles as flat columns over the tile's pixels took.
+  static constexpr int CPF(int l) { return R(l) ? (kS + PH(l) - 1) / PH(l) : 0; }
+  static constexpr int NRT(int l) { return R(l) ? (N::kTF * CPF(l) + 15) / 16 : 0; }
   static constexpr int kRemSlots = 2;                       // remainder tiles per wave, at most (waves 7..2 first, see rem_tile)
   // packet of layer l (floats): main pass b64 steps, b32 tails; remainder pass likewise; 32 shifts; 16 remainder-row shifts
   static constexpr int K(int l) { return (l == 0 ? 8 : 1) * N::layer[l].taps * N::layer[l].cinp; }
@@ -495,7 +514,15 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
     for (int jj = 0; jj < G::kRemSlots; ++jj) {
       const int rt = rem_tile(wave, jj);            // wave-uniform
       if (rt >= NRT) break;
-      const int pb = PHS * (16 * rt + n);           // first pixel of this lane's column
+      constexpr int CPF = G::CPF(L);
+      static_assert(CPF > 16, "a tile of 16 columns touches two frames at most");
+      const int fr0 = (16 * rt) / CPF;              // wave-uniform: the frame of the tile's first column
+      const int col = 16 * rt + n - fr0 * CPF;      // this lane's column, counted from frame fr0's first
+      const bool nextf = col >= CPF;
+      const int fbase = nextf ? (fr0 + 1) * G::kS : fr0 * G::kS;   // its frame's first pixel
+      const int pb = fbase + (nextf ? col - CPF : col) * PHS;      // the column's first pixel (frame-aligned columns: Geo::CPF)
+      // stores stop at the frame's stride (a last column's pixels past it are the next frame's first bins) and at the buffer's last row
+      const int plim = fbase + G::kS < 16 * G::kTiles ? fbase + G::kS : 16 * G::kTiles;
       f32x4 sk = {0.f, 0.f, 0.f, 0.f};
       if constexpr (D.skip_from >= 0 && !(RCED_CHAIN_EXP & 2))
         sk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -505,7 +532,9 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
       f32x4 v = racc[0][0];
       if constexpr (D.skip_from >= 0) v += sk;      // module.py:30-31: before the ReLU
       v = relu4(v);
-      const bool gap = span_has_gap<N>(16 * PHS * rt, 16 * PHS);   // wave-uniform
+      // wave-uniform: does the tile hold a column with a gap pixel (from the column of bin 129 to the frame's last), or columns past the
+      // tile's frames (they follow the last frame's)?
+      const bool gap = 16 * rt + 15 >= fr0 * CPF + kF / PHS;
       float vv[4] = {v.x, v.y, v.z, v.w};
       if (gap) {
         asm volatile("" ::: "memory");   // a wave-uniform branch (see the main epilogue)
@@ -524,7 +553,7 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = 4 * kq + j, px = pb + i / R;
-        if (i < PHS * R && px < 16 * G::kTiles) out[px * D.coutp + 16 + i % R] = vv[j];   // rows past the tile are not allocated
+        if (i < PHS * R && px < plim) out[px * D.coutp + 16 + i % R] = vv[j];
       }
     }
   }
@@ -542,7 +571,9 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
     auto dma = [&] { packet_dma<G::packet(nxt)>(P.wpack + G::packet_off(nxt), wdst, wave, lane); };   // issued inside the main pass
     if constexpr (L == N::kLayers - 1) xst = xstage_load<N>(P, tile + gridDim.x, tid);
     const float* w = wbase + wcur * G::kWRegion;
-    if constexpr (L > 0 && G::MT(L) == 2 && G::kSplitExtra) {
+    if constexpr ((RCED_CHAIN_EXP & 8) != 0) {   // timing experiment (wrong results): ONE copy of the layer's code for every wave
+      run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
+    } else if constexpr (L > 0 && G::MT(L) == 2 && G::kSplitExtra) {
       if (wave < G::kExtra) run_layer<N, L, 1, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
       else if (wave < 2 * G::kExtra) run_layer<N, L, 1, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
       else run_layer<N, L, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);

@@ -57,10 +57,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int round4(int c) { return (c + 3) & ~3; }
 
 // The same net with more frames per tile (bf16 activations need half the LDS): geometry only.
-template <class N, int TF>
-struct WithTF : N {
-  static constexpr int kTF = TF;
-};
+using chain::WithTF;
 
 template <class N>
 struct Geo {

@@ -79,6 +79,9 @@ __device__ unsigned long long g_tm[4][4];   // [wave][gemm, barrier 2, epilogue,
                         // bit1 = conv kernels store nothing, bit2 = conv kernels skip the MFMA pass, bit3 = they commit only their first tile,
                         // bit4 = no masked sums in the SUMS epilogue
 #endif
+#if RCED_TM_EXP != 0 && !defined(RCED_TIMING_ONLY)
+#error "RCED_TM_EXP builds compute wrong results: timing experiments only (tools/mkexp.sh ... -DRCED_TIMING_ONLY -DRCED_TM_EXP=...)"
+#endif
 #ifndef RCED_TM_OPQ_MIN
 #define RCED_TM_OPQ_MIN 1000   // prefetch size (VGPRs) from which the conv kernels' epilogue re-derives its lane coordinates
                                // (64 paid while the largest dgrad spilled; with the loop-invariant staging channels nothing

@@ -106,6 +106,9 @@ int rced_reserve(rced_model* m, int N, int T);
  *   "final_x6", "final_lds", "bf16_final16"   R-CED V1 / V2 only: the 1x129 output layer's kernel -- three-part bf16 products (1,
  *                 default) or the fp32 MFMA (0), the latter with (1) / without (0) LDS staging of its B operand; in "bf16" mode the
  *                 bf16 MFMA (1) or the kernel the first two select (0)
+ *   "latency_form"  R-CED V1 / V2 only (fp32 kernel): 1 (default) = a call with fewer 3-frame tiles than the part has CUs (BASELINE
+ *                 config 1: one utterance of 256 frames) runs on ONE-frame tiles -- three times the workgroups, a third of the work
+ *                 each, bit-identical results; 0 = always 3-frame tiles
  *   "inject_handoff_error"  set only, CR-CED: writes the value into the sticky hand-off error word as the kernel would on a
  *                 time-out (0 clears it) -- a test hook for rced_check / RCED_ERR_STATE handling
  *   "has_fused", "num_cus", "fused_final"  get only ("fused_final": the 1x129 output layer runs inside the fused kernel)

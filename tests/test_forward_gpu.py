@@ -380,6 +380,35 @@ def test_results_do_not_depend_on_the_tile_to_workgroup_map(built):
                 assert np.abs(y[u, fr] - ref).max() <= RTOL * scale, (b, tile, fr)
 
 
+@pytest.mark.parametrize("net_work,tag,variant", [n for n in NETS if n[2] != 3])
+def test_latency_form_is_bit_identical_to_the_throughput_form(net_work, tag, variant, built):
+    """R-CED V1 / V2: a call with fewer 3-frame tiles than the part has CUs runs on one-frame tiles (option `latency_form`, on by
+    default; BASELINE configs[0] = one utterance of 256 frames is such a call).  Same packets, same arithmetic per pixel -- the
+    remainder pass's columns of pixels are frame-aligned, so a bin's taps meet in the same K-steps wherever its frame sits in a
+    tile -- hence bit-identical masks (an utterance's result does not depend on the batch it came in), for ragged T and T < 8 too."""
+    w, g = load_golden(tag)
+    m = make_model(variant, w)
+    assert m.get_option("latency_form") == 1
+    cases = [g["x_c1"], rced_np.make_input(1, 1, seed=5), rced_np.make_input(2, 7, seed=6), rced_np.make_input(3, 100, seed=7),
+             rced_np.make_input(5, 151, seed=8)]          # 5 x 151: 255 three-frame tiles, one under the CU count of the part
+    fast = [m(x) for x in cases]
+    m.set_option("latency_form", 0)
+    assert m.get_option("latency_form") == 0
+    for x, y in zip(cases, fast):
+        assert np.array_equal(m(x), y), x.shape
+    check_parity(fast[0], g["y_c1"])
+    check_parity(fast[4], rced_c.forward(net_work, w, cases[4], np.float64))
+    m.set_option("latency_form", 1)
+    m.set_option("fused_grid", 3)            # the rule counts the workgroups the call may use
+    assert np.array_equal(m(cases[3]), fast[3])
+    m.set_option("fused_grid", 0)
+    with pytest.raises(Exception, match="0 or 1"):
+        m.set_option("latency_form", 2)
+    w3 = rced_np.make_weights("FullyCNNV3", seed=3)
+    with pytest.raises(Exception, match="one form of tile"):
+        make_model(3, w3).set_option("latency_form", 1)
+
+
 def _scaled_inner_channels(w, rng, lo=-4.0, hi=4.0):
     """CR-CED weights in which every channel of the 18- and 30-channel tensors (one consumer each, no skip) carries its own
     scale 10^U(lo, hi): BatchNorm gamma / beta of the producer are multiplied by it and the consumer's kernel slice divided,
