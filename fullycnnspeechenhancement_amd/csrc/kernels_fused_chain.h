@@ -25,9 +25,10 @@
 #ifndef RCED_CHAIN_EXP
 #define RCED_CHAIN_EXP 0     // timing experiments only (wrong results): 1 = no skip-fragment stores, 2 = no skip-fragment loads,
                              // 4 = the two-M-tile layers issue half of their MFMAs (the bound on a bf16-pipe form of those layers),
-                             // 8 = every wave runs the extra-tile copy of a layer's code (the kernels are 88 / 109 KB of code for a 64-KB
-                             //     instruction cache: one copy per layer is 50 / 63 KB -- and 13 / 16 % SLOWER with a fourth tile on every
-                             //     wave, + 23 % MFMAs on the fullest SIMD: the cache is worth single digits here)
+                             // 8 = every wave runs the extra-tile copy of a layer's code: ONE copy per layer, 49 / 61 KB of code instead of
+                             //     88 / 109 KB; 24 = the same work from THREE marked copies (125 / 155 KB).  Measured (A/B in one call): V1
+                             //     11.63 ms with one copy, 11.48 with three; V2 13.92 / 13.80 -- the instruction cache (64 KB per two CUs)
+                             //     is NOT what these kernels wait for
 #endif
 #if RCED_CHAIN_EXP != 0 && !defined(RCED_TIMING_ONLY)
 #error "RCED_CHAIN_EXP builds compute wrong results: timing experiments only (tools/mkexp.sh ... -DRCED_TIMING_ONLY -DRCED_CHAIN_EXP=...)"
@@ -571,7 +572,11 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
     auto dma = [&] { packet_dma<G::packet(nxt)>(P.wpack + G::packet_off(nxt), wdst, wave, lane); };   // issued inside the main pass
     if constexpr (L == N::kLayers - 1) xst = xstage_load<N>(P, tile + gridDim.x, tid);
     const float* w = wbase + wcur * G::kWRegion;
-    if constexpr ((RCED_CHAIN_EXP & 8) != 0) {   // timing experiment (wrong results): ONE copy of the layer's code for every wave
+    if constexpr ((RCED_CHAIN_EXP & 24) == 24) {   // ... the same work from THREE copies of the code (what the instruction cache is worth)
+      if (wave < 2) { asm volatile("; copy 0"); run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT); }
+      else if (wave < 4) { asm volatile("; copy 1"); run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT); }
+      else { asm volatile("; copy 2"); run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT); }
+    } else if constexpr ((RCED_CHAIN_EXP & 8) != 0) {   // timing experiment (wrong results): ONE copy of the layer's code for every wave
       run_layer<N, L, 1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
     } else if constexpr (L > 0 && G::MT(L) == 2 && G::kSplitExtra) {
       if (wave < G::kExtra) run_layer<N, L, 1, 0>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
