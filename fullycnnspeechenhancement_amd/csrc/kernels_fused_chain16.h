@@ -34,6 +34,13 @@
                            // (K rounds up to 32 per layer).  Halving the MFMA cycles buys < 1 %: this kernel is not bound by
                            // the matrix pipe -- so the default stays the K = 16 form
 #endif
+#ifndef RCED_C16_EMU_X6
+#define RCED_C16_EMU_X6 0  // timing experiment only (wrong results): the COST of a three-part (six-product) form of this kernel -- three reads per
+                           // operand fragment, six MFMAs per product, a three-part split and three stores per output fragment
+#endif
+#if RCED_C16_EMU_X6 && !defined(RCED_TIMING_ONLY)
+#error "RCED_C16_EMU_X6 computes wrong results: timing experiments only (-DRCED_TIMING_ONLY)"
+#endif
 #ifndef RCED_C16_DEPTH
 #define RCED_C16_DEPTH 1   // operand prefetch depth of the bf16 pass (steps)
 #endif
@@ -148,6 +155,9 @@ __device__ __forceinline__ void pass32(const __bf16* act, int off0, int offx, co
     offs[t] = t < NR ? off0 + t * STRIDE : offx;
     asm volatile("" : "+v"(offs[t]));
   }
+#if RCED_C16_EMU_X6
+  s16x8 a1[RING][MT], a2[RING][MT], b1[RING][NT], b2[RING][NT];
+#endif
   auto load = [&](int s, int buf) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a[buf][mt] = wp[(s * MT + mt) * 64];
@@ -157,6 +167,20 @@ __device__ __forceinline__ void pass32(const __bf16* act, int off0, int offx, co
       const s16x4 hi = *reinterpret_cast<const s16x4*>(act + offs[t] + 32 * s + 4);
       b[buf][t] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     }
+#if RCED_C16_EMU_X6
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      a1[buf][mt] = wp[(s * MT + mt) * 64 + 1];     // (another lane's fragment: a different address, the same cost)
+      a2[buf][mt] = wp[(s * MT + mt) * 64 + 2];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const s16x4 lo1 = *reinterpret_cast<const s16x4*>(act + offs[t] + 32 * s + 64), hi1 = *reinterpret_cast<const s16x4*>(act + offs[t] + 32 * s + 68);
+      const s16x4 lo2 = *reinterpret_cast<const s16x4*>(act + offs[t] + 32 * s + 128), hi2 = *reinterpret_cast<const s16x4*>(act + offs[t] + 32 * s + 132);
+      b1[buf][t] = s16x8{lo1.x, lo1.y, lo1.z, lo1.w, hi1.x, hi1.y, hi1.z, hi1.w};
+      b2[buf][t] = s16x8{lo2.x, lo2.y, lo2.z, lo2.w, hi2.x, hi2.y, hi2.z, hi2.w};
+    }
+#endif
   };
 #pragma unroll
   for (int s = 0; s < DEPTH && s < STEPS; ++s) load(s, s % RING);
@@ -170,7 +194,17 @@ __device__ __forceinline__ void pass32(const __bf16* act, int off0, int offx, co
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma32(a[s % RING][mt], b[s % RING][t], acc[t][mt]);
+      for (int mt = 0; mt < MT; ++mt) {
+        const int r = s % RING;
+        acc[t][mt] = mfma32(a[r][mt], b[r][t], acc[t][mt]);
+#if RCED_C16_EMU_X6
+        acc[t][mt] = mfma32(a1[r][mt], b1[r][t], acc[t][mt]);
+        acc[t][mt] = mfma32(a2[r][mt], b[r][t], acc[t][mt]);
+        acc[t][mt] = mfma32(a[r][mt], b2[r][t], acc[t][mt]);
+        acc[t][mt] = mfma32(a1[r][mt], b[r][t], acc[t][mt]);
+        acc[t][mt] = mfma32(a[r][mt], b1[r][t], acc[t][mt]);
+#endif
+      }
     pin();
   }
 }
@@ -284,6 +318,15 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
         if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       const s16x4 h = to_bf16x4(v);                       // the layer's output IS this rounded value
+#if RCED_C16_EMU_X6
+      s16x4 hm, hl;
+      {
+        const f32x4 r1 = v - from_bf16x4(h);
+        hm = to_bf16x4(r1);
+        const f32x4 r2 = r1 - from_bf16x4(hm);
+        hl = to_bf16x4(r2);
+      }
+#endif
       if constexpr (D.saves_skip || kLast) v = from_bf16x4(h);
       if constexpr (D.saves_skip)
       {
@@ -294,6 +337,10 @@ __device__ __forceinline__ void run_layer(const Params& P, float* lds, const flo
       const int co0 = 16 * mt + 4 * kq;
       if constexpr (!kLast) {
         if (co0 < cpo) *reinterpret_cast<s16x4*>(out + px * cpo + co0) = h;
+#if RCED_C16_EMU_X6
+        if (co0 < cpo && hm.x == 0x7fff) *reinterpret_cast<s16x4*>(out + px * cpo + co0) = hm;   // (never true for real data; keeps the split alive)
+        if (co0 < cpo && hl.x == 0x7fff) *reinterpret_cast<s16x4*>(out + px * cpo + co0) = hl;
+#endif
         // padding channels past the last M-tile (stride 20 for 16 channels): keep them zero -- stale bits of another
         // layer's layout could read as bf16 NaN, and NaN x 0 weight is not 0
         if constexpr (cpo > 16 * MT) {
