@@ -19,4 +19,13 @@ for net, dtype, reps in (("FullyCNNV3", "float32", 400), ("FullyCNN", "float32",
             bad += 1
     torch.cuda.synchronize()
     out["%s %s" % (net, dtype)] = {"launches": reps, "different": bad, "finite": bool(torch.isfinite(ref).all())}
+# the R-CED kernels' latency form (one-frame tiles; calls with fewer 3-frame tiles than CUs): BASELINE config 1's shape, many launches
+for net in ("FullyCNN", "FullyCNNV2"):
+    m = build_model(net, False, weights=weights.synthetic_weights(spec.variant_of(net)))
+    x = torch.randn((1, 256, 129, 1), device="cuda").abs_()
+    ref = m(x).clone()
+    bad = sum(0 if torch.equal(m(x), ref) else 1 for _ in range(1000))
+    m.set_option("latency_form", 0)
+    same = bool(torch.equal(m(x), ref))
+    out["%s float32 [1,256] latency form" % net] = {"launches": 1000, "different": bad, "equals_3_frame_form": same}
 print(json.dumps(out))
