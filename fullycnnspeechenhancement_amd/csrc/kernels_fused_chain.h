@@ -29,6 +29,8 @@
                              //     88 / 109 KB; 24 = the same work from THREE marked copies (125 / 155 KB).  Measured (A/B in one call): V1
                              //     11.63 ms with one copy, 11.48 with three; V2 13.92 / 13.80 -- the instruction cache (64 KB per two CUs)
                              //     is NOT what these kernels wait for
+                             // 32 = no layer-end wait and no barrier at all, 64 = the wait but no barrier: V2 12.01 -> 11.08 / 11.06 ms, V1 10.20 ->
+                             //     9.83 / 9.84: the fifteen (nine) barriers cost 7.9 % (3.6 %), the wait for the next packet nothing
 #endif
 #if RCED_CHAIN_EXP != 0 && !defined(RCED_TIMING_ONLY)
 #error "RCED_CHAIN_EXP builds compute wrong results: timing experiments only (tools/mkexp.sh ... -DRCED_TIMING_ONLY -DRCED_CHAIN_EXP=...)"
@@ -221,7 +223,9 @@ __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float*
   }
 }
 __device__ __forceinline__ void layer_end_sync() {
+  if (RCED_CHAIN_EXP & 32) return;   // timing experiment (wrong results): no wait for the next packet, no barrier (the skip-saving layers keep theirs)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (RCED_CHAIN_EXP & 64) return;   // ... the wait, but no barrier
   __syncthreads();
 }
 
@@ -587,8 +591,11 @@ __device__ __forceinline__ void run_layers(const Params& P, float* lds, __amdgpu
       else run_layer<N, L, 0, -1>(P, lds, w, scratch, wave, lane, tid, utt, t0, dma, LT);
     }
     wcur ^= 1;
-    if constexpr (N::layer[L].saves_skip || L == N::kLayers - 1) __syncthreads();
-    else layer_end_sync();
+    if constexpr (N::layer[L].saves_skip || L == N::kLayers - 1) {
+      if (!(RCED_CHAIN_EXP & 96)) __syncthreads();
+    } else {
+      layer_end_sync();
+    }
     run_layers<N, L + 1>(P, lds, scratch, wcur, xst, tile, wave, lane, tid, utt, t0, LT);
   }
 }
