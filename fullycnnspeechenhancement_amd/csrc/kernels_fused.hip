@@ -24,7 +24,7 @@ inline unsigned short bf16_rne(float f) {
   return (unsigned short)(u >> 16);
 }
 
-inline int env_default_early(const char* name, int dflt) {
+inline int env_default(const char* name, int dflt) {   // an environment variable as the DEFAULT of a per-handle option
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
@@ -56,7 +56,7 @@ struct rced_fused {
   float* scratch16 = nullptr; // skip fragments for 2 workgroups per CU
   int bf16_wgs_per_cu = 1;
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
-  int latency_form = env_default_early("RCED_LATENCY_FORM", 1);   // option "latency_form" (V1/V2, fp32): one-frame tiles for calls with fewer
+  int latency_form = env_default("RCED_LATENCY_FORM", 1);   // option "latency_form" (V1/V2, fp32): one-frame tiles for calls with fewer
                                                                   // 3-frame tiles than CUs (chain_forward)
   unsigned* err_host = nullptr;   // sticky error word of the CR-CED kernel's wave-to-wave hand-offs: pinned host memory the
   unsigned* err_dev = nullptr;    // kernel reaches through its device alias, so the host reads it without a device sync
@@ -348,10 +348,6 @@ void pack_chain(const rced_model* m, std::vector<float>* wpack, std::vector<floa
   *fin_bias = lf.host_shift[0];
 }
 
-inline int env_default(const char* name, int dflt) {   // an environment variable as the DEFAULT of a per-handle option
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 template <int CH>
 void chain_final_layer(const rced_fused* f, float* y, int frames, hipStream_t st) {
   const dim3 grid((frames + chain::kFinFrames - 1) / chain::kFinFrames);
