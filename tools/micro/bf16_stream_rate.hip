@@ -18,7 +18,7 @@ template <int CTRL>
 __device__ __forceinline__ float dpp0(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-template <int R, int M, int V, int W = 8>
+template <int R, int M, int V, int W = 8, bool PLAIN = false>   // PLAIN: v_add_f32 instead of v_add_f32_dpp
 __global__ __launch_bounds__(64 * W) __attribute__((target("no-packed-fp32-ops"))) void k(float* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -48,7 +48,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((target("no-packed-fp32-ops")
         a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, op[i & 1][(m + 1) % RR]), __builtin_bit_cast(bf16x8, op[i & 1][m % RR]), a1, 0, 0, 0);
       }
 #pragma unroll
-      for (int v = 0; v < V; ++v) o[v & 3] += dpp0<0x111>(c[(i & 1) ^ 1][(v >> 2) & 1][v & 3]);
+      for (int v = 0; v < V; ++v) {
+        if constexpr (PLAIN) {
+          float t = c[(i & 1) ^ 1][(v >> 2) & 1][v & 3];
+          asm volatile("" : "+v"(t));          // (no re-association into fewer adds)
+          o[v & 3] += t;
+        } else {
+          o[v & 3] += dpp0<0x111>(c[(i & 1) ^ 1][(v >> 2) & 1][v & 3]);
+        }
+      }
       c[i & 1][0] = a0;
       c[i & 1][1] = a1;
       pin();
@@ -57,23 +65,23 @@ __global__ __launch_bounds__(64 * W) __attribute__((target("no-packed-fp32-ops")
   const float s = o[0] + o[1] + o[2] + o[3] + c[0][0].x + c[0][1].y + c[1][0].z + c[1][1].w;
   if (s == 12345.f) out[threadIdx.x] = s;
 }
-template <int R, int M, int V, int W = 8>
+template <int R, int M, int V, int W = 8, bool PLAIN = false>
 void run(float* d) {
   const int cus = 256, iters = 2000 * 8 / W;       // the same work per SIMD for every W
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k<R, M, V, W>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k<R, M, V, W, PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  k<R, M, V, W><<<cus, 64 * W, 131072>>>(d, 50);
+  k<R, M, V, W, PLAIN><<<cus, 64 * W, 131072>>>(d, 50);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k<R, M, V, W><<<cus, 64 * W, 131072>>>(d, iters);
+  k<R, M, V, W, PLAIN><<<cus, 64 * W, 131072>>>(d, iters);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double mfmas = (double)iters * 16.0 * M * (W / 4);   // per SIMD (W / 4 waves)
   const double cyc = ms * 1e-3 * 2.4e9;
-  printf("waves/SIMD=%d b128 reads/slot=%2d mfma/slot=%2d dpp-adds/slot=%2d: %.2f ms  %.1f cycles per MFMA (16 = peak; at 2.4 GHz)\n", W / 4, R, M, V, ms, cyc / mfmas);
+  printf("waves/SIMD=%d b128 reads/slot=%2d mfma/slot=%2d %s/slot=%2d: %.2f ms  %.1f cycles per MFMA (16 = peak; at 2.4 GHz)\n", W / 4, R, M, PLAIN ? "v_add_f32" : "dpp-adds", V, ms, cyc / mfmas);
 }
 int main() {
   float* d;
@@ -85,5 +93,7 @@ int main() {
   run<9, 12, 24, 8>(d); run<9, 12, 24, 12>(d); run<9, 12, 24, 16>(d);
   run<12, 12, 24, 8>(d); run<12, 12, 24, 12>(d); run<12, 12, 24, 16>(d);
   run<0, 12, 24, 8>(d); run<0, 12, 24, 12>(d); run<0, 12, 24, 16>(d);
+  // plain VALU instead of DPP
+  run<0, 12, 12, 8, true>(d); run<0, 12, 24, 8, true>(d); run<9, 12, 24, 8, true>(d); run<9, 12, 24, 12, true>(d); run<0, 12, 48, 8, true>(d);
   return 0;
 }
