@@ -11,6 +11,7 @@
 #include "kernels_fused_chain.h"
 #include "kernels_fused_v3.h"
 #include "kernels_fused_chain16.h"
+#include "kernels_frame16.h"
 #include "kernels_final_x6.h"
 #include "rced_internal.h"
 
@@ -50,10 +51,10 @@ struct rced_fused {
   size_t h_bytes = 0;
   unsigned long long* stamps = nullptr;  // diagnostic builds (RCED_STAMPS) only
   int bf16 = 0;               // option "bf16" (V1/V2): bf16 activations + weights (kernels_fused_chain16.h)
-  float* wpack16 = nullptr;   // its packet stream (built when the option is first set)
+  unsigned* wpack16 = nullptr;   // its packet stream (built when the option is first set)
   unsigned short* fin_apack16 = nullptr;   // the output layer's Toeplitz A fragments in bf16 (chain16::final_gemm16_kernel)
   unsigned short* fin_apack_x6 = nullptr;  // ... as three bf16 parts per value: fp32 quality on the bf16 pipe (x6::final_gemm_x6_kernel)
-  float* scratch16 = nullptr; // skip fragments for 2 workgroups per CU
+  unsigned* scratch16 = nullptr; // its skip fragments, per wave (2 workgroups per CU x 4 waves)
   int bf16_wgs_per_cu = 1;
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
   int latency_form = env_default("RCED_LATENCY_FORM", 1);   // option "latency_form" (V1/V2, fp32): one-frame tiles for calls with fewer
@@ -445,48 +446,47 @@ int chain_create(rced_model* m, rced_fused* f) {
   return RCED_OK;
 }
 
-// ---- bf16 variant (kernels_fused_chain16.h) ----------------------------------------------------
+// ---- bf16 variant (kernels_frame16.h) ----------------------------------------------------------
+// Packets: [K-step s][M-tile mt][lane] x 8 bf16 -- lane (kq, m): row 16 mt + m (cout), K slot j = 4 s + kq = (tap j / OCT, octet
+// j % OCT), element e = channel 8 (j % OCT) + e (first layer: OCT = 1, e = the kernel's time row) -- then 32 fp32 shifts.
 template <class N>
-void pack_chain16(const rced_model* m, std::vector<float>* wpack) {
-  using G = chain16::Geo<N>;
-  using G32 = chain::Geo<N>;
-  wpack->assign(G::kWTotal, 0.f);
-  float* dst = wpack->data();
+void pack_frame16(const rced_model* m, std::vector<unsigned>* wpack) {
+  using G = frame16::Geo<N>;
+  wpack->assign(G::kWBytes / 4, 0u);
   for (int l = 0; l < N::kLayers; ++l) {
     const rced_layer_dev& L = m->layers[l];
     const chain::LayerDesc d = N::layer[l];
-    const int MT = G::MT(l);
-    if (l == 0) {   // fp32, as pack_chain
-      for (int s = 0; s < 2 * d.taps; ++s)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int i = lane & 15, kq = lane >> 4, ih = s / d.taps, j = s % d.taps, ti = 4 * ih + kq;
-          dst[s * 64 + lane] = i < d.cout ? wq(L, ti * d.taps + j, 0, i, 1) : 0.f;
-        }
-      static_assert(G::data(0) == G32::data(0), "layer 0 packet is the fp32 one");
-    } else {
-      const int cpi = G::cp(l - 1), K = G::K(l);
-      unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
-      constexpr int KS = G::kKStep, PL = KS / 4;     // k per MFMA (16 or 32) and per lane (4 or 8): k = KS s + PL kq + e
-      for (int s = 0; s < G::steps(l); ++s)
-        for (int mt = 0; mt < MT; ++mt)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < PL; ++e) {
-              const int k = KS * s + PL * (lane >> 4) + e, co = 16 * mt + (lane & 15), tap = k / cpi, ci = k % cpi;
-              const float v = (k < K && co < d.cout && ci < d.cin) ? wq(L, tap, ci, co, d.cin) : 0.f;
-              d16[((size_t)(s * MT + mt) * 64 + lane) * PL + e] = bf16_rne(v);
+    const int MT = G::MT(l), OCT = G::oct_in(l);
+    unsigned char* pk = reinterpret_cast<unsigned char*>(wpack->data()) + G::packet_off(l);
+    unsigned short* d16 = reinterpret_cast<unsigned short*>(pk);
+    for (int s = 0; s < G::steps(l); ++s)
+      for (int mt = 0; mt < MT; ++mt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int j = 4 * s + (lane >> 4), tap = j / OCT, ch = 8 * (j % OCT) + e, co = 16 * mt + (lane & 15);
+            float v = 0.f;
+            if (tap < d.taps && co < d.cout) {
+              if (l == 0) v = wq(L, e * d.taps + tap, 0, co, 1);            // [kh = 8 time rows][kw = taps][1][cout]
+              else if (ch < d.cin) v = wq(L, tap, ch, co, d.cin);
             }
-    }
-    for (int c = 0; c < d.cout; ++c) dst[G::data(l) + c] = L.host_shift[c];
-    dst += G::packet(l);
+            d16[((size_t)(s * MT + mt) * 64 + lane) * 8 + e] = bf16_rne(v);
+          }
+    float* sh = reinterpret_cast<float*>(pk + (size_t)G::frags(l) * 1024);
+    for (int c = 0; c < d.cout; ++c) sh[c] = L.host_shift[c];
   }
 }
 template <class N>
-int chain16_enable(rced_model* m, rced_fused* f) {
-  using G = chain16::Geo<N>;
+int frame16_enable(rced_model* m, rced_fused* f) {
+  using G = frame16::Geo<N>;
   if (f->wpack16) return RCED_OK;
-  std::vector<float> wpack;
-  pack_chain16<N>(m, &wpack);
-  if (int rc = upload(&f->wpack16, wpack)) return rc;
+  std::vector<unsigned> wpack;
+  pack_frame16<N>(m, &wpack);
+  unsigned* wdev = nullptr;
+  HIP_TRY(hipMalloc(&wdev, wpack.size() * sizeof(unsigned)));
+  if (hipMemcpy(wdev, wpack.data(), wpack.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(wdev);
+    return rced_fail(RCED_ERR_HIP, "hipMemcpy(bf16 packets)");
+  }
   {  // output layer: the fp32 pack's values A[f, k] (pack_chain), rounded to bf16, in K-16 fragment order
     constexpr int CH = N::kFinalCh;
     using F16 = chain16::Final16<CH>;
@@ -500,35 +500,37 @@ int chain16_enable(rced_model* m, rced_fused* f) {
             const float v = (k < F16::kK && fo < 129 && tap >= 0 && tap < 129) ? wq(lf, tap, ci, 0, CH) : 0.f;
             fin16[((size_t)(S * F16::kMT + mt) * 64 + lane) * 4 + j] = bf16_rne(v);
           }
-    HIP_TRY(hipMalloc(&f->fin_apack16, fin16.size() * sizeof(unsigned short)));
+    if (!f->fin_apack16) HIP_TRY(hipMalloc(&f->fin_apack16, fin16.size() * sizeof(unsigned short)));
     HIP_TRY(hipMemcpy(f->fin_apack16, fin16.data(), fin16.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   }
-  HIP_TRY(hipMalloc(&f->scratch16, (size_t)2 * m->num_cus * G::kScratchFloatsPerWg * sizeof(float)));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain16::fused_chain16_kernel<N>),
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(frame16::frame16_kernel<N>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
   int per_cu = 1;   // resident workgroups per CU with this LDS footprint and the kernel's register count
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(chain16::fused_chain16_kernel<N>),
-                                                   chain::kThreads, G::kLdsBytes) != hipSuccess || per_cu < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(frame16::frame16_kernel<N>),
+                                                   frame16::kThreads, G::kLdsBytes) != hipSuccess || per_cu < 1)
     per_cu = 1;
   f->bf16_wgs_per_cu = per_cu > 2 ? 2 : per_cu;
+  if (!f->scratch16)
+    HIP_TRY(hipMalloc(&f->scratch16, (size_t)2 * m->num_cus * frame16::kWaves * G::kScratchBytesPerWave));
+  f->wpack16 = wdev;   // published last: the mode counts as built only when everything above succeeded
   return RCED_OK;
 }
 template <class N>
-int chain16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
-  using G = chain16::Geo<N>;
-  chain::Params P;
+int frame16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
+  using G = frame16::Geo<N>;
+  frame16::Params P;
   P.x = x;
   P.h = f->h;
   P.wpack = f->wpack16;
   P.scratch = f->scratch16;
   P.N = Nb;
   P.T = T;
-  P.tiles_per_utt = (T + N::kTF - 1) / N::kTF;
+  P.tiles_per_utt = (T + frame16::kWaves - 1) / frame16::kWaves;
   P.total_tiles = Nb * P.tiles_per_utt;
-  const int wgs = f->bf16_wgs_per_cu * m->num_cus;       // LDS (<= 80 KB) allows two per CU; VGPRs decide (chain16_enable)
+  const int wgs = f->bf16_wgs_per_cu * m->num_cus;       // LDS (<= 80 KB) allows two per CU; VGPRs decide (frame16_enable)
   const int grid = std::min(P.total_tiles, f->grid_limit > 0 ? std::min(f->grid_limit, wgs) : wgs);
   m->prof_begin(RCED_K_FUSED, st);
-  hipLaunchKernelGGL(chain16::fused_chain16_kernel<N>, dim3(grid), dim3(chain::kThreads), G::kLdsBytes, st, P);
+  hipLaunchKernelGGL(frame16::frame16_kernel<N>, dim3(grid), dim3(frame16::kThreads), G::kLdsBytes, st, P);
   m->prof_end(RCED_K_FUSED, st);
   HIP_TRY(hipGetLastError());
   const int frames = Nb * T;
@@ -687,10 +689,10 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   rced_fused* f = m->fused;
   if (int rc = fused_reserve(m, N, T)) return rc;
   if (m->variant == RCED_V1)
-    return f->bf16 ? chain16_forward<chain16::WithTF<chain::NetV1, RCED_C16_TF>>(m, f, x, y, N, T, st)
+    return f->bf16 ? frame16_forward<chain::NetV1>(m, f, x, y, N, T, st)
                    : chain_forward<chain::NetV1>(m, f, x, y, N, T, st);
   if (m->variant == RCED_V2)
-    return f->bf16 ? chain16_forward<chain16::WithTF<chain::NetV2, RCED_C16_TF>>(m, f, x, y, N, T, st)
+    return f->bf16 ? frame16_forward<chain::NetV2>(m, f, x, y, N, T, st)
                    : chain_forward<chain::NetV2>(m, f, x, y, N, T, st);
   if (int rc = fused_check(m)) return rc;   // a hand-off flag that never came in an EARLIER launch: refuse to go on
   v3::Params P;
@@ -751,7 +753,7 @@ int fused_set_option(rced_model* m, const char* key, int value) {
   if (!strcmp(key, "bf16")) {
     if (m->variant == RCED_V3) return value ? rced_fail(RCED_ERR_ARG, "bf16 is built for R-CED V1 / V2 only") : RCED_OK;
     if (value) {
-      if (int rc = m->variant == RCED_V1 ? chain16_enable<chain16::WithTF<chain::NetV1, RCED_C16_TF>>(m, m->fused) : chain16_enable<chain16::WithTF<chain::NetV2, RCED_C16_TF>>(m, m->fused))
+      if (int rc = m->variant == RCED_V1 ? frame16_enable<chain::NetV1>(m, m->fused) : frame16_enable<chain::NetV2>(m, m->fused))
         return rc;
     }
     m->fused->bf16 = value != 0;

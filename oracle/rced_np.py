@@ -94,16 +94,17 @@ def bf16_round(a):
 
 
 def forward_bf16(net_work, weights, x, final_bf16=True):
-    """Emulation of the bf16 variant of the R-CED kernels (csrc/kernels_fused_chain16.h; BASELINE config 2).
+    """Emulation of the bf16 mode of the R-CED kernels (csrc/kernels_frame16.h; BASELINE config 2).
 
     Not a statement about the reference (which is fp32): it restates what the bf16 KERNEL computes, so that the
-    kernel can be tested.  Inner layers: BatchNorm-folded kernels rounded to bf16, bf16 activations in, fp32 (here
-    fp64) accumulation, fp32 shift, (+ skip), ReLU, result rounded to bf16.  First layer: fp32 input and folded fp32
-    kernel, output rounded to bf16.  Last layer (1x129): kernel rounded to bf16 (chain16::final_gemm16_kernel; with
-    RCED_C16_FINAL16=0 the library keeps it fp32 -- final_bf16=False) on the bf16 activations, fp32 output.
+    kernel can be tested.  The input is cast to bf16 ("C2 ... (cast bf16)"); every layer: BatchNorm-folded
+    kernel rounded to bf16, bf16 activations in, fp32 (here fp64) accumulation, fp32 shift, (+ skip), ReLU, result
+    rounded to bf16.  (Until round 6 the first layer ran on the fp32 input with its fp32 kernel.)  Last layer (1x129):
+    kernel rounded to bf16 (chain16::final_gemm16_kernel; with RCED_C16_FINAL16=0 the library keeps it fp32 --
+    final_bf16=False) on the bf16 activations, fp32 output.
     """
     layers = L.layers_for(net_work)
-    tensors = [np.asarray(x, dtype=np.float64)]
+    tensors = [bf16_round(np.asarray(x, dtype=np.float32)).astype(np.float64)]
     for i, l in enumerate(layers):
         k = np.asarray(weights[l.scope + "/kernel"], np.float64)
         shift = np.asarray(weights[l.scope + "/bias"], np.float64)
@@ -114,8 +115,8 @@ def forward_bf16(net_work, weights, x, final_bf16=True):
             k = k * s
             shift = (shift - m) * s + b
         k = k.astype(np.float32)                 # the folded kernel as the library holds it
-        first, last = i == 0, i == len(layers) - 1
-        if not (first or (last and not final_bf16)):
+        last = i == len(layers) - 1
+        if not (last and not final_bf16):
             k = bf16_round(k)
         y = conv2d_same(tensors[l.src], k, shift.astype(np.float32), np.float64)
         if l.skip_pre >= 0:
