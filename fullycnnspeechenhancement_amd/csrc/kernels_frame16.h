@@ -40,10 +40,15 @@
 #include "lds_dma.h"
 
 #ifndef RCED_F16_EXP
-#define RCED_F16_EXP 0   // timing experiments only (wrong results): 1 = no skip stores, 2 = no skip loads / adds, 4 = no barriers
+#define RCED_F16_EXP 0   // timing experiments only (wrong results): 1 = no skip stores, 2 = no skip loads / adds, 4 = no barriers,
+                         // 8 = A fragments read for the first K-step only, 16 = no input-row loads, 64 = no packet DMA
 #endif
 #if RCED_F16_EXP != 0 && !defined(RCED_TIMING_ONLY)
 #error "RCED_F16_EXP builds compute wrong results: timing experiments only (-DRCED_TIMING_ONLY)"
+#endif
+
+#ifndef RCED_F16_STAMPS
+#define RCED_F16_STAMPS 0   // diagnostic build: s_memtime stamps of workgroup 0 / wave 0 on its second tile (tools/stamps16.py)
 #endif
 
 namespace rced {
@@ -77,7 +82,13 @@ struct Params {
   int N, T;
   int tiles_per_utt;         // ceil(T / 4)
   int total_tiles;
+  unsigned long long* stamps;   // RCED_F16_STAMPS builds only
 };
+#if RCED_F16_STAMPS
+#define F16_STAMP(on, i) do { if ((on) && (lane & 63) == 0) P.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define F16_STAMP(on, i) do { } while (0)
+#endif
 
 template <class N>
 struct Geo {
@@ -88,13 +99,15 @@ struct Geo {
   static constexpr int slots(int l) { return N::layer[l].taps * oct_in(l); }   // K slots of 8 (layer 0: 8 time rows per tap)
   static constexpr int steps(int l) { return (slots(l) + 3) / 4; }
   static constexpr int frags(int l) { return steps(l) * MT(l); }
-  static constexpr int packet_bytes(int l) { return frags(l) * 1024 + 128; }
+  static constexpr int packet_bytes(int l) { return frags(l) * 1024; }
   static constexpr int packet_off(int l) {
     int o = 0;
     for (int i = 0; i < l; ++i) o += packet_bytes(i);
     return o;
   }
-  static constexpr int kWBytes = packet_off(kLayers);
+  static constexpr int kShiftOff = packet_off(kLayers);         // 32 fp32 shifts per layer behind the packets
+  static constexpr int kShiftBytes = kLayers * 128;
+  static constexpr int kWBytes = kShiftOff + kShiftBytes;
   static constexpr int maxpacket() {
     int m = 0;
     for (int l = 0; l < kLayers; ++l) m = packet_bytes(l) > m ? packet_bytes(l) : m;
@@ -118,7 +131,8 @@ struct Geo {
   static constexpr int kRegion = kPlanes * kPlane;  // one frame's image
   static constexpr int kActBytes = kWaves * kRegion;
   static constexpr int kWOff = kActBytes;
-  static constexpr int kLdsBytes = kWOff + 2 * kWRegion;
+  static constexpr int kSOff = kWOff + 2 * kWRegion;            // every layer's shifts, resident (loaded once per workgroup)
+  static constexpr int kLdsBytes = kSOff + kShiftBytes;
   static_assert(kLdsBytes <= 80 * 1024, "two workgroups per CU");
   static constexpr bool pads_ok() {
     for (int l = 0; l < kLayers; ++l)
@@ -126,15 +140,21 @@ struct Geo {
     return true;
   }
   static_assert(pads_ok(), "the widest kernel's left halo fits the leading zero rows");
-  // skip scratch, per wave: units of 512 bytes (64 lanes x 8), unit = (saving layer, tile, M-tile)
-  static constexpr int skip_unit(int l) {
+  // skip scratch, per wave: per (saving layer, M-tile) four 1-KiB units -- the fragments of tiles (0,1) .. (6,7), 16 bytes per
+  // lane -- and 512 bytes for tile 8.  Only the lanes whose four channels exist are stored and loaded (k-quads 0 .. quads - 1:
+  // whole 256-byte runs), so an M-tile with 3 real channels moves a quarter of its unit.
+  static constexpr int kSkipSet = 4 * 1024 + 512;
+  static constexpr int skip_off(int l, int mt) {
     int u = 0;
     for (int i = 0; i < l; ++i)
-      if (N::layer[i].saves_skip) u += kTiles * MT(i);
-    return u;
+      if (N::layer[i].saves_skip) u += MT(i);
+    return (u + mt) * kSkipSet;
   }
-  static constexpr int kSkipUnits = skip_unit(kLayers);
-  static constexpr size_t kScratchBytesPerWave = (size_t)kSkipUnits * 512;
+  static constexpr int skip_quads(int l, int mt) {   // k-quads of M-tile mt that hold real channels
+    const int q = (N::layer[l].cout + 3) / 4 - 4 * mt;
+    return q > 4 ? 4 : q;
+  }
+  static constexpr size_t kScratchBytesPerWave = (size_t)skip_off(kLayers, 0);
 };
 
 __device__ __forceinline__ f32x4 mfma32(u32x4 a, u32x4 b, f32x4 c) {
@@ -144,8 +164,9 @@ __device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
 }
 // two floats -> packed bf16 (round to nearest even; v_cvt_pk_bf16_f32 keeps a NaN a NaN)
+// (as a vector conversion: element-wise casts followed by an integer use of the pair came out as two conversions + v_perm_b32)
 __device__ __forceinline__ unsigned pack2(float a, float b) {
-  const bf16x2 h = {(__bf16)a, (__bf16)b};
+  const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
   return __builtin_bit_cast(unsigned, h);
 }
 // ReLU on two packed bf16: a signed 16-bit max with zero (negative values, -0 and NaNs with the sign bit set become +0)
@@ -154,17 +175,30 @@ __device__ __forceinline__ unsigned relu2(unsigned v) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
 }
 
-// LDS-DMA of one packet, 1-KiB pieces dealt round-robin to the four waves (the last piece is the 128 bytes of shifts)
+// LDS-DMA of one packet: whole 1-KiB pieces dealt round-robin to the four waves.  The piece's source is a wave-uniform
+// base + lane * 16, its LDS address goes through M0 (readfirstlane: hipcc is free to compute a uniform address on the VALU,
+// and an "s" operand of an asm statement does not make it move the value).
 template <int BYTES>
 __device__ __forceinline__ void packet_dma(const unsigned* __restrict__ src, char* dst, int wave, int lane) {
-  static_assert(BYTES % 16 == 0, "16-byte pieces");
-  constexpr int n16 = BYTES / 16, chunks = (n16 + 63) / 64;
+  static_assert(BYTES % 1024 == 0, "whole pieces");
+  constexpr int chunks = BYTES / 1024;
+  const unsigned d0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)dst);
 #pragma unroll
   for (int i = 0; i < (chunks + kWaves - 1) / kWaves; ++i) {
     const int c = wave + i * kWaves;
     if (c < chunks) {
-      if (c * 64 + lane < n16)
-        lds_dma16s(reinterpret_cast<const float*>(src) + c * 256, (unsigned)lane * 16u, reinterpret_cast<float*>(dst + c * 1024));
+      const unsigned m0v = d0 + c * 1024;
+      const unsigned* sp = src + c * 256;
+      unsigned saved;   // m0 is saved and restored inside the statement, so the compiler's view of it stays valid
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 3\n\t"
+          "global_load_lds_dwordx4 %1, %2\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(saved)
+          : "v"((unsigned)lane * 16u), "s"(sp), "s"(m0v)
+          : "memory");
     }
   }
 }
@@ -173,22 +207,22 @@ __device__ __forceinline__ void packet_dma(const unsigned* __restrict__ src, cha
 struct XRows {
   float v[3][8];
 };
+// Buffer loads over the utterance's [T, 129] floats: a row in front of the first or behind the last frame (TF 'SAME' for the
+// 8-tall kernel: 3 rows before, 4 after) is out of the descriptor's range and reads as zero -- no per-row predicates, one
+// scalar offset per row.  Lanes past bin 128 of the third column read the next row's bins; x_store drops them.
 __device__ __forceinline__ XRows x_load(const Params& P, int tile, int wave, int lane) {
   XRows r;
   const bool live = tile < P.total_tiles;
   const int utt = live ? tile / P.tiles_per_utt : 0;
   const int t = live ? (tile - utt * P.tiles_per_utt) * kWaves + wave : 0;
-  const float* xu = P.x + (size_t)utt * P.T * kF;
+  const __amdgpu_buffer_rsrc_t xu = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(P.x) + (size_t)utt * P.T * kF, 0, live ? P.T * kF * 4 : 0, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int p = lane + 64 * i;
+  for (int k = 0; k < 8; ++k) {
+    const int row = (t + k - 3) * (kF * 4);           // negative: wraps past the range
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int tt = t + k - 3;                       // TF 'SAME' for the 8-tall kernel: 3 rows before, 4 after
-      float v = 0.f;
-      if (live && p < kF && t < P.T && tt >= 0 && tt < P.T) v = xu[(size_t)tt * kF + p];
-      r.v[i][k] = v;
-    }
+    for (int i = 0; i < 3; ++i)
+      r.v[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xu, lane * 4 + 256 * i, row, 0));
   }
   return r;
 }
@@ -206,9 +240,11 @@ __device__ __forceinline__ void x_store(const XRows& r, char* region, int lane) 
 // One layer of one frame (one wave).  `w` = the layer's packet in LDS; `pre` = issued once the first operand reads are in
 // flight (the next packet's LDS-DMA, the next tile's input rows).
 template <class N, int L, class Pre>
-__device__ __forceinline__ void run_layer(const Params& P, char* region, const char* w, __amdgpu_buffer_rsrc_t scratch, int lane,
-                                          long long hrow /* first float of this frame's hand-off rows, < 0: no frame */, Pre pre) {
+__device__ __forceinline__ void run_layer(const Params& P, char* region, const char* w, const char* shifts, __amdgpu_buffer_rsrc_t scratch, int lane,
+                                          long long hrow /* first float of this frame's hand-off rows, < 0: no frame */, Pre pre,
+                                          bool stamp = false) {
   using G = Geo<N>;
+  F16_STAMP(stamp, 4 * L + 0);
   constexpr LayerDesc D = N::layer[L];
   constexpr int OCT = G::oct_in(L), OCTO = G::oct_out(L), MT = G::MT(L), STEPS = G::steps(L), PADL = G::pad(L);
   constexpr bool kLast = (L == N::kLayers - 1);
@@ -216,16 +252,27 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
   asm volatile("" : "+v"(lane));                    // no hoisting of every layer's address arithmetic out of the tile loop
   const int n = lane & 15, kq = lane >> 4;
 
-  // skip fragments of the matching encoder layer: issued now, used after the last K-step
+  // skip fragments of the matching encoder layer: issued now, used after the last K-step (lanes without real channels: zero)
   u32x2 skip[D.skip_from >= 0 ? kTiles : 1][D.skip_from >= 0 ? MT : 1];
   if constexpr (D.skip_from >= 0 && !(RCED_F16_EXP & 2)) {
     static_assert(N::layer[D.skip_from >= 0 ? D.skip_from : 0].cout == D.cout, "skip shapes match");
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t)
+    for (int mt = 0; mt < MT; ++mt) {
+      constexpr int SF = D.skip_from >= 0 ? D.skip_from : 0;
+      const int so = G::skip_off(SF, mt);
+      const bool real = kq < G::skip_quads(SF, mt);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        skip[t][mt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                                                    scratch, lane * 8, (G::skip_unit(D.skip_from) + t * MT + mt) * 512, 0));
+      for (int t = 0; t < kTiles; ++t) skip[t][mt] = u32x2{0u, 0u};
+      if (real) {
+#pragma unroll
+        for (int t = 0; t + 1 < kTiles; t += 2) {
+          const u32x4 q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(scratch, lane * 16, so + (t / 2) * 1024, 0));
+          skip[t][mt] = u32x2{q.x, q.y};
+          skip[t + 1][mt] = u32x2{q.z, q.w};
+        }
+        skip[kTiles - 1][mt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(scratch, lane * 8, so + 4096, 0));
+      }
+    }
   }
 
   int base[NB];
@@ -242,14 +289,16 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
   f32x4 acc[kTiles][MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(w + G::frags(L) * 1024 + (16 * mt + 4 * kq) * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shifts + (32 * L + 16 * mt + 4 * kq) * 4);
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) acc[t][mt] = sh;
   }
   u32x4 a[2][MT], b[2][kTiles];
   auto load = [&](int s, int buf) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[buf][mt] = *reinterpret_cast<const u32x4*>(wp + (s * MT + mt) * 1024);
+    for (int mt = 0; mt < MT; ++mt)
+      if (!(RCED_F16_EXP & 8) || s == 0) a[buf][mt] = *reinterpret_cast<const u32x4*>(wp + (s * MT + mt) * 1024);
+      else a[buf][mt] = a[buf ^ 1][mt];
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
       b[buf][t] = *reinterpret_cast<const u32x4*>(region + base[s % OCT % NB] + (s / OCT) * 64 + t * 256);
@@ -278,21 +327,27 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
       for (int t = 0; t < kTiles; ++t) acc[t][mt] = mfma16(eye, skip[t][mt], acc[t][mt]);
   }
   // ---- epilogue: round to bf16, ReLU, store in place (every read of this layer has been consumed by an MFMA above)
+  // The next packet's LDS-DMA (issued a whole K loop ago) and the skip loads have landed: wait for them HERE, in front of the
+  // epilogue's global stores (skip fragments, the hand-off tensor), and end the layer on a bare s_barrier -- the stores stay in
+  // flight across it instead of exposing their latency at every layer's end.  Nobody reads them before a later layer's wait
+  // at this place has retired them (a skip fragment is read two layers later at the earliest).
+  F16_STAMP(stamp, 4 * L + 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0f70);                // ... and hipcc's wait-count pass knows it (vmcnt(0), nothing else)
+  F16_STAMP(stamp, 4 * L + 2);
+  // A fragment (tile t, M-tile mt) goes to octet 2 mt + (kq >> 1), bytes 8 (kq & 1) .. + 7 of pixel 16 t + n's row.  An M-tile whose
+  // upper octet lies past the layer's last one stores it all the same (zeros: those rows of the packet are zero): the plane is
+  // dead, and an unconditional store is one instruction where a lane mask is four.
   char* const out = region + (n + kRowPad) * 16 + (kq >> 1) * G::kPlane + (kq & 1) * 8;
+  u32x2 prev[MT];                                   // the even tile of a pair (skip stores are 16 bytes per lane), tile 8 at the end
 #pragma unroll
   for (int t = 0; t < kTiles; ++t) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const f32x4 v = acc[t][mt];
       const u32x2 hq = {relu2(pack2(v.x, v.y)), relu2(pack2(v.z, v.w))};
-      if constexpr (D.saves_skip && !(RCED_F16_EXP & 1)) {
-        __builtin_amdgcn_raw_buffer_store_b64(hq, scratch, lane * 8, (G::skip_unit(L) + t * MT + mt) * 512, 0);
-        store_wait_state();
-      }
       if constexpr (!kLast) {
-        // octet 2 mt + (kq >> 1); the planes past the layer's last octet are not written (nobody reads them)
-        const bool oct_ok = 2 * mt + 1 < OCTO || kq < 2;
-        if (oct_ok && (t < kTiles - 1 || n == 0)) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + t * 256) = hq;
+        if (t < kTiles - 1) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + t * 256) = hq;
       } else {
         const int f = 16 * t + n, co0 = 16 * mt + 4 * kq;
         if (hrow >= 0 && f < kF) {
@@ -301,32 +356,54 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
           if (co0 + 3 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp + 2) = f32x2{__builtin_bit_cast(float, hq.y << 16), __builtin_bit_cast(float, hq.y & 0xffff0000u)};
         }
       }
+      if constexpr (D.saves_skip && !(RCED_F16_EXP & 1)) {
+        if ((t & 1) && kq < G::skip_quads(L, mt)) {
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{prev[mt].x, prev[mt].y, hq.x, hq.y}, scratch, lane * 16, G::skip_off(L, mt) + (t / 2) * 1024, 0);
+          store_wait_state();
+        }
+      }
+      if ((t & 1) == 0) prev[mt] = hq;
     }
   }
+  // tile 8: bin 128 alone (lane n = 0) -- the other rows stay zero
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if constexpr (D.saves_skip && !(RCED_F16_EXP & 1)) {
+      if (kq < G::skip_quads(L, mt)) {
+        __builtin_amdgcn_raw_buffer_store_b64(prev[mt], scratch, lane * 8, G::skip_off(L, mt) + 4096, 0);
+        store_wait_state();
+      }
+    }
+    if constexpr (!kLast) {
+      if (n == 0) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + (kTiles - 1) * 256) = prev[mt];
+    }
+  }
+  F16_STAMP(stamp, 4 * L + 3);
 }
 
+// A bare s_barrier (not __syncthreads(), whose release fence waits for every global store in flight): what the four waves hand
+// each other is the weight ring alone -- this wave's pieces of the next packet have landed (run_layer's wait in front of its
+// epilogue), and it has read the last fragment of the packet that the next layer's DMA will overwrite.
 __device__ __forceinline__ void layer_end_sync() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next packet have landed; its skip stores are out
-  __builtin_amdgcn_s_waitcnt(0x0f70);                // ... and hipcc's wait-count pass knows it (vmcnt(0), nothing else)
-  if (!(RCED_F16_EXP & 4)) __syncthreads();
+  if (!(RCED_F16_EXP & 4)) asm volatile("s_barrier" ::: "memory");
 }
 
 template <class N, int L>
 __device__ __forceinline__ void run_layers(const Params& P, char* lds, char* region, __amdgpu_buffer_rsrc_t scratch, int& wcur,
-                                           XRows& xr, int tile, int wave, int lane, long long hrow) {
+                                           XRows& xr, int tile, int wave, int lane, long long hrow, bool stamp) {
   using G = Geo<N>;
   if constexpr (L < N::kLayers) {
     constexpr int nxt = (L + 1 < N::kLayers) ? L + 1 : 0;   // the stream wraps: the next tile's first packet
     char* const wbase = lds + G::kWOff;
     char* const wdst = wbase + (wcur ^ 1) * G::kWRegion;
     auto pre = [&] {
-      packet_dma<G::packet_bytes(nxt)>(P.wpack + G::packet_off(nxt) / 4, wdst, wave, lane);
-      if constexpr (L == N::kLayers - 3) xr = x_load(P, tile + 1, wave, lane);   // the next tile's input rows, two layers early
+      if (!(RCED_F16_EXP & 64)) packet_dma<G::packet_bytes(nxt)>(P.wpack + G::packet_off(nxt) / 4, wdst, wave, lane);
+      if constexpr (L == N::kLayers - 3 && !(RCED_F16_EXP & 16)) xr = x_load(P, tile + 1, wave, lane);   // the next tile's input rows, two layers early
     };
-    run_layer<N, L>(P, region, wbase + wcur * G::kWRegion, scratch, lane, hrow, pre);
+    run_layer<N, L>(P, region, wbase + wcur * G::kWRegion, lds + G::kSOff, scratch, lane, hrow, pre, stamp);
     wcur ^= 1;
     layer_end_sync();
-    run_layers<N, L + 1>(P, lds, region, scratch, wcur, xr, tile, wave, lane, hrow);
+    run_layers<N, L + 1>(P, lds, region, scratch, wcur, xr, tile, wave, lane, hrow, stamp);
   }
 }
 
@@ -338,6 +415,7 @@ __global__ __launch_bounds__(kThreads, 2) void frame16_kernel(Params P) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int e = tid; e < G::kActBytes / 16; e += kThreads) reinterpret_cast<u32x4*>(lds)[e] = u32x4{0u, 0u, 0u, 0u};
+  for (int e = tid; e < G::kShiftBytes / 4; e += kThreads) reinterpret_cast<unsigned*>(lds + G::kSOff)[e] = P.wpack[G::kShiftOff / 4 + e];
   __syncthreads();
   // a workgroup walks a CONTIGUOUS range of tiles: consecutive frames share seven of their eight input rows (L1 / L2 hits)
   const int per = (P.total_tiles + gridDim.x - 1) / gridDim.x;
@@ -348,6 +426,7 @@ __global__ __launch_bounds__(kThreads, 2) void frame16_kernel(Params P) {
   packet_dma<G::packet_bytes(0)>(P.wpack, lds + G::kWOff, wave, lane);
   int wcur = 0;
   XRows xr = x_load(P, first, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const __amdgpu_buffer_rsrc_t scratch = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(P.scratch) + ((size_t)blockIdx.x * kWaves + wave) * G::kScratchBytesPerWave, 0,
       (int)G::kScratchBytesPerWave, 0x00020000);
@@ -357,7 +436,9 @@ __global__ __launch_bounds__(kThreads, 2) void frame16_kernel(Params P) {
     const int t = (tile - utt * P.tiles_per_utt) * kWaves + wave;
     const long long hrow = t < P.T ? ((long long)utt * P.T + t) * kF * N::kFinalCh : -1;
     x_store(xr, region, lane);   // plane 0 of the wave's own image: its last reader was this wave's previous layer 1
-    run_layers<N, 0>(P, lds, region, scratch, wcur, xr, tile, wave, lane, hrow);
+    const bool stamp = RCED_F16_STAMPS && P.stamps && blockIdx.x == 0 && wave == 0 && tile == first + 1;
+    run_layers<N, 0>(P, lds, region, scratch, wcur, xr, tile, wave, lane, hrow, stamp);
+    F16_STAMP(stamp, 4 * N::kLayers);
   }
 }
 

@@ -448,7 +448,8 @@ int chain_create(rced_model* m, rced_fused* f) {
 
 // ---- bf16 variant (kernels_frame16.h) ----------------------------------------------------------
 // Packets: [K-step s][M-tile mt][lane] x 8 bf16 -- lane (kq, m): row 16 mt + m (cout), K slot j = 4 s + kq = (tap j / OCT, octet
-// j % OCT), element e = channel 8 (j % OCT) + e (first layer: OCT = 1, e = the kernel's time row) -- then 32 fp32 shifts.
+// j % OCT), element e = channel 8 (j % OCT) + e (first layer: OCT = 1, e = the kernel's time row); behind all packets 32 fp32
+// shifts per layer.
 template <class N>
 void pack_frame16(const rced_model* m, std::vector<unsigned>* wpack) {
   using G = frame16::Geo<N>;
@@ -471,7 +472,7 @@ void pack_frame16(const rced_model* m, std::vector<unsigned>* wpack) {
             }
             d16[((size_t)(s * MT + mt) * 64 + lane) * 8 + e] = bf16_rne(v);
           }
-    float* sh = reinterpret_cast<float*>(pk + (size_t)G::frags(l) * 1024);
+    float* sh = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(wpack->data()) + G::kShiftOff) + 32 * l;
     for (int c = 0; c < d.cout; ++c) sh[c] = L.host_shift[c];
   }
 }
@@ -527,6 +528,11 @@ int frame16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int 
   P.T = T;
   P.tiles_per_utt = (T + frame16::kWaves - 1) / frame16::kWaves;
   P.total_tiles = Nb * P.tiles_per_utt;
+  P.stamps = nullptr;
+#if RCED_F16_STAMPS
+  if (!f->stamps && hipMalloc(&f->stamps, 216 * sizeof(unsigned long long)) != hipSuccess) f->stamps = nullptr;
+  P.stamps = f->stamps;
+#endif
   const int wgs = f->bf16_wgs_per_cu * m->num_cus;       // LDS (<= 80 KB) allows two per CU; VGPRs decide (frame16_enable)
   const int grid = std::min(P.total_tiles, f->grid_limit > 0 ? std::min(f->grid_limit, wgs) : wgs);
   m->prof_begin(RCED_K_FUSED, st);
@@ -769,6 +775,16 @@ int fused_set_option(rced_model* m, const char* key, int value) {
 
 int fused_get_option(rced_model* m, const char* key, int* value) {
   if (!m->fused) return RCED_ERR_ARG;
+#if RCED_F16_STAMPS
+  if (!strncmp(key, "f16stamp", 8) && m->fused->stamps) {  // "f16stampNN": cycles since stamp 0 (kernels_frame16.h)
+    unsigned long long h[216];
+    if (hipMemcpy(h, m->fused->stamps, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return RCED_ERR_HIP;
+    const int i = atoi(key + 8);
+    if (i < 0 || i >= 216) return RCED_ERR_ARG;
+    *value = (int)(h[i] - h[0]);
+    return RCED_OK;
+  }
+#endif
 #if RCED_STAMPS
   if (!strncmp(key, "stamp", 5) && m->fused->stamps) {  // "stampNN": kilo-cycles, NN = wave*8 + slot
     unsigned long long h[216];
