@@ -47,6 +47,9 @@
 #error "RCED_F16_EXP builds compute wrong results: timing experiments only (-DRCED_TIMING_ONLY)"
 #endif
 
+#ifndef RCED_F16_DBGEXPOSE
+#define RCED_F16_DBGEXPOSE 0   // debugging: bit L = layer L keeps all three groups' accumulators and runs its whole epilogue behind the K loop
+#endif
 #ifndef RCED_F16_STAMPS
 #define RCED_F16_STAMPS 0   // diagnostic build: s_memtime stamps of workgroup 0 / wave 0 on its second tile (tools/stamps16.py)
 #endif
@@ -140,10 +143,10 @@ struct Geo {
     return true;
   }
   static_assert(pads_ok(), "the widest kernel's left halo fits the leading zero rows");
-  // skip scratch, per wave: per (saving layer, M-tile) four 1-KiB units -- the fragments of tiles (0,1) .. (6,7), 16 bytes per
-  // lane -- and 512 bytes for tile 8.  Only the lanes whose four channels exist are stored and loaded (k-quads 0 .. quads - 1:
-  // whole 256-byte runs), so an M-tile with 3 real channels moves a quarter of its unit.
-  static constexpr int kSkipSet = 4 * 1024 + 512;
+  // skip scratch, per wave: per (saving layer, M-tile) and group of three tiles a 1-KiB unit -- the group's first two fragments,
+  // 16 bytes per lane -- and a 512-byte one for the third.  Only the lanes whose four channels exist are stored and loaded
+  // (k-quads 0 .. quads - 1: whole 256-byte runs), so an M-tile with 3 real channels moves a quarter of its unit.
+  static constexpr int kSkipSet = 3 * (1024 + 512);
   static constexpr int skip_off(int l, int mt) {
     int u = 0;
     for (int i = 0; i < l; ++i)
@@ -237,40 +240,82 @@ __device__ __forceinline__ void x_store(const XRows& r, char* region, int lane) 
   }
 }
 
+// Skip fragments that never leave the register file: the one-M-tile encoder layers' (V2: encode_1..4, V1: encode_1..2),
+// two registers per tile, 72 / 36 in all.  The other saving layers' fragments go through the global scratch.
+#ifndef RCED_F16_RESMASK
+#define RCED_F16_RESMASK 0xffff
+#endif
+#ifndef RCED_F16_MAXRES
+#define RCED_F16_MAXRES 4
+#endif
+constexpr int kMaxRes = RCED_F16_MAXRES;
+template <class N>
+struct Res {
+  static constexpr int slot(int l) {   // register slot of saving layer l, or -1
+    if (l < 0 || !N::layer[l].saves_skip || Geo<N>::MT(l) != 1 || !((RCED_F16_RESMASK >> l) & 1)) return -1;
+    int k = 0;
+    for (int i = 0; i < l; ++i)
+      if (N::layer[i].saves_skip && Geo<N>::MT(i) == 1 && ((RCED_F16_RESMASK >> i) & 1)) ++k;
+    return k < kMaxRes ? k : -1;
+  }
+  static constexpr int count() {
+    int k = 0;
+    for (int i = 0; i < N::kLayers; ++i)
+      if (slot(i) >= 0) ++k;
+    return k;
+  }
+  u32x2 v[kMaxRes > 0 ? kMaxRes : 1][kTiles];
+};
+
 // One layer of one frame (one wave).  `w` = the layer's packet in LDS; `pre` = issued once the first operand reads are in
 // flight (the next packet's LDS-DMA, the next tile's input rows).
+//
+// The nine tiles run as THREE GROUPS of three through one software pipeline of 3 x STEPS slots (operands of slot i + 1 are read
+// while the MFMAs of slot i issue; a group's accumulators are the registers of the group before last).  The epilogue of group
+// g -- round, ReLU, LDS store, skip store: 4 VALU + 1-2 stores per fragment -- rides between the MFMAs of group g + 1, one
+// fragment per two MFMAs; only the last group's is exposed.  In place: group g + 1 reads pixels 48 (g + 1) - 6 and up, so group
+// g's first two tiles (pixels 48 g .. 48 g + 31) may be stored while it does; its third tile waits for group g + 1's last slot,
+// whose reads were issued a slot earlier (the LDS serves a wave's requests in order).
 template <class N, int L, class Pre>
 __device__ __forceinline__ void run_layer(const Params& P, char* region, const char* w, const char* shifts, __amdgpu_buffer_rsrc_t scratch, int lane,
                                           long long hrow /* first float of this frame's hand-off rows, < 0: no frame */, Pre pre,
-                                          bool stamp = false) {
+                                          Res<N>& res, bool stamp = false) {
   using G = Geo<N>;
   F16_STAMP(stamp, 4 * L + 0);
   constexpr LayerDesc D = N::layer[L];
-  constexpr int OCT = G::oct_in(L), OCTO = G::oct_out(L), MT = G::MT(L), STEPS = G::steps(L), PADL = G::pad(L);
+  constexpr int OCT = G::oct_in(L), MT = G::MT(L), STEPS = G::steps(L), PADL = G::pad(L);
   constexpr bool kLast = (L == N::kLayers - 1);
   constexpr int NB = OCT < STEPS ? OCT : STEPS;     // per-lane window bases: slot j + 4 OCT is the same octet four taps on
+  constexpr int GT = 3, NG = kTiles / GT;           // tiles per group, groups
+  constexpr int SF = D.skip_from >= 0 ? D.skip_from : 0;
+  constexpr int kResIn = D.skip_from >= 0 ? Res<N>::slot(SF) : -1;     // the skip comes out of registers
+  constexpr int kResOut = D.saves_skip ? Res<N>::slot(L) : -1;         // ... goes into registers
+  constexpr bool kSkipMem = D.skip_from >= 0 && kResIn < 0 && !(RCED_F16_EXP & 2);
+  constexpr bool kSaveMem = D.saves_skip && kResOut < 0 && !(RCED_F16_EXP & 1);
+  static_assert(STEPS >= 2 && kTiles == GT * NG, "the third tile of a group is stored in the next group's last slot");
+  constexpr int kPer = (2 * MT + STEPS - 2) / (STEPS - 1);   // fragments of the previous group per slot (slots 0 .. STEPS - 2)
+  static_assert(kPer <= (GT * MT + 1) / 2 && MT <= (GT * MT + 1) / 2, "one fragment behind every second MFMA of a slot");
   asm volatile("" : "+v"(lane));                    // no hoisting of every layer's address arithmetic out of the tile loop
   const int n = lane & 15, kq = lane >> 4;
 
-  // skip fragments of the matching encoder layer: issued now, used after the last K-step (lanes without real channels: zero)
-  u32x2 skip[D.skip_from >= 0 ? kTiles : 1][D.skip_from >= 0 ? MT : 1];
-  if constexpr (D.skip_from >= 0 && !(RCED_F16_EXP & 2)) {
-    static_assert(N::layer[D.skip_from >= 0 ? D.skip_from : 0].cout == D.cout, "skip shapes match");
+  // skip fragments of the matching encoder layer that wait in the scratch: issued now, used after their group's last K-step.
+  // A lane whose four channels do not exist gets an offset past the descriptor's range: its load returns zero, its store is
+  // dropped -- no lane mask, no branch.
+  constexpr int kOob = 0x40000000;
+  u32x2 skip[kSkipMem ? kTiles : 1][kSkipMem ? MT : 1];
+  if constexpr (kSkipMem) {
+    static_assert(N::layer[SF].cout == D.cout, "skip shapes match");
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      constexpr int SF = D.skip_from >= 0 ? D.skip_from : 0;
       const int so = G::skip_off(SF, mt);
       const bool real = kq < G::skip_quads(SF, mt);
+      const int o16 = real ? lane * 16 : kOob, o8 = real ? lane * 8 : kOob;
 #pragma unroll
-      for (int t = 0; t < kTiles; ++t) skip[t][mt] = u32x2{0u, 0u};
-      if (real) {
-#pragma unroll
-        for (int t = 0; t + 1 < kTiles; t += 2) {
-          const u32x4 q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(scratch, lane * 16, so + (t / 2) * 1024, 0));
-          skip[t][mt] = u32x2{q.x, q.y};
-          skip[t + 1][mt] = u32x2{q.z, q.w};
-        }
-        skip[kTiles - 1][mt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(scratch, lane * 8, so + 4096, 0));
+      for (int g = 0; g < NG; ++g) {
+        const u32x4 q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(scratch, o16, so + g * 1536, 0));
+        skip[GT * g][mt] = u32x2{q.x, q.y};
+        skip[GT * g + 1][mt] = u32x2{q.z, q.w};
+        skip[GT * g + 2][mt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(scratch, o8, so + g * 1536 + 1024, 0));
       }
     }
   }
@@ -285,99 +330,144 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
   int wl = lane * 16;
   asm volatile("" : "+v"(wl));
   const char* wp = w + wl;
+  f32x4 sh[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) sh[mt] = *reinterpret_cast<const f32x4*>(shifts + (32 * L + 16 * mt + 4 * kq) * 4);
+  // identity A fragment of the K = 16 instruction: A[m][4 kq + i] = (m == 4 kq + i)
+  const int dg = n - 4 * kq;
+  const u32x2 eye = {dg == 0 ? 0x3F80u : dg == 1 ? 0x3F800000u : 0u, dg == 2 ? 0x3F80u : dg == 3 ? 0x3F800000u : 0u};
 
-  f32x4 acc[kTiles][MT];
+  // ---- one fragment's epilogue (tile t, M-tile mt): the layer's output IS the rounded value.  It goes to octet 2 mt + (kq >> 1),
+  // bytes 8 (kq & 1) .. + 7 of pixel 16 t + n's row; an M-tile whose upper octet lies past the layer's last one stores it all the
+  // same (zeros: those rows of the packet are zero) -- the plane is dead, and an unconditional store is one instruction.
+  char* const out = region + (n + kRowPad) * 16 + (kq >> 1) * G::kPlane + (kq & 1) * 8;
+  int so16[MT], so8[MT];
+  if constexpr (kSaveMem) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shifts + (32 * L + 16 * mt + 4 * kq) * 4);
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) acc[t][mt] = sh;
+    for (int mt = 0; mt < MT; ++mt) {
+      const bool real = kq < G::skip_quads(L, mt);
+      so16[mt] = real ? lane * 16 : kOob;
+      so8[mt] = real ? lane * 8 : kOob;
+    }
   }
-  u32x4 a[2][MT], b[2][kTiles];
-  auto load = [&](int s, int buf) {
+  u32x2 pair[MT];                                   // a group's first tile, until its second completes the 16-byte skip store
+  auto fragment = [&](const f32x4 v, int t, int mt) {
+    const u32x2 hq = {relu2(pack2(v.x, v.y)), relu2(pack2(v.z, v.w))};
+    if constexpr (kResOut >= 0) res.v[kResOut >= 0 ? kResOut : 0][t] = hq;
+    if constexpr (!kLast) {
+      if (t < kTiles - 1) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + t * 256) = hq;
+      else if (n == 0) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + t * 256) = hq;   // tile 8: bin 128 alone, the other rows stay zero
+    } else {
+      const int f = 16 * t + n, co0 = 16 * mt + 4 * kq;
+      if (hrow >= 0 && f < kF) {
+        float* hp = P.h + hrow + (size_t)f * N::kFinalCh + co0;
+        if (co0 + 1 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp) = f32x2{__builtin_bit_cast(float, hq.x << 16), __builtin_bit_cast(float, hq.x & 0xffff0000u)};
+        if (co0 + 3 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp + 2) = f32x2{__builtin_bit_cast(float, hq.y << 16), __builtin_bit_cast(float, hq.y & 0xffff0000u)};
+      }
+    }
+    if constexpr (kSaveMem) {
+      const int g = t / GT, j = t % GT, so = G::skip_off(L, mt) + g * 1536;
+      if (j == 0) pair[mt] = hq;
+      if (j == 1) __builtin_amdgcn_raw_buffer_store_b128(u32x4{pair[mt].x, pair[mt].y, hq.x, hq.y}, scratch, so16[mt], so, 0);
+      if (j == 2) __builtin_amdgcn_raw_buffer_store_b64(hq, scratch, so8[mt], so + 1024, 0);
+      if (j > 0) store_wait_state();
+    }
+  };
+
+  constexpr bool kExpose = (RCED_F16_DBGEXPOSE >> L) & 1;
+  constexpr int AM = kExpose ? 3 : 1;               // accumulator sets: g & AM
+  f32x4 acc[kExpose ? NG : 2][GT][MT];
+  u32x4 a[2][MT], b[2][GT];
+  auto load = [&](int slot, int buf) {
+    const int g = slot / STEPS, s = slot % STEPS;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      if (!(RCED_F16_EXP & 8) || s == 0) a[buf][mt] = *reinterpret_cast<const u32x4*>(wp + (s * MT + mt) * 1024);
-      else a[buf][mt] = a[buf ^ 1][mt];
+    for (int mt = 0; mt < MT; ++mt) a[buf][mt] = *reinterpret_cast<const u32x4*>(wp + (s * MT + mt) * 1024);
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-      b[buf][t] = *reinterpret_cast<const u32x4*>(region + base[s % OCT % NB] + (s / OCT) * 64 + t * 256);
+    for (int j = 0; j < GT; ++j)
+      b[buf][j] = *reinterpret_cast<const u32x4*>(region + base[s % OCT % NB] + (s / OCT) * 64 + (GT * g + j) * 256);
   };
   load(0, 0);
   pin();
   pre();
   pin();
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    if (s + 1 < STEPS) load(s + 1, (s + 1) & 1);
-    pin();
+  for (int g = 0; g < NG; ++g) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int s = 0; s < STEPS; ++s) {
+      const int slot = g * STEPS + s, buf = slot & 1;
+      if (slot + 1 < NG * STEPS) load(slot + 1, buf ^ 1);
+      pin();
+      // this slot's share of the previous group's epilogue: tiles 0 and 1 of that group spread over slots 0 .. STEPS - 2, tile 2
+      // in the last slot
+      int q = 0;
 #pragma unroll
-      for (int t = 0; t < kTiles; ++t) acc[t][mt] = mfma32(a[s & 1][mt], b[s & 1][t], acc[t][mt]);
-    pin();
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          acc[g & AM][j][mt] = mfma32(a[buf][mt], b[buf][j], s == 0 ? sh[mt] : acc[g & AM][j][mt]);
+          if (g > 0 && (q & 1) == 0 && !kExpose) {
+            // behind every second MFMA one fragment of the previous group: pieces p = jj * MT + mm (tile jj < 2 of that group, in
+            // this order: a skip store pairs a group's first tile with its second), kPer per slot; tile 2 in the last slot
+            const int k = q / 2;
+            if (s < STEPS - 1) {
+              const int p = s * kPer + k;
+              if (k < kPer && p < 2 * MT) {
+                pin();
+                fragment(acc[(g - 1) & 1][p / MT][p % MT], GT * (g - 1) + p / MT, p % MT);
+                pin();
+              }
+            } else if (k < MT) {
+              pin();
+              fragment(acc[(g - 1) & 1][2][k], GT * (g - 1) + 2, k);
+              pin();
+            }
+          }
+          ++q;
+        }
+      pin();
+    }
+    if constexpr (D.skip_from >= 0 && !(RCED_F16_EXP & 2)) {
+      // HAZARD (found the hard way, round 6): a v_mfma_f32_16x16x16_bf16 issued DIRECTLY behind the v_mfma_f32_16x16x32_bf16
+      // that wrote its srcC -- same registers as vdst, the ordinary accumulation chain, but two opcodes of different pass
+      // counts -- read a stale accumulator on this part (one tile's skip landed on the previous K-step's sum; deterministic),
+      // and hipcc pads no wait state between them.  Left to itself the scheduler does produce that pair (it reorders these
+      // three to six MFMAs freely), so their order is pinned to the order of the last K-step's: every accumulator is two
+      // MFMAs old at least when its skip arrives.  tools/isa_lint.py scans every build for the pair.
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          pin();
+          if constexpr (kResIn >= 0) acc[g & AM][j][mt] = mfma16(eye, res.v[kResIn >= 0 ? kResIn : 0][GT * g + j], acc[g & AM][j][mt]);
+          else acc[g & AM][j][mt] = mfma16(eye, skip[kSkipMem ? GT * g + j : 0][kSkipMem ? mt : 0], acc[g & AM][j][mt]);
+        }
+      pin();
+    }
   }
-  if constexpr (D.skip_from >= 0 && !(RCED_F16_EXP & 2)) {
-    // identity A fragment of the K = 16 instruction: A[m][4 kq + i] = (m == 4 kq + i)
-    const int d = n - 4 * kq;
-    const u32x2 eye = {d == 0 ? 0x3F80u : d == 1 ? 0x3F800000u : 0u, d == 2 ? 0x3F80u : d == 3 ? 0x3F800000u : 0u};
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int t = 0; t < kTiles; ++t) acc[t][mt] = mfma16(eye, skip[t][mt], acc[t][mt]);
-  }
-  // ---- epilogue: round to bf16, ReLU, store in place (every read of this layer has been consumed by an MFMA above)
-  // The next packet's LDS-DMA (issued a whole K loop ago) and the skip loads have landed: wait for them HERE, in front of the
-  // epilogue's global stores (skip fragments, the hand-off tensor), and end the layer on a bare s_barrier -- the stores stay in
-  // flight across it instead of exposing their latency at every layer's end.  Nobody reads them before a later layer's wait
-  // at this place has retired them (a skip fragment is read two layers later at the earliest).
+  // The next packet's LDS-DMA was issued in front of every global store of this layer; the vector-memory counter retires in
+  // order, so waiting until only the stores issued since (the first two groups' skip fragments: exactly 4 per M-tile -- their
+  // masked lanes are out-of-range offsets, not skipped instructions) are outstanding means the packet has landed.  The stores
+  // themselves stay in flight across the barrier: nobody reads them before a later layer's wait at this place has retired them.
   F16_STAMP(stamp, 4 * L + 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0x0f70);                // ... and hipcc's wait-count pass knows it (vmcnt(0), nothing else)
+  if constexpr (kSaveMem && !kExpose) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * MT) : "memory");
+  else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0f70);              // ... and hipcc's wait-count pass knows it (vmcnt(0), nothing else)
+  }
   F16_STAMP(stamp, 4 * L + 2);
-  // A fragment (tile t, M-tile mt) goes to octet 2 mt + (kq >> 1), bytes 8 (kq & 1) .. + 7 of pixel 16 t + n's row.  An M-tile whose
-  // upper octet lies past the layer's last one stores it all the same (zeros: those rows of the packet are zero): the plane is
-  // dead, and an unconditional store is one instruction where a lane mask is four.
-  char* const out = region + (n + kRowPad) * 16 + (kq >> 1) * G::kPlane + (kq & 1) * 8;
-  u32x2 prev[MT];                                   // the even tile of a pair (skip stores are 16 bytes per lane), tile 8 at the end
+  if constexpr (kExpose) {
 #pragma unroll
-  for (int t = 0; t < kTiles; ++t) {
+    for (int g = 0; g + 1 < NG; ++g)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const f32x4 v = acc[t][mt];
-      const u32x2 hq = {relu2(pack2(v.x, v.y)), relu2(pack2(v.z, v.w))};
-      if constexpr (!kLast) {
-        if (t < kTiles - 1) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + t * 256) = hq;
-      } else {
-        const int f = 16 * t + n, co0 = 16 * mt + 4 * kq;
-        if (hrow >= 0 && f < kF) {
-          float* hp = P.h + hrow + (size_t)f * N::kFinalCh + co0;
-          if (co0 + 1 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp) = f32x2{__builtin_bit_cast(float, hq.x << 16), __builtin_bit_cast(float, hq.x & 0xffff0000u)};
-          if (co0 + 3 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp + 2) = f32x2{__builtin_bit_cast(float, hq.y << 16), __builtin_bit_cast(float, hq.y & 0xffff0000u)};
-        }
-      }
-      if constexpr (D.saves_skip && !(RCED_F16_EXP & 1)) {
-        if ((t & 1) && kq < G::skip_quads(L, mt)) {
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{prev[mt].x, prev[mt].y, hq.x, hq.y}, scratch, lane * 16, G::skip_off(L, mt) + (t / 2) * 1024, 0);
-          store_wait_state();
-        }
-      }
-      if ((t & 1) == 0) prev[mt] = hq;
-    }
+      for (int j = 0; j < GT; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fragment(acc[g][j][mt], GT * g + j, mt);
   }
-  // tile 8: bin 128 alone (lane n = 0) -- the other rows stay zero
+  // ---- the last group's epilogue
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    if constexpr (D.saves_skip && !(RCED_F16_EXP & 1)) {
-      if (kq < G::skip_quads(L, mt)) {
-        __builtin_amdgcn_raw_buffer_store_b64(prev[mt], scratch, lane * 8, G::skip_off(L, mt) + 4096, 0);
-        store_wait_state();
-      }
-    }
-    if constexpr (!kLast) {
-      if (n == 0) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + (kTiles - 1) * 256) = prev[mt];
-    }
-  }
+  for (int j = 0; j < GT; ++j)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) fragment(acc[(NG - 1) & AM][j][mt], GT * (NG - 1) + j, mt);
   F16_STAMP(stamp, 4 * L + 3);
 }
 
@@ -390,20 +480,20 @@ __device__ __forceinline__ void layer_end_sync() {
 
 template <class N, int L>
 __device__ __forceinline__ void run_layers(const Params& P, char* lds, char* region, __amdgpu_buffer_rsrc_t scratch, int& wcur,
-                                           XRows& xr, int tile, int wave, int lane, long long hrow, bool stamp) {
+                                           XRows& xr, Res<N>& res, int tile, int wave, int lane, long long hrow, bool stamp) {
   using G = Geo<N>;
   if constexpr (L < N::kLayers) {
     constexpr int nxt = (L + 1 < N::kLayers) ? L + 1 : 0;   // the stream wraps: the next tile's first packet
     char* const wbase = lds + G::kWOff;
     char* const wdst = wbase + (wcur ^ 1) * G::kWRegion;
     auto pre = [&] {
-      if (!(RCED_F16_EXP & 64)) packet_dma<G::packet_bytes(nxt)>(P.wpack + G::packet_off(nxt) / 4, wdst, wave, lane);
       if constexpr (L == N::kLayers - 3 && !(RCED_F16_EXP & 16)) xr = x_load(P, tile + 1, wave, lane);   // the next tile's input rows, two layers early
+      if (!(RCED_F16_EXP & 64)) packet_dma<G::packet_bytes(nxt)>(P.wpack + G::packet_off(nxt) / 4, wdst, wave, lane);   // the layer's LAST vector-memory issue in front of its stores
     };
-    run_layer<N, L>(P, region, wbase + wcur * G::kWRegion, lds + G::kSOff, scratch, lane, hrow, pre, stamp);
+    run_layer<N, L>(P, region, wbase + wcur * G::kWRegion, lds + G::kSOff, scratch, lane, hrow, pre, res, stamp);
     wcur ^= 1;
     layer_end_sync();
-    run_layers<N, L + 1>(P, lds, region, scratch, wcur, xr, tile, wave, lane, hrow, stamp);
+    run_layers<N, L + 1>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, hrow, stamp);
   }
 }
 
@@ -437,7 +527,8 @@ __global__ __launch_bounds__(kThreads, 2) void frame16_kernel(Params P) {
     const long long hrow = t < P.T ? ((long long)utt * P.T + t) * kF * N::kFinalCh : -1;
     x_store(xr, region, lane);   // plane 0 of the wave's own image: its last reader was this wave's previous layer 1
     const bool stamp = RCED_F16_STAMPS && P.stamps && blockIdx.x == 0 && wave == 0 && tile == first + 1;
-    run_layers<N, 0>(P, lds, region, scratch, wcur, xr, tile, wave, lane, hrow, stamp);
+    Res<N> res;
+    run_layers<N, 0>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, hrow, stamp);
     F16_STAMP(stamp, 4 * N::kLayers);
   }
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lint of the compiled gfx950 kernels (the shipped librced_hip.so by default) for two instruction sequences that hipcc emits without complaint and
-that misbehaved on MI355X in this project ("Things that did not pay" / the reproducibility hunt):
+that misbehaved on MI355X in this project (the reproducibility hunts of rounds 2 and 6):
 
   A. VALU writes VCC  /  vector-memory instruction  /  SALU reads VCC   (three consecutive instructions).
      Measured: `v_cmp_gt_i32 vcc` / `buffer_store_dwordx4` / `s_and_saveexec_b64 s[0:1], vcc` lost lanes of the LDS store
@@ -10,6 +10,11 @@ that misbehaved on MI355X in this project ("Things that did not pay" 
   B. An LDS-DMA with an SGPR base (`global_load_lds_* v, s[a:b]`, issued from inline asm, where hipcc pads no hazard wait
      states) fewer than 5 wait states behind a VALU instruction that wrote s[a] or s[b] (v_readlane of a spilled SGPR,
      v_readfirstlane).
+
+  C. A matrix instruction of one shape DIRECTLY behind a matrix instruction of ANOTHER shape whose destination it reads as srcC
+     (`v_mfma_f32_16x16x32_bf16 v[a:b], ...` / `v_mfma_f32_16x16x16_bf16 v[a:b], ..., v[a:b]`).  The same-shape chain is what the
+     hardware interlocks; the mixed pair read the accumulator before the first instruction's last pass had written it (round 6,
+     kernels_frame16.h: one tile's skip added to a stale sum, deterministic) and hipcc pads nothing between them.
 
 Usage: tools/isa_lint.py [object or shared-object files...]   (default: the library the package loads,
 fullycnnspeechenhancement_amd/librced_hip.so -- the code that actually runs, not objects that may be stale or absent).  Exit status 1 and a
@@ -33,6 +38,7 @@ SALU_READS_SPAIR = re.compile(r"^s_\w+\s+[^,]+,.*\bs\[(\d+):(\d+)\]")
 DMA_SBASE = re.compile(r"^global_load_lds_\w+\s+v\d+, s\[(\d+):(\d+)\]")
 VALU_WRITES_SGPR = re.compile(r"^v_(readlane|readfirstlane)_b32\s+s(\d+)\b")
 NOP = re.compile(r"^s_nop\s+(\d+)")
+MFMA = re.compile(r"^(v_mfma_\w+)\s+(v\[\d+:\d+\]|a\[\d+:\d+\]), (\S+), (\S+), (v\[\d+:\d+\]|a\[\d+:\d+\]|\S+)")
 
 
 def disassemble(obj, tmp):
@@ -77,6 +83,10 @@ def lint_function(fn, ins):
             # the SALU instruction's SOURCE operands: everything behind the first comma
             if r and ("s[%s:%s]" % w.groups()) in ins[i + 2].split(",", 1)[1]:
                 found.append(("A", fn, i, ins[i:i + 3]))
+    for i in range(len(ins) - 1):
+        m0, m1 = MFMA.match(ins[i]), MFMA.match(ins[i + 1])
+        if m0 and m1 and m0.group(1) != m1.group(1) and m1.group(5).rstrip(",") == m0.group(2):
+            found.append(("C", fn, i, ins[i:i + 2]))
     for i, s in enumerate(ins):
         m = DMA_SBASE.match(s)
         if not m:
