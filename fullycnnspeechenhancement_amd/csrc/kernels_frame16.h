@@ -79,7 +79,8 @@ constexpr int kTiles = 9;                 // 16-pixel tiles per frame
 
 struct Params {
   const float* x;            // [N, T, 129]
-  float* h;                  // [N*T, 129, kFinalCh] fp32: input of the output layer's kernel (values are bf16-exact)
+  float* y;                  // [N, T, 129]: the masks
+  float fin_bias;            // the output layer's bias
   const unsigned* wpack;     // Geo::kWBytes
   unsigned* scratch;         // gridDim.x * kWaves * Geo::kScratchBytesPerWave (skip fragments)
   int N, T;
@@ -102,18 +103,22 @@ struct Geo {
   static constexpr int slots(int l) { return N::layer[l].taps * oct_in(l); }   // K slots of 8 (layer 0: 8 time rows per tap)
   static constexpr int steps(int l) { return (slots(l) + 3) / 4; }
   static constexpr int frags(int l) { return steps(l) * MT(l); }
-  static constexpr int packet_bytes(int l) { return frags(l) * 1024; }
+  // Packet kLayers is the output layer's (1 x 129, CH -> 1): a TAP TABLE [159 rows][2 octets][8 channels] bf16, row i = tap i - 15
+  // (zero rows around taps 0 .. 128), 5,088 bytes in five pieces -- run_final reads its Toeplitz A operand straight out of it.
+  static constexpr int kFinRows = 159;
+  static constexpr int kFinPacket = 5 * 1024;
+  static constexpr int packet_bytes(int l) { return l == kLayers ? kFinPacket : frags(l) * 1024; }
   static constexpr int packet_off(int l) {
     int o = 0;
     for (int i = 0; i < l; ++i) o += packet_bytes(i);
     return o;
   }
-  static constexpr int kShiftOff = packet_off(kLayers);         // 32 fp32 shifts per layer behind the packets
+  static constexpr int kShiftOff = packet_off(kLayers + 1);     // 32 fp32 shifts per layer behind the packets
   static constexpr int kShiftBytes = kLayers * 128;
   static constexpr int kWBytes = kShiftOff + kShiftBytes;
   static constexpr int maxpacket() {
     int m = 0;
-    for (int l = 0; l < kLayers; ++l) m = packet_bytes(l) > m ? packet_bytes(l) : m;
+    for (int l = 0; l <= kLayers; ++l) m = packet_bytes(l) > m ? packet_bytes(l) : m;
     return m;
   }
   static constexpr int kWRegion = maxpacket();
@@ -143,6 +148,15 @@ struct Geo {
     return true;
   }
   static_assert(pads_ok(), "the widest kernel's left halo fits the leading zero rows");
+  // The last fused layer writes its output (<= 16 channels) for the output layer as an image H over planes 2, 3 (it reads planes
+  // 0, 1): 32-byte rows [octet 0][octet 1], bin f at row f + (f >> 4) -- a pad row per 16 bins, so that the nine 16-bin blocks a
+  // ds_read_b128 of run_final touches start 544 bytes apart (eight different bank slots) and not 512 -- and behind row 136 a zero
+  // area of 512 bytes that every out-of-range window position reads.
+  static constexpr int kHOff = 2 * kPlane;
+  static constexpr int kHRows = 137;
+  static constexpr int kZOff = kHOff + kHRows * 32;
+  static_assert(kZOff + 512 <= kRegion && oct_in(kLayers - 1) <= 2 && N::kFinalCh <= 16 && MT(kLayers - 1) == 1,
+                "H + its zero area fit planes 2, 3; the last layer reads planes 0, 1 only");
   // skip scratch, per wave: per (saving layer, M-tile) and group of three tiles a 1-KiB unit -- the group's first two fragments,
   // 16 bytes per lane -- and a 512-byte one for the third.  Only the lanes whose four channels exist are stored and loaded
   // (k-quads 0 .. quads - 1: whole 256-byte runs), so an M-tile with 3 real channels moves a quarter of its unit.
@@ -185,13 +199,16 @@ template <int BYTES>
 __device__ __forceinline__ void packet_dma(const unsigned* __restrict__ src, char* dst, int wave, int lane) {
   static_assert(BYTES % 1024 == 0, "whole pieces");
   constexpr int chunks = BYTES / 1024;
-  const unsigned d0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)dst);
+  const unsigned d0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)dst;
 #pragma unroll
   for (int i = 0; i < (chunks + kWaves - 1) / kWaves; ++i) {
     const int c = wave + i * kWaves;
     if (c < chunks) {
-      const unsigned m0v = d0 + c * 1024;
-      const unsigned* sp = src + c * 256;
+      const unsigned m0v = __builtin_amdgcn_readfirstlane(d0 + c * 1024);
+      const unsigned long long sa = (unsigned long long)(size_t)(src + c * 256);
+      // (the builtin returns a SIGNED int: widened as it stands, a low half with bit 31 set turns the pointer into 0xffffffff........)
+      const unsigned long long sp = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)sa) |
+                                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(sa >> 32)) << 32);
       unsigned saved;   // m0 is saved and restored inside the statement, so the compiler's view of it stays valid
       asm volatile(
           "s_mov_b32 %0, m0\n\t"
@@ -210,22 +227,28 @@ __device__ __forceinline__ void packet_dma(const unsigned* __restrict__ src, cha
 struct XRows {
   float v[3][8];
 };
-// Buffer loads over the utterance's [T, 129] floats: a row in front of the first or behind the last frame (TF 'SAME' for the
-// 8-tall kernel: 3 rows before, 4 after) is out of the descriptor's range and reads as zero -- no per-row predicates, one
-// scalar offset per row.  Lanes past bin 128 of the third column read the next row's bins; x_store drops them.
+// Buffer loads over the utterance's [T, 129] floats.  A row in front of the first or behind the last frame (TF 'SAME' for the
+// 8-tall kernel: 3 rows before, 4 after) is skipped by a wave-uniform branch and stays zero: offsets are never negative (a
+// "negative" offset is a huge unsigned one to the range check but, with a positive immediate folded in behind it, an address
+// 4 GB away to the address unit -- measured: memory faults).  Lanes past bin 128 of the third column read the next row's bins
+// (x_store drops them) or, on the utterance's last row, past the descriptor's range (zero).
 __device__ __forceinline__ XRows x_load(const Params& P, int tile, int wave, int lane) {
   XRows r;
   const bool live = tile < P.total_tiles;
   const int utt = live ? tile / P.tiles_per_utt : 0;
   const int t = live ? (tile - utt * P.tiles_per_utt) * kWaves + wave : 0;
   const __amdgpu_buffer_rsrc_t xu = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(P.x) + (size_t)utt * P.T * kF, 0, live ? P.T * kF * 4 : 0, 0x00020000);
+      const_cast<float*>(P.x) + (size_t)utt * P.T * kF, 0, P.T * kF * 4, 0x00020000);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int row = (t + k - 3) * (kF * 4);           // negative: wraps past the range
+    const int tt = t + k - 3;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      r.v[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xu, lane * 4 + 256 * i, row, 0));
+    for (int i = 0; i < 3; ++i) r.v[i][k] = 0.f;
+    if (live && tt >= 0 && tt < P.T) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        r.v[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xu, lane * 4 + 256 * i, tt * (kF * 4), 0));
+    }
   }
   return r;
 }
@@ -278,8 +301,7 @@ struct Res {
 // whose reads were issued a slot earlier (the LDS serves a wave's requests in order).
 template <class N, int L, class Pre>
 __device__ __forceinline__ void run_layer(const Params& P, char* region, const char* w, const char* shifts, __amdgpu_buffer_rsrc_t scratch, int lane,
-                                          long long hrow /* first float of this frame's hand-off rows, < 0: no frame */, Pre pre,
-                                          Res<N>& res, bool stamp = false) {
+                                          Pre pre, Res<N>& res, bool stamp = false) {
   using G = Geo<N>;
   F16_STAMP(stamp, 4 * L + 0);
   constexpr LayerDesc D = N::layer[L];
@@ -320,6 +342,9 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
     }
   }
 
+  if constexpr (kLast) {   // planes 2, 3 hold an earlier layer's activations: the zero area behind H is rewritten for every frame
+    if (lane < 32) *reinterpret_cast<u32x4*>(region + G::kZOff + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
   int base[NB];
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
@@ -358,12 +383,10 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
       if (t < kTiles - 1) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + t * 256) = hq;
       else if (n == 0) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + t * 256) = hq;   // tile 8: bin 128 alone, the other rows stay zero
     } else {
-      const int f = 16 * t + n, co0 = 16 * mt + 4 * kq;
-      if (hrow >= 0 && f < kF) {
-        float* hp = P.h + hrow + (size_t)f * N::kFinalCh + co0;
-        if (co0 + 1 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp) = f32x2{__builtin_bit_cast(float, hq.x << 16), __builtin_bit_cast(float, hq.x & 0xffff0000u)};
-        if (co0 + 3 < N::kFinalCh) *reinterpret_cast<f32x2*>(hp + 2) = f32x2{__builtin_bit_cast(float, hq.y << 16), __builtin_bit_cast(float, hq.y & 0xffff0000u)};
-      }
+      // the output layer's image H (Geo::kHOff): row 17 t + n, octet kq >> 1, bytes 8 (kq & 1) .. + 7
+      char* const hp = region + G::kHOff + (17 * t + n) * 32 + (kq >> 1) * 16 + (kq & 1) * 8;
+      if (t < kTiles - 1) *reinterpret_cast<u32x2*>(hp) = hq;
+      else if (n == 0) *reinterpret_cast<u32x2*>(hp) = hq;
     }
     if constexpr (kSaveMem) {
       const int g = t / GT, j = t % GT, so = G::skip_off(L, mt) + g * 1536;
@@ -471,6 +494,67 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
   F16_STAMP(stamp, 4 * L + 3);
 }
 
+// The 1 x 129 output layer (decode_5 / decode_8: CH -> 1, no BatchNorm, no ReLU; model.py:24,55) of one frame, inside the kernel:
+// a GEMM with the 16 bin phases m on the M axis, the nine 16-bin blocks n of the frame on N and K = (window position u < 144,
+// channel):  y[16 n + m] = sum_u sum_c W[u - m][c] H[16 n + u - 64][c].  Lane (kq, .) of K-step s holds slot (u = 2 s + (kq >> 1),
+// octet kq & 1): the A fragment is 16 bytes of the tap table at row u - m + 15 (out-of-range taps are its zero rows), the B
+// fragment 16 bytes of H at bin f' = 16 n + u - 64 -- for the eight steps of a block q = s / 8 one per-lane base + immediates
+// (f' >> 4 = n - 4 + q is the same for all of them), out-of-range blocks read the zero area.  72 MFMAs per frame (nine of
+// sixteen columns used) against 1,026 for the layers in front of it; no hand-off tensor in HBM, no second launch.
+template <class N, class Pre>
+__device__ __forceinline__ void run_final(const Params& P, const char* region, const char* tt, int lane, long long yrow, Pre pre) {
+  using G = Geo<N>;
+  asm volatile("" : "+v"(lane));
+  const int n = lane & 15, kq = lane >> 4;
+  int ab = ((kq >> 1) - n + 15) * 32 + (kq & 1) * 16;
+  asm volatile("" : "+v"(ab));
+  const char* ap = tt + ab;
+  f32x4 acc[2] = {f32x4{P.fin_bias, P.fin_bias, P.fin_bias, P.fin_bias}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  constexpr int SS = 6, NS = 72 / SS;               // steps per slot (12 reads in flight: the LDS counter holds 15), slots
+  u32x4 a[2][SS], b[2][SS];
+  auto load = [&](int slot, int buf) {
+#pragma unroll
+    for (int e = 0; e < SS; ++e) {
+      const int s = SS * slot + e, q = s / 8;
+      const int blk = n - 4 + q;
+      const bool ok = n <= 8 && blk >= 0 && blk <= 8;
+      const int off = (ok ? G::kHOff + 17 * blk * 32 : G::kZOff) + (kq >> 1) * 32 + (kq & 1) * 16;
+      a[buf][e] = *reinterpret_cast<const u32x4*>(ap + s * 64);
+      b[buf][e] = *reinterpret_cast<const u32x4*>(region + off + (s % 8) * 64);
+    }
+  };
+  load(0, 0);
+  pin();
+  pre();
+  pin();
+#pragma unroll
+  for (int slot = 0; slot < NS; ++slot) {
+    if (slot + 1 < NS) load(slot + 1, (slot + 1) & 1);
+    pin();
+#pragma unroll
+    for (int e = 0; e < SS; ++e) acc[e & 1] = mfma32(a[slot & 1][e], b[slot & 1][e], acc[e & 1]);
+    pin();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's first packet has landed (see run_layer); the mask stores follow
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  // H lay over planes 2 and 3, zero rows included (8 in front of the bins, 23 behind: every layer's SAME padding): put the zeros
+  // back -- 2 x 31 rows of 16 bytes (V2), one store (the LDS serves this wave's reads above first)
+  {
+    constexpr int PR = kRowPad + G::kRows - (kRowPad + kF);   // zero rows per plane
+#pragma unroll
+    for (int i = 0; i < (2 * PR + 63) / 64; ++i) {
+      const int idx = lane + 64 * i, pl = idx / PR, r = idx - pl * PR;
+      if (idx < 2 * PR) *reinterpret_cast<u32x4*>(const_cast<char*>(region) + (2 + pl) * G::kPlane + (r < kRowPad ? r : kF + r) * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  const f32x4 v = acc[0] + acc[1];
+  if (yrow >= 0) {
+    float* yp = P.y + yrow + 16 * n + 4 * kq;
+    if (n < 8) *reinterpret_cast<f32x4*>(yp) = v;
+    else if (n == 8 && kq == 0) *yp = v.x;
+  }
+}
+
 // A bare s_barrier (not __syncthreads(), whose release fence waits for every global store in flight): what the four waves hand
 // each other is the weight ring alone -- this wave's pieces of the next packet have landed (run_layer's wait in front of its
 // epilogue), and it has read the last fragment of the packet that the next layer's DMA will overwrite.
@@ -480,20 +564,21 @@ __device__ __forceinline__ void layer_end_sync() {
 
 template <class N, int L>
 __device__ __forceinline__ void run_layers(const Params& P, char* lds, char* region, __amdgpu_buffer_rsrc_t scratch, int& wcur,
-                                           XRows& xr, Res<N>& res, int tile, int wave, int lane, long long hrow, bool stamp) {
+                                           XRows& xr, Res<N>& res, int tile, int wave, int lane, long long yrow, bool stamp) {
   using G = Geo<N>;
-  if constexpr (L < N::kLayers) {
-    constexpr int nxt = (L + 1 < N::kLayers) ? L + 1 : 0;   // the stream wraps: the next tile's first packet
+  if constexpr (L <= N::kLayers) {
+    constexpr int nxt = (L + 1 <= N::kLayers) ? L + 1 : 0;   // the stream wraps: the next tile's first packet
     char* const wbase = lds + G::kWOff;
     char* const wdst = wbase + (wcur ^ 1) * G::kWRegion;
     auto pre = [&] {
-      if constexpr (L == N::kLayers - 3 && !(RCED_F16_EXP & 16)) xr = x_load(P, tile + 1, wave, lane);   // the next tile's input rows, two layers early
+      if constexpr (L == N::kLayers - 3 && !(RCED_F16_EXP & 16)) xr = x_load(P, tile + 1, wave, lane);   // the next tile's input rows, three layers early
       if (!(RCED_F16_EXP & 64)) packet_dma<G::packet_bytes(nxt)>(P.wpack + G::packet_off(nxt) / 4, wdst, wave, lane);   // the layer's LAST vector-memory issue in front of its stores
     };
-    run_layer<N, L>(P, region, wbase + wcur * G::kWRegion, lds + G::kSOff, scratch, lane, hrow, pre, res, stamp);
+    if constexpr (L < N::kLayers) run_layer<N, L>(P, region, wbase + wcur * G::kWRegion, lds + G::kSOff, scratch, lane, pre, res, stamp);
+    else run_final<N>(P, region, wbase + wcur * G::kWRegion, lane, yrow, pre);
     wcur ^= 1;
     layer_end_sync();
-    run_layers<N, L + 1>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, hrow, stamp);
+    run_layers<N, L + 1>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, yrow, stamp);
   }
 }
 
@@ -524,11 +609,11 @@ __global__ __launch_bounds__(kThreads, 2) void frame16_kernel(Params P) {
   for (int tile = first; tile < last; ++tile) {
     const int utt = tile / P.tiles_per_utt;
     const int t = (tile - utt * P.tiles_per_utt) * kWaves + wave;
-    const long long hrow = t < P.T ? ((long long)utt * P.T + t) * kF * N::kFinalCh : -1;
+    const long long yrow = t < P.T ? ((long long)utt * P.T + t) * kF : -1;
     x_store(xr, region, lane);   // plane 0 of the wave's own image: its last reader was this wave's previous layer 1
     const bool stamp = RCED_F16_STAMPS && P.stamps && blockIdx.x == 0 && wave == 0 && tile == first + 1;
     Res<N> res;
-    run_layers<N, 0>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, hrow, stamp);
+    run_layers<N, 0>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, yrow, stamp);
     F16_STAMP(stamp, 4 * N::kLayers);
   }
 }

@@ -10,7 +10,6 @@
 #include "../../include/rced.h"
 #include "kernels_fused_chain.h"
 #include "kernels_fused_v3.h"
-#include "kernels_fused_chain16.h"
 #include "kernels_frame16.h"
 #include "kernels_final_x6.h"
 #include "rced_internal.h"
@@ -41,7 +40,6 @@ struct rced_fused {
   // defaults, read when the handle is created (rced_create), never afterwards.
   int final_x6 = 1;           // option "final_x6" (default: RCED_FINAL_X6): 1 = x6::final_gemm_x6_kernel (three-part bf16 products), 0 = fp32 MFMA
   int final_lds = 1;          // option "final_lds" (default: RCED_FINAL_LDS): the fp32 kernel with (1) / without (0) LDS staging of its B operand
-  int bf16_final16 = 1;       // option "bf16_final16" (default: RCED_C16_FINAL16): bf16 mode: the output layer on the bf16 MFMA (1) or as above (0)
   int v3_l2x6 = 3;            // option "v3_l2x6": 3 = every layer at fp32 quality on the bf16 matrix pipe (the product); 2 = all but the first layer and
                               // decode_final (round 4's product); 1 = the 18 -> 30 layers only (round 4's first form); 0 = every layer on the fp32
                               // MFMA (the comparator): kernels_fused_v3.h
@@ -50,9 +48,8 @@ struct rced_fused {
   float* h = nullptr;         // [frames, 129, 8] hand-off to the final layer
   size_t h_bytes = 0;
   unsigned long long* stamps = nullptr;  // diagnostic builds (RCED_STAMPS) only
-  int bf16 = 0;               // option "bf16" (V1/V2): bf16 activations + weights (kernels_fused_chain16.h)
+  int bf16 = 0;               // option "bf16" (V1/V2): bf16 activations + weights, one launch (kernels_frame16.h)
   unsigned* wpack16 = nullptr;   // its packet stream (built when the option is first set)
-  unsigned short* fin_apack16 = nullptr;   // the output layer's Toeplitz A fragments in bf16 (chain16::final_gemm16_kernel)
   unsigned short* fin_apack_x6 = nullptr;  // ... as three bf16 parts per value: fp32 quality on the bf16 pipe (x6::final_gemm_x6_kernel)
   unsigned* scratch16 = nullptr; // its skip fragments, per wave (2 workgroups per CU x 4 waves)
   int bf16_wgs_per_cu = 1;
@@ -475,6 +472,15 @@ void pack_frame16(const rced_model* m, std::vector<unsigned>* wpack) {
     float* sh = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(wpack->data()) + G::kShiftOff) + 32 * l;
     for (int c = 0; c < d.cout; ++c) sh[c] = L.host_shift[c];
   }
+  // the output layer's tap table (frame16::run_final): row i = tap i - 15, [octet][8 channels] bf16, zero outside taps 0 .. 128
+  constexpr int CH = N::kFinalCh;
+  const rced_layer_dev& lf = m->layers[N::kLayers];
+  unsigned short* tt = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(wpack->data()) + G::packet_off(N::kLayers));
+  for (int i = 0; i < G::kFinRows; ++i)
+    for (int c = 0; c < 16; ++c) {
+      const int tap = i - 15;
+      tt[i * 16 + c] = bf16_rne((tap >= 0 && tap < 129 && c < CH) ? wq(lf, tap, c, 0, CH) : 0.f);
+    }
 }
 template <class N>
 int frame16_enable(rced_model* m, rced_fused* f) {
@@ -487,22 +493,6 @@ int frame16_enable(rced_model* m, rced_fused* f) {
   if (hipMemcpy(wdev, wpack.data(), wpack.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(wdev);
     return rced_fail(RCED_ERR_HIP, "hipMemcpy(bf16 packets)");
-  }
-  {  // output layer: the fp32 pack's values A[f, k] (pack_chain), rounded to bf16, in K-16 fragment order
-    constexpr int CH = N::kFinalCh;
-    using F16 = chain16::Final16<CH>;
-    const rced_layer_dev& lf = m->layers[N::kLayers];
-    std::vector<unsigned short> fin16(F16::kPack16, 0);
-    for (int S = 0; S < F16::kSteps; ++S)
-      for (int mt = 0; mt < F16::kMT; ++mt)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 4; ++j) {
-            const int k = 16 * S + 4 * (lane >> 4) + j, fo = 16 * mt + (lane & 15), fp = k / CH, ci = k % CH, tap = fp - fo + 64;
-            const float v = (k < F16::kK && fo < 129 && tap >= 0 && tap < 129) ? wq(lf, tap, ci, 0, CH) : 0.f;
-            fin16[((size_t)(S * F16::kMT + mt) * 64 + lane) * 4 + j] = bf16_rne(v);
-          }
-    if (!f->fin_apack16) HIP_TRY(hipMalloc(&f->fin_apack16, fin16.size() * sizeof(unsigned short)));
-    HIP_TRY(hipMemcpy(f->fin_apack16, fin16.data(), fin16.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(frame16::frame16_kernel<N>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
@@ -521,7 +511,8 @@ int frame16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int 
   using G = frame16::Geo<N>;
   frame16::Params P;
   P.x = x;
-  P.h = f->h;
+  P.y = y;
+  P.fin_bias = f->fin_bias;
   P.wpack = f->wpack16;
   P.scratch = f->scratch16;
   P.N = Nb;
@@ -535,19 +526,9 @@ int frame16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int 
 #endif
   const int wgs = f->bf16_wgs_per_cu * m->num_cus;       // LDS (<= 80 KB) allows two per CU; VGPRs decide (frame16_enable)
   const int grid = std::min(P.total_tiles, f->grid_limit > 0 ? std::min(f->grid_limit, wgs) : wgs);
-  m->prof_begin(RCED_K_FUSED, st);
+  m->prof_begin(RCED_K_FUSED, st);   // all 16 / 10 layers: the output layer is the kernel's last phase
   hipLaunchKernelGGL(frame16::frame16_kernel<N>, dim3(grid), dim3(frame16::kThreads), G::kLdsBytes, st, P);
   m->prof_end(RCED_K_FUSED, st);
-  HIP_TRY(hipGetLastError());
-  const int frames = Nb * T;
-  m->prof_begin(RCED_K_FINAL, st);
-  if (f->bf16_final16 && f->fin_apack16)
-    hipLaunchKernelGGL(chain16::final_gemm16_kernel<N::kFinalCh>, dim3((frames + chain::kFinFrames - 1) / chain::kFinFrames),
-                       dim3(chain::kFinThreads), 0, st, (const float*)f->h, (const unsigned short*)f->fin_apack16, f->fin_bias, y,
-                       frames);
-  else
-    chain_final_layer<N::kFinalCh>(f, y, frames, st);
-  m->prof_end(RCED_K_FINAL, st);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
 }
@@ -608,7 +589,6 @@ int fused_create(rced_model* m) {
   rced_fused* f = new rced_fused();
   f->final_x6 = env_default("RCED_FINAL_X6", 1) != 0;
   f->final_lds = env_default("RCED_FINAL_LDS", 1) != 0;
-  f->bf16_final16 = env_default("RCED_C16_FINAL16", 1) != 0;
   if (m->variant != RCED_V3) {
     m->fused = f;
     const int rc = m->variant == RCED_V1 ? chain_create<chain::NetV1>(m, f) : chain_create<chain::NetV2>(m, f);
@@ -651,7 +631,6 @@ void fused_destroy(rced_model* m) {
   if (f->wpack_a) (void)hipFree(f->wpack_a);
   if (f->fin_tab) (void)hipFree(f->fin_tab);
   if (f->wpack16) (void)hipFree(f->wpack16);
-  if (f->fin_apack16) (void)hipFree(f->fin_apack16);
   if (f->fin_apack_x6) (void)hipFree(f->fin_apack_x6);
   if (f->scratch16) (void)hipFree(f->scratch16);
   if (f->fin_apack) (void)hipFree(f->fin_apack);
@@ -735,12 +714,12 @@ int fused_set_option(rced_model* m, const char* key, int value) {
     m->fused->grid_limit = value;
     return RCED_OK;
   }
-  for (int i = 0; i < 3; ++i) {   // the R-CED output layer's kernel selection
-    static const char* const names[3] = {"final_x6", "final_lds", "bf16_final16"};
+  for (int i = 0; i < 2; ++i) {   // the R-CED output layer's kernel selection (fp32 mode; the bf16 mode's runs inside its kernel)
+    static const char* const names[2] = {"final_x6", "final_lds"};
     if (strcmp(key, names[i])) continue;
     if (m->variant == RCED_V3) return rced_fail(RCED_ERR_ARG, "%s selects the R-CED V1 / V2 output-layer kernel; CR-CED's runs inside its fused kernel", key);
     if (value != 0 && value != 1) return rced_fail(RCED_ERR_ARG, "%s takes 0 or 1, got %d", key, value);
-    (i == 0 ? m->fused->final_x6 : i == 1 ? m->fused->final_lds : m->fused->bf16_final16) = value;
+    (i == 0 ? m->fused->final_x6 : m->fused->final_lds) = value;
     return RCED_OK;
   }
   if (!strcmp(key, "latency_form")) {
@@ -800,15 +779,15 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
     return RCED_OK;
   }
   if (!strcmp(key, "fused_final")) {   // 1: the 1x129 output layer runs inside the fused kernel (no hand-off tensor in HBM)
-    *value = m->variant == RCED_V3;
+    *value = m->variant == RCED_V3 || m->fused->bf16;
     return RCED_OK;
   }
   if (!strcmp(key, "v3_l2x6")) {
     *value = m->variant == RCED_V3 ? m->fused->v3_l2x6 : 0;
     return RCED_OK;
   }
-  if (!strcmp(key, "final_x6") || !strcmp(key, "final_lds") || !strcmp(key, "bf16_final16")) {
-    *value = !strcmp(key, "final_x6") ? m->fused->final_x6 : !strcmp(key, "final_lds") ? m->fused->final_lds : m->fused->bf16_final16;
+  if (!strcmp(key, "final_x6") || !strcmp(key, "final_lds")) {
+    *value = !strcmp(key, "final_x6") ? m->fused->final_x6 : m->fused->final_lds;
     return RCED_OK;
   }
   if (!strcmp(key, "bf16")) {
