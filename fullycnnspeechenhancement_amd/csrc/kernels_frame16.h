@@ -47,6 +47,9 @@
 #error "RCED_F16_EXP builds compute wrong results: timing experiments only (-DRCED_TIMING_ONLY)"
 #endif
 
+#ifndef RCED_F16_AREG
+#define RCED_F16_AREG 8   // A fragments of a layer kept in registers when it has at most this many (0 = never)
+#endif
 #ifndef RCED_F16_DBGEXPOSE
 #define RCED_F16_DBGEXPOSE 0   // debugging: bit L = layer L keeps all three groups' accumulators and runs its whole epilogue behind the K loop
 #endif
@@ -400,11 +403,23 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
   constexpr bool kExpose = (RCED_F16_DBGEXPOSE >> L) & 1;
   constexpr int AM = kExpose ? 3 : 1;               // accumulator sets: g & AM
   f32x4 acc[kExpose ? NG : 2][GT][MT];
-  u32x4 a[2][MT], b[2][GT];
+  // A fragments: a layer of at most RCED_F16_AREG fragments reads them ONCE, into registers (the three groups would read them
+  // three times: the LDS is this kernel's busiest unit); a larger one reads its step's with the step's B fragments
+  constexpr bool kAReg = G::frags(L) <= RCED_F16_AREG;
+  u32x4 areg[kAReg ? STEPS : 1][kAReg ? MT : 1];
+  if constexpr (kAReg) {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) areg[s][mt] = *reinterpret_cast<const u32x4*>(wp + (s * MT + mt) * 1024);
+  }
+  u32x4 a[2][kAReg ? 1 : MT], b[2][GT];
   auto load = [&](int slot, int buf) {
     const int g = slot / STEPS, s = slot % STEPS;
+    if constexpr (!kAReg) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[buf][mt] = *reinterpret_cast<const u32x4*>(wp + (s * MT + mt) * 1024);
+      for (int mt = 0; mt < MT; ++mt) a[buf][mt] = *reinterpret_cast<const u32x4*>(wp + (s * MT + mt) * 1024);
+    }
 #pragma unroll
     for (int j = 0; j < GT; ++j)
       b[buf][j] = *reinterpret_cast<const u32x4*>(region + base[s % OCT % NB] + (s / OCT) * 64 + (GT * g + j) * 256);
@@ -427,7 +442,7 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < GT; ++j) {
-          acc[g & AM][j][mt] = mfma32(a[buf][mt], b[buf][j], s == 0 ? sh[mt] : acc[g & AM][j][mt]);
+          acc[g & AM][j][mt] = mfma32(kAReg ? areg[kAReg ? s : 0][kAReg ? mt : 0] : a[buf][kAReg ? 0 : mt], b[buf][j], s == 0 ? sh[mt] : acc[g & AM][j][mt]);
           if (g > 0 && (q & 1) == 0 && !kExpose) {
             // behind every second MFMA one fragment of the previous group: pieces p = jj * MT + mm (tile jj < 2 of that group, in
             // this order: a skip store pairs a group's first tile with its second), kPer per slot; tile 2 in the last slot
