@@ -48,7 +48,7 @@
 #endif
 
 #ifndef RCED_F16_AREG
-#define RCED_F16_AREG 8   // A fragments of a layer kept in registers when it has at most this many (0 = never)
+#define RCED_F16_AREG 18  // A fragments of a layer kept in registers when it has at most this many (0 = never)
 #endif
 #ifndef RCED_F16_DBGEXPOSE
 #define RCED_F16_DBGEXPOSE 0   // debugging: bit L = layer L keeps all three groups' accumulators and runs its whole epilogue behind the K loop
