@@ -81,10 +81,10 @@ def forward_flops_by_pipe(spec, variant, kernel, dtype="f32", v3_l2x6=3):
         on_x6 = {0: (), 1: ((18, 30),), 2: ((18, 30), (30, 8), (8, 18))}[form]
         x6 = sum(f for f, l in zip(fl, spec.layers(3)) if (l.cin, l.cout) in on_x6)
         return {"mfma_f32": sum(fl) - x6, "mfma_bf16x6": x6}
-    if kernel == "rced_final_gemm":             # R-CED's 1x129 output layer: x6::final_gemm_x6_kernel / chain16::final_gemm16_kernel
-        return {"mfma_bf16" if dtype == "bf16" else "mfma_bf16x6": fl[-1]}
-    if dtype == "bf16":                         # fused_chain16: the first layer (8 x k on the fp32 input) stays on the fp32 MFMA
-        return {"mfma_f32": fl[0], "mfma_bf16": sum(fl[1:-1])}
+    if dtype == "bf16":                         # frame16_kernel: ONE launch, every layer (first and output layers included) on the plain bf16 MFMA
+        return {"mfma_bf16": sum(fl)} if kernel == "rced_fused" else {}
+    if kernel == "rced_final_gemm":             # R-CED's 1x129 output layer (fp32 mode): x6::final_gemm_x6_kernel
+        return {"mfma_bf16x6": fl[-1]}
     return {"mfma_f32": sum(fl[:-1])}
 
 
@@ -397,9 +397,8 @@ def secondary_config2(torch, build_model, spec, _lib, _weights, local_rank):
            "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "bf16",
            "tflops": flops / (ms * 1e-3) / 1e12,
            "roofline": dict(pr, frac_bf16_peak=flops / (ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
-                            note="whole forward (nominal dense FLOPs) over wall time per step, priced on the pipes it runs on: the "
-                                 "first layer (8 x 11 on the fp32 input) on the fp32 MFMA, the rest on the plain bf16 MFMA; "
-                                 "frac_bf16_peak = every FLOP against the dense bf16 peak"),
+                            note="whole forward (nominal dense FLOPs) over wall time per step; one kernel, every layer on the plain bf16 "
+                                 "MFMA (the input is cast to bf16, SURVEY 8 d2), so frac = frac_bf16_peak = TFLOP/s / 2500"),
            "kernels": {k: dict(pipe_roofline({p: f * B * T * steps for p, f in forward_flops_by_pipe(spec, 2, k, "bf16").items()}, v[0] * 1e-3),
                                avg_launch_ms=v[0] / v[1], launches=v[1]) for k, v in times.items() if v[1]},
            "kernels_ms_per_step": {k: v[0] / steps for k, v in times.items() if v[1]}, "dominant_kernel": dom}
@@ -708,7 +707,7 @@ def main():
             if launches:
                 # FLOPs the dominant kernel kind performs per forward (nominal dense count)
                 final = 2 * spec.FEATURE_DIM * sum(l.kh * l.kw * l.cin * l.cout for l in spec.layers(variant)[-1:])
-                fused_all = bool(model.get_option("fused_final")) if variant == 3 else False
+                fused_all = bool(model.get_option("fused_final"))     # the output layer runs inside the fused kernel (CR-CED; R-CED in bf16)
                 if dom == "conv_layer_generic" or (dom == "rced_fused" and fused_all):
                     kflops = flops_frame
                 else:

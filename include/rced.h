@@ -103,9 +103,9 @@ int rced_reserve(rced_model* m, int N, int T);
  *                 layers only; 0 = every layer on the fp32 MFMA (bit-for-bit an fp32 fmaf chain; the in-build comparator: the forms
  *                 agree to ~1e-6 of the largest output).  All four kernels are in the library; a form's weight stream is built when it
  *                 is first selected.
- *   "final_x6", "final_lds", "bf16_final16"   R-CED V1 / V2 only: the 1x129 output layer's kernel -- three-part bf16 products (1,
- *                 default) or the fp32 MFMA (0), the latter with (1) / without (0) LDS staging of its B operand; in "bf16" mode the
- *                 bf16 MFMA (1) or the kernel the first two select (0)
+ *   "final_x6", "final_lds"   R-CED V1 / V2 only, fp32 mode: the 1x129 output layer's kernel -- three-part bf16 products (1,
+ *                 default) or the fp32 MFMA (0), the latter with (1) / without (0) LDS staging of its B operand.  (In "bf16" mode the
+ *                 output layer runs inside the one fused kernel.)
  *   "latency_form"  R-CED V1 / V2 only (fp32 kernel): 1 (default) = a call with fewer 3-frame tiles than the part has CUs (BASELINE
  *                 config 1: one utterance of 256 frames) runs on ONE-frame tiles -- three times the workgroups, a third of the work
  *                 each, bit-identical results; 0 = always 3-frame tiles
@@ -113,7 +113,7 @@ int rced_reserve(rced_model* m, int N, int T);
  *                 time-out (0 clears it) -- a test hook for rced_check / RCED_ERR_STATE handling
  *   "has_fused", "num_cus", "fused_final"  get only ("fused_final": the 1x129 output layer runs inside the fused kernel)
  * Options are PER HANDLE.  Environment variables only supply DEFAULTS, read once when a handle is created (rced_create /
- * rced_train_create) and never afterwards: RCED_V3_L2X6, RCED_FINAL_X6, RCED_FINAL_LDS, RCED_C16_FINAL16 (the options of the
+ * rced_train_create) and never afterwards: RCED_V3_L2X6, RCED_FINAL_X6, RCED_FINAL_LDS (the options of the
  * same meaning above); for rced_train_create RCED_TRAIN_MFMA=0 (direct-conv kernels only), RCED_TRAIN_FUSE_ACT=0,
  * RCED_TRAIN_FUSE_DZ=0 (materialise activations / dz), RCED_TRAIN_FUSE_SUMS, RCED_TRAIN_FUSE_BWD, RCED_TRAIN_DET, RCED_TRAIN_X6. */
 int rced_set_option(rced_model* m, const char* key, int value);

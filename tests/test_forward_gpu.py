@@ -14,8 +14,15 @@ from oracle import layers as L, rced_c, rced_np
 pytestmark = pytest.mark.gpu
 
 PATHS = ["layerwise", "auto"]
-# bf16 (opt-in, BASELINE config 2): bounds at about twice the measured error, relative to the largest output
-BF16_VS_EMULATION, BF16_VS_FP32 = 5e-3, 1.5e-2
+# bf16 (opt-in, BASELINE config 2): bounds at about twice the measured error, relative to the largest output.  Against the emulation the
+# LARGEST element error is one bf16 ulp of a mid-size activation that a differently ordered fp32 sum rounds the other way (measured
+# 1.1e-3 .. 4.3e-3 over the nets and shapes below: single elements); the ROOT-MEAN-SQUARE error is what a systematic fault moves first
+# (measured 1e-4 .. 2.3e-4; round 6's stale-accumulator hazard: 6e-2 largest, 1.1e-2 rms), so both are bounded.
+BF16_VS_EMULATION, BF16_RMS_VS_EMULATION, BF16_VS_FP32 = 1e-2, 1e-3, 1.5e-2
+
+
+def rms_err(y, ref):
+    return float(np.sqrt(np.mean((np.asarray(y, np.float64) - np.asarray(ref, np.float64)) ** 2)) / np.abs(ref).max())
 
 
 def make_model(variant, w, path="auto"):
@@ -115,12 +122,13 @@ def test_pipelined_host_path_equals_resident_path(chunks, built):
 
 @pytest.mark.parametrize("net_work,tag,variant", [n for n in NETS if n[2] in (1, 2)])
 def test_bf16_variant_matches_its_emulation(net_work, tag, variant, built, capsys):
-    """BASELINE config 2 names bf16 for R-CED V2: kernels_fused_chain16.h keeps activations and inner-layer weights
-    in bf16 (fp32 accumulation).  Checked against oracle.rced_np.forward_bf16, which rounds at the same places.
-    Bounds = 2x what is measured (printed), relative to the largest output: 5e-3 against the emulation -- fp32
+    """BASELINE config 2 names bf16 for R-CED V2: kernels_frame16.h keeps the input, every activation and every kernel
+    in bf16 (fp32 accumulation), all layers in one launch.  Checked against oracle.rced_np.forward_bf16, which rounds at the
+    same places.  Bounds = 2x what is measured (printed), relative to the largest output: against the emulation -- fp32
     accumulation order differs, and a sum that lands on the other side of a bf16 rounding boundary moves that
-    activation by one bf16 ulp (2^-8); measured 2-3e-3 -- and 1.5e-2 against the fp32 oracle, which is what 15 layers
-    of 8-bit mantissas cost (measured 6-7e-3).  NOT within the 1e-4 bar of the fp32 path, which remains the default."""
+    activation by one bf16 ulp (2^-8) -- largest element 1e-2 (measured 1.1e-3 / 4.3e-3), rms 1e-3 (measured 9.5e-5 / 2.3e-4);
+    and 1.5e-2 against the fp32 oracle, which is what 16 layers of 8-bit mantissas cost (measured 6.5e-3 / 9.1e-3).  NOT
+    within the 1e-4 bar of the fp32 path, which remains the default."""
     from fullycnnspeechenhancement_amd import build_model
     w, g = load_golden(tag)
     x = rced_np.make_input(3, 20, seed=5)            # 20 frames: full tiles + a ragged one (3 frames per tile)
@@ -129,16 +137,42 @@ def test_bf16_variant_matches_its_emulation(net_work, tag, variant, built, capsy
     y = m(x)
     ref16 = rced_np.forward_bf16(net_work, w, x)
     ref32 = rced_np.forward(net_work, w, x)
-    e16, e32 = rel_err(y, ref16), rel_err(y, ref32)
+    e16, r16, e32 = rel_err(y, ref16), rms_err(y, ref16), rel_err(y, ref32)
     with capsys.disabled():
-        print("\n[bf16 %s] vs bf16 emulation %.2e, vs fp32 oracle %.2e (of the largest output)" % (net_work, e16, e32))
-    assert e16 < BF16_VS_EMULATION
+        print("\n[bf16 %s] vs bf16 emulation %.2e (rms %.2e), vs fp32 oracle %.2e (of the largest output)" % (net_work, e16, r16, e32))
+    assert e16 < BF16_VS_EMULATION and r16 < BF16_RMS_VS_EMULATION
     assert e32 < BF16_VS_FP32
     assert np.array_equal(m(x), y)                   # deterministic
     m.restore(w)                                     # restore() keeps the options set before it (bf16 stays on)
     assert m.get_option("bf16") == 1 and np.array_equal(m(x), y)
     m.set_option("bf16", 0)                          # and back: the fp32 kernel is untouched
     check_parity(m(x), ref32)
+
+
+@pytest.mark.parametrize("net_work,tag,variant", [n for n in NETS if n[2] in (1, 2)])
+def test_bf16_ragged_batches_and_tile_maps(net_work, tag, variant, built, capsys):
+    """The bf16 kernel gives a wave a frame and a workgroup four consecutive frames of one utterance: utterances whose length is no
+    multiple of four (the last tile's idle waves), shorter than the first kernel is tall, and workgroups that walk SEVERAL tiles
+    (option fused_grid: the state a tile leaves in LDS -- the output layer's image lies over two activation planes' zero rows --
+    and in the weight ring) against the emulation, and bit-identical whatever the grid."""
+    from fullycnnspeechenhancement_amd import build_model
+    w = rced_np.make_weights(net_work, seed=77 + variant)
+    m = build_model(net_work, False, weights=w, dtype="bfloat16")
+    worst = 0.0
+    for n, t in ((1, 1), (1, 3), (2, 5), (3, 37), (1, 64)):
+        x = rced_np.make_input(n, t, seed=31 * n + t)
+        ref16 = rced_np.forward_bf16(net_work, w, x)
+        m.set_option("fused_grid", 0)
+        y = m(x)
+        assert np.isfinite(y).all()
+        e16, r16 = rel_err(y, ref16), rms_err(y, ref16)
+        worst = max(worst, e16)
+        assert e16 < BF16_VS_EMULATION and r16 < BF16_RMS_VS_EMULATION, (n, t, e16, r16)
+        for grid in (1, 2, 5):
+            m.set_option("fused_grid", grid)
+            assert np.array_equal(m(x), y), (n, t, grid)
+    with capsys.disabled():
+        print("\n[bf16 %s ragged] worst vs bf16 emulation %.2e" % (net_work, worst))
 
 
 def test_full_size_config2_bf16_sampled_against_its_emulation(built, capsys):
