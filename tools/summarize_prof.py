@@ -13,7 +13,7 @@ def find(d, pat):
 
 
 def short(name):
-    for key in ("fused_v3_kernel", "final_gemm_kernel", "conv_layer_generic", "fused_v1", "fused_v2"):
+    for key in ("fused_v3_kernel", "final_gemm_kernel", "conv_layer_generic", "fused_v1", "fused_v2", "frame16_kernel"):
         if key in name:
             return key
     return name[:60]
@@ -106,7 +106,7 @@ def main(out):
         per = defaultdict(list)
         for r in rows:
             n = r.get("Kernel_Name", "")
-            if any(s in n for s in ("fused", "final", "conv_layer")):
+            if any(s in n for s in ("fused", "final", "conv_layer", "frame16")):
                 per[n].append(r)
         print("\n## dispatches (kernel_trace.csv): steady state = without each kernel's first %d dispatches" % WARMUP_DISPATCHES)
         for n, rs in per.items():
@@ -135,7 +135,7 @@ def main(out):
             with open(f) as fh:
                 for r in csv.DictReader(fh):
                     k = (short(r.get("Kernel_Name", "")), r.get("Counter_Name"))
-                    if any(s in k[0] for s in ("fused", "final", "conv_layer")):
+                    if any(s in k[0] for s in ("fused", "final", "conv_layer", "frame16")):
                         acc[k][0] += float(r.get("Counter_Value", 0) or 0)
                         acc[k][1] += 1
         for (k, c), (tot, n) in sorted(acc.items()):
@@ -154,6 +154,16 @@ def main(out):
                 line += "  other_valu_per_mfma=%.2f" % ((valu - mf) / mf)
             if busy and gui:
                 line += "  mfma_pipe_busy=%.1f %% (BUSY_CYCLES / (1024 SIMDs x GUI_ACTIVE / 8))" % (100.0 * busy / (1024.0 * gui / 8.0))
+            print(line)
+        elif mf and busy and gui:   # any other matrix kernel: VALU mix, pipe occupancy, LDS occupancy
+            lds, conf = pmc.get((k, "SQ_LDS_IDX_ACTIVE")), pmc.get((k, "SQ_LDS_BANK_CONFLICT"))
+            line = "%-22s derived: mfma_issued=%.4g" % (k, mf)
+            if valu:
+                line += "  other_valu_per_mfma=%.2f" % ((valu - mf) / mf)
+            line += "  mfma_pipe_busy=%.1f %%" % (100.0 * busy / (1024.0 * gui / 8.0))
+            if lds:
+                line += "  lds_active=%.1f %% of CU-cycles (IDX_ACTIVE / (256 CUs x GUI_ACTIVE / 8)), %.0f %% of it bank conflicts" % (
+                    100.0 * lds / (256.0 * gui / 8.0), 100.0 * (conf or 0) / lds)
             print(line)
 
 
