@@ -81,20 +81,28 @@ inline int resident_grid(const void* kernel, size_t lds, int cus, int& occ_cache
   return cus * occ_cache;
 }
 
-inline int tm_packet_parities(int cout) { return cout == 8 ? 2 : 1; }   // Geo::kPH
-inline size_t tm_packet_floats(int cin, int taps, int cout) {     // Geo::kPacket
-  const int ph = tm_packet_parities(cout), R = ph == 1 ? tmm::tm_rem(cout) : 0, P = R ? 16 / R : 0;
-  const int cinp = (cin + 1) & ~1, K = (taps + ph - 1) * cinp, MT = R ? 1 : (cout + 15) / 16;
+constexpr int tm_packet_parities(int cout) { return cout == 8 ? 2 : 1; }   // Geo::kPH
+constexpr size_t tm_packet_floats(int cin, int taps, int cout) {     // Geo::kPacket (static_asserts below)
+  const int cinp = (cin + 1) & ~1;
+  const int ph = tm_packet_parities(cout), R = ph == 1 ? tmm::tm_rem(cout) : 0, P = tmm::tm_rem_p(R, cinp);   // as Geo::kP
+  const int K = (taps + ph - 1) * cinp, MT = R ? 1 : (cout + 15) / 16;
   const int KR = R ? (taps + P - 1) * cinp : 0;
   return (size_t)(K / 8) * MT * 128 + (size_t)((K % 8 + 3) / 4) * MT * 64 + (R ? (size_t)(KR / 8) * 128 + (size_t)((KR % 8 + 3) / 4) * 64 : 0) + 32;
 }
 
 // ---- the forward convolutions in the three-part bf16 form (tmm::conv_x6_fwd) ----
-inline size_t tm_packet_x6_floats(int cin, int taps, int cout) {   // tmm::GeoX6::kPacket
+constexpr size_t tm_packet_x6_floats(int cin, int taps, int cout) {   // tmm::GeoX6::kPacket (static_assert below)
   const int ph = tm_packet_parities(cout), cs = tmm::x6_cs(cin, ph), K = (taps + ph - 1) * cs;
-  const int R = ph == 1 ? tmm::tm_rem(cout) : 0, P = R ? 16 / R : 0, KR = R ? (taps + P - 1) * cs : 0;
+  const int R = ph == 1 ? tmm::tm_rem(cout) : 0, P = tmm::tm_rem_p(R, (cin + 1) & ~1), KR = R ? (taps + P - 1) * cs : 0;   // as GeoX6 / pack_packet_x6
   return (size_t)(((K + 31) / 32) * (R ? 1 : (cout + 15) / 16) + (KR + 31) / 32) * 3 * 64 * 4 + 32;
 }
+// the host-side sizes are the kernels' own for every shape the three nets' training steps launch
+static_assert(tm_packet_floats(8, 9, 18) == (size_t)tmm::Geo<8, 9, 18>::kPacket && tm_packet_floats(18, 5, 30) == (size_t)tmm::Geo<18, 5, 30>::kPacket &&
+              tm_packet_floats(30, 9, 8) == (size_t)tmm::Geo<30, 9, 8>::kPacket && tm_packet_floats(18, 9, 8) == (size_t)tmm::Geo<18, 9, 8>::kPacket &&
+              tm_packet_floats(30, 5, 18) == (size_t)tmm::Geo<30, 5, 18>::kPacket && tm_packet_floats(8, 9, 30) == (size_t)tmm::Geo<8, 9, 30>::kPacket,
+              "tm_packet_floats == Geo::kPacket");
+static_assert(tm_packet_x6_floats(18, 5, 30) == (size_t)tmm::GeoX6<18, 5, 30>::kPacket && tm_packet_x6_floats(8, 9, 30) == (size_t)tmm::GeoX6<8, 9, 30>::kPacket,
+              "tm_packet_x6_floats == GeoX6::kPacket");
 inline int tm_packet_x6_threads(int cin, int taps, int cout) {     // pack_packet_x6: one thread per (step, M-tile, lane, element) + 32 shifts
   return (int)((tm_packet_x6_floats(cin, taps, cout) - 32) / (3 * 4) * 8) + 32;
 }

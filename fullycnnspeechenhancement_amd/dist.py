@@ -35,8 +35,9 @@ and output tensors (CUDA IPC memory handles, pickled by torch.multiprocessing's 
 group; under gloo with CPU tensors: shared-memory files, the same code) and every peer PULLS its chunks out of the root's
 input and PUSHES its results into the root's output with plain device-to-device copies -- hipMemcpyAsync between peers, which
 the runtime puts on the SDMA engines -- on two side streams, pipelined pull c+1 || compute c || push c-1 like the RCCL form.
-The copies need no CU, so the persistent forward grids keep every CU (no `reserved_cus`).  Opened handles are cached by torch per
-storage: a caller that reuses its input tensor (and this object's output buffer, kept per shape) pays the open once.
+The copies need no CU, so the persistent forward grids keep every CU (no `reserved_cus`).  A handle is made once per storage on the
+root and opened once per peer (both sides cache it until close()): a caller that reuses its input tensor pays neither again; the
+root's output is one of two buffers kept per shape, used alternately.
 bench.py's from_root leg times both transports; tests hold them bit-equal (gloo world 2..4 on CPU; two processes sharing one GPU
 through IPC handles on the GPU box).
 
@@ -138,11 +139,15 @@ class _ShmTensor(object):
     def close(self):
         self.tensor = None
         try:
-            self.shm.close()
-            if self.owner:
-                self.shm.unlink()
+            self.shm.close()         # raises BufferError while a caller still holds a view of the block ...
         except Exception:
             pass
+        finally:
+            if self.owner:           # ... the name goes away all the same: the memory is freed with its last mapping
+                try:
+                    self.shm.unlink()
+                except Exception:
+                    pass
 
 
 class BatchShardedForward(object):
@@ -168,7 +173,9 @@ class BatchShardedForward(object):
         self._poisoned = None        # set by a transfer time-out: see TransferTimeout
         self._pending = []           # works / buffers of a timed-out call, kept alive until close()
         self._out_cache = {}         # transport "copy": the root's output buffer (CPU: also its shared input copy) per (shape, dtype)
-        self._opened = {}            # transport "copy" on CPU: shared-memory blocks of the root this peer has mapped, by name
+        self._opened = {}            # transport "copy": what this peer has mapped of the root's memory -- CPU: shared-memory blocks by
+                                     # name; CUDA: tensors over opened IPC handles, by the handle's bytes -- kept until close()
+        self._shared = {}            # transport "copy" on CUDA, root: IPC handle blobs already made, per storage (_shared_blob)
         self._streams = None         # transport "copy" on CUDA: (pull stream, push stream)
         if (scatter_group is None) != (gather_group is None):
             raise ValueError("pass both scatter_group and gather_group, or neither")
@@ -223,10 +230,10 @@ class BatchShardedForward(object):
         on every rank).  Groups handed in by the caller are the caller's."""
         groups, self._own_groups = self._own_groups, []
         for v in list(self._out_cache.values()) + list(self._opened.values()):
-            for o in (v if isinstance(v, tuple) else (v,)):
+            for o in (v[0] if isinstance(v, list) else (v,)):
                 if isinstance(o, _ShmTensor):
                     o.close()
-        self._pending, self._out_cache, self._opened = [], {}, {}
+        self._pending, self._out_cache, self._opened, self._shared = [], {}, {}, {}
         for g in groups:
             try:
                 dist.destroy_process_group(g)
@@ -245,16 +252,25 @@ class BatchShardedForward(object):
                 w.wait()
 
     def _finish(self, err):
-        """End of a forward_from_root call on every rank: one status all-reduce (MAX over 1 + failing rank), then raise
-        where something failed."""
+        """End of a forward_from_root call on every rank: one status all-reduce (MAX over [1 + failing rank, 1 + rank whose
+        transfer timed out]), then raise where something failed.  A time-out ANYWHERE poisons the object on EVERY rank: the
+        direction groups may hold pending transfers on ranks whose own waits all completed, and a rank that went on would
+        sit in the next call's broadcast while the poisoned root refuses to enter it."""
+        mine = self._poisoned is not None
         if self.world > 1:
-            flag = torch.tensor([0 if err is None else self.rank + 1], dtype=torch.int32, device=self._ctl_device)
+            flag = torch.tensor([0 if err is None else self.rank + 1, self.rank + 1 if mine else 0], dtype=torch.int32,
+                                device=self._ctl_device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-            bad = int(flag.item())
+            bad, timed = int(flag[0].item()), int(flag[1].item())
         else:
-            bad = 0 if err is None else self.rank + 1
+            bad, timed = (0 if err is None else self.rank + 1), (self.rank + 1 if mine else 0)
+        if timed and self._poisoned is None:
+            self._poisoned = "a transfer of rank %d timed out" % (timed - 1)
         if err is not None:
             raise err
+        if timed:
+            raise TransferTimeout("forward_from_root: a transfer of rank %d timed out; the gathered result is incomplete and this "
+                                  "object refuses further calls -- close() it and build a new one" % (timed - 1))
         if bad:
             raise PeerForwardError("forward_from_root: the forward of rank %d raised; the gathered result is incomplete"
                                    % (bad - 1))
@@ -267,6 +283,10 @@ class BatchShardedForward(object):
     def forward_from_root(self, x_root, root=0, chunks=1, direction="both"):
         """x_root: [N, T, 129, 1] on `root` (ignored elsewhere).  Returns [N, T, 129, 1] on root, None
         on the other ranks.  `root` is a rank of `group`.  chunks > 1 pipelines each peer's slice.
+        transport="rccl" returns a fresh tensor per call.  transport="copy" returns one of TWO output buffers this object keeps
+        per shape, alternately (the peers write into memory they have mapped): the result of call k is overwritten by call
+        k + 2 -- copy it if it must live longer.  `timeout_s` has no effect with transport="copy" (its waits are stream
+        waits on plain copies; a peer that dies is seen by the status all-reduce's own process-group time-out).
         direction (measurement only): "scatter" = the peers receive their slices and nothing else happens, "gather" =
         the peers send zero-filled results of the right shape and nothing else happens -- the compute-free transfer
         times bench.py reports next to the pipelined figure; the returned tensor is then meaningless."""
@@ -399,6 +419,19 @@ class BatchShardedForward(object):
         self._pending.extend(keep)
 
     # -- transport "copy": the peers pull / push through handles to the root's tensors ---------------------------
+    def _shared_blob(self, t):
+        """The IPC handle of a device tensor, made ONCE per storage: every `_share_cuda_()` allocates a reference-counter slot
+        and an interprocess event that live as long as the storage does, so a serving loop that shared its tensors per call
+        would grow without bound.  The cache holds the tensor too (a handle must not outlive its memory)."""
+        st = t.untyped_storage()
+        key = (st.data_ptr(), st.nbytes(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype)
+        hit = self._shared.get(key)
+        if hit is None:
+            if len(self._shared) >= 8:      # a caller that hands a fresh input tensor every call: forget the oldest
+                self._shared.pop(next(iter(self._shared)))
+            hit = self._shared[key] = (_share(t), t)
+        return hit[0]
+
     def _from_root_copy(self, x_root, root, chunks, direction):
         cuda = self.device.type == "cuda"
         meta, bad_input = [None], None
@@ -412,24 +445,32 @@ class BatchShardedForward(object):
                 try:
                     x_root = x_root.contiguous()
                     key = (tuple(x_root.shape), x_root.dtype)
+                    bounds_r = shard_bounds(x_root.shape[0], self.world)
+                    peers = any(b > a for r, (a, b) in enumerate(bounds_r) if r != root)   # does any peer hold a shard?
                     if cuda:
-                        y = self._out_cache.get(key)
-                        if y is None:
-                            y = torch.empty_like(x_root)
-                            self._out_cache = {key: y}
+                        slot = self._out_cache.get(key)
+                        if slot is None:        # two output buffers per shape, used alternately (forward_from_root's docstring)
+                            slot = [[torch.empty_like(x_root), torch.empty_like(x_root)], 0]
+                            self._out_cache = {key: slot}
+                        y = slot[0][slot[1]]
+                        slot[1] ^= 1
                         torch.cuda.current_stream().synchronize()    # the input is complete before a peer reads it
-                        meta = [(tuple(x_root.shape), str(x_root.dtype), _share(x_root), _share(y))]
+                        meta = [(tuple(x_root.shape), str(x_root.dtype), self._shared_blob(x_root) if peers else None,
+                                 self._shared_blob(y) if peers else None)]
                     else:                                            # CPU / gloo: named shared-memory blocks; the input is copied in
-                        pair = self._out_cache.get(key)
-                        if pair is None:
+                        slot = self._out_cache.get(key)
+                        if slot is None:
                             for v in self._out_cache.values():
-                                v[0].close()
-                                v[1].close()
-                            pair = (_ShmTensor(x_root.shape, x_root.dtype), _ShmTensor(x_root.shape, x_root.dtype))
-                            self._out_cache = {key: pair}
-                        pair[0].tensor.copy_(x_root)
-                        x_root, y = pair[0].tensor, pair[1].tensor
-                        meta = [(tuple(x_root.shape), str(x_root.dtype), pair[0].handle, pair[1].handle)]
+                                for o in v[0]:
+                                    o.close()
+                            slot = [[_ShmTensor(x_root.shape, x_root.dtype), _ShmTensor(x_root.shape, x_root.dtype),
+                                     _ShmTensor(x_root.shape, x_root.dtype)], 0]    # the input's copy and two outputs
+                            self._out_cache = {key: slot}
+                        xin, yout = slot[0][0], slot[0][1 + slot[1]]
+                        slot[1] ^= 1
+                        xin.tensor.copy_(x_root)
+                        x_root, y = xin.tensor, yout.tensor
+                        meta = [(tuple(x_root.shape), str(x_root.dtype), xin.handle, yout.handle)]
                 except Exception as e:
                     bad_input = "cannot share the root's tensors: %s: %s" % (type(e).__name__, e)
                     meta = [("error", bad_input)]
@@ -464,71 +505,80 @@ class BatchShardedForward(object):
         if not pieces:
             self._finish(None)
             return None
-        try:                           # views of the root's memory
-            if cuda:
-                xv, yv = _open_shared(xb), _open_shared(yb)   # (opened IPC handles are cached by torch per storage)
+        # Everything this peer does between here and the status all-reduce is inside ONE try: an allocation that fails, a
+        # mapping or a peer copy that raises, must still reach _finish -- the root and the other peers are waiting in it.
+        try:
+            if cuda:                   # views of the root's memory: an opened handle is kept, keyed by its bytes, until close()
+                views = []
+                for blob in (xb, yb):
+                    v = self._opened.get(blob)
+                    if v is None:
+                        if len(self._opened) >= 16:
+                            self._opened.pop(next(iter(self._opened)))
+                        v = self._opened[blob] = _open_shared(blob)
+                    views.append(v)
+                xv, yv = views
             else:
                 for h in (xb, yb):
                     if h[1] not in self._opened:
                         self._opened[h[1]] = _ShmTensor(handle=h)
                 xv, yv = self._opened[xb[1]].tensor, self._opened[yb[1]].tensor
+            dtype = xv.dtype
+            t = shape[1]
+            alloc = torch.empty if do_scatter else torch.zeros
+            bufs = [alloc((b - a, t) + tuple(shape[2:]), dtype=dtype, device=self.device) for a, b in pieces]
+            if cuda:
+                if self._streams is None:
+                    self._streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+                pull_s, push_s = self._streams
+                cur = torch.cuda.current_stream()
+                pull_s.wait_stream(cur)
+                push_s.wait_stream(cur)
+                pulled = []
+                if do_scatter:
+                    for (a, b), buf in zip(pieces, bufs):     # every pull is queued up front: chunk c+1 lands while chunk c computes
+                        with torch.cuda.stream(pull_s):
+                            buf.copy_(xv[a:b], non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record(pull_s)
+                        pulled.append(ev)
+            outs = []
+            for c, ((a, b), buf) in enumerate(zip(pieces, bufs)):
+                if do_scatter:
+                    if cuda:
+                        cur.wait_event(pulled[c])
+                    else:
+                        buf.copy_(xv[a:b])
+                self._note("recv", c)
+                out = buf
+                if do_compute:
+                    if err is None:
+                        try:
+                            out = self.forward(buf).contiguous()
+                            if out.shape != buf.shape or out.dtype != buf.dtype:
+                                raise ValueError("forward returned %s %s for an input of %s %s"
+                                                 % (tuple(out.shape), out.dtype, tuple(buf.shape), buf.dtype))
+                        except Exception as e:
+                            err = e
+                    if err is not None:
+                        out = torch.zeros_like(buf)
+                    self._note("fwd", c)
+                if do_gather:
+                    outs.append(out)
+                    if cuda:
+                        done = torch.cuda.Event()
+                        done.record(cur)
+                        with torch.cuda.stream(push_s):
+                            push_s.wait_event(done)
+                            yv[a:b].copy_(out, non_blocking=True)
+                    else:
+                        yv[a:b].copy_(out)
+                    self._note("send", c)
+            if cuda:
+                cur.wait_stream(push_s)        # the status all-reduce below is behind the last push on this rank's stream ...
+                cur.wait_stream(pull_s)
+                cur.synchronize()              # ... and this rank does not enter it before its copies have completed
         except Exception as e:
-            self._finish(e)            # raises
-        dtype = xv.dtype
-        t = shape[1]
-        alloc = torch.empty if do_scatter else torch.zeros
-        bufs = [alloc((b - a, t) + tuple(shape[2:]), dtype=dtype, device=self.device) for a, b in pieces]
-        if cuda:
-            if self._streams is None:
-                self._streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
-            pull_s, push_s = self._streams
-            cur = torch.cuda.current_stream()
-            pull_s.wait_stream(cur)
-            push_s.wait_stream(cur)
-            pulled = []
-            if do_scatter:
-                for (a, b), buf in zip(pieces, bufs):     # every pull is queued up front: chunk c+1 lands while chunk c computes
-                    with torch.cuda.stream(pull_s):
-                        buf.copy_(xv[a:b], non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(pull_s)
-                    pulled.append(ev)
-        outs = []
-        for c, ((a, b), buf) in enumerate(zip(pieces, bufs)):
-            if do_scatter:
-                if cuda:
-                    cur.wait_event(pulled[c])
-                else:
-                    buf.copy_(xv[a:b])
-            self._note("recv", c)
-            out = buf
-            if do_compute:
-                if err is None:
-                    try:
-                        out = self.forward(buf).contiguous()
-                        if out.shape != buf.shape or out.dtype != buf.dtype:
-                            raise ValueError("forward returned %s %s for an input of %s %s"
-                                             % (tuple(out.shape), out.dtype, tuple(buf.shape), buf.dtype))
-                    except Exception as e:
-                        err = e
-                if err is not None:
-                    out = torch.zeros_like(buf)
-                self._note("fwd", c)
-            if do_gather:
-                outs.append(out)
-                if cuda:
-                    done = torch.cuda.Event()
-                    done.record(cur)
-                    with torch.cuda.stream(push_s):
-                        push_s.wait_event(done)
-                        yv[a:b].copy_(out, non_blocking=True)
-                else:
-                    yv[a:b].copy_(out)
-                self._note("send", c)
-        if cuda:
-            cur.wait_stream(push_s)        # the status all-reduce below is behind the last push on this rank's stream ...
-            cur.wait_stream(pull_s)
-            cur.synchronize()              # ... and this rank does not enter it before its copies have completed
-        del xv, yv
+            err = err or e
         self._finish(err)
         return None

@@ -349,10 +349,14 @@ def _copy_worker(rank, world, port, n, t, chunks, root, out_path):
         x = (torch.arange(n * t * 129, dtype=torch.float32).reshape(n, t, 129, 1) * 1e-3) if rank == root else None
         y_ref = ref_eng.forward_from_root(x, root=root, chunks=chunks)
         del sizes[:]
-        for _ in range(2):        # reusable; the second call reuses the root's output buffer and the opened handles
+        ys = []
+        for _ in range(3):        # reusable; two output buffers per shape, used alternately: call k's result lives until call k + 2
             y = eng.forward_from_root(x, root=root, chunks=chunks)
+            ys.append(y)
+        if rank == root:
+            assert ys[0] is not ys[1] and ys[2].data_ptr() == ys[0].data_ptr() and torch.equal(ys[1], ys[2])
         lo, hi = shard_bounds(n, world)[rank]
-        assert sum(sizes) == 2 * (hi - lo), (rank, sizes)
+        assert sum(sizes) == 3 * (hi - lo), (rank, sizes)
         if rank == root:
             assert torch.equal(y, y_ref) and torch.equal(y, torch.sin(x) * 3.0 + 1.0)     # bit-equal with the send / recv transport
             open(out_path, "w").write("ok")
@@ -388,8 +392,10 @@ def test_copy_transport_equals_send_recv(tmp_path, world, n, chunks, root):
 
 
 def _poison_worker(rank, world, port, out_path):
-    """A transfer that times out ends the call on every rank with an error AND poisons the object: its sends / receives may
-    still be pending on the direction groups, so later calls are refused until it is closed and rebuilt."""
+    """A transfer that times out ends the call on every rank with an error AND poisons the object ON EVERY RANK -- also on a
+    peer whose own transfers all completed (world 3: rank 2): its sends / receives may still be pending on the direction groups,
+    so later calls are refused everywhere (a rank that went on would wait in the next call's broadcast for a root that refuses
+    to enter it) until the object is closed and rebuilt."""
     import sys
     import time
     sys.path.insert(0, ROOT)
@@ -406,18 +412,19 @@ def _poison_worker(rank, world, port, out_path):
             return x + 1.0
 
         eng = BatchShardedForward(forward, device="cpu", timeout_s=1.0)
-        x = torch.ones(4, 2, 129, 1) if rank == 0 else None
+        x = torch.ones(6, 2, 129, 1) if rank == 0 else None
         failed = False
         try:
             eng.forward_from_root(x, root=0, chunks=1)
         except Exception:
             failed = True
         assert failed                                         # every rank leaves the call with an exception
+        assert eng._poisoned is not None, rank                # ... and knows of the time-out, whoever saw it
         if rank == 0:
-            assert eng._poisoned is not None and eng._pending
-            with pytest.raises(TransferTimeout):
-                eng.forward_from_root(x, root=0, chunks=1)    # refused without touching the groups
-            open(out_path, "w").write("ok")
+            assert eng._pending
+        with pytest.raises(TransferTimeout):                  # EVERY rank makes the second call: refused without touching the groups
+            eng.forward_from_root(x, root=0, chunks=1)
+        open(out_path + str(rank), "w").write("ok")
         time.sleep(3.5)                                       # let the late message drain before the groups go away
         eng.close()
         fresh = BatchShardedForward(lambda v: v + 1.0, device="cpu", timeout_s=30)
@@ -429,7 +436,8 @@ def _poison_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_transfer_timeout_poisons_the_engine(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_transfer_timeout_poisons_the_engine(tmp_path, world):
     out = str(tmp_path / "ok")
-    mp.spawn(_poison_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    assert open(out).read() == "ok"
+    mp.spawn(_poison_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(open(out + str(r)).read() == "ok" for r in range(world))

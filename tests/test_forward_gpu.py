@@ -717,6 +717,16 @@ def test_from_root_on_rccl_world_size_1(built):
                 assert m.get_option("fused_grid") == cus - r
                 assert torch.equal(eng.forward_from_root(xb, root=0, chunks=2), yb)
             assert m.get_option("fused_grid") == 0
+        # BASELINE configs[3]'s WORKLOAD on the real backend, as far as one rank goes: the whole global batch [2048, 512, 129, 1]
+        # (541 MB in, 541 MB out: indices past 2^27 floats, the default chunking of bench.py's from_root leg) through the no-peer path
+        g = torch.Generator(device="cuda").manual_seed(4)
+        xg = torch.randn((2048, 512, 129, 1), generator=g, device="cuda").abs_()
+        yg = eng.forward_from_root(xg, root=0, chunks=8)
+        torch.cuda.synchronize()
+        assert yg.shape == xg.shape and bool(torch.isfinite(yg).all())
+        for a, b in ((0, 3), (1023, 1026), (2045, 2048)):
+            assert torch.equal(yg[a:b], m(xg[a:b].contiguous())), (a, b)
+        del xg, yg
     finally:
         dist.destroy_process_group()
 
@@ -873,6 +883,76 @@ def _copy_gpu_worker(rank, world, port, out_path):
         model.close()
     finally:
         dist.destroy_process_group()
+
+
+def _config4_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT_DIR)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullycnnspeechenhancement_amd import build_model
+        from fullycnnspeechenhancement_amd.dist import BatchShardedForward, shard_bounds
+        torch.cuda.set_device(0)
+        w = rced_np.make_weights("FullyCNNV3", seed=42)
+        model = build_model("FullyCNNV3", False, weights=w, device=0)
+        eng = BatchShardedForward(model, device="cuda:0", forward_into=lambda a, out: model(a, out=out), transport="copy")
+        x = None
+        if rank == 0:
+            g = torch.Generator(device="cuda").manual_seed(1234)
+            x = torch.randn((2048, 512, 129, 1), generator=g, device="cuda").abs_()
+        ys = [eng.forward_from_root(x, root=0, chunks=8) for _ in range(2)]      # twice: the handle caches, the second output buffer
+        if rank == 0:
+            torch.cuda.synchronize()
+            y = ys[1]
+            assert ys[0].data_ptr() != ys[1].data_ptr() and torch.equal(ys[0], ys[1])
+            assert bool(torch.isfinite(y).all())
+            (lo0, hi0), (lo1, hi1) = shard_bounds(2048, 2)
+            assert (lo1, hi1) == (1024, 2048)
+            # sampled pieces of both shards, chunk seams and the ends included, against the root computing them itself: bit for bit
+            for a, b in ((0, 2), (127, 130), (1022, 1024), (1024, 1027), (1151, 1154), (1535, 1538), (2046, 2048)):
+                assert torch.equal(y[a:b], model(x[a:b].contiguous())), (a, b)
+            # ... and sampled frames against the oracle on their receptive fields (frames t - 3 .. t + 4)
+            rng = np.random.default_rng(5)
+            picks = [(0, 0), (2047, 511), (1024, 0), (1023, 511)] + [(int(rng.integers(2048)), int(rng.integers(512))) for _ in range(8)]
+            scale = float(y.abs().max())
+            worst = 0.0
+            for n, t in picks:
+                lo, hi = max(t - 3, 0), min(t + 5, 512)
+                ref = rced_c.forward("FullyCNNV3", w, x[n:n + 1, lo:hi].cpu().numpy(), np.float64)[0, t - lo]
+                worst = max(worst, float(np.abs(y[n, t].cpu().numpy() - ref).max()) / scale)
+            assert worst < RTOL, worst
+            open(out_path, "w").write("ok %.3e" % worst)
+        dist.barrier()
+        eng.close()
+        model.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_workload_through_the_copy_transport(built, tmp_path, capsys):
+    """BASELINE configs[3]'s workload -- the global batch [2048, 512, 129, 1] of one host process (tester.py:85-90; layout
+    data_loader.py:198-209) -- through BatchShardedForward.forward_from_root with transport="copy", bench.py's default chunking,
+    between two processes that share this box's GPU: 541 MB in and out through IPC handles, shards of 1,024 utterances in 8
+    chunks, indices past 2^27 floats, the handle caches and both output buffers.  Sampled pieces of both shards are bit-equal to
+    the root computing them itself; twelve sampled frames meet the oracle on their receptive fields.  (What one GPU cannot
+    show is the scaling: no byte crosses xGMI here.)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ok")
+    mp.spawn(_config4_worker, args=(2, port, out), nprocs=2, join=True)
+    res = open(out).read()
+    assert res.startswith("ok")
+    with capsys.disabled():
+        print("\n[config 4 workload, copy transport, two processes on one GPU] worst sampled frame vs oracle %s" % res[3:])
 
 
 def test_from_root_copy_transport_through_ipc_handles(built, tmp_path):
