@@ -38,7 +38,8 @@ SYMBOLS = {
     "rced_stft_num_frames": (ctypes.c_int, [ctypes.c_int]),
     "rced_stft": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
     "rced_istft": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
-    "rced_audio_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "rced_stft_ex": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int]),
+    "rced_istft_ex": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, ctypes.c_int]),
     "rced_train_create": (ctypes.c_int, [ctypes.c_int, _c_float_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(_vp)]),
     "rced_train_destroy": (None, [_vp]),

@@ -21,13 +21,13 @@ def num_frames(length):
     return int(_lib.load().rced_stft_num_frames(int(length)))
 
 
-def kernel_option(key, value=None):
-    """rced_audio_option: which kernels stft_batch / istft_batch launch (process-wide).  key "x6": 1 (default) = the three-part bf16
-    kernels, 0 = the fp32-MFMA comparators.  Returns the value in force (value=None only queries)."""
-    r = int(_lib.load().rced_audio_option(key.encode(), -1 if value is None else int(value)))
-    if r < 0:
-        raise ValueError("rced_audio_option(%r, %r): unknown key or bad value" % (key, value))
-    return r
+KERNELS = {"x6": 1, "f32": 0}     # rced.h: RCED_AUDIO_X6 (the product: three-part bf16 products), RCED_AUDIO_F32 (the fp32-MFMA comparators)
+
+
+def _kernels(name):
+    if name not in KERNELS:
+        raise ValueError("kernels must be 'x6' (the product) or 'f32' (the fp32-MFMA comparator), got %r" % (name,))
+    return KERNELS[name]
 
 
 def _check_cfg(sample_rate, window_s, stride_s, nfft=None):
@@ -37,7 +37,7 @@ def _check_cfg(sample_rate, window_s, stride_s, nfft=None):
         raise ValueError("only rfft(256) -> 129 bins is built (data_loader.py:59 hard-codes it)")
 
 
-def stft_batch(pcm, lengths=None, frames=None, with_phase=True):
+def stft_batch(pcm, lengths=None, frames=None, with_phase=True, kernels="x6"):
     """pcm: torch.cuda float32 [N, L]; lengths: per-utterance sample counts (list / tensor) or None.
     Returns (mag [N, T, 129, 1], phase [N, T, 129] complex64 or None); T = frames or the batch maximum
     (zero-padded like DataLoader.padding_batch, data_loader.py:198-209)."""
@@ -60,12 +60,12 @@ def stft_batch(pcm, lengths=None, frames=None, with_phase=True):
     ph = torch.empty((n, t, BINS, 2), dtype=torch.float32, device=dev) if with_phase else None
     if n and t:
         st = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(_lib.load().rced_stft(pcm.data_ptr(), ldev.data_ptr() if ldev is not None else None, n, L, t,
-                                         mag.data_ptr(), ph.data_ptr() if ph is not None else None, dev.index, st))
+        _lib.check(_lib.load().rced_stft_ex(pcm.data_ptr(), ldev.data_ptr() if ldev is not None else None, n, L, t,
+                                            mag.data_ptr(), ph.data_ptr() if ph is not None else None, dev.index, st, _kernels(kernels)))
     return mag, (torch.view_as_complex(ph) if ph is not None else None)
 
 
-def istft_batch(mag, phase, nfft=512):
+def istft_batch(mag, phase, nfft=512, kernels="x6"):
     """mag [N, T, 129(,1)] float32, phase [N, T, 129] complex64 (torch.cuda) -> audio [N, (T+1)*128]."""
     import torch
     if mag.dim() == 4:
@@ -78,18 +78,19 @@ def istft_batch(mag, phase, nfft=512):
     out = torch.empty((n, (t + 1) * STEP), dtype=torch.float32, device=mag.device)
     if n and t:
         st = torch.cuda.current_stream(mag.device).cuda_stream
-        _lib.check(_lib.load().rced_istft(mag.data_ptr(), ph.data_ptr(), n, t, int(nfft), out.data_ptr(),
-                                          mag.device.index, st))
+        _lib.check(_lib.load().rced_istft_ex(mag.data_ptr(), ph.data_ptr(), n, t, int(nfft), out.data_ptr(),
+                                             mag.device.index, st, _kernels(kernels)))
     return out
 
 
 class AudioFeature(object):
     """data_utils/audio_feature.py:12-115 on the GPU (numpy in, numpy out, like the reference)."""
 
-    def __init__(self, windows_name=None, device=0):
+    def __init__(self, windows_name=None, device=0, kernels="x6"):
         if windows_name not in (None, "hamming"):
             raise ValueError("only the hamming window is built (it is what every reference run uses: SURVEY F7)")
-        self.device = device
+        self.device, self.kernels = device, kernels
+        _kernels(kernels)
 
     def compute_spectrogram(self, signal, sample_rate, window_s=0.02, stride_s=0.01, nfft=512, use_complex=False):
         import torch
@@ -97,7 +98,7 @@ class AudioFeature(object):
             raise ValueError("Stride size must not be greater than window size.")   # audio_feature.py:29-30
         _check_cfg(sample_rate, window_s, stride_s, nfft)
         sig = torch.as_tensor(np.asarray(signal, dtype=np.float32), device="cuda:%d" % self.device)[None]
-        mag, ph = stft_batch(sig, with_phase=use_complex)
+        mag, ph = stft_batch(sig, with_phase=use_complex, kernels=self.kernels)
         if use_complex:   # [129, T] complex, like np.transpose(fft_frames)
             return (mag[0, :, :, 0] * ph[0]).cpu().numpy().T
         return mag[0, :, :, 0].cpu().numpy().T
@@ -114,12 +115,13 @@ class AudioFeature(object):
 class AudioReBuild(object):
     """model_utils/utils.py:93-183 on the GPU.  nfft defaults to 512 exactly as the reference's does."""
 
-    def __init__(self, windows_name=None, nfft=512, device=0):
+    def __init__(self, windows_name=None, nfft=512, device=0, kernels="x6"):
         if windows_name not in (None, "hamming"):
             raise ValueError("only the hamming window is built")
         if nfft not in (256, 512):
             raise ValueError("nfft must be 512 (reference default) or 256")
-        self.nfft, self.device = nfft, device
+        self.nfft, self.device, self.kernels = nfft, device, kernels
+        _kernels(kernels)
 
     def rebuild_audio(self, sig_length_list, spec, phase, sample_rate, windows_ms, stride_ms):
         import torch
@@ -127,5 +129,5 @@ class AudioReBuild(object):
         dev = "cuda:%d" % self.device
         mag = torch.as_tensor(np.asarray(spec, dtype=np.float32), device=dev)
         ph = torch.as_tensor(np.asarray(phase).astype(np.complex64), device=dev)
-        audio = istft_batch(mag, ph, self.nfft).cpu().numpy()
+        audio = istft_batch(mag, ph, self.nfft, kernels=self.kernels).cpu().numpy()
         return [audio[i][:sig_length_list[i]] for i in range(len(audio))]

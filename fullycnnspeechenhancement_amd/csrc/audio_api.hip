@@ -155,18 +155,6 @@ int build_x6(AudioTables& t) {
   return RCED_OK;
 }
 
-// rced_audio_option("x6"): 1 = the three-part bf16 kernels, 0 = the fp32-MFMA kernels (the in-build comparator).  The environment
-// variable RCED_AUDIO_X6 only supplies the default, read once.
-std::atomic<int> g_x6{-1};
-bool use_x6() {
-  int v = g_x6.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("RCED_AUDIO_X6");
-    v = e ? (atoi(e) != 0) : 1;
-    g_x6.store(v, std::memory_order_relaxed);
-  }
-  return v != 0;
-}
 // frame-range split of an utterance over workgroups: enough workgroups for every CU when the batch is small
 int range_split(int N, int T) {
   const int nblk = (T + audio::kFramesPerWg - 1) / audio::kFramesPerWg;
@@ -214,15 +202,14 @@ extern "C" {
 
 int rced_stft_num_frames(int length) { return length > 0 ? audio::num_frames(length) : 0; }
 
-int rced_audio_option(const char* key, int value) {
-  if (!key || strcmp(key, "x6") || value < -1 || value > 1) return -1;
-  const bool now = use_x6();
-  if (value >= 0) g_x6.store(value, std::memory_order_relaxed);
-  return value >= 0 ? value : (now ? 1 : 0);
-}
-
 int rced_stft(const float* pcm_dev, const int* lengths_dev, int N, int L, int T, float* mag_dev, float* phase_dev,
               int device, void* stream) {
+  return rced_stft_ex(pcm_dev, lengths_dev, N, L, T, mag_dev, phase_dev, device, stream, RCED_AUDIO_X6);
+}
+
+int rced_stft_ex(const float* pcm_dev, const int* lengths_dev, int N, int L, int T, float* mag_dev, float* phase_dev,
+                 int device, void* stream, int kernels) {
+  if (kernels != RCED_AUDIO_X6 && kernels != RCED_AUDIO_F32) return rced_fail(RCED_ERR_ARG, "kernels must be RCED_AUDIO_X6 (1) or RCED_AUDIO_F32 (0), got %d", kernels);
   if (N < 0 || L < 0 || T < 0) return rced_fail(RCED_ERR_ARG, "negative shape");
   if (N == 0 || T == 0) return RCED_OK;
   if (L == 0) return rced_fail(RCED_ERR_ARG, "empty signals (L = 0) with T > 0");
@@ -232,7 +219,7 @@ int rced_stft(const float* pcm_dev, const int* lengths_dev, int N, int L, int T,
   AudioTables* t = nullptr;
   if (int rc = tables(device, &t)) return rc;
   if (!g.ok) return rced_fail(RCED_ERR_HIP, "hipSetDevice(%d) failed", device);
-  if (use_x6()) {
+  if (kernels == RCED_AUDIO_X6) {
     hipLaunchKernelGGL(audio::x6::stft_x6_kernel, dim3(N, 2, range_split(N, T)), dim3(audio::x6::kThreadsX), 0, static_cast<hipStream_t>(stream),
                        pcm_dev, lengths_dev, (const unsigned short*)t->stft_x6, L, T, mag_dev, phase_dev);
   } else {
@@ -246,6 +233,12 @@ int rced_stft(const float* pcm_dev, const int* lengths_dev, int N, int L, int T,
 
 int rced_istft(const float* mag_dev, const float* phase_dev, int N, int T, int nfft, float* audio_dev, int device,
                void* stream) {
+  return rced_istft_ex(mag_dev, phase_dev, N, T, nfft, audio_dev, device, stream, RCED_AUDIO_X6);
+}
+
+int rced_istft_ex(const float* mag_dev, const float* phase_dev, int N, int T, int nfft, float* audio_dev, int device,
+                  void* stream, int kernels) {
+  if (kernels != RCED_AUDIO_X6 && kernels != RCED_AUDIO_F32) return rced_fail(RCED_ERR_ARG, "kernels must be RCED_AUDIO_X6 (1) or RCED_AUDIO_F32 (0), got %d", kernels);
   if (N < 0 || T < 0) return rced_fail(RCED_ERR_ARG, "negative shape");
   if (nfft != 512 && nfft != 256) return rced_fail(RCED_ERR_ARG, "nfft must be 512 (reference default) or 256");
   if (N == 0 || T == 0) return RCED_OK;
@@ -256,7 +249,7 @@ int rced_istft(const float* mag_dev, const float* phase_dev, int N, int T, int n
   if (int rc = tables(device, &t)) return rc;
   if (!g.ok) return rced_fail(RCED_ERR_HIP, "hipSetDevice(%d) failed", device);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (use_x6()) {
+  if (kernels == RCED_AUDIO_X6) {
     const int v = nfft == 512, split = range_split(N, T);
     if (split == 1) {   // one workgroup per utterance: de_frame and de_emphasis inside the kernel
       hipLaunchKernelGGL(audio::x6::istft_x6_kernel<true>, dim3(N, 1, 1), dim3(audio::x6::kThreadsX), audio::x6::kIstftLdsBytes, st, mag_dev, phase_dev,

@@ -1,6 +1,6 @@
 // STFT front-end / ISTFT rebuild at fp32 quality on the bf16 matrix pipe (three-part operands, six products per MFMA-sized term: the
 // form of the CR-CED kernel, kernels_fused_v3.h).  Same reference rows as kernels_audio.h (N1: data_utils/audio_feature.py:22-44,
-// N2: model_utils/utils.py:171-183); the fp32-MFMA kernels there stay in the library as the comparator (rced_audio_option("x6", 0); RCED_AUDIO_X6 supplies the default).
+// N2: model_utils/utils.py:171-183); the fp32-MFMA kernels there stay in the library as the comparator (rced_stft_ex / rced_istft_ex with RCED_AUDIO_F32).
 //
 // Both transforms are dense DFT GEMMs with K = 256 exactly once the two identically-zero terms are dropped:
 //   STFT : 258 real rows (re, im of 129 bins) -> 256: im of bin 0 and of bin 128 are zero for a real signal, so row 1 carries re of bin

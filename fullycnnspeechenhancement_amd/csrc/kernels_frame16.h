@@ -31,7 +31,7 @@
 //     wave stores, L2 / MALL resident), loaded at the start of the decoder layer and used after its last K-step.
 //   * Weights: per layer a packet of 1-KiB A fragments [step][M-tile][lane] x 8 bf16 + 32 fp32 shifts, LDS-DMA'd one
 //     layer ahead into a two-packet ring.
-// Precision contract: tests/test_forward_gpu.py against oracle/rced_np.forward_bf16, which rounds at the same places
+// Precision contract: tests/test_forward_gpu.py against the test suite's bf16 emulation, which rounds at the same places
 // (input, every folded kernel, every layer's output).  NOT within the fp32 path's 1e-4 bar: opt-in (option "bf16").
 #pragma once
 #include <hip/hip_runtime.h>

@@ -40,9 +40,8 @@ struct rced_fused {
   // defaults, read when the handle is created (rced_create), never afterwards.
   int final_x6 = 1;           // option "final_x6" (default: RCED_FINAL_X6): 1 = x6::final_gemm_x6_kernel (three-part bf16 products), 0 = fp32 MFMA
   int final_lds = 1;          // option "final_lds" (default: RCED_FINAL_LDS): the fp32 kernel with (1) / without (0) LDS staging of its B operand
-  int v3_l2x6 = 3;            // option "v3_l2x6": 3 = every layer at fp32 quality on the bf16 matrix pipe (the product); 2 = all but the first layer and
-                              // decode_final (round 4's product); 1 = the 18 -> 30 layers only (round 4's first form); 0 = every layer on the fp32
-                              // MFMA (the comparator): kernels_fused_v3.h
+  int v3_l2x6 = 3;            // option "v3_l2x6": 3 = every layer at fp32 quality on the bf16 matrix pipe (the product); 0 = every layer on the fp32
+                              // MFMA (the bit-exact comparator): kernels_fused_v3.h.  (1, 2: rounds 3 / 4's forms, RCED_V3_LEGACY_FORMS builds only)
   float* fin_apack = nullptr; // v3::kFinPack
   float fin_bias = 0.f;
   float* h = nullptr;         // [frames, 129, 8] hand-off to the final layer
@@ -548,8 +547,12 @@ int upload(float** dev, const std::vector<float>& host) {   // *dev is set only 
 }  // namespace
 
 // tools/summarize_prof.py prints these next to a profile (the kernel-trace CSV reports 0 for dynamic LDS)
-static_assert(v3::MapA::kLdsBytes == 159024 && v3::MapT::kLdsBytes == 163792 && v3::MapX6::kLdsBytes == 162976 && v3::MapF32::kLdsBytes == 163024,
-              "update DYNAMIC_LDS in tools/summarize_prof.py");
+static_assert(v3::MapA::kLdsBytes == 159024 && v3::MapF32::kLdsBytes == 163024, "update DYNAMIC_LDS in tools/summarize_prof.py");
+#if RCED_V3_LEGACY_FORMS
+static_assert(v3::MapT::kLdsBytes == 163792 && v3::MapX6::kLdsBytes == 162976, "update DYNAMIC_LDS in tools/summarize_prof.py");
+#endif
+// forms of the CR-CED kernel this build holds: 3 (the product) and 0 (the bit-exact fp32-MFMA comparator); 1 and 2 in legacy builds only
+inline bool v3_form_built(int form) { return form == 0 || form == 3 || (RCED_V3_LEGACY_FORMS && (form == 1 || form == 2)); }
 template <class M>
 int v3_set_lds() {
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v3::fused_v3_kernel<M>),
@@ -560,6 +563,8 @@ int v3_set_lds() {
 // option "v3_l2x6": a form's weight stream is built when it is first selected
 // (a form counts as built only when its upload AND its LDS attribute succeeded -- the device pointer is published last)
 int v3_enable_form(rced_model* m, rced_fused* f, int form) {
+  if (!v3_form_built(form)) return rced_fail(RCED_ERR_ARG, "v3_l2x6 takes 3 (the product: every layer at fp32 quality on the bf16 matrix pipe) or 0 (every "
+                                                         "layer on the fp32 MFMA, the bit-exact comparator), got %d", form);
   float** dev = form == 0 ? &f->wpack : form == 1 ? &f->wpack_x6 : form == 2 ? &f->wpack_t : &f->wpack_a;
   if (*dev) return RCED_OK;
   std::vector<float> wpack;
@@ -575,7 +580,10 @@ int v3_enable_form(rced_model* m, rced_fused* f, int form) {
       f->fin_tab = nullptr;
     }
   }
-  if (!rc) rc = form == 0 ? v3_set_lds<v3::MapF32>() : form == 1 ? v3_set_lds<v3::MapX6>() : form == 2 ? v3_set_lds<v3::MapT>() : v3_set_lds<v3::MapA>();
+#if RCED_V3_LEGACY_FORMS
+  if (!rc && (form == 1 || form == 2)) rc = form == 1 ? v3_set_lds<v3::MapX6>() : v3_set_lds<v3::MapT>();
+#endif
+  if (!rc && (form == 0 || form == 3)) rc = form == 0 ? v3_set_lds<v3::MapF32>() : v3_set_lds<v3::MapA>();
   if (rc) {
     if (fresh) (void)hipFree(fresh);
     return rc;
@@ -600,7 +608,7 @@ int fused_create(rced_model* m) {
   int rc = upload(&f->fin_apack, fin);
   if (!rc) {   // the environment only supplies the DEFAULT of the per-handle option
     const int form = env_default("RCED_V3_L2X6", 3);
-    f->v3_l2x6 = form < 0 || form > 3 ? 3 : form;
+    f->v3_l2x6 = v3_form_built(form) ? form : 3;
     rc = v3_enable_form(m, f, f->v3_l2x6);
   }
   if (!rc) {
@@ -696,8 +704,10 @@ int fused_forward(rced_model* m, const float* x, float* y, int N, int T, hipStre
   const int grid = std::min(P.total_tiles, cus);
   m->prof_begin(RCED_K_FUSED, st);   // all 16 layers: decode_final is the kernel's last phase
   if (f->v3_l2x6 == 3) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapA>, dim3(grid), dim3(v3::kThreads), v3::MapA::kLdsBytes, st, P);
+#if RCED_V3_LEGACY_FORMS
   else if (f->v3_l2x6 == 2) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapT>, dim3(grid), dim3(v3::kThreads), v3::MapT::kLdsBytes, st, P);
-  else if (f->v3_l2x6) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapX6>, dim3(grid), dim3(v3::kThreads), v3::MapX6::kLdsBytes, st, P);
+  else if (f->v3_l2x6 == 1) hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapX6>, dim3(grid), dim3(v3::kThreads), v3::MapX6::kLdsBytes, st, P);
+#endif
   else hipLaunchKernelGGL(v3::fused_v3_kernel<v3::MapF32>, dim3(grid), dim3(v3::kThreads), v3::MapF32::kLdsBytes, st, P);
   m->prof_end(RCED_K_FUSED, st);
   HIP_TRY(hipGetLastError());
@@ -730,7 +740,6 @@ int fused_set_option(rced_model* m, const char* key, int value) {
   }
   if (!strcmp(key, "v3_l2x6")) {
     if (m->variant != RCED_V3) return rced_fail(RCED_ERR_ARG, "v3_l2x6 selects the form of the CR-CED kernel only");
-    if (value < 0 || value > 3) return rced_fail(RCED_ERR_ARG, "v3_l2x6 takes 0 .. 3 (the forms of the CR-CED kernel), got %d", value);
     if (int rc = v3_enable_form(m, m->fused, value)) return rc;
     m->fused->v3_l2x6 = value;
     return RCED_OK;

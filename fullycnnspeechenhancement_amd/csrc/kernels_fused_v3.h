@@ -44,6 +44,10 @@
 
 #include "lds_dma.h"
 
+#ifndef RCED_V3_LEGACY_FORMS
+#define RCED_V3_LEGACY_FORMS 0   // 1: forms 1 and 2 of the kernel (rounds 3 / 4: kernels_fused_v3_legacy*.h) are compiled too -- history runs through
+                                 // tools/ab.sh only; the product library holds form 3 (the product) and form 0 (the bit-exact fp32-MFMA comparator)
+#endif
 #ifndef RCED_D1
 #define RCED_D1 1   // operand prefetch depth (slots) of the layer-1 / layer-2 / layer-3 jobs (1..4 measured: +-0.5 %)
 #endif
@@ -225,7 +229,9 @@ struct Map {
   static constexpr int kTileB18 = X6 ? 16 * 32 : 16 * 18 * 4;          // ... between adjacent 16-pixel tiles of B18
 };
 typedef Map<0> MapF32;
+#if RCED_V3_LEGACY_FORMS
 typedef Map<1> MapX6;
+#endif
 
 // ---- packed weight streams (floats), per block -----------------------------------------------
 //  first layer main (8x9x1 -> ch 0..15): 18 k-steps x 64 lanes (b32 steps, k = (time tap, freq tap))
@@ -261,7 +267,7 @@ constexpr int kGTotal = 5 * kGBlock;
 static_assert(kG1 % 4 == 0 && kG2 % 4 == 0 && kW3 % 4 == 0, "16-byte aligned pieces");
 static_assert(kW1 + kFin128 <= kWRegion && (kW1 % 4) == 0, "F32 form: the bin-128 weights fit behind a layer-1 packet in its LDS region");
 
-// ---- FUSED form (Map<2>): layers 2 AND 3 on the bf16 pipe, the 30-channel tensor never stored ------------------------
+// ---- layers 2 AND 3 as one stream on the bf16 pipe, the 30-channel tensor never stored (the product form, Map<3>; legacy form 2) ----
 // Layer 3 (1x9, 30 -> 8) is computed TAP BY TAP from layer 2's accumulators: a wave that has layer 2's two M-tiles of a 16-pixel
 // tile in registers (lane (kq, n): channels 4kq..+3 and 16+4kq..+3 of pixel n) applies the ReLU, splits them into three bf16 parts
 // -- which IS the B fragment of a K = 32 MFMA whose k-slot 8kq + e is channel (e < 4 ? 4kq + e : 16 + 4kq + e - 4) -- and
@@ -285,55 +291,10 @@ constexpr int kG1X = kG1XMain + kG1XRem + kShiftPerLayer;
 constexpr int kTBlockX = kG1X + kG2 + kW3T;                 // blocks 1..4 (block 0's first layer keeps the fp32 images)
 constexpr int kTTotal = RCED_T_L1X6 ? kTBlock + 4 * kTBlockX : 5 * kTBlock;
 constexpr int kB8PlaneBytes = kB8Rows * 16;                 // one bf16 plane of the 8-channel tensor: [pixel][8] = 16-byte rows
-template <>
-struct Map<2> {
-  static constexpr bool X6 = true, kX6 = true, kFused = true, kAllX6 = false;
-  static constexpr int kB8Off = 0;
-  static constexpr bool kL1X6 = RCED_T_L1X6 != 0;
-  static constexpr int kB18Off = kB8Off + (kL1X6 ? 3 * kB8PlaneBytes / 4 : kB8Rows * kB8S);
-  // B18 here: three blocks (h, m, l), each = the plane [pixel][16] bf16 (32-byte rows) followed by the remainder channels' rows
-  // [c16 c17] (4 bytes per pixel).  With the same stride between the parts of both, the last K = 32 chunk of layer 2 is, for EVERY
-  // lane, four consecutive dwords from one per-lane address (lower lanes: tap 4 of the plane; upper lanes: the remainder channels'
-  // window) + the part's stride: four ds_read_b32 per part straight into the fragment, no select (the other X6 form reads 16 + 8 + 4
-  // bytes and merges them with 12 v_cndmask).
-  static constexpr int kRemOff = kB18Rows * 32;                                   // the remainder rows inside a block
-  static constexpr int kRemRows = kB18Rows + 6;
-  static constexpr int kPlaneBytes = ((kRemOff + kRemRows * 4 + 15) / 16) * 16;   // stride between the parts: 19,248
-  static constexpr int kRemHMBytes = 0, kRemLBytes = 0;                           // (the other X6 form's layout)
-  static constexpr int kB18Bytes = 3 * kPlaneBytes;
-  // one weight region: layer 2's A fragments + shifts, then layer 3's (the block's stream images of both, one LDS-DMA during layer 1).
-  // (Reads that run past B18 land here: masked pixels only.)
-  static constexpr int kWOff = kB18Off + kB18Bytes / 4;
-  static constexpr int kW3TOff = kWOff + kG2;
-  static constexpr int kWRegions = 1;
-  static constexpr int kB30Off = kWOff;                     // (no such buffer: make_lane's unused layer-2/3 addresses of the other forms)
-  static constexpr int kX0Off = kW3TOff + kW3T;             // the buffers below have places of their own: nothing aliases B18, nothing is re-zeroed
-  static constexpr int kHOff = kX0Off + kX0Floats;
-  static constexpr int kFin128Off = kHOff + kHPix * kHS;
-  static constexpr int kEdgeOff = kFin128Off + kFin128;     // [frame 4][direction 2][lane 64] x 8 bytes: the partial sums that cross the middle of a frame
-  static constexpr int kEdgeFlagOff = kEdgeOff + 4 * 2 * 128;
-  static constexpr int kLdsFloats = kEdgeFlagOff + 8;
-  static constexpr int kLdsBytes = kLdsFloats * 4;
-  static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
-  static_assert((kWOff * 4) % 16 == 0 && (kW3TOff * 4) % 16 == 0 && (kB18Off * 4) % 16 == 0 && (kHOff % 2) == 0, "aligned buffers");
-  static_assert((kFin128Off * 4) % 16 == 0 && (kEdgeOff * 4) % 16 == 0, "aligned buffers");
-  // decode_final's partial sums (8 waves x 2 column tiles x 1 KiB) lie in B8, dead from block 4's layer 1 to the next tile's block 0
-  // (whose layers 2 + 3 rewrite every real pixel): 4 KiB in the rows of each frame's first 103 bins, never a gap row
-  // (planes: 2 KiB in the first 128 rows of frame w % 4 of plane w / 4)
-  static constexpr int finscr0(int w) {
-    return kL1X6 ? kB8Off * 4 + (w >> 2) * kB8PlaneBytes + (kB8Pad + kS * (w & 3)) * 16
-                 : (kB8Off + (kB8Pad + kS * (w >> 1)) * kB8S) * 4 + 8 * ((w >> 1) & 1) + (w & 1) * 2048;
-  }
-  static constexpr int kFinScrCt = 1024;
-  static constexpr int kT1R = 128 * kB8S * 4, kT1W = 128 * 32;
-  static constexpr int kT2R = 0, kT2W = 0, kT3R = 0, kT3W = 0;   // (other forms' layers)
-  static constexpr int kTileB18 = 16 * 32;
-};
-typedef Map<2> MapT;
-static_assert(MapT::finscr0(7) % 16 == 0 && MapT::finscr0(2) % 16 == 0 && (MapT::kL1X6 || MapT::finscr0(1) + 2048 <= (kB8Pad + kF) * kB8S * 4), "decode_final's partial sums: 16-byte aligned, inside real rows of B8");
 static_assert(kW3T % 4 == 0 && kG2 + kW3T <= 2 * kWRegion, "layer 3's fused-form packet: 16-byte pieces, inside a weight region");
-
-
+#if RCED_V3_LEGACY_FORMS
+#include "kernels_fused_v3_legacy_map.h"
+#endif
 // ---- ALL-X6 form (Map<3>, the product): as the fused form, and the FIRST layer and decode_final on the bf16 pipe too ------------
 // * The first layer (8x9, 1 -> 18) is layer1_x6l like blocks 1..4's: its K axis (8 time rows x 9 frequency taps) becomes "8 channels x 9
 //   taps" once the input rows of a tile are laid out as bf16 planes [pixel (frame i, bin f)][8] with entry r = x[t0 + i + r - 3][f] -- an
@@ -1327,58 +1288,10 @@ __device__ __forceinline__ void layer2_f32(const Lane& L, unsigned lds0, unsigne
   l2_reduce<M>(L, lds0, wave, tag, err, accx, part, pflag);
 }
 
-// ---- X6 form ------------------------------------------------------------------------------------------------
-// K = 96 slots in three K = 32 chunks; slot k = 32 c + 8 kq + e of the MFMA's K axis is
-//   c = 0, 1:        tap 2c + (kq >> 1), channel 8 (kq & 1) + e              (one 16-byte row half of a plane)
-//   c = 2, kq < 2:   tap 4, channel 8 kq + e
-//   c = 2, kq = 2:   tap e >> 1 (0..3), channel 16 + (e & 1)                 (the remainder channels' window, four rows)
-//   c = 2, kq = 3:   tap 4, channel 16 + e for e < 2; zero weights for e >= 2 (they meet the next three rows: finite values)
-// A wave computes ONE M-tile: waves 0..3 channels 0..15, waves 4..7 channels 16..29 (g = wave >> 2), each for the tiles
-// j + 4t (j = wave & 3, t < 8) -- half the A fragments per wave (36 registers, half the global loads) for twice the B reads,
-// which the LDS has room for: a slot of the stream = one chunk of one tile = three conflict-free ds_read_b128 (the fragment's
-// h, m, l parts; in the last chunk the remainder rows besides, selected into the upper lanes by 12 v_cndmask) for six MFMAs of
-// 16 cycles, 8 waves: half of the LDS's cycles.  No other VALU (beside bf16 MFMAs, which hold the SIMD's issue port for half of
-// their 16 cycles, up to two VALU per MFMA are nearly free -- MI355X guide -- but layer 1's epilogue already did the split).
-// Tile 32 is cut by chunk inside each M-tile group: members j = 0, 1 are the helpers (chunks 0, 1), j = 2 the reducer (chunk 2,
-// the shift, the epilogue): 150 / 150 / 150 / 144 MFMAs per wave.
+// ---- the three-part operand of one K = 32 chunk and its six products (kernels_fused_v3_l23.h, kernels_fused_v3_allx6.h) ----
 struct Parts {
   s16x8 h, m, l;
 };
-struct RemRaw {          // the remainder channels' rows of one window half, as loaded: [h16 h17 | m16 m17] x 4, [l16 l17] x 4
-  u32x2 hm[4];
-  unsigned lq[4];
-};
-template <int C>
-__device__ __forceinline__ void l2x_load(unsigned rdm, unsigned rdr, unsigned rdrl, int om, int orr, int orl, Parts& b, RemRaw& rr) {
-  b.h = lds_ld<s16x8>(rdm, om + 64 * C);
-  if (RCED_X6_EXP & 32) {
-    b.m = b.l = b.h;
-  } else {
-    b.m = lds_ld<s16x8>(rdm, om + 64 * C + MapX6::kPlaneBytes);
-    b.l = lds_ld<s16x8>(rdm, om + 64 * C + 2 * MapX6::kPlaneBytes);
-  }
-  if constexpr (C == 2 && !(RCED_X6_EXP & 16)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      rr.hm[j] = lds_ld<u32x2>(rdr, orr + 8 * j);
-      rr.lq[j] = lds_ld<unsigned>(rdrl, orl + 4 * j);
-    }
-  }
-}
-// last chunk: the upper lanes' slots are the remainder channels
-__device__ __forceinline__ void l2x_merge(Parts& b, const RemRaw& rr, bool upper) {
-  if (RCED_X6_EXP & 16) return;
-  u32x4 h = __builtin_bit_cast(u32x4, b.h), m = __builtin_bit_cast(u32x4, b.m), l = __builtin_bit_cast(u32x4, b.l);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    h[j] = upper ? rr.hm[j].x : h[j];
-    m[j] = upper ? rr.hm[j].y : m[j];
-    l[j] = upper ? rr.lq[j] : l[j];
-  }
-  b.h = __builtin_bit_cast(s16x8, h);
-  b.m = __builtin_bit_cast(s16x8, m);
-  b.l = __builtin_bit_cast(s16x8, l);
-}
 // the six products of one chunk, smallest first
 __device__ __forceinline__ f32x4 l2x_mma(const s16x8 (&a)[3], const Parts& b, f32x4 acc) {
   acc = mfma32(a[1], b.m, acc);
@@ -1389,184 +1302,9 @@ __device__ __forceinline__ f32x4 l2x_mma(const s16x8 (&a)[3], const Parts& b, f3
   acc = mfma32(a[0], b.h, acc);
   return acc;
 }
-// ReLU, [pixel][30] store of this wave's M-tile: lanes kq = 3 of M-tile 1 hold channels 28,29 and the padding 30,31
-__device__ __forceinline__ void l2x_store(const Lane& L, f32x4 acc4, unsigned wr, int off, bool masked, int vb) {
-  if (RCED_X6_EXP & 64) {
-    if (acc4.x == 12345.678f) lds_st<float>(wr, off, acc4.y);
-    return;
-  }
-  const f32x4 v = relu4(acc4);
-  if (!masked || vbit(L, vb)) {
-    lds_st<f32x2>(wr, off, f32x2{v.x, v.y});
-    if (vbit(L, kVSt2)) lds_st<f32x2>(wr, off + 8, f32x2{v.z, v.w});
-  }
-}
-// chunk C of tile 32 (this wave's M-tile)
-template <int C, class Pre>
-__device__ __forceinline__ f32x4 l2x_share(const Lane& L, const A2Regs& A, unsigned rdm, unsigned rdr, unsigned rdrl, f32x4 init, Pre& pre) {
-  Parts b;
-  RemRaw rr;
-  l2x_load<C>(rdm, rdr, rdrl, 0, 0, 0, b, rr);
-  pin();
-  pre();
-  pin();
-  if constexpr (C == 2) l2x_merge(b, rr, vbit(L, kVUpper));
-  return l2x_mma(A.a[0][C], b, init);
-}
-
-template <class M, class Dma>
-__device__ __forceinline__ void layer2_x6(const Lane& L, unsigned lds0, const A2Regs& A, int wave, unsigned tag, unsigned* err, Dma dma DET_ARG) {
-  constexpr int kT2R = M::kT2R, kT2W = M::kT2W;
-  DET_BEGIN();
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const bool upper = vbit(L, kVUpper);
-  const int g = wave >> 2, j = wave & 3;
-  // ---- the share of tile 32 (members 0..2 of either group), first
-  f32x4 accx = zero4, part0 = zero4, part1 = zero4;
-  unsigned pflag0 = 0u, pflag1 = 0u;
-  auto pre = once(dma);
-  if (j < 3) {
-    const int dt = 32 - j;   // tiles from this lane's tile j to tile 32
-    const unsigned rdm = L.rd2m + dt * 512, rdr = L.rd2r + dt * 128, rdrl = L.rd2rl + dt * 64;
-    if (j == 0) accx = l2x_share<0>(L, A, rdm, rdr, rdrl, zero4, pre);        // a helper's share starts from zero,
-    else if (j == 1) accx = l2x_share<1>(L, A, rdm, rdr, rdrl, zero4, pre);
-    else accx = l2x_share<2>(L, A, rdm, rdr, rdrl, A.sh[0], pre);             // the reducer's from the shift
-    if (j < 2) {   // publish (LDS operations of a wave execute in order: data, then flag)
-      lds_st<f32x4>(lds0 + L.scr + (2 * g + j) * 1024, M::kScratch2Off * 4, accx);
-      cbar();
-      if (L.a4 == 0) lds_poke_a(lds0 + (M::kFlag2Off + 2 * g + j) * 4, tag);
-    }
-  }
-  DET(7);
-  // ---- the eight regular tiles j + 4t as ONE stream of 24 chunk slots; tile t's stores ride behind tile t+1's first MFMAs
-  {
-    constexpr int NS = 8 * kL2Chunks, D = RCED_D2X, RING = D + 1;
-    static_assert(D < kL2Chunks, "one last-chunk fragment in flight at a time (RemRaw is not ringed)");
-    Parts b[RING];
-    RemRaw rr;
-    f32x4 acc[2];   // [tile & 1]
-    const bool gj = j == 0;   // tiles 8, 16, 24 (member 0's t = 2, 4, 6) contain gap pixels
-    run_job<NS, D>(
-        [&](auto ic) {
-          constexpr int i = decltype(ic)::value, t = i / kL2Chunks, c = i % kL2Chunks;
-          l2x_load<c>(L.rd2m, L.rd2r, L.rd2rl, t * kT2R, t * 64 * 8, t * 64 * 4, b[i % RING], rr);
-        },
-        [&](auto ic) {
-          constexpr int i = decltype(ic)::value, t = i / kL2Chunks, c = i % kL2Chunks, r = i % RING, u = t & 1;
-          if constexpr (c == 2) l2x_merge(b[r], rr, upper);
-          acc[u] = l2x_mma(A.a[0][c], b[r], c == 0 ? A.sh[0] : acc[u]);
-          if constexpr (t > 0 && c == 0) {   // the previous tile's results
-            constexpr bool gt = t - 1 == 2 || t - 1 == 4 || t - 1 == 6;
-            l2x_store(L, acc[u ^ 1], L.wr2, (t - 1) * kT2W, gt && gj, kVL2 + t - 1);
-          }
-          if constexpr (t == 7 && c == 2) {   // reducers: the helpers' flags and partial sums, fetched inside the stream
-            if (j == 2) {
-              pflag0 = lds_peek_a(lds0 + (M::kFlag2Off + 2 * g) * 4);
-              pflag1 = lds_peek_a(lds0 + (M::kFlag2Off + 2 * g + 1) * 4);
-              cbar();
-              part0 = lds_ld<f32x4>(lds0 + L.scr + (2 * g) * 1024, M::kScratch2Off * 4);
-              part1 = lds_ld<f32x4>(lds0 + L.scr + (2 * g + 1) * 1024, M::kScratch2Off * 4);
-            }
-          }
-        },
-        pre);
-    l2x_store(L, acc[1], L.wr2, 7 * kT2W, false, kVL2 + 7);   // tile j + 28: no gap
-  }
-  // ---- reducers: add the helpers' shares (fixed order), store tile 32 (pixels 512..527: no gap inside)
-  if (j == 2) {
-    if (!__builtin_amdgcn_readfirstlane(pflag0 == tag && pflag1 == tag)) {   // not there yet when fetched (not seen in practice)
-      flag_wait(lds0 + (M::kFlag2Off + 2 * g) * 4, tag, err, 2u);
-      flag_wait(lds0 + (M::kFlag2Off + 2 * g + 1) * 4, tag, err, 2u);
-      part0 = lds_ld<f32x4>(lds0 + L.scr + (2 * g) * 1024, M::kScratch2Off * 4);
-      part1 = lds_ld<f32x4>(lds0 + L.scr + (2 * g + 1) * 1024, M::kScratch2Off * 4);
-    }
-    f32x4 v = accx + part0;
-    v += part1;
-    l2x_store(L, v, L.wr2 + (32 - j) * (16 * 30 * 4), 0, false, 0);
-  }
-}
-
-// ---- the same layer with BOTH M-tiles per wave (RCED_L2_BOTH): tiles w + 8t, a slot = one chunk of one tile = 12 MFMAs on two
-// accumulation chains; tile 32 cut M-tile x K-part over waves 0..3 (helpers: chunk 0; reducers: chunks 1, 2)
-template <int XM, bool HELPER, class Pre>
-__device__ __forceinline__ f32x4 l2b_share(const Lane& L, const A2Regs& A, unsigned rdm, unsigned rdr, unsigned rdrl, f32x4 init, Pre& pre) {
-  constexpr int C0 = HELPER ? 0 : 1, NC = HELPER ? 1 : 2, XS = XM < kL2MT ? XM : 0;
-  Parts b[2];
-  RemRaw rr;
-  f32x4 acc = init;
-  const bool upper = vbit(L, kVUpper);
-  run_job<NC, 1>(
-      [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        l2x_load<C0 + i>(rdm, rdr, rdrl, 0, 0, 0, b[i % 2], rr);
-      },
-      [&](auto ic) {
-        constexpr int i = decltype(ic)::value, c = C0 + i;
-        if constexpr (c == 2) l2x_merge(b[i % 2], rr, upper);
-        acc = l2x_mma(A.a[XS][c], b[i % 2], acc);
-      },
-      pre);
-  return acc;
-}
-template <class M, class Dma>
-__device__ __forceinline__ void layer2_x6_both(const Lane& L, unsigned lds0, const A2Regs& A, int wave, unsigned tag, unsigned* err, Dma dma DET_ARG) {
-  constexpr int kT2R = M::kT2R, kT2W = M::kT2W, S1 = kL2MT - 1;
-  DET_BEGIN();
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const bool upper = vbit(L, kVUpper);
-  f32x4 accx = zero4, part = zero4;
-  unsigned pflag = 0u;
-  auto pre = once(dma);
-  if (wave < 4) {
-    const int dt = 32 - wave;
-    const unsigned rdm = L.rd2m + dt * 512, rdr = L.rd2r + dt * 128, rdrl = L.rd2rl + dt * 64;
-    if (wave == 0) accx = l2b_share<0, true>(L, A, rdm, rdr, rdrl, zero4, pre);
-    else if (wave == 1) accx = l2b_share<1, true>(L, A, rdm, rdr, rdrl, zero4, pre);
-    else if (wave == 2) accx = l2b_share<0, false>(L, A, rdm, rdr, rdrl, A.sh[0], pre);
-    else accx = l2b_share<1, false>(L, A, rdm, rdr, rdrl, A.sh[S1], pre);
-    if (wave < 2) {
-      lds_st<f32x4>(lds0 + L.scr + wave * 1024, M::kScratch2Off * 4, accx);
-      cbar();
-      if (L.a4 == 0) lds_poke_a(lds0 + (M::kFlag2Off + wave) * 4, tag);
-    }
-  }
-  DET(7);
-  {
-    constexpr int NS = 4 * kL2Chunks, D = RCED_D2X, RING = D + 1;
-    Parts b[RING];
-    RemRaw rr;
-    f32x4 acc[2][2];   // [tile & 1][M-tile]
-    const bool g1 = tile_has_gap(wave + 8), g2 = tile_has_gap(wave + 16), g3 = tile_has_gap(wave + 24);
-    run_job<NS, D>(
-        [&](auto ic) {
-          constexpr int i = decltype(ic)::value, t = i / kL2Chunks, c = i % kL2Chunks;
-          l2x_load<c>(L.rd2m, L.rd2r, L.rd2rl, t * kT2R, t * 128 * 8, t * 128 * 4, b[i % RING], rr);
-        },
-        [&](auto ic) {
-          constexpr int i = decltype(ic)::value, t = i / kL2Chunks, c = i % kL2Chunks, r = i % RING, u = t & 1;
-          if constexpr (c == 2) l2x_merge(b[r], rr, upper);
-          acc[u][0] = l2x_mma(A.a[0][c], b[r], c == 0 ? A.sh[0] : acc[u][0]);
-          acc[u][1] = l2x_mma(A.a[S1][c], b[r], c == 0 ? A.sh[S1] : acc[u][1]);
-          if constexpr (t > 0 && c < 2) {   // the previous tile's results: M-tile 0 behind this tile's first slot, M-tile 1 behind its second
-            const bool g = t == 2 ? g1 : t == 3 ? g2 : false;
-            if constexpr (c == 0) l2_store<0>(L, acc[u ^ 1][0], L.wr2, (t - 1) * kT2W, g, kVMain + t - 1);
-            else l2_store<1>(L, acc[u ^ 1][1], L.wr2, (t - 1) * kT2W, g, kVMain + t - 1);
-          }
-          if constexpr (t == 3 && c == 2) {
-            if (wave == 2 || wave == 3) {
-              pflag = lds_peek_a(lds0 + (M::kFlag2Off + wave - 2) * 4);
-              cbar();
-              part = lds_ld<f32x4>(lds0 + L.scr + (wave - 2) * 1024, M::kScratch2Off * 4);
-            }
-          }
-        },
-        pre);
-    l2_store<0>(L, acc[1][0], L.wr2, 3 * kT2W, g3, kVMain + 3);
-    l2_store<1>(L, acc[1][1], L.wr2, 3 * kT2W, g3, kVMain + 3);
-  }
-  l2_reduce<M>(L, lds0, wave, tag, err, accx, part, pflag);
-}
-
+#if RCED_V3_LEGACY_FORMS
+#include "kernels_fused_v3_legacy.h"
+#endif
 // ---- layer 3: 1x9, 30 -> 8 on pixel pairs ------------------------------------------------------------
 // Rows = 2 pixel phases x 8 channels, K = 10 taps x 30 = 300 (37 b64 slots + the b32 tail).  Every wave has two regular
 // pair tiles, run in lockstep (one A fragment per slot for both, one accumulation chain per tile).
@@ -2037,8 +1775,12 @@ __global__ __launch_bounds__(RCED_V3_LB) __attribute__((target("no-packed-fp32-o
           STAMP_BEGIN();
           const unsigned tag2 = 0xC0000000u | (epoch + 1u);   // distinct from layer 3's tags (0x8.......)
           if constexpr (M::kX6) {
+#if RCED_V3_LEGACY_FORMS
             if constexpr (RCED_L2_BOTH) layer2_x6_both<M>(L, lds0, A2, wave, tag2, P.err, [] {} DET_PASS);
             else layer2_x6<M>(L, lds0, A2, wave, tag2, P.err, [] {} DET_PASS);
+#else
+            static_assert(!M::kX6 || M::kFused, "form 1 is a legacy form (RCED_V3_LEGACY_FORMS)");
+#endif
           } else {
             auto dma3 = [&] { packet_dma<kW3>(wsrc + kW1 + kW2, WREG(wcur ^ 1), wave, lane); };
             layer2_f32<M>(L, lds0, lds_addr(WREG(wcur)), wave, tag2, P.err, dma3 DET_PASS);

@@ -427,9 +427,11 @@ constexpr int a1x_shift_off() {
   if constexpr (M::kAllX6) return M::kW1Off * 4 + 21 * 1024;
   else return M::kX0Off * 4 + 5 * 1024;
 }
+#if RCED_V3_LEGACY_FORMS
 static_assert(a1x_shift_off<MapT>() + 128 <= (MapT::kX0Off + kX0Floats) * 4 && a1x_off<MapT>(20) + 1024 <= (MapT::kHOff + (kHFrame * 3 + 64 + kF) * kHS) * 4 &&
               a1x_off<MapT>(8) % 16 == 0 && a1x_off<MapT>(9) % 16 == 0 && a1x_off<MapT>(13) % 16 == 0 && a1x_off<MapT>(17) % 16 == 0,
               "layer 1's LDS-resident images: inside the input-row area / the real bins of the H image, 16-byte aligned");
+#endif
 // the DMA of one block's image (src = its first float in the weight stream): 22 chunks over the 8 waves
 template <class M>
 __device__ __forceinline__ void a1x_dma(const float* src, float* lds, int wave, int lane) {

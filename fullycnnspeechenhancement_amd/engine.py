@@ -21,9 +21,9 @@ class FullyCNNTester(object):
 
     def __init__(self, test_config=None, net_work=None, checkpoint_file=None, weights=None, device=0, reuse_output=False):
         self.device = device
-        # reuse_output: test_step returns one of TWO pooled output arrays per shape, alternating, instead of a fresh ndarray per call as
-        # sess.run does (a fresh 67 MB array at config 3 is ~5 ms of page faults: 12.4 against 6.9 ms per call).  Opt-in: the result of
-        # call k is overwritten by call k + 2 -- copy it if it has to live longer.
+        # test_step's default already avoids the page faults of a fresh 67 MB ndarray per call (model.HostOutputPool: a new ndarray object
+        # over recycled warm pages, never one the caller still holds).  reuse_output is the blunt form: one of TWO pooled arrays per shape,
+        # alternating, whatever the caller holds -- the result of call k is overwritten by call k + 2.
         self.reuse_output = bool(reuse_output)
         self._out_pool = {}
         self.net_work = net_work

@@ -151,11 +151,15 @@ int rced_stft(const float* pcm_dev, const int* lengths_dev, int N, int L, int T,
 int rced_istft(const float* mag_dev, const float* phase_dev, int N, int T, int nfft, float* audio_dev,
                int device, void* stream);
 
-/* Which kernels rced_stft / rced_istft launch (process-wide: these entry points have no handle).  key "x6": 1 (default) = the
- * three-part bf16 kernels (fp32 quality on the bf16 matrix pipe, kernels_audio_x6.h), 0 = the fp32-MFMA kernels (the in-build
- * comparator; both pass the same reference-pinned tests).  value 0 / 1 sets, -1 only queries; returns the value now in force, or
- * -1 for an unknown key / a bad value.  The environment variable RCED_AUDIO_X6 supplies the default, read once. */
-int rced_audio_option(const char* key, int value);
+/* The same two entries with the kernel family as an ARGUMENT (there is no process-wide state): RCED_AUDIO_X6 = the three-part bf16
+ * kernels (fp32 quality on the bf16 matrix pipe, kernels_audio_x6.h: what rced_stft / rced_istft launch), RCED_AUDIO_F32 = the
+ * fp32-MFMA kernels (the in-build comparator; both pass the same reference-pinned tests).  Any other value: RCED_ERR_ARG. */
+#define RCED_AUDIO_F32 0
+#define RCED_AUDIO_X6 1
+int rced_stft_ex(const float* pcm_dev, const int* lengths_dev, int N, int L, int T, float* mag_dev,
+                 float* phase_dev, int device, void* stream, int kernels);
+int rced_istft_ex(const float* mag_dev, const float* phase_dev, int N, int T, int nfft, float* audio_dev,
+                  int device, void* stream, int kernels);
 
 /* ---- training step: FullyCNNTrainer.creat_graph + train_step,
  * model_utils/trainer.py:156-192, over Model(is_training=True).  Layer-by-layer, correctness first. ---- */

@@ -310,16 +310,18 @@ def test_full_size_config3_sampled_against_oracle(net_work, tag, variant, built)
         assert torch.equal(m(x), y)
 
 
-# the four forms of the CR-CED kernel (kernels_fused_v3.h): agree with each other to fp32 summation noise
+# the two forms of the CR-CED kernel in the product library (kernels_fused_v3.h): the product (every layer as three-part bf16 products) and
+# the comparator (every layer on the fp32 MFMA, bit-for-bit an fp32 fmaf chain) agree to fp32 summation noise.  (Rounds 3 / 4's forms 1
+# and 2 are history: RCED_V3_LEGACY_FORMS builds only.)
 V3_FORMS_AGREE = 5e-6
-V3_FORM_NAMES = ("all x6", "fused x6", "x6", "fp32-MFMA")
+V3_FORMS = (3, 0)
+V3_FORM_NAMES = ("all x6", "fp32-MFMA")
 
 
 def v3_forms(w):
-    """Models running (the product form: every layer as three-part bf16 products; round 4's product: all but the first layer and
-    decode_final; round 4's first form: the 18 -> 30 layers only; every layer on the fp32 MFMA) -- option v3_l2x6 = 3, 2, 1, 0."""
+    """Models running the product form and the fp32-MFMA comparator -- option v3_l2x6 = 3, 0."""
     ms = []
-    for form in (3, 2, 1, 0):
+    for form in V3_FORMS:
         m = make_model(3, w)
         if form == 3:
             assert m.get_option("v3_l2x6") == 3   # the default
@@ -335,17 +337,17 @@ def v3_check_forms(ms, x, ref, what=""):
     ys = [m(x) for m in ms]
     ys = [y.cpu().numpy() if hasattr(y, "cpu") else y for y in ys]
     eo = [check_parity(y, ref, what="%s %s form" % (what, n)) for y, n in zip(ys, V3_FORM_NAMES)]
-    ef = [rel_err(y, ys[3]) for y in ys[:3]]
+    ef = [rel_err(y, ys[-1]) for y in ys[:-1]]
     return ys, eo, ef
 
 
 def test_v3_kernel_forms_agree_with_the_oracle_and_each_other(built, capsys):
-    """rced_set_option(m, "v3_l2x6", 0 | 1 | 2 | 3): all four kernels are in the library; same inputs through all -- the golden
-    vectors and a fuzz set (shapes across the tile size, input scales 1e-3 .. 30, silent frames) -- each held to the oracle
-    (1e-4) and the x6 forms to the fp32-MFMA one (5e-6 of the scale: fp32 summation noise; measured errors printed)."""
+    """rced_set_option(m, "v3_l2x6", 3 | 0): same inputs through the product form and the comparator -- the golden vectors and a
+    fuzz set (shapes across the tile size, input scales 1e-3 .. 30, silent frames) -- each held to the oracle (1e-4) and the
+    product to the fp32-MFMA form (5e-6 of the scale: fp32 summation noise; measured errors printed)."""
     w, g = load_golden("v3")
     ms = v3_forms(w)
-    worst = [0.0] * 7
+    worst = [0.0] * 3
     cases = [(w, g["x_small"], g["y_small"]), (w, g["x_long"], g["y_long"]), (w, g["x_c1"], g["y_c1"])]
     rng = np.random.default_rng(4242)
     for _ in range(8):
@@ -362,15 +364,14 @@ def test_v3_kernel_forms_agree_with_the_oracle_and_each_other(built, capsys):
         worst = [max(a, b) for a, b in zip(worst, eo + ef)]
         assert max(ef) <= V3_FORMS_AGREE, ef
     with capsys.disabled():
-        print("\n[v3 forms] worst error of the scale vs the oracle: all x6 %.2e, fused x6 %.2e, x6 %.2e, fp32-MFMA %.2e; vs the fp32-MFMA form: "
-              "all x6 %.2e, fused x6 %.2e, x6 %.2e" % tuple(worst))
+        print("\n[v3 forms] worst error of the scale vs the oracle: all x6 %.2e, fp32-MFMA %.2e; the product vs the fp32-MFMA form: %.2e" % tuple(worst))
 
 
 @pytest.mark.parametrize("net_work,tag,variant", NETS)
 def test_whole_output_config3_against_the_fp64_restatement(net_work, tag, variant, built, capsys):
     """BASELINE config 3 (batch 256, 129x512), EVERY one of the 131,072 output frames (the reference boundary returns all of
-    them: tester.py:85-90) against oracle/infer_ref.py run in float64 on the same GPU -- all three nets, and for CR-CED all
-    four forms of the kernel, which must also agree with each other."""
+    them: tester.py:85-90) against oracle/infer_ref.py run in float64 on the same GPU -- all three nets, and for CR-CED both
+    forms of the kernel, which must also agree with each other."""
     import torch
     import bench
     from oracle import infer_ref
@@ -381,7 +382,7 @@ def test_whole_output_config3_against_the_fp64_restatement(net_work, tag, varian
     if variant == 3:
         _, eo, ef = v3_check_forms(v3_forms(w), x, ref)
         assert max(ef) <= V3_FORMS_AGREE, ef
-        msg = "all x6 %.2e, fused x6 %.2e, x6 %.2e, fp32-MFMA %.2e; vs the fp32-MFMA form %.2e, %.2e, %.2e" % tuple(eo + ef)
+        msg = "all x6 %.2e, fp32-MFMA %.2e; the product vs the fp32-MFMA form %.2e" % tuple(eo + ef)
     else:
         msg = "%.2e" % check_parity(make_model(variant, w)(x).cpu().numpy(), ref)
     with capsys.disabled():
@@ -461,7 +462,7 @@ def _scaled_inner_channels(w, rng, lo=-4.0, hi=4.0):
 def test_three_part_products_on_adversarial_magnitudes(built, capsys):
     """The split x = h + m + l (bf16 parts) of the CR-CED kernel's 18-channel tensor under magnitudes the synthetic inputs never
     produce: per-channel scales spanning 1e-4 .. 1e4 inside one K = 32 chunk, inputs x 1e-6 and x 1e4, a frame of exact zeros
-    next to a frame of 1e4.  All four forms of the kernel against the oracle (1e-4) and each other; measured errors printed."""
+    next to a frame of 1e4.  Both forms of the kernel against the oracle (1e-4) and each other; measured errors printed."""
     rng = np.random.default_rng(2024)
     base = rced_np.make_weights("FullyCNNV3", seed=5)
     rows = []
@@ -483,11 +484,11 @@ def test_three_part_products_on_adversarial_magnitudes(built, capsys):
     with capsys.disabled():
         print()
         for r in rows:
-            print("[adversarial] %-40s all x6 %.2e  fused x6 %.2e  x6 %.2e  fp32-MFMA %.2e  vs fp32-MFMA %.2e %.2e %.2e" % r)
+            print("[adversarial] %-40s all x6 %.2e  fp32-MFMA %.2e  product vs fp32-MFMA %.2e" % r)
 
 
 @pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
-@pytest.mark.parametrize("form", [3, 2, 1, 0])
+@pytest.mark.parametrize("form", [3, 0])
 def test_non_finite_input_stays_inside_its_tiles(bad, form, built):
     """One Inf / NaN magnitude at (utterance 1, frame 21, bin 40).  Frame t of the output needs frames t-3 .. t+4 of the input
     (only the first layer looks along time), so frames 17..24 of utterance 1 are the ones the oracle changes.  The kernel
@@ -671,8 +672,9 @@ def test_c_abi_status_codes_on_device(built):
     assert lib.rced_set_option(h, b"nonsense", 1) == _lib.RCED_ERR_ARG
     v = ctypes.c_int(-1)
     assert lib.rced_get_option(h, b"v3_l2x6", ctypes.byref(v)) == 0 and v.value == 3        # the product form is the default
-    assert lib.rced_set_option(h, b"v3_l2x6", 4) == _lib.RCED_ERR_ARG                       # 0 .. 3 are the forms in the library
-    assert b"v3_l2x6 takes 0 .. 3" in lib.rced_last_error()                                 # the specific refusal, not "unknown option"
+    assert lib.rced_set_option(h, b"v3_l2x6", 4) == _lib.RCED_ERR_ARG                       # 3 and 0 are the forms in the library
+    assert b"v3_l2x6 takes 3" in lib.rced_last_error()                                      # the specific refusal, not "unknown option"
+    assert lib.rced_set_option(h, b"v3_l2x6", 2) == _lib.RCED_ERR_ARG                       # round 4's product: a legacy build's
     assert lib.rced_set_option(h, b"final_x6", 1) == _lib.RCED_ERR_ARG and b"R-CED V1 / V2 output-layer" in lib.rced_last_error()
     assert lib.rced_set_option(h, b"nonsense", 1) == _lib.RCED_ERR_ARG and b"unknown option" in lib.rced_last_error()
     assert lib.rced_set_option(h, b"v3_l2x6", -1) == _lib.RCED_ERR_ARG

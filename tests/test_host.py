@@ -134,3 +134,27 @@ def test_compiled_kernels_are_free_of_the_two_measured_hazard_sequences(built):
     found, nfn, nins = isa_lint.lint(objs)
     assert nfn > 100 and nins > 100000, (nfn, nins)
     assert not found, found[:3]
+
+
+def test_host_output_pool_hands_out_fresh_looking_arrays():
+    """model.HostOutputPool, the default of the numpy boundary (tester.py:85-90 returns a new ndarray per call): every take() is a new
+    ndarray object; pages are recycled only when the caller holds nothing of the earlier result any more -- a slice counts; results that
+    are kept are never written again; past the cap plain numpy.empty."""
+    import numpy as np
+    from fullycnnspeechenhancement_amd.model import HostOutputPool
+    pool = HostOutputPool(max_bytes=3 * 4 * 24, per_shape=4)
+    a = pool.take((2, 3, 4))
+    a[...] = 1.0
+    pa = a.__array_interface__["data"][0]
+    b = pool.take((2, 3, 4))
+    assert b is not a and b.__array_interface__["data"][0] != pa          # `a` is held: other pages
+    keep = a[0, 1]                                                        # a slice keeps a's pages alive too
+    del a
+    c = pool.take((2, 3, 4))
+    assert c.__array_interface__["data"][0] != pa and float(keep[0]) == 1.0
+    del keep
+    d = pool.take((2, 3, 4))
+    assert d.__array_interface__["data"][0] == pa                         # dropped: the warm pages come back
+    e = pool.take((2, 3, 4))                                              # b, c, d held, the cap (three buffers) reached: numpy.empty
+    assert e.base is None and e.shape == (2, 3, 4) and e.dtype == np.float32
+    assert pool.take((5, 1, 129, 1)).shape == (5, 1, 129, 1)
