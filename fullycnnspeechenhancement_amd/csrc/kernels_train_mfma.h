@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(kThreads, RCED_TM_OCC) void conv_x6_fwd(const float
   float* lw = lds + GX::kInFloats;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  static_assert(GX::kFits && G::kR == 0, "two workgroups per CU; the forward form has no remainder pass");
+  static_assert(GX::kFits, "two workgroups per CU");
   for (int e = tid; e < GX::kLdsFloats; e += kThreads) lds[e] = e < GX::kInFloats ? 0.f : packet[e - GX::kInFloats];
   float* xt = lds + GX::kLdsFloats;                      // [2][CIN], only with XF
   if constexpr (XF == kXfBnRelu) xform_table_fill<CIN>(xt, xa.mu, xa.rstd, xa.gamma, xa.beta, tid);

@@ -122,7 +122,16 @@ int tm_conv_x6_launch1(const float* in, const float* packet, float* out, int fra
 }
 // forward shapes built in this form: CR-CED's 18 -> 30 layers (no remainder pass; the 30 -> 8 layers' three planes + packet do not
 // leave room for two workgroups per CU: tmm::GeoX6::kFits).  Returns the grid, 0 if not built.
+#ifndef RCED_TM_X6_FWD_818
+#define RCED_TM_X6_FWD_818 0   // 1: the 8 -> 18 forward convolutions (main pass + remainder pass) in the three-part bf16 form too.  Measured (round 6,
+                               // A/B in one call, parity tests green): the step 40.30 -> 40.60 ms -- these layers (K = 72, 1.8 GB per call) wait for
+                               // their tiles, not for the fp32 matrix pipe; not adopted
+#endif
+#if RCED_TM_X6_FWD_818
+#define RCED_TM_X6_FWD(X) X(18, 5, 30) X(8, 9, 18)
+#else
 #define RCED_TM_X6_FWD(X) X(18, 5, 30)
+#endif
 inline bool tm_x6_has(int cin, int taps, int cout) {
 #define X(CI, TP, CO) if (cin == CI && taps == TP && cout == CO) return true;
   RCED_TM_X6_FWD(X)
