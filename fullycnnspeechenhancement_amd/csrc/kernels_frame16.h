@@ -106,10 +106,22 @@ struct Geo {
   static constexpr int slots(int l) { return N::layer[l].taps * oct_in(l); }   // K slots of 8 (layer 0: 8 time rows per tap)
   static constexpr int steps(int l) { return (slots(l) + 3) / 4; }
   static constexpr int frags(int l) { return steps(l) * MT(l); }
-  // Packet kLayers is the output layer's (1 x 129, CH -> 1): a TAP TABLE [159 rows][2 octets][8 channels] bf16, row i = tap i - 15
-  // (zero rows around taps 0 .. 128), 5,088 bytes in five pieces -- run_final reads its Toeplitz A operand straight out of it.
-  static constexpr int kFinRows = 159;
-  static constexpr int kFinPacket = 5 * 1024;
+  // Packet kLayers is the output layer's (1 x 129, CH -> 1; run_final reads its Toeplitz A operand straight out of it).  Octet 0
+  // (channels 0 .. 7) has a K slot per window position; of octet 1 only CB channels exist (V2: 2, V1: 4), so its slots hold RB =
+  // 8 / CB consecutive window positions x CB channels: 36 + 36 / RB K-steps per frame instead of 72.  The packet:
+  //   TA[4 copies kq][160 rows][8 channels]: row r of copy kq = tap r + kq - 15 (zero outside taps 0 .. 128) -- the four k-quads
+  //     of a read land 2,560 bytes apart (the same bank slots: the lane groups of a ds_read_b128 stay conflict-free);
+  //   TB[RB copies c][k][RB positions j][CB channels]: tap RB k + c + j - 15 of channels 8 .. 8 + CB - 1 -- copy c serves the
+  //     lanes whose bin phase leaves the remainder c, so that every read is 16-byte aligned.
+  static constexpr int kFinCB = N::kFinalCh <= 10 ? 2 : 4;
+  static constexpr int kFinRB = 8 / kFinCB;
+  static constexpr int kFinStepsA = 36, kFinStepsB = 36 / kFinRB;
+  static constexpr int kTARows = 160, kTACopy = kTARows * 16;
+  static constexpr int kTBOff = 4 * kTACopy;
+  static constexpr int kTBRows = 4 * (kFinStepsB - 1) + 3 + 15 / kFinRB + 1;     // k values a read reaches
+  static constexpr int kTBCopy = kFinRB == 4 ? 704 : 1408;                        // 12 / 8 bank slots (mod 16) from copy to copy
+  static constexpr int kFinPacket = 13 * 1024;
+  static_assert(N::kFinalCh > 8 && N::kFinalCh <= 12 && kTBRows * 16 <= kTBCopy && kTBOff + kFinRB * kTBCopy <= kFinPacket, "tap tables fit");
   static constexpr int packet_bytes(int l) { return l == kLayers ? kFinPacket : frags(l) * 1024; }
   static constexpr int packet_off(int l) {
     int o = 0;
@@ -151,15 +163,21 @@ struct Geo {
     return true;
   }
   static_assert(pads_ok(), "the widest kernel's left halo fits the leading zero rows");
-  // The last fused layer writes its output (<= 16 channels) for the output layer as an image H over planes 2, 3 (it reads planes
-  // 0, 1): 32-byte rows [octet 0][octet 1], bin f at row f + (f >> 4) -- a pad row per 16 bins, so that the nine 16-bin blocks a
-  // ds_read_b128 of run_final touches start 544 bytes apart (eight different bank slots) and not 512 -- and behind row 136 a zero
-  // area of 512 bytes that every out-of-range window position reads.
+  // The last fused layer writes its output for the output layer as two images (it reads planes 0, 1 only):
+  //   H over plane 2: octet 0, 16-byte rows, bin f at row f + 2 (f >> 4) -- two pad rows per 16 bins, so that the nine 16-bin
+  //     blocks a ds_read_b128 of run_final touches start 288 bytes apart (with the k-quads 16 bytes apart: sixteen different
+  //     bank slots per lane group); block 8's rows behind bin 128 are the plane's own zero rows;
+  //   H2 over plane 3's bin rows: channels 8 .. 8 + CB - 1, 2 CB bytes per bin, blocks kH2Stride apart (6 / 10 bank slots);
+  //   out-of-range window positions read plane 3's trailing zero rows (kZOff), which nothing ever writes.
   static constexpr int kHOff = 2 * kPlane;
-  static constexpr int kHRows = 137;
-  static constexpr int kZOff = kHOff + kHRows * 32;
-  static_assert(kZOff + 512 <= kRegion && oct_in(kLayers - 1) <= 2 && N::kFinalCh <= 16 && MT(kLayers - 1) == 1,
-                "H + its zero area fit planes 2, 3; the last layer reads planes 0, 1 only");
+  static constexpr int kHStride = 18 * 16;
+  static constexpr int kH2Off = 3 * kPlane + kRowPad * 16;
+  static constexpr int kH2Stride = kFinRB == 4 ? 96 : 160;
+  static constexpr int kH2Block = 16 * 2 * kFinCB;    // bytes of a block's sixteen bins
+  static constexpr int kZOff = 3 * kPlane + (kRowPad + kF) * 16;
+  static_assert(8 * kHStride + 16 * 16 <= kPlane && kH2Off + 8 * kH2Stride + kH2Block <= kZOff && kZOff + 64 <= kRegion &&
+                    oct_in(kLayers - 1) <= 2 && MT(kLayers - 1) == 1,
+                "H, H2 and the zero rows fit planes 2, 3; the last layer reads planes 0, 1 only");
   // skip scratch, per wave: per (saving layer, M-tile) and group of three tiles a 1-KiB unit -- the group's first two fragments,
   // 16 bytes per lane -- and a 512-byte one for the third.  Only the lanes whose four channels exist are stored and loaded
   // (k-quads 0 .. quads - 1: whole 256-byte runs), so an M-tile with 3 real channels moves a quarter of its unit.
@@ -345,8 +363,8 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
     }
   }
 
-  if constexpr (kLast) {   // planes 2, 3 hold an earlier layer's activations: the zero area behind H is rewritten for every frame
-    if (lane < 32) *reinterpret_cast<u32x4*>(region + G::kZOff + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+  if constexpr (kLast) {   // plane 3 holds an earlier layer's activations: H2's block 8 is zero behind bin 128
+    if (lane < G::kH2Block / 16) *reinterpret_cast<u32x4*>(region + G::kH2Off + 8 * G::kH2Stride + lane * 16) = u32x4{0u, 0u, 0u, 0u};
   }
   int base[NB];
 #pragma unroll
@@ -386,10 +404,15 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
       if (t < kTiles - 1) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + t * 256) = hq;
       else if (n == 0) *reinterpret_cast<u32x2*>(out + 2 * mt * G::kPlane + t * 256) = hq;   // tile 8: bin 128 alone, the other rows stay zero
     } else {
-      // the output layer's image H (Geo::kHOff): row 17 t + n, octet kq >> 1, bytes 8 (kq & 1) .. + 7
-      char* const hp = region + G::kHOff + (17 * t + n) * 32 + (kq >> 1) * 16 + (kq & 1) * 8;
-      if (t < kTiles - 1) *reinterpret_cast<u32x2*>(hp) = hq;
-      else if (n == 0) *reinterpret_cast<u32x2*>(hp) = hq;
+      // the output layer's images (Geo::kHOff, kH2Off): k-quads 0, 1 hold octet 0 of bin 16 t + n, k-quad 2 channels 8 .. 11
+      if (t < kTiles - 1 || n == 0) {
+        if (kq < 2) *reinterpret_cast<u32x2*>(region + G::kHOff + t * G::kHStride + n * 16 + kq * 8) = hq;
+        else if (kq == 2) {
+          char* const h2 = region + G::kH2Off + t * G::kH2Stride + n * (2 * G::kFinCB);
+          if constexpr (G::kFinCB == 2) *reinterpret_cast<unsigned*>(h2) = hq.x;
+          else *reinterpret_cast<u32x2*>(h2) = hq;
+        }
+      }
     }
     if constexpr (kSaveMem) {
       const int g = t / GT, j = t % GT, so = G::skip_off(L, mt) + g * 1536;
@@ -511,31 +534,39 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
 
 // The 1 x 129 output layer (decode_5 / decode_8: CH -> 1, no BatchNorm, no ReLU; model.py:24,55) of one frame, inside the kernel:
 // a GEMM with the 16 bin phases m on the M axis, the nine 16-bin blocks n of the frame on N and K = (window position u < 144,
-// channel):  y[16 n + m] = sum_u sum_c W[u - m][c] H[16 n + u - 64][c].  Lane (kq, .) of K-step s holds slot (u = 2 s + (kq >> 1),
-// octet kq & 1): the A fragment is 16 bytes of the tap table at row u - m + 15 (out-of-range taps are its zero rows), the B
-// fragment 16 bytes of H at bin f' = 16 n + u - 64 -- for the eight steps of a block q = s / 8 one per-lane base + immediates
-// (f' >> 4 = n - 4 + q is the same for all of them), out-of-range blocks read the zero area.  72 MFMAs per frame (nine of
-// sixteen columns used) against 1,026 for the layers in front of it; no hand-off tensor in HBM, no second launch.
+// channel):  y[16 n + m] = sum_u sum_c W[u - m][c] H[16 n + u - 64][c].  Octet 0: lane (kq, .) of K-step s holds position u =
+// 4 s + kq (36 steps); channels 8 ..: lane (kq, .) of step s' holds positions RB (4 s' + kq) .. + RB - 1 x CB channels (36 / RB
+// steps; Geo's packet comment).  The A fragment is 16 bytes of a tap table (out-of-range taps are its zero rows), the B fragment 16
+// bytes of H / H2 at bin f' = 16 n + u - 64 -- for the steps of a 16-bin block q one per-lane base + immediates (f' >> 4 = n - 4 + q
+// is the same for all of them), out-of-range blocks read zero rows.  45 MFMAs per frame (V2; nine of sixteen columns used) against
+// 1,026 for the layers in front of it; no hand-off tensor in HBM, no second launch.
 template <class N, class Pre>
 __device__ __forceinline__ void run_final(const Params& P, const char* region, const char* tt, int lane, long long yrow, Pre pre) {
   using G = Geo<N>;
   asm volatile("" : "+v"(lane));
   const int n = lane & 15, kq = lane >> 4;
-  int ab = ((kq >> 1) - n + 15) * 32 + (kq & 1) * 16;
-  asm volatile("" : "+v"(ab));
-  const char* ap = tt + ab;
+  constexpr int RB = G::kFinRB, NA = G::kFinStepsA, NT = NA + G::kFinStepsB;
+  int ta = kq * G::kTACopy + (15 - n) * 16;
+  int tb = G::kTBOff + ((15 - n) % RB) * G::kTBCopy + (kq + (15 - n) / RB) * 16;
+  asm volatile("" : "+v"(ta), "+v"(tb));
+  const char* const ap = tt + ta;
+  const char* const bp = tt + tb;
   f32x4 acc[2] = {f32x4{P.fin_bias, P.fin_bias, P.fin_bias, P.fin_bias}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  constexpr int SS = 6, NS = 72 / SS;               // steps per slot (12 reads in flight: the LDS counter holds 15), slots
+  constexpr int SS = NT % 6 == 0 ? 6 : 5, NS = NT / SS;   // steps per slot (<= 12 reads in flight: the LDS counter holds 15), slots
+  static_assert(NT % SS == 0, "whole slots");
   u32x4 a[2][SS], b[2][SS];
   auto load = [&](int slot, int buf) {
 #pragma unroll
     for (int e = 0; e < SS; ++e) {
-      const int s = SS * slot + e, q = s / 8;
+      const int s = SS * slot + e;
+      const bool first = s < NA;                      // octet 0 / the packed channels
+      const int t = first ? s : s - NA, spb = first ? 4 : 4 / RB;   // steps per 16-bin block
+      const int q = t / spb, i = t % spb;
       const int blk = n - 4 + q;
       const bool ok = n <= 8 && blk >= 0 && blk <= 8;
-      const int off = (ok ? G::kHOff + 17 * blk * 32 : G::kZOff) + (kq >> 1) * 32 + (kq & 1) * 16;
-      a[buf][e] = *reinterpret_cast<const u32x4*>(ap + s * 64);
-      b[buf][e] = *reinterpret_cast<const u32x4*>(region + off + (s % 8) * 64);
+      const int off = (ok ? (first ? G::kHOff + blk * G::kHStride : G::kH2Off + blk * G::kH2Stride) : G::kZOff) + kq * 16;
+      a[buf][e] = *reinterpret_cast<const u32x4*>((first ? ap : bp) + t * 64);
+      b[buf][e] = *reinterpret_cast<const u32x4*>(region + off + i * 64);
     }
   };
   load(0, 0);
@@ -552,15 +583,12 @@ __device__ __forceinline__ void run_final(const Params& P, const char* region, c
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's first packet has landed (see run_layer); the mask stores follow
   __builtin_amdgcn_s_waitcnt(0x0f70);
-  // H lay over planes 2 and 3, zero rows included (8 in front of the bins, 23 behind: every layer's SAME padding): put the zeros
-  // back -- 2 x 31 rows of 16 bytes (V2), one store (the LDS serves this wave's reads above first)
+  // H lay over plane 2, zero rows included (8 in front of the bins, 23 behind: every layer's SAME padding): put the zeros back --
+  // 31 rows of 16 bytes (V2), one store (the LDS serves this wave's reads above first)
   {
-    constexpr int PR = kRowPad + G::kRows - (kRowPad + kF);   // zero rows per plane
-#pragma unroll
-    for (int i = 0; i < (2 * PR + 63) / 64; ++i) {
-      const int idx = lane + 64 * i, pl = idx / PR, r = idx - pl * PR;
-      if (idx < 2 * PR) *reinterpret_cast<u32x4*>(const_cast<char*>(region) + (2 + pl) * G::kPlane + (r < kRowPad ? r : kF + r) * 16) = u32x4{0u, 0u, 0u, 0u};
-    }
+    constexpr int PR = kRowPad + G::kRows - (kRowPad + kF);   // zero rows of a plane
+    static_assert(PR <= 64, "one store");
+    if (lane < PR) *reinterpret_cast<u32x4*>(const_cast<char*>(region) + 2 * G::kPlane + (lane < kRowPad ? lane : kF + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
   }
   const f32x4 v = acc[0] + acc[1];
   if (yrow >= 0) {

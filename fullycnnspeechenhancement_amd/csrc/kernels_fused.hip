@@ -471,15 +471,21 @@ void pack_frame16(const rced_model* m, std::vector<unsigned>* wpack) {
     float* sh = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(wpack->data()) + G::kShiftOff) + 32 * l;
     for (int c = 0; c < d.cout; ++c) sh[c] = L.host_shift[c];
   }
-  // the output layer's tap table (frame16::run_final): row i = tap i - 15, [octet][8 channels] bf16, zero outside taps 0 .. 128
-  constexpr int CH = N::kFinalCh;
+  // the output layer's tap tables (frame16::Geo's packet comment): TA[kq][r] = tap r + kq - 15 of channels 0 .. 7;
+  // TB[c][k][j] = tap RB k + c + j - 15 of channels 8 .. 8 + CB - 1; zero outside taps 0 .. 128
+  constexpr int CH = N::kFinalCh, RB = G::kFinRB, CB = G::kFinCB;
   const rced_layer_dev& lf = m->layers[N::kLayers];
-  unsigned short* tt = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(wpack->data()) + G::packet_off(N::kLayers));
-  for (int i = 0; i < G::kFinRows; ++i)
-    for (int c = 0; c < 16; ++c) {
-      const int tap = i - 15;
-      tt[i * 16 + c] = bf16_rne((tap >= 0 && tap < 129 && c < CH) ? wq(lf, tap, c, 0, CH) : 0.f);
-    }
+  unsigned char* tt = reinterpret_cast<unsigned char*>(wpack->data()) + G::packet_off(N::kLayers);
+  auto tapw = [&](int tap, int c) { return bf16_rne((tap >= 0 && tap < 129 && c < CH) ? wq(lf, tap, c, 0, CH) : 0.f); };
+  for (int kq = 0; kq < 4; ++kq)
+    for (int r = 0; r < G::kTARows; ++r)
+      for (int c = 0; c < 8; ++c)
+        reinterpret_cast<unsigned short*>(tt + kq * G::kTACopy)[r * 8 + c] = tapw(r + kq - 15, c);
+  for (int c = 0; c < RB; ++c)
+    for (int k = 0; k < G::kTBRows; ++k)
+      for (int j = 0; j < RB; ++j)
+        for (int e = 0; e < CB; ++e)
+          reinterpret_cast<unsigned short*>(tt + G::kTBOff + c * G::kTBCopy)[(k * RB + j) * CB + e] = tapw(RB * k + c + j - 15, 8 + e);
 }
 template <class N>
 int frame16_enable(rced_model* m, rced_fused* f) {
