@@ -40,7 +40,7 @@
 #include "lds_dma.h"
 
 #ifndef RCED_F16_EXP
-#define RCED_F16_EXP 0   // timing experiments only (wrong results): 1 = no skip stores, 2 = no skip loads / adds, 4 = no barriers,
+#define RCED_F16_EXP 0   // timing experiments only (wrong results): 1 = no skip stores, 2 = no skip loads / adds (128: loads issued, data dropped at the layer's end), 4 = no barriers,
                          // 8 = A fragments read for the first K-step only, 16 = no input-row loads, 64 = no packet DMA
 #endif
 #if RCED_F16_EXP != 0 && !defined(RCED_TIMING_ONLY)
@@ -52,6 +52,9 @@
 #endif
 #ifndef RCED_F16_DBGEXPOSE
 #define RCED_F16_DBGEXPOSE 0   // debugging: bit L = layer L keeps all three groups' accumulators and runs its whole epilogue behind the K loop
+#endif
+#ifndef RCED_F16_WAVES
+#define RCED_F16_WAVES 4   // frames (= waves) per workgroup: 4 (two workgroups per CU) or 8 (one: every packet feeds eight frames)
 #endif
 #ifndef RCED_F16_STAMPS
 #define RCED_F16_STAMPS 0   // diagnostic build: s_memtime stamps of workgroup 0 / wave 0 on its second tile (tools/stamps16.py)
@@ -74,7 +77,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kWaves = 4;                 // one per SIMD; two workgroups per CU
+constexpr int kWaves = RCED_F16_WAVES;    // 4: one per SIMD, two workgroups per CU
 constexpr int kThreads = kWaves * 64;
 constexpr int kRowPad = 8;                // bin f lives at row f + kRowPad
 constexpr int kPlanes = 4;                // 32 channels at most (V1's 24 -> 32 layer, V2's 23 -> 25)
@@ -156,7 +159,7 @@ struct Geo {
   static constexpr int kWOff = kActBytes;
   static constexpr int kSOff = kWOff + 2 * kWRegion;            // every layer's shifts, resident (loaded once per workgroup)
   static constexpr int kLdsBytes = kSOff + kShiftBytes;
-  static_assert(kLdsBytes <= 80 * 1024, "two workgroups per CU");
+  static_assert(kLdsBytes <= (kWaves == 4 ? 80 : 160) * 1024, "two workgroups per CU (four waves each), or one of eight");
   static constexpr bool pads_ok() {
     for (int l = 0; l < kLayers; ++l)
       if (pad(l) > kRowPad) return false;
@@ -244,15 +247,18 @@ __device__ __forceinline__ void packet_dma(const unsigned* __restrict__ src, cha
   }
 }
 
-// The eight input rows t - 3 .. t + 4 of one frame, three 64-bin columns per lane, fetched one tile ahead
+// The eight input rows t - 3 .. t + 4 of one frame, fetched one tile ahead: bins 4 l .. 4 l + 3 of every row in lane l <= 32, ONE
+// 16-byte load per row (a vector-memory instruction costs its wave ~100 cycles of issue in this kernel whatever it moves: eight
+// of them, not twenty-four four-byte ones -- 4 % of the kernel's time)
 struct XRows {
-  float v[3][8];
+  f32x4 v[8];
 };
-// Buffer loads over the utterance's [T, 129] floats.  A row in front of the first or behind the last frame (TF 'SAME' for the
-// 8-tall kernel: 3 rows before, 4 after) is skipped by a wave-uniform branch and stays zero: offsets are never negative (a
-// "negative" offset is a huge unsigned one to the range check but, with a positive immediate folded in behind it, an address
-// 4 GB away to the address unit -- measured: memory faults).  Lanes past bin 128 of the third column read the next row's bins
-// (x_store drops them) or, on the utterance's last row, past the descriptor's range (zero).
+// Buffer loads over the utterance's [T, 129] floats (a row is 516 bytes: dword-aligned, which is all a buffer load asks for).  A row
+// in front of the first or behind the last frame (TF 'SAME' for the 8-tall kernel: 3 rows before, 4 after) is skipped by a
+// wave-uniform branch and stays zero: offsets are never negative (a "negative" offset is a huge unsigned one to the range check
+// but, with a positive immediate folded in behind it, an address 4 GB away to the address unit -- measured: memory faults).  Lanes
+// 33 .. 63 carry an offset past the descriptor's range (zero, no traffic); lane 32 fetches bins 125 .. 128 -- its sixteen bytes end
+// with the row, so the utterance's last row is in range whatever the range check does with a partly covered access.
 __device__ __forceinline__ XRows x_load(const Params& P, int tile, int wave, int lane) {
   XRows r;
   const bool live = tile < P.total_tiles;
@@ -260,26 +266,23 @@ __device__ __forceinline__ XRows x_load(const Params& P, int tile, int wave, int
   const int t = live ? (tile - utt * P.tiles_per_utt) * kWaves + wave : 0;
   const __amdgpu_buffer_rsrc_t xu = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(P.x) + (size_t)utt * P.T * kF, 0, P.T * kF * 4, 0x00020000);
+  const int vo = lane < kF / 4 ? lane * 16 : lane == kF / 4 ? (kF - 4) * 4 : 0x40000000;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int tt = t + k - 3;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) r.v[i][k] = 0.f;
-    if (live && tt >= 0 && tt < P.T) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        r.v[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xu, lane * 4 + 256 * i, tt * (kF * 4), 0));
-    }
+    r.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live && tt >= 0 && tt < P.T)
+      r.v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xu, vo, tt * (kF * 4), 0));
   }
   return r;
 }
 __device__ __forceinline__ void x_store(const XRows& r, char* region, int lane) {   // plane 0 (its stride does not matter)
+  if (lane <= kF / 4) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int p = lane + 64 * i;
-    if (p < kF) {
-      const u32x4 q = {pack2(r.v[i][0], r.v[i][1]), pack2(r.v[i][2], r.v[i][3]), pack2(r.v[i][4], r.v[i][5]), pack2(r.v[i][6], r.v[i][7])};
-      *reinterpret_cast<u32x4*>(region + (p + kRowPad) * 16) = q;
+    for (int i = 0; i < 4; ++i) {
+      const int p = (lane < kF / 4 ? 4 * lane : kF - 4) + i;
+      const u32x4 q = {pack2(r.v[0][i], r.v[1][i]), pack2(r.v[2][i], r.v[3][i]), pack2(r.v[4][i], r.v[5][i]), pack2(r.v[6][i], r.v[7][i])};
+      if (i == 3 || lane < kF / 4) *reinterpret_cast<u32x4*>(region + (p + kRowPad) * 16) = q;
     }
   }
 }
@@ -487,7 +490,7 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
         }
       pin();
     }
-    if constexpr (D.skip_from >= 0 && !(RCED_F16_EXP & 2)) {
+    if constexpr (D.skip_from >= 0 && !(RCED_F16_EXP & (2 | 128))) {
       // HAZARD (found the hard way, round 6): a v_mfma_f32_16x16x16_bf16 issued DIRECTLY behind the v_mfma_f32_16x16x32_bf16
       // that wrote its srcC -- same registers as vdst, the ordinary accumulation chain, but two opcodes of different pass
       // counts -- read a stale accumulator on this part (one tile's skip landed on the previous K-step's sum; deterministic),
@@ -504,6 +507,12 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
         }
       pin();
     }
+  }
+  if constexpr (kSkipMem && (RCED_F16_EXP & 128)) {   // timing only: the skip loads issued, their data waited for here and dropped
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(skip[t][mt]));
   }
   // The next packet's LDS-DMA was issued in front of every global store of this layer; the vector-memory counter retires in
   // order, so waiting until only the stores issued since (the first two groups' skip fragments: exactly 4 per M-tile -- their
@@ -626,7 +635,7 @@ __device__ __forceinline__ void run_layers(const Params& P, char* lds, char* reg
 }
 
 template <class N>
-__global__ __launch_bounds__(kThreads, 2) void frame16_kernel(Params P) {
+__global__ __launch_bounds__(kThreads, kWaves == 4 ? 2 : 1) void frame16_kernel(Params P) {
   using G = Geo<N>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;

@@ -216,9 +216,10 @@ __device__ __forceinline__ void packet_dma(const float* __restrict__ src, float*
     const int c = wave + i * kWaves;
     if (c < chunks) {
       const int idx = c * 64 + lane;
-      if (idx < n4)
+      if (idx < n4) {
         if constexpr (SBASE) lds_dma16s(src + c * 256, (unsigned)lane * 16u, dst + c * 256);
         else lds_dma16(src + (size_t)idx * 4, dst + c * 256);
+      }
     }
   }
 }

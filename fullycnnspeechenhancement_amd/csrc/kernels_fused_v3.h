@@ -1410,7 +1410,7 @@ __device__ __forceinline__ void layer3(const Params& P, const Lane& L, unsigned 
   // ---- the two regular pair tiles
   {
     f32x2 a[RING], b[RING][2];
-    f32x4 accb[2] = {zero4, zero4};   // second chain of each tile (the slot's second k-quad)
+    [[maybe_unused]] f32x4 accb[2] = {zero4, zero4};   // second chain of each tile (the slot's second k-quad)
     pflag[0] = pflag[1] = pflag[2] = 0u;
     run_job<NS, D>(
         [&](auto ic) {

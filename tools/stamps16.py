@@ -26,4 +26,5 @@ for l in range(layers):
     for i in range(4):
         tot[i] += parts[i]
     print("%5d %7d %7d %7d %7d %7d" % ((l,) + parts + (e - a,)))
-print("total %7d %7d %7d %7d %7d" % (tuple(tot) + (st[-1],)))
+print("total %7d %7d %7d %7d %7d" % (tuple(tot) + (sum(tot),)))
+print("output layer + its barrier %d; tile %d" % (st[-1] - st[-2], st[-1] - st[0]))
