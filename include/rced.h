@@ -97,12 +97,12 @@ int rced_reserve(rced_model* m, int N, int T);
  *   "bf16"        R-CED V1 / V2 only: 1 = bf16 activations + inner-layer weights, fp32 accumulation (BASELINE config 2;
  *                 ~6e-3 of the largest output away from the fp32 result -- opt-in)
  *   "v3_l2x6"     CR-CED only: which form of the fused kernel runs.  3 (default) = EVERY layer at fp32 quality on the bf16 matrix pipe
- *                 (three-part operands, six products): the first layer from an im2col-along-time of the input rows, decode_final as a GEMM
- *                 over a tap table resident in LDS; 2 = all but the first layer and decode_final (those on the fp32 MFMA), the 18 -> 30 and
- *                 30 -> 8 layers as one stream in which the 30-channel tensor never leaves the registers (in 3 too); 1 = the 18 -> 30
- *                 layers only; 0 = every layer on the fp32 MFMA (bit-for-bit an fp32 fmaf chain; the in-build comparator: the forms
- *                 agree to ~1e-6 of the largest output).  All four kernels are in the library; a form's weight stream is built when it
- *                 is first selected.
+ *                 (three-part operands, six products): the first layer from an im2col-along-time of the input rows, the 18 -> 30 and
+ *                 30 -> 8 layers as one stream in which the 30-channel tensor never leaves the registers, decode_final as a GEMM over a
+ *                 tap table resident in LDS; 0 = every layer on the fp32 MFMA (bit-for-bit an fp32 fmaf chain; the in-build comparator:
+ *                 the two agree to ~1e-6 of the largest output).  The intermediate forms of rounds 3 - 4 (1, 2) are in the library only
+ *                 when it is compiled with -DRCED_V3_LEGACY_FORMS=1; otherwise they are refused ("v3_l2x6 takes 3 ... or 0").  A form's
+ *                 weight stream is built when it is first selected.
  *   "final_x6", "final_lds"   R-CED V1 / V2 only, fp32 mode: the 1x129 output layer's kernel -- three-part bf16 products (1,
  *                 default) or the fp32 MFMA (0), the latter with (1) / without (0) LDS staging of its B operand.  (In "bf16" mode the
  *                 output layer runs inside the one fused kernel.)

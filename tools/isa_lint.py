@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Lint of the compiled gfx950 kernels (the shipped librced_hip.so by default) for two instruction sequences that hipcc emits without complaint and
+"""Lint of the compiled gfx950 kernels (the shipped librced_hip.so by default) for three instruction sequences that hipcc emits without complaint and
 that misbehaved on MI355X in this project (the reproducibility hunts of rounds 2 and 6):
 
   A. VALU writes VCC  /  vector-memory instruction  /  SALU reads VCC   (three consecutive instructions).
