@@ -388,7 +388,8 @@ def from_root_line(args, torch, dist, model, spec, world, rank, dev_index, B, T,
 
 def secondary_config2(torch, build_model, spec, _lib, _weights, local_rank):
     """BASELINE configs[1]: R-CED V2 (16-layer) forward, batch 64, 129x512, bf16 (model_utils/model.py:32-61)."""
-    B, T, steps, warmup = 64, 512, 50, 10
+    B, T, steps, warmup = 64, 512, 200, 100   # a 0.5-ms kernel: 10 warm-up launches (5 ms) left the clocks where the CPU baseline's idle
+                                              # seconds had put them (0.531 ms per launch against 0.496 in a run of its own, same box)
     w = _weights.synthetic_weights(2, seed=42)
     model = build_model("FullyCNNV2", False, weights=w, device=local_rank, dtype="bfloat16")
     args = None
