@@ -56,6 +56,9 @@
 #ifndef RCED_F16_WAVES
 #define RCED_F16_WAVES 4   // frames (= waves) per workgroup: 4 (two workgroups per CU) or 8 (one: every packet feeds eight frames)
 #endif
+#ifndef RCED_F16_SKIP_LDS
+#define RCED_F16_SKIP_LDS 1   // eight-wave form only: one skip fragment set in LDS (Geo::kSkipLdsLayer)
+#endif
 #ifndef RCED_F16_STAMPS
 #define RCED_F16_STAMPS 0   // diagnostic build: s_memtime stamps of workgroup 0 / wave 0 on its second tile (tools/stamps16.py)
 #endif
@@ -158,7 +161,18 @@ struct Geo {
   static constexpr int kActBytes = kWaves * kRegion;
   static constexpr int kWOff = kActBytes;
   static constexpr int kSOff = kWOff + 2 * kWRegion;            // every layer's shifts, resident (loaded once per workgroup)
-  static constexpr int kLdsBytes = kSOff + kShiftBytes;
+  // Eight-wave workgroups leave LDS free: M-tile 0 of the FIRST two-M-tile encoder layer's skip -- the longest-lived one, the one
+  // that never survives in the L2 -- waits there, 9 tiles x 512 bytes per wave, instead of in the global scratch
+  static constexpr int skip_lds_layer() {
+    if (kWaves != 8 || !RCED_F16_SKIP_LDS) return -1;
+    for (int l = 0; l < kLayers; ++l)
+      if (N::layer[l].saves_skip && MT(l) == 2) return l;   // (a two-M-tile layer is never register-resident: Res::slot)
+    return -1;
+  }
+  static constexpr int kSkipLdsLayer = skip_lds_layer();
+  static constexpr int kSkipLdsBytes = kSkipLdsLayer >= 0 ? kTiles * 512 : 0;
+  static constexpr int kSkipLOff = kSOff + kShiftBytes;
+  static constexpr int kLdsBytes = kSkipLOff + kWaves * kSkipLdsBytes;
   static_assert(kLdsBytes <= (kWaves == 4 ? 80 : 160) * 1024, "two workgroups per CU (four waves each), or one of eight");
   static constexpr bool pads_ok() {
     for (int l = 0; l < kLayers; ++l)
@@ -324,7 +338,7 @@ struct Res {
 // g's first two tiles (pixels 48 g .. 48 g + 31) may be stored while it does; its third tile waits for group g + 1's last slot,
 // whose reads were issued a slot earlier (the LDS serves a wave's requests in order).
 template <class N, int L, class Pre>
-__device__ __forceinline__ void run_layer(const Params& P, char* region, const char* w, const char* shifts, __amdgpu_buffer_rsrc_t scratch, int lane,
+__device__ __forceinline__ void run_layer(const Params& P, char* region, const char* w, const char* shifts, __amdgpu_buffer_rsrc_t scratch, char* skl, int lane,
                                           Pre pre, Res<N>& res, bool stamp = false) {
   using G = Geo<N>;
   F16_STAMP(stamp, 4 * L + 0);
@@ -338,6 +352,9 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
   constexpr int kResOut = D.saves_skip ? Res<N>::slot(L) : -1;         // ... goes into registers
   constexpr bool kSkipMem = D.skip_from >= 0 && kResIn < 0 && !(RCED_F16_EXP & 2);
   constexpr bool kSaveMem = D.saves_skip && kResOut < 0 && !(RCED_F16_EXP & 1);
+  constexpr bool kSaveLds = kSaveMem && L == G::kSkipLdsLayer;             // ... its M-tile 0 goes to LDS
+  constexpr bool kSkipLds = kSkipMem && SF == G::kSkipLdsLayer && G::kSkipLdsLayer >= 0;
+  constexpr int kMemMT = MT - (kSaveLds ? 1 : 0);                          // M-tiles whose skip fragments go to the global scratch
   static_assert(STEPS >= 2 && kTiles == GT * NG, "the third tile of a group is stored in the next group's last slot");
   constexpr int kPer = (2 * MT + STEPS - 2) / (STEPS - 1);   // fragments of the previous group per slot (slots 0 .. STEPS - 2)
   static_assert(kPer <= (GT * MT + 1) / 2 && MT <= (GT * MT + 1) / 2, "one fragment behind every second MFMA of a slot");
@@ -352,7 +369,7 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
   if constexpr (kSkipMem) {
     static_assert(N::layer[SF].cout == D.cout, "skip shapes match");
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = kSkipLds ? 1 : 0; mt < MT; ++mt) {
       const int so = G::skip_off(SF, mt);
       const bool real = kq < G::skip_quads(SF, mt);
       const int o16 = real ? lane * 16 : kOob, o8 = real ? lane * 8 : kOob;
@@ -366,6 +383,10 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
     }
   }
 
+  if constexpr (kSkipLds) {
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) skip[t][0] = *reinterpret_cast<const u32x2*>(skl + t * 512 + lane * 8);
+  }
   if constexpr (kLast) {   // plane 3 holds an earlier layer's activations: H2's block 8 is zero behind bin 128
     if (lane < G::kH2Block / 16) *reinterpret_cast<u32x4*>(region + G::kH2Off + 8 * G::kH2Stride + lane * 16) = u32x4{0u, 0u, 0u, 0u};
   }
@@ -417,7 +438,9 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
         }
       }
     }
-    if constexpr (kSaveMem) {
+    if (kSaveLds && mt == 0) {
+      *reinterpret_cast<u32x2*>(skl + t * 512 + lane * 8) = hq;
+    } else if constexpr (kSaveMem) {
       const int g = t / GT, j = t % GT, so = G::skip_off(L, mt) + g * 1536;
       if (j == 0) pair[mt] = hq;
       if (j == 1) __builtin_amdgcn_raw_buffer_store_b128(u32x4{pair[mt].x, pair[mt].y, hq.x, hq.y}, scratch, so16[mt], so, 0);
@@ -519,7 +542,7 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
   // masked lanes are out-of-range offsets, not skipped instructions) are outstanding means the packet has landed.  The stores
   // themselves stay in flight across the barrier: nobody reads them before a later layer's wait at this place has retired them.
   F16_STAMP(stamp, 4 * L + 1);
-  if constexpr (kSaveMem && !kExpose) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * MT) : "memory");
+  if constexpr (kSaveMem && !kExpose) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * kMemMT) : "memory");
   else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0f70);              // ... and hipcc's wait-count pass knows it (vmcnt(0), nothing else)
@@ -626,7 +649,7 @@ __device__ __forceinline__ void run_layers(const Params& P, char* lds, char* reg
       if constexpr (L == N::kLayers - 3 && !(RCED_F16_EXP & 16)) xr = x_load(P, tile + 1, wave, lane);   // the next tile's input rows, three layers early
       if (!(RCED_F16_EXP & 64)) packet_dma<G::packet_bytes(nxt)>(P.wpack + G::packet_off(nxt) / 4, wdst, wave, lane);   // the layer's LAST vector-memory issue in front of its stores
     };
-    if constexpr (L < N::kLayers) run_layer<N, L>(P, region, wbase + wcur * G::kWRegion, lds + G::kSOff, scratch, lane, pre, res, stamp);
+    if constexpr (L < N::kLayers) run_layer<N, L>(P, region, wbase + wcur * G::kWRegion, lds + G::kSOff, scratch, lds + G::kSkipLOff + wave * G::kSkipLdsBytes, lane, pre, res, stamp);
     else run_final<N>(P, region, wbase + wcur * G::kWRegion, lane, yrow, pre);
     wcur ^= 1;
     layer_end_sync();
