@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/__graft_entry__.py > /dev/null 2>&1   # build first, in a process of its own (never under the profiler)
 BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-profile --no-secondary $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps 10 --warmup 3 > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps ${TRACE_STEPS:-10} --warmup ${TRACE_WARMUP:-3} > "$OUT/trace.log" 2>&1
 pmc() { # name counters...
   local name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- $BENCH --steps 2 --warmup 1 > "$OUT/pmc_$name.log" 2>&1

@@ -85,7 +85,7 @@ def code_object_resources():
 # pinned by static_asserts in kernels_fused.hip ("tools/summarize_prof.py prints these")
 DYNAMIC_LDS = {"Map<3>": 159024, "Map<2>": 163792, "Map<1>": 162976, "Map<0>": 163024}
 
-WARMUP_DISPATCHES = 3      # tools/profile.sh runs bench.py --steps 10 --warmup 3: the first dispatches of a kernel include cold caches / clocks
+WARMUP_DISPATCHES = int(os.environ.get("TRACE_WARMUP", "3"))   # the trace pass's --warmup (tools/profile.sh)
 
 
 def main(out):
