@@ -93,7 +93,7 @@ def bf16_round(a):
     return r.view(np.float32).reshape(np.shape(a))
 
 
-def forward_bf16(net_work, weights, x, final_bf16=True):
+def forward_bf16(net_work, weights, x, final_bf16=True, accumulate=np.float64):
     """Emulation of the bf16 mode of the R-CED kernels (csrc/kernels_frame16.h; BASELINE config 2).
 
     Not a statement about the reference (which is fp32): it restates what the bf16 KERNEL computes, so that the
@@ -102,6 +102,11 @@ def forward_bf16(net_work, weights, x, final_bf16=True):
     rounded to bf16.  (Until round 6 the first layer ran on the fp32 input with its fp32 kernel.)  Last layer (1x129):
     kernel rounded to bf16 (chain16::final_gemm16_kernel; with RCED_C16_FINAL16=0 the library keeps it fp32 --
     final_bf16=False) on the bf16 activations, fp32 output.
+
+    `accumulate`: the dtype the convolution sums run in.  A sum that lands within its own rounding error of a bf16 midpoint rounds
+    either way, a layer's output then differs by one bf16 step (2^-8 of the value) and fifteen layers pass that on: two runs of THIS
+    emulation that differ in nothing but the accumulation dtype (fp64 / fp32) are 3e-3 of the scale apart on typical inputs and
+    1-2e-2 on some (small input scales, where the shifts dominate) -- the yardstick tests/tools/fuzz_bf16.py holds the kernel to.
     """
     layers = L.layers_for(net_work)
     tensors = [bf16_round(np.asarray(x, dtype=np.float32)).astype(np.float64)]
@@ -118,7 +123,8 @@ def forward_bf16(net_work, weights, x, final_bf16=True):
         last = i == len(layers) - 1
         if not (last and not final_bf16):
             k = bf16_round(k)
-        y = conv2d_same(tensors[l.src], k, shift.astype(np.float32), np.float64)
+        y = conv2d_same(tensors[l.src].astype(accumulate), k.astype(accumulate), shift.astype(np.float32).astype(accumulate),
+                        accumulate).astype(np.float64)
         if l.skip_pre >= 0:
             y = y + tensors[l.skip_pre]
         if l.use_act:
