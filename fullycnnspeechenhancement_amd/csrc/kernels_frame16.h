@@ -53,9 +53,6 @@
 #ifndef RCED_F16_DBGEXPOSE
 #define RCED_F16_DBGEXPOSE 0   // debugging: bit L = layer L keeps all three groups' accumulators and runs its whole epilogue behind the K loop
 #endif
-#ifndef RCED_F16_WAVES
-#define RCED_F16_WAVES 4   // frames (= waves) per workgroup: 4 (two workgroups per CU) or 8 (one: every packet feeds eight frames)
-#endif
 #ifndef RCED_F16_SKIP_LDS
 #define RCED_F16_SKIP_LDS 1   // eight-wave form only: one skip fragment set in LDS (Geo::kSkipLdsLayer)
 #endif
@@ -80,8 +77,8 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kWaves = RCED_F16_WAVES;    // 4: one per SIMD, two workgroups per CU
-constexpr int kThreads = kWaves * 64;
+// Frames (= waves) per workgroup, a template parameter W of everything below: 4 (one wave per SIMD, two workgroups per CU: the form
+// for calls of few tiles) or 8 (one workgroup per CU: every packet feeds eight frames, and the LDS that frees holds a skip: Geo)
 constexpr int kRowPad = 8;                // bin f lives at row f + kRowPad
 constexpr int kPlanes = 4;                // 32 channels at most (V1's 24 -> 32 layer, V2's 23 -> 25)
 constexpr int kTiles = 9;                 // 16-pixel tiles per frame
@@ -103,8 +100,10 @@ struct Params {
 #define F16_STAMP(on, i) do { } while (0)
 #endif
 
-template <class N>
+template <class N, int W = 4>
 struct Geo {
+  static_assert(W == 4 || W == 8, "four or eight frames per workgroup");
+  static constexpr int kWaves = W, kThreads = W * 64;
   static constexpr int kLayers = N::kLayers;
   static constexpr int oct_out(int l) { return (N::layer[l].cout + 7) / 8; }
   static constexpr int oct_in(int l) { return l == 0 ? 1 : oct_out(l - 1); }
@@ -164,7 +163,7 @@ struct Geo {
   // Eight-wave workgroups leave LDS free: M-tile 0 of the FIRST two-M-tile encoder layer's skip -- the longest-lived one, the one
   // that never survives in the L2 -- waits there, 9 tiles x 512 bytes per wave, instead of in the global scratch
   static constexpr int skip_lds_layer() {
-    if (kWaves != 8 || !RCED_F16_SKIP_LDS) return -1;
+    if (W != 8 || !RCED_F16_SKIP_LDS) return -1;
     for (int l = 0; l < kLayers; ++l)
       if (N::layer[l].saves_skip && MT(l) == 2) return l;   // (a two-M-tile layer is never register-resident: Res::slot)
     return -1;
@@ -233,7 +232,7 @@ __device__ __forceinline__ unsigned relu2(unsigned v) {
 // LDS-DMA of one packet: whole 1-KiB pieces dealt round-robin to the four waves.  The piece's source is a wave-uniform
 // base + lane * 16, its LDS address goes through M0 (readfirstlane: hipcc is free to compute a uniform address on the VALU,
 // and an "s" operand of an asm statement does not make it move the value).
-template <int BYTES>
+template <int BYTES, int kWaves>
 __device__ __forceinline__ void packet_dma(const unsigned* __restrict__ src, char* dst, int wave, int lane) {
   static_assert(BYTES % 1024 == 0, "whole pieces");
   constexpr int chunks = BYTES / 1024;
@@ -273,6 +272,7 @@ struct XRows {
 // but, with a positive immediate folded in behind it, an address 4 GB away to the address unit -- measured: memory faults).  Lanes
 // 33 .. 63 carry an offset past the descriptor's range (zero, no traffic); lane 32 fetches bins 125 .. 128 -- its sixteen bytes end
 // with the row, so the utterance's last row is in range whatever the range check does with a partly covered access.
+template <int kWaves>
 __device__ __forceinline__ XRows x_load(const Params& P, int tile, int wave, int lane) {
   XRows r;
   const bool live = tile < P.total_tiles;
@@ -337,10 +337,10 @@ struct Res {
 // fragment per two MFMAs; only the last group's is exposed.  In place: group g + 1 reads pixels 48 (g + 1) - 6 and up, so group
 // g's first two tiles (pixels 48 g .. 48 g + 31) may be stored while it does; its third tile waits for group g + 1's last slot,
 // whose reads were issued a slot earlier (the LDS serves a wave's requests in order).
-template <class N, int L, class Pre>
+template <class N, int W, int L, class Pre>
 __device__ __forceinline__ void run_layer(const Params& P, char* region, const char* w, const char* shifts, __amdgpu_buffer_rsrc_t scratch, char* skl, int lane,
                                           Pre pre, Res<N>& res, bool stamp = false) {
-  using G = Geo<N>;
+  using G = Geo<N, W>;
   F16_STAMP(stamp, 4 * L + 0);
   constexpr LayerDesc D = N::layer[L];
   constexpr int OCT = G::oct_in(L), MT = G::MT(L), STEPS = G::steps(L), PADL = G::pad(L);
@@ -572,9 +572,9 @@ __device__ __forceinline__ void run_layer(const Params& P, char* region, const c
 // bytes of H / H2 at bin f' = 16 n + u - 64 -- for the steps of a 16-bin block q one per-lane base + immediates (f' >> 4 = n - 4 + q
 // is the same for all of them), out-of-range blocks read zero rows.  45 MFMAs per frame (V2; nine of sixteen columns used) against
 // 1,026 for the layers in front of it; no hand-off tensor in HBM, no second launch.
-template <class N, class Pre>
+template <class N, int W, class Pre>
 __device__ __forceinline__ void run_final(const Params& P, const char* region, const char* tt, int lane, long long yrow, Pre pre) {
-  using G = Geo<N>;
+  using G = Geo<N, W>;
   asm volatile("" : "+v"(lane));
   const int n = lane & 15, kq = lane >> 4;
   constexpr int RB = G::kFinRB, NA = G::kFinStepsA, NT = NA + G::kFinStepsB;
@@ -637,29 +637,30 @@ __device__ __forceinline__ void layer_end_sync() {
   if (!(RCED_F16_EXP & 4)) asm volatile("s_barrier" ::: "memory");
 }
 
-template <class N, int L>
+template <class N, int W, int L>
 __device__ __forceinline__ void run_layers(const Params& P, char* lds, char* region, __amdgpu_buffer_rsrc_t scratch, int& wcur,
                                            XRows& xr, Res<N>& res, int tile, int wave, int lane, long long yrow, bool stamp) {
-  using G = Geo<N>;
+  using G = Geo<N, W>;
   if constexpr (L <= N::kLayers) {
     constexpr int nxt = (L + 1 <= N::kLayers) ? L + 1 : 0;   // the stream wraps: the next tile's first packet
     char* const wbase = lds + G::kWOff;
     char* const wdst = wbase + (wcur ^ 1) * G::kWRegion;
     auto pre = [&] {
-      if constexpr (L == N::kLayers - 3 && !(RCED_F16_EXP & 16)) xr = x_load(P, tile + 1, wave, lane);   // the next tile's input rows, three layers early
-      if (!(RCED_F16_EXP & 64)) packet_dma<G::packet_bytes(nxt)>(P.wpack + G::packet_off(nxt) / 4, wdst, wave, lane);   // the layer's LAST vector-memory issue in front of its stores
+      if constexpr (L == N::kLayers - 3 && !(RCED_F16_EXP & 16)) xr = x_load<W>(P, tile + 1, wave, lane);   // the next tile's input rows, three layers early
+      if (!(RCED_F16_EXP & 64)) packet_dma<G::packet_bytes(nxt), W>(P.wpack + G::packet_off(nxt) / 4, wdst, wave, lane);   // the layer's LAST vector-memory issue in front of its stores
     };
-    if constexpr (L < N::kLayers) run_layer<N, L>(P, region, wbase + wcur * G::kWRegion, lds + G::kSOff, scratch, lds + G::kSkipLOff + wave * G::kSkipLdsBytes, lane, pre, res, stamp);
-    else run_final<N>(P, region, wbase + wcur * G::kWRegion, lane, yrow, pre);
+    if constexpr (L < N::kLayers) run_layer<N, W, L>(P, region, wbase + wcur * G::kWRegion, lds + G::kSOff, scratch, lds + G::kSkipLOff + wave * G::kSkipLdsBytes, lane, pre, res, stamp);
+    else run_final<N, W>(P, region, wbase + wcur * G::kWRegion, lane, yrow, pre);
     wcur ^= 1;
     layer_end_sync();
-    run_layers<N, L + 1>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, yrow, stamp);
+    run_layers<N, W, L + 1>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, yrow, stamp);
   }
 }
 
-template <class N>
-__global__ __launch_bounds__(kThreads, kWaves == 4 ? 2 : 1) void frame16_kernel(Params P) {
-  using G = Geo<N>;
+template <class N, int W>
+__global__ __launch_bounds__(W * 64, W == 4 ? 2 : 1) void frame16_kernel(Params P) {
+  using G = Geo<N, W>;
+  constexpr int kWaves = W, kThreads = W * 64;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -673,9 +674,9 @@ __global__ __launch_bounds__(kThreads, kWaves == 4 ? 2 : 1) void frame16_kernel(
   const int last = first + per < P.total_tiles ? first + per : P.total_tiles;
   if (first >= last) return;
   char* const region = lds + wave * G::kRegion;
-  packet_dma<G::packet_bytes(0)>(P.wpack, lds + G::kWOff, wave, lane);
+  packet_dma<G::packet_bytes(0), W>(P.wpack, lds + G::kWOff, wave, lane);
   int wcur = 0;
-  XRows xr = x_load(P, first, wave, lane);
+  XRows xr = x_load<W>(P, first, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const __amdgpu_buffer_rsrc_t scratch = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(P.scratch) + ((size_t)blockIdx.x * kWaves + wave) * G::kScratchBytesPerWave, 0,
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(kThreads, kWaves == 4 ? 2 : 1) void frame16_kernel(
     x_store(xr, region, lane);   // plane 0 of the wave's own image: its last reader was this wave's previous layer 1
     const bool stamp = RCED_F16_STAMPS && P.stamps && blockIdx.x == 0 && wave == 0 && tile == first + 1;
     Res<N> res;
-    run_layers<N, 0>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, yrow, stamp);
+    run_layers<N, W, 0>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, yrow, stamp);
     F16_STAMP(stamp, 4 * N::kLayers);
   }
 }

@@ -52,6 +52,7 @@ struct rced_fused {
   unsigned short* fin_apack_x6 = nullptr;  // ... as three bf16 parts per value: fp32 quality on the bf16 pipe (x6::final_gemm_x6_kernel)
   unsigned* scratch16 = nullptr; // its skip fragments, per wave (2 workgroups per CU x 4 waves)
   int bf16_wgs_per_cu = 1;
+  int bf16_frames = 0;        // option "bf16_frames": frames per workgroup of the bf16 kernel (0 = chosen per call, 4, 8)
   int grid_limit = 0;         // option "fused_grid": workgroups of the persistent kernel (0 = #CUs)
   int latency_form = env_default("RCED_LATENCY_FORM", 1);   // option "latency_form" (V1/V2, fp32): one-frame tiles for calls with fewer
                                                                   // 3-frame tiles than CUs (chain_forward)
@@ -487,9 +488,19 @@ void pack_frame16(const rced_model* m, std::vector<unsigned>* wpack) {
         for (int e = 0; e < CB; ++e)
           reinterpret_cast<unsigned short*>(tt + G::kTBOff + c * G::kTBCopy)[(k * RB + j) * CB + e] = tapw(RB * k + c + j - 15, 8 + e);
 }
+template <class N, int W>
+int frame16_prepare(rced_model* m, int* per_cu) {
+  using G = frame16::Geo<N, W>;
+  const void* k = reinterpret_cast<const void*>(frame16::frame16_kernel<N, W>);
+  HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+  int n = 1;   // resident workgroups per CU with this LDS footprint and the kernel's register count
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, G::kThreads, G::kLdsBytes) != hipSuccess || n < 1) n = 1;
+  *per_cu = std::min(n, W == 4 ? 2 : 1);
+  return RCED_OK;
+}
 template <class N>
 int frame16_enable(rced_model* m, rced_fused* f) {
-  using G = frame16::Geo<N>;
+  using G = frame16::Geo<N>;   // packets and the skip scratch do not depend on the frames per workgroup
   if (f->wpack16) return RCED_OK;
   std::vector<unsigned> wpack;
   pack_frame16<N>(m, &wpack);
@@ -499,21 +510,20 @@ int frame16_enable(rced_model* m, rced_fused* f) {
     (void)hipFree(wdev);
     return rced_fail(RCED_ERR_HIP, "hipMemcpy(bf16 packets)");
   }
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(frame16::frame16_kernel<N>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
-  int per_cu = 1;   // resident workgroups per CU with this LDS footprint and the kernel's register count
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(frame16::frame16_kernel<N>),
-                                                   frame16::kThreads, G::kLdsBytes) != hipSuccess || per_cu < 1)
-    per_cu = 1;
-  f->bf16_wgs_per_cu = per_cu > 2 ? 2 : per_cu;
-  if (!f->scratch16)
-    HIP_TRY(hipMalloc(&f->scratch16, (size_t)2 * m->num_cus * frame16::kWaves * G::kScratchBytesPerWave));
+  if (int rc = frame16_prepare<N, 4>(m, &f->bf16_wgs_per_cu)) { (void)hipFree(wdev); return rc; }
+  int one = 1;
+  if (int rc = frame16_prepare<N, 8>(m, &one)) { (void)hipFree(wdev); return rc; }
+  static_assert(G::kScratchBytesPerWave == frame16::Geo<N, 8>::kScratchBytesPerWave, "one scratch serves both forms");
+  if (!f->scratch16 && hipMalloc(&f->scratch16, (size_t)8 * m->num_cus * G::kScratchBytesPerWave) != hipSuccess) {   // 8 waves per CU either way
+    (void)hipFree(wdev);
+    return rced_fail(RCED_ERR_HIP, "hipMalloc(bf16 skip scratch)");
+  }
   f->wpack16 = wdev;   // published last: the mode counts as built only when everything above succeeded
   return RCED_OK;
 }
-template <class N>
-int frame16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
-  using G = frame16::Geo<N>;
+template <class N, int W>
+int frame16_launch(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
+  using G = frame16::Geo<N, W>;
   frame16::Params P;
   P.x = x;
   P.y = y;
@@ -522,20 +532,30 @@ int frame16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int 
   P.scratch = f->scratch16;
   P.N = Nb;
   P.T = T;
-  P.tiles_per_utt = (T + frame16::kWaves - 1) / frame16::kWaves;
+  P.tiles_per_utt = (T + W - 1) / W;
   P.total_tiles = Nb * P.tiles_per_utt;
   P.stamps = nullptr;
 #if RCED_F16_STAMPS
   if (!f->stamps && hipMalloc(&f->stamps, 216 * sizeof(unsigned long long)) != hipSuccess) f->stamps = nullptr;
   P.stamps = f->stamps;
 #endif
-  const int wgs = f->bf16_wgs_per_cu * m->num_cus;       // LDS (<= 80 KB) allows two per CU; VGPRs decide (frame16_enable)
+  const int wgs = (W == 4 ? f->bf16_wgs_per_cu : 1) * m->num_cus;   // four waves: LDS (<= 80 KB) allows two per CU, VGPRs decide (frame16_enable)
   const int grid = std::min(P.total_tiles, f->grid_limit > 0 ? std::min(f->grid_limit, wgs) : wgs);
   m->prof_begin(RCED_K_FUSED, st);   // all 16 / 10 layers: the output layer is the kernel's last phase
-  hipLaunchKernelGGL(frame16::frame16_kernel<N>, dim3(grid), dim3(frame16::kThreads), G::kLdsBytes, st, P);
+  hipLaunchKernelGGL((frame16::frame16_kernel<N, W>), dim3(grid), dim3(G::kThreads), G::kLdsBytes, st, P);
   m->prof_end(RCED_K_FUSED, st);
   HIP_TRY(hipGetLastError());
   return RCED_OK;
+}
+// Frames per workgroup, per call (option "bf16_frames": 0 = this rule, 4 / 8 = always that form; results are bit-identical either way --
+// a frame's arithmetic does not depend on it).  Eight (one workgroup per CU, every packet feeds eight frames, one skip in LDS) is 2 - 5 %
+// faster once every CU has two full tiles; four (two workgroups per CU) starts twice as many workgroups on a small call and leaves a
+// lone tile one wave per SIMD: [1, 256] 23 us against 32 us.
+template <class N>
+int frame16_forward(rced_model* m, rced_fused* f, const float* x, float* y, int Nb, int T, hipStream_t st) {
+  const long long frames = (long long)Nb * T;
+  const int w = f->bf16_frames ? f->bf16_frames : frames >= 16LL * m->num_cus ? 8 : 4;
+  return w == 8 ? frame16_launch<N, 8>(m, f, x, y, Nb, T, st) : frame16_launch<N, 4>(m, f, x, y, Nb, T, st);
 }
 
 int upload(float** dev, const std::vector<float>& host) {   // *dev is set only when the copy succeeded
@@ -759,6 +779,12 @@ int fused_set_option(rced_model* m, const char* key, int value) {
     m->fused->bf16 = value != 0;
     return RCED_OK;
   }
+  if (!strcmp(key, "bf16_frames")) {
+    if (m->variant == RCED_V3) return rced_fail(RCED_ERR_ARG, "bf16_frames selects the form of the bf16 R-CED V1 / V2 kernel only");
+    if (value != 0 && value != 4 && value != 8) return rced_fail(RCED_ERR_ARG, "bf16_frames takes 0 (chosen per call), 4 or 8, got %d", value);
+    m->fused->bf16_frames = value;
+    return RCED_OK;
+  }
   if (!strcmp(key, "inject_handoff_error")) {   // test hook: write `value` into the sticky error word as the kernel would
     if (!m->fused->err_host) return rced_fail(RCED_ERR_ARG, "this variant's fused kernel has no hand-off error word");
     *reinterpret_cast<volatile unsigned*>(m->fused->err_host) = (unsigned)value;
@@ -791,6 +817,10 @@ int fused_get_option(rced_model* m, const char* key, int* value) {
 #endif
   if (!strcmp(key, "fused_grid")) {
     *value = m->fused->grid_limit;
+    return RCED_OK;
+  }
+  if (!strcmp(key, "bf16_frames")) {
+    *value = m->fused->bf16_frames;
     return RCED_OK;
   }
   if (!strcmp(key, "fused_final")) {   // 1: the 1x129 output layer runs inside the fused kernel (no hand-off tensor in HBM)

@@ -96,6 +96,8 @@ int rced_reserve(rced_model* m, int N, int T);
  *   "fused_grid"  workgroups of the persistent fused kernel (0 = one per CU)
  *   "bf16"        R-CED V1 / V2 only: 1 = bf16 activations + inner-layer weights, fp32 accumulation (BASELINE config 2;
  *                 ~6e-3 of the largest output away from the fp32 result -- opt-in)
+ *   "bf16_frames" R-CED V1 / V2 in "bf16" mode: frames (= waves) per workgroup of the kernel, 0 (default) = chosen per call -- eight once
+ *                 the call has 16 frames per CU, four below that --, 4 or 8 = always that form.  Results are bit-identical either way.
  *   "v3_l2x6"     CR-CED only: which form of the fused kernel runs.  3 (default) = EVERY layer at fp32 quality on the bf16 matrix pipe
  *                 (three-part operands, six products): the first layer from an im2col-along-time of the input rows, the 18 -> 30 and
  *                 30 -> 8 layers as one stream in which the 30-channel tensor never leaves the registers, decode_final as a GEMM over a

@@ -159,7 +159,7 @@ def test_bf16_ragged_batches_and_tile_maps(net_work, tag, variant, built, capsys
     w = rced_np.make_weights(net_work, seed=77 + variant)
     m = build_model(net_work, False, weights=w, dtype="bfloat16")
     worst = 0.0
-    for n, t in ((1, 1), (1, 3), (2, 5), (3, 37), (1, 64)):
+    for n, t in ((1, 1), (1, 3), (2, 5), (3, 37), (1, 64), (2, 9)):
         x = rced_np.make_input(n, t, seed=31 * n + t)
         ref16 = rced_np.forward_bf16(net_work, w, x)
         m.set_option("fused_grid", 0)
@@ -171,6 +171,14 @@ def test_bf16_ragged_batches_and_tile_maps(net_work, tag, variant, built, capsys
         for grid in (1, 2, 5):
             m.set_option("fused_grid", grid)
             assert np.array_equal(m(x), y), (n, t, grid)
+        # four or eight frames per workgroup (option bf16_frames; 0 = chosen per call): a frame's arithmetic does not depend on it
+        for frames, grid in ((4, 0), (8, 0), (8, 1), (8, 3), (4, 3)):
+            m.set_option("bf16_frames", frames)
+            m.set_option("fused_grid", grid)
+            assert np.array_equal(m(x), y), (n, t, frames, grid)
+        m.set_option("bf16_frames", 0)
+    with pytest.raises(Exception, match="bf16_frames takes"):
+        m.set_option("bf16_frames", 2)
     with capsys.disabled():
         print("\n[bf16 %s ragged] worst vs bf16 emulation %.2e" % (net_work, worst))
 
@@ -203,6 +211,9 @@ def test_full_size_config2_bf16_sampled_against_its_emulation(built, capsys):
         print("\n[config 2 full size] %d sampled frames: vs bf16 emulation %.2e, vs fp32 oracle %.2e" % (len(picks), w16, w32))
     assert w16 < BF16_VS_EMULATION and w32 < BF16_VS_FP32
     assert torch.equal(m(x[10:12].contiguous()), y[10:12])      # utterances are independent, launches deterministic
+    m.set_option("bf16_frames", 4)                              # this size runs eight frames per workgroup by default
+    assert torch.equal(m(x), y)
+    m.set_option("bf16_frames", 0)
 
 
 @pytest.mark.parametrize("net_work,dtype,batch", [("FullyCNN", "bfloat16", 64), ("FullyCNNV2", "bfloat16", 64),
