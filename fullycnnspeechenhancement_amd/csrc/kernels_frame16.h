@@ -53,6 +53,9 @@
 #ifndef RCED_F16_DBGEXPOSE
 #define RCED_F16_DBGEXPOSE 0   // debugging: bit L = layer L keeps all three groups' accumulators and runs its whole epilogue behind the K loop
 #endif
+#ifndef RCED_F16_GROUPS
+#define RCED_F16_GROUPS 1   // small layers' packets travel together, no barrier between them (0: one packet, one barrier per layer)
+#endif
 #ifndef RCED_F16_SKIP_LDS
 #define RCED_F16_SKIP_LDS 1   // eight-wave form only: one skip fragment set in LDS (Geo::kSkipLdsLayer)
 #endif
@@ -142,6 +145,27 @@ struct Geo {
     return m;
   }
   static constexpr int kWRegion = maxpacket();
+  // Consecutive layers whose packets fit one ring slot TOGETHER travel as one transfer and run back to back: the barrier at a
+  // layer's end is the weight ring's alone (who has read the slot the next transfer overwrites, whose pieces have landed), so inside
+  // a group there is none.  Greedy from layer 0 -- V2: {0..3} {4,5} {6} {7} {8} {9,10} {11..14} {output layer}: 8 barriers per tile
+  // instead of 16.
+  static constexpr int group_first(int l) {
+    int f = 0, bytes = 0;
+    for (int i = 0; i <= l; ++i) {
+      if (i > f && (bytes + packet_bytes(i) > kWRegion || !RCED_F16_GROUPS)) {
+        f = i;
+        bytes = 0;
+      }
+      bytes += packet_bytes(i);
+    }
+    return f;
+  }
+  static constexpr int group_last(int l) {
+    int j = l;
+    while (j + 1 <= kLayers && group_first(j + 1) == group_first(l)) ++j;
+    return j;
+  }
+  static constexpr int group_bytes(int f) { return packet_off(group_last(f) + 1) - packet_off(f); }
   static constexpr int pad(int l) { return (N::layer[l].taps - 1) / 2; }
   // rows per plane: 8 zero rows, 129 bins, then zero rows up to the last row any window reaches -- tile 8's pixel 143 at the
   // last slot of a layer's last K-step (zero-weight pad slots included: they read up to three taps past the window) --
@@ -642,17 +666,22 @@ __device__ __forceinline__ void run_layers(const Params& P, char* lds, char* reg
                                            XRows& xr, Res<N>& res, int tile, int wave, int lane, long long yrow, bool stamp) {
   using G = Geo<N, W>;
   if constexpr (L <= N::kLayers) {
-    constexpr int nxt = (L + 1 <= N::kLayers) ? L + 1 : 0;   // the stream wraps: the next tile's first packet
+    constexpr int gf = G::group_first(L), gl = G::group_last(L);
+    constexpr int nxt = gl + 1 <= N::kLayers ? gl + 1 : 0;   // the next group's first layer; the stream wraps to the next tile's first group
     char* const wbase = lds + G::kWOff;
     char* const wdst = wbase + (wcur ^ 1) * G::kWRegion;
+    const char* const wl = wbase + wcur * G::kWRegion + (G::packet_off(L) - G::packet_off(gf));
     auto pre = [&] {
       if constexpr (L == N::kLayers - 3 && !(RCED_F16_EXP & 16)) xr = x_load<W>(P, tile + 1, wave, lane);   // the next tile's input rows, three layers early
-      if (!(RCED_F16_EXP & 64)) packet_dma<G::packet_bytes(nxt), W>(P.wpack + G::packet_off(nxt) / 4, wdst, wave, lane);   // the layer's LAST vector-memory issue in front of its stores
+      // the next group's packets, issued by the group's FIRST layer: its last vector-memory issue in front of its stores
+      if constexpr (L == gf && !(RCED_F16_EXP & 64)) packet_dma<G::group_bytes(nxt), W>(P.wpack + G::packet_off(nxt) / 4, wdst, wave, lane);
     };
-    if constexpr (L < N::kLayers) run_layer<N, W, L>(P, region, wbase + wcur * G::kWRegion, lds + G::kSOff, scratch, lds + G::kSkipLOff + wave * G::kSkipLdsBytes, lane, pre, res, stamp);
-    else run_final<N, W>(P, region, wbase + wcur * G::kWRegion, lane, yrow, pre);
-    wcur ^= 1;
-    layer_end_sync();
+    if constexpr (L < N::kLayers) run_layer<N, W, L>(P, region, wl, lds + G::kSOff, scratch, lds + G::kSkipLOff + wave * G::kSkipLdsBytes, lane, pre, res, stamp);
+    else run_final<N, W>(P, region, wl, lane, yrow, pre);
+    if constexpr (L == gl) {
+      wcur ^= 1;
+      layer_end_sync();
+    }
     run_layers<N, W, L + 1>(P, lds, region, scratch, wcur, xr, res, tile, wave, lane, yrow, stamp);
   }
 }
@@ -674,7 +703,7 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 2 : 1) void frame16_kernel(Params 
   const int last = first + per < P.total_tiles ? first + per : P.total_tiles;
   if (first >= last) return;
   char* const region = lds + wave * G::kRegion;
-  packet_dma<G::packet_bytes(0), W>(P.wpack, lds + G::kWOff, wave, lane);
+  packet_dma<G::group_bytes(0), W>(P.wpack, lds + G::kWOff, wave, lane);
   int wcur = 0;
   XRows xr = x_load<W>(P, first, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
