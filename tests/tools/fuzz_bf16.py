@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fuzz of the bf16 R-CED kernel (kernels_frame16.h), outside the test suite (GPU box): random weights, shapes and input scales for
 R-CED V1 / V2 with option bf16, each against the numpy emulation with the same rounding places (oracle/rced_np.forward_bf16), bit-identical
-over grids of 1 / 3 / the default number of workgroups and over two calls.  Criterion: TWICE the suite's bf16 bounds (tests/test_forward_gpu.py
+over grids of 1 / 3 / the default number of workgroups, over both forms of the kernel (four / eight frames per workgroup) and over two calls.  Criterion: TWICE the suite's bf16 bounds (tests/test_forward_gpu.py
 holds its fixed seeds to 1e-2 of the scale element-wise, 1e-3 rms) or three times the emulation's own accumulation noise on that case --
 the distance between its fp64- and fp32-accumulating runs, which reaches 2e-2 / 1.5e-3 where a small input leaves the shifts in charge
 (a sum that lands on a bf16 midpoint rounds either way, and fifteen layers pass the step on): the kernel's fp32 sums are a third order of
@@ -50,6 +50,11 @@ for net in ("FullyCNN", "FullyCNNV2"):
         for grid in (1, 3):
             model.set_option("fused_grid", grid)
             same = same and bool(np.array_equal(model(x), y))
+        for frames, grid in ((8, 0), (8, 2), (4, 0)):      # both forms of the kernel (these shapes run the four-frame one by default)
+            model.set_option("bf16_frames", frames)
+            model.set_option("fused_grid", grid)
+            same = same and bool(np.array_equal(model(x), y))
+        model.set_option("bf16_frames", 0)
         if not (np.isfinite(y).all() and el < max(2 * EL, 3 * n_el) and rms < max(2 * RMS, 3 * n_rms) and same):
             failed.append({"weights_seed": wseed, "shape": [n, t], "scale": scale, "element": el, "rms": rms, "emulation_noise": [n_el, n_rms],
                            "bit_identical": same})
