@@ -1,38 +1,41 @@
-// R-CED V1 / V2 forward in bf16 (BASELINE config 2: "R-CED V2 forward, batch 64, 129x512, bf16"): every layer but the
-// 1x129 output layer in ONE kernel on v_mfma_f32_16x16x32_bf16.  Round 6's rebuild of kernels_fused_chain16.h, whose
-// 3-frame tiles crossed fifteen workgroup barriers with 4-17 half-rate MFMAs per tile and layer between them (0.107 of
-// the bf16 peak for four rounds).  Reference: model_utils/model.py:6-61 over module.py:11-34 (conv -> BN -> +skip -> ReLU).
+// R-CED V1 / V2 forward in bf16 (BASELINE config 2: "R-CED V2 forward, batch 64, 129x512, bf16"): ALL layers, the 1x129 output
+// layer included, in ONE kernel on v_mfma_f32_16x16x32_bf16.  Round 6's rebuild of kernels_fused_chain16.h, whose 3-frame tiles
+// crossed fifteen workgroup barriers with 4-17 half-rate MFMAs per tile and layer between them (0.107 of the bf16 peak for four
+// rounds; this kernel: 0.225).  Reference: model_utils/model.py:6-61 over module.py:11-34 (conv -> BN -> +skip -> ReLU).
 //
-// A WAVE OWNS A FRAME.  Only the first conv (8 x k) looks along time; every later layer is 1 x k along frequency, so a
-// frame runs through all the layers without ever reading another frame's activations.  A workgroup is four waves (one
-// per SIMD), two workgroups share a CU; a work item is four consecutive frames of one utterance, wave w takes frame
-// t0 + w.  No activation ever crosses a wave: the only thing the waves of a workgroup share is the weight stream, and the
-// one barrier per layer exists for that alone (it meets four waves that have done exactly the same work).
+// A WAVE OWNS A FRAME.  Only the first conv (8 x k) looks along time; every later layer is 1 x k along frequency, so a frame runs
+// through all the layers without ever reading another frame's activations.  A workgroup's W waves take W consecutive frames of one
+// utterance, wave w frame t0 + w; the kernel is a template over W (frame16_kernel<N, W>, bit-identical results): W = 4, one wave
+// per SIMD and two workgroups per CU, for calls of few tiles; W = 8, one workgroup per CU, for the others -- every packet then
+// feeds eight frames, and the LDS that frees holds one skip (below).  No activation ever crosses a wave: the only thing the waves of
+// a workgroup share is the weight stream, and the barriers -- one per GROUP of layers whose packets share a ring slot, 8 per tile
+// for V2 -- exist for that alone (they meet waves that have done exactly the same work).
 //
-//   * Pixel space of a frame: bin f at row f + 8 of a 160-row image; rows 0..7 and 137..159 stay zero for the kernel's
-//     lifetime (the SAME padding of every layer).  Nine 16-pixel tiles (the ninth holds bin 128 alone).
-//   * Activations are bf16 PLANES  [octet of channels][row][8 channels]  = 16-byte rows, 2,560 bytes per plane (a
-//     multiple of 256: the lane groups of a ds_read_b128 -- {n 0-3, 12-15 of k-quad kq, n 4-11 of kq + 1} -- land on
-//     sixteen different 16-byte bank slots).  A layer works IN PLACE: all nine tiles' accumulators are in registers
-//     (<= 72) before the first output row is stored, so one 10-KB image per frame is all the LDS a frame needs.
-//   * A conv is an implicit GEMM, cout on the M axis, pixels on N, K = (tap, octet) slots of 8 channels: lane (kq, n) of
-//     K-step s reads slot j = 4 s + kq = (tap j / OCT, octet j % OCT) of pixel n's window -- ONE aligned ds_read_b128
-//     out of the image, no im2col copy.  (The old kernel's [pixel][channel] rows gave 8-byte-aligned 16-byte reads,
-//     which the LDS replays: its K = 32 switch bought nothing.)
-//   * The first layer (8 x k on the 1-channel input) is the same code: the wave lays its eight input rows out as ONE
-//     plane [row f + 8][8 time rows] (an im2col along time only), the input cast to bf16 ("C2 ... (cast
-//     bf16)"), weights packed with the time row in the channel slot.
-//   * Epilogue per fragment: two v_cvt_pk_bf16_f32, two v_pk_max_i16 (ReLU on the rounded value: the same result as
-//     rounding the ReLU), one ds_write_b64.
-//   * Skips (module.py:30-31: decoder layer += encoder output BEFORE the ReLU; 72 / 114 channels): the encoder layer's
-//     packed bf16 fragment -- lane (kq, n): channels 4 kq .. + 3 of pixel n -- is exactly the B operand of a
-//     v_mfma_f32_16x16x16_bf16 whose k is the channel, so the decoder adds it with ONE MFMA against an identity
-//     A fragment: no unpacking, no VALU.  The fragments wait in a per-wave global scratch (8 bytes per lane, 512-byte
-//     wave stores, L2 / MALL resident), loaded at the start of the decoder layer and used after its last K-step.
-//   * Weights: per layer a packet of 1-KiB A fragments [step][M-tile][lane] x 8 bf16 + 32 fp32 shifts, LDS-DMA'd one
-//     layer ahead into a two-packet ring.
-// Precision contract: tests/test_forward_gpu.py against the test suite's bf16 emulation, which rounds at the same places
-// (input, every folded kernel, every layer's output).  NOT within the fp32 path's 1e-4 bar: opt-in (option "bf16").
+//   * Pixel space of a frame: bin f at row f + 8 of a 160-row image; rows 0..7 and 137..159 stay zero for the kernel's lifetime
+//     (the SAME padding of every layer).  Nine 16-pixel tiles (the ninth holds bin 128 alone).
+//   * Activations are bf16 PLANES  [octet of channels][row][8 channels]  = 16-byte rows, 2,560 bytes per plane (a multiple of
+//     256: the lane groups of a ds_read_b128 -- {n 0-3, 12-15 of k-quad kq, n 4-11 of kq + 1} -- land on sixteen different
+//     16-byte bank slots).  A layer works IN PLACE: every tile's accumulators are in registers before the rows its successors
+//     read are overwritten (run_layer), so one 10-KB image per frame is all the LDS a frame's activations need.
+//   * A conv is an implicit GEMM, cout on the M axis, pixels on N, K = (tap, octet) slots of 8 channels: lane (kq, n) of K-step s
+//     reads slot j = 4 s + kq = (tap j / OCT, octet j % OCT) of pixel n's window -- ONE aligned ds_read_b128 out of the image, no
+//     im2col copy.  (The old kernel's [pixel][channel] rows gave 8-byte-aligned 16-byte reads, which the LDS replays.)
+//   * The first layer (8 x k on the 1-channel input) is the same code: the wave lays its eight input rows out as ONE plane
+//     [row f + 8][8 time rows] (an im2col along time only), the input cast to bf16 ("C2 ... (cast bf16)"), weights
+//     packed with the time row in the channel slot.
+//   * Epilogue per fragment: two v_cvt_pk_bf16_f32, two v_pk_max_i16 (ReLU on the rounded value: the same result as rounding
+//     the ReLU), one ds_write_b64; it rides between the MFMAs of the next group of tiles.
+//   * Skips (module.py:30-31: decoder layer += encoder output BEFORE the ReLU; 72 / 114 channels): the encoder layer's packed
+//     bf16 fragment -- lane (kq, n): channels 4 kq .. + 3 of pixel n -- is exactly the B operand of a v_mfma_f32_16x16x16_bf16
+//     whose k is the channel, so the decoder adds it with ONE MFMA against an identity A fragment: no unpacking, no VALU.  The
+//     one-M-tile encoder layers' fragments wait in REGISTERS (Res); the two-M-tile ones' in a per-wave global scratch (compact:
+//     8 bytes per lane whose four channels exist), except -- W = 8 -- M-tile 0 of the first of them, which waits in LDS.
+//   * Weights: per layer a packet of 1-KiB A fragments [step][M-tile][lane] x 8 bf16 (+ 32 fp32 shifts per layer, resident),
+//     LDS-DMA'd a group ahead into a two-slot ring; a layer reads its fragments ONCE, into registers.
+//   * The output layer (run_final) is a Toeplitz GEMM over tap tables in its packet and images the last hidden layer writes.
+// Precision contract: tests/test_forward_gpu.py against the test suite's bf16 emulation, which rounds at the same places (input,
+// every folded kernel, every layer's output), and tests/tools/fuzz_bf16.py.  NOT within the fp32 path's 1e-4 bar: opt-in
+// (option "bf16").
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -90,8 +90,8 @@ struct NetV2 {
       {15, 16, 5, 14, 14, 2, 0},   {14, 14, 7, 12, 12, 1, 0},   {12, 12, 11, 10, 10, 0, 0}};
 };
 
-// The same net with another number of frames per tile: geometry only (the packets do not depend on it).  Used by the bf16 kernel
-// (kernels_fused_chain16.h) and by the fp32 kernel's latency form (one-frame tiles when a call has fewer tiles than the part has CUs).
+// The same net with another number of frames per tile: geometry only (the packets do not depend on it).  Used by the fp32 kernel's
+// latency form (one-frame tiles when a call has fewer tiles than the part has CUs).
 template <class N, int TF>
 struct WithTF : N {
   static constexpr int kTF = TF;

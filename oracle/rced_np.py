@@ -100,8 +100,8 @@ def forward_bf16(net_work, weights, x, final_bf16=True, accumulate=np.float64):
     kernel can be tested.  The input is cast to bf16 ("C2 ... (cast bf16)"); every layer: BatchNorm-folded
     kernel rounded to bf16, bf16 activations in, fp32 (here fp64) accumulation, fp32 shift, (+ skip), ReLU, result
     rounded to bf16.  (Until round 6 the first layer ran on the fp32 input with its fp32 kernel.)  Last layer (1x129):
-    kernel rounded to bf16 (chain16::final_gemm16_kernel; with RCED_C16_FINAL16=0 the library keeps it fp32 --
-    final_bf16=False) on the bf16 activations, fp32 output.
+    kernel rounded to bf16 (frame16::run_final; final_bf16=False keeps it fp32, as an earlier form of the library could)
+    on the bf16 activations, fp32 output.
 
     `accumulate`: the dtype the convolution sums run in.  A sum that lands within its own rounding error of a bf16 midpoint rounds
     either way, a layer's output then differs by one bf16 step (2^-8 of the value) and fifteen layers pass that on: two runs of THIS
